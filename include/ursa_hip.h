@@ -1,0 +1,169 @@
+/* ursa_hip.h — C ABI of the MI355X (gfx950) SG-MCMC + Bayesian-model-averaging kernels.
+ *
+ * This is the drop-in boundary under URSABench's Python plug-in API. The reference has no
+ * native layer: each entry point below replaces an *implicit* sequence of stock torch ops
+ * that the reference launches from Python. Citations are relative to /root/reference/.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller
+ *   - nothing here allocates, frees, copies to the host or synchronises: every call only
+ *     enqueues work on `stream` (a hipStream_t passed as void*), so a caller may capture
+ *     it into a hipGraph
+ *   - return 0 on success, a negative URSA_E* for argument errors, a positive hipError_t
+ *     if the launch itself failed; no C++ exception crosses the boundary
+ *   - all arithmetic is IEEE fp32 with the rounding sequence of the reference's CPU path
+ *     (no contraction except the explicit fused multiply-adds named below)
+ */
+#ifndef URSA_HIP_H
+#define URSA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define URSA_ABI_VERSION 1
+
+typedef void* ursa_stream_t; /* hipStream_t */
+
+/* error codes (negative); positive values are hipError_t */
+#define URSA_OK        0
+#define URSA_ENULL    (-1) /* a required pointer is NULL */
+#define URSA_ESIZE    (-2) /* negative / overflowing size */
+#define URSA_EALIGN   (-3) /* pointer not 4-byte aligned */
+#define URSA_EFLAGS   (-4) /* unknown flag bits or inconsistent flag/pointer combination */
+#define URSA_EVALUE   (-5) /* scalar outside its domain (e.g. num_classes > URSA_BMA_MAX_CLASSES) */
+
+/* ------------------------------------------------------------------------------------
+ * K1  optimSGHMC.step            URSABench/inference/optim_sghmc.py:43-67
+ *
+ * One fused pass over the flat parameter arena (all parameter tensors of a chain, or of
+ * several chains, laid end to end). Per element i, fp32, in this order:
+ *     g~ = WD ? fmaf(c_wd, theta, g) : g                              (:47-48)
+ *     mu != 0:  v0 = FIRST ? g~ : mom                                 (:51-52 clone)
+ *               v  = fmaf(-lr, g~, v0 * mu)                           (:53 / :56)
+ *               d  = v
+ *     mu == 0:  d  = g~ * (-lr)                                       (:62)
+ *     NOISE:    d  = d + (eps * c_noise) / n_train                    (:64, true division)
+ *     theta = theta + d                                               (:65)
+ *     mu != 0:  mom = d                                               (:67, buffer includes noise)
+ * eps: if `eps` != NULL it is read from there (parity mode: noise captured from the
+ * reference's generator); if NULL it is generated in registers: Philox4x32-10 keyed by
+ * `seed`, counter (i/4, step), Box-Muller (see csrc/ursa_rng.h).
+ * Optional fusions: ZERO_GRAD stores 0 to grad[i] (replaces optimizer.zero_grad(),
+ * sghmc.py:79); snapshot != NULL also stores the new theta there (the posterior-sample
+ * snapshot of sghmc.py:99, as a device-resident member-bank row).
+ * HBM traffic: 20 B/param (mu != 0), 12 B/param (mu == 0); +4 each for eps / ZERO_GRAD /
+ * snapshot.
+ */
+#define URSA_STEP_NOISE     0x1u
+#define URSA_STEP_FIRST     0x2u
+#define URSA_STEP_ZERO_GRAD 0x4u
+#define URSA_STEP_WD        0x8u
+#define URSA_STEP_ALLFLAGS  0xFu
+
+int ursa_sgmcmc_step_f32(float* theta, float* grad, float* mom /* NULL iff mu == 0 */,
+                         const float* eps /* NULL => Philox */, float* snapshot /* or NULL */,
+                         int64_t n, float lr, float mu, float c_wd, float c_noise,
+                         float n_train, uint64_t seed, uint64_t step, uint32_t flags,
+                         ursa_stream_t stream);
+
+/* Same update with the per-step scalars read from a DEVICE control block, so the launch
+ * can sit inside a captured hipGraph and be replayed while lr / step / flags change.
+ * ursa_step_ctl_advance (1 thread) does step += 1, clears FIRST, and if `sched` != NULL
+ * loads (lr, c_noise) = sched[step % sched_len] — the per-iteration cyclical schedule of
+ * csghmc.py:64-72 precomputed by the host in float64 and rounded once. */
+typedef struct ursa_step_ctl {
+    float lr, mu, c_wd, c_noise, n_train;
+    uint32_t flags;
+    uint64_t seed, step;
+} ursa_step_ctl;
+
+int ursa_sgmcmc_step_ctl_f32(float* theta, float* grad, float* mom, const float* eps,
+                             float* snapshot, int64_t n, const ursa_step_ctl* ctl,
+                             ursa_stream_t stream);
+int ursa_step_ctl_advance(ursa_step_ctl* ctl, const float* sched /* [sched_len][2] or NULL */,
+                          uint32_t sched_len, ursa_stream_t stream);
+
+/* Standard-normal fill with the same Philox/Box-Muller stream as K1 (element i of call
+ * (seed, step) is exactly the eps K1 would use). Used by tests and by SWAG/HMC hosts. */
+int ursa_philox_normal_f32(float* out, int64_t n, uint64_t seed, uint64_t step,
+                           ursa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K2  SWA._collect_model         URSABench/inference/swa.py:81-88
+ *     mean = mean * decay + w / denom ;  sq = sq * decay + (w * w) / denom
+ * with decay = float(n/(n+1.0)), denom = float(n+1.0) computed by the host in float64
+ * (n = num_models_collected). Each product, quotient and sum is rounded separately.
+ * HBM traffic: 20 B/param.
+ */
+int ursa_swag_collect_f32(float* mean, float* sq, const float* w, int64_t n, float decay,
+                          float denom, ursa_stream_t stream);
+
+/* K3  SWAG diagonal draw         URSABench/inference/swag.py:84-86 + swa.py:106-108
+ *     var   = max(sq - mean*mean, var_clamp)
+ *     theta = eps * (sqrt(var) * scale) + mean          (torch.normal(mean, std))
+ * eps as in K1 (pointer, or Philox keyed by (seed, draw)). theta_out is a member-bank row.
+ * HBM traffic: 12 B/param/member.
+ */
+int ursa_swag_draw_f32(float* theta_out, const float* mean, const float* sq,
+                       const float* eps, int64_t n, float var_clamp, float scale,
+                       uint64_t seed, uint64_t draw, ursa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K5  tasks accumulators         URSABench/tasks/prediction.py:57-63,
+ *                                URSABench/tasks/ood_detection.py:59-65,
+ *                                URSABench/tasks/decision_making.py:124-129,
+ *                                URSABench/util.py:126-144
+ * logits[S, B, C] (S ensemble members evaluated on the same B rows). Per row b, for
+ * s = 0..S-1 in order:
+ *     p   = exp((z - max z) - log(sum exp(z - max z)))        (log_softmax().exp_())
+ *     ps  = p * (1-gamma) + gamma/C                           (central_smoothing)
+ *     proba_sum[b, :] += SMOOTHED ? ps : p
+ *     ent_sum[b]      += -sum_c ps * log(ps)                  (compute_predictive_entropy)
+ *     risk_sum[b, :]  += ps @ cost            (only if risk_sum != NULL; cost is [C, C])
+ * one_minus_gamma = float(1-gamma), gamma_over_c = float(gamma*1/C) from the host.
+ * ent_sum may be NULL (Decision). 1 <= C <= URSA_BMA_MAX_CLASSES.
+ * HBM traffic: 4*S*B*C read + read-modify-write of the accumulators.
+ */
+#define URSA_BMA_SMOOTHED 0x1u
+#define URSA_BMA_MAX_CLASSES 1024
+
+int ursa_bma_accumulate_f32(const float* logits, float* proba_sum, float* ent_sum,
+                            float* risk_sum, const float* cost, int32_t S, int64_t B,
+                            int32_t C, float one_minus_gamma, float gamma_over_c,
+                            uint32_t flags, ursa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K4  HMC leapfrog               call site URSABench/inference/hmc.py:71-75; arithmetic is
+ *     hamiltorch's (un-vendored dependency: parity unpinned). grad is
+ *     d log p / d theta.
+ *     KICK : mom   = mom + kick_coef * grad          (kick_coef = eps/2, eps or -eps/2)
+ *     DRIFT: theta = theta + (step_size * inv_mass) * mom        (after the kick, if both)
+ *     kinetic_out != NULL: kinetic_out[0] += 0.5 * inv_mass * sum(mom^2) (after the kick)
+ * Reductions are deterministic (fixed grid, per-block partials in `ws`, summed in block
+ * order by a second 1-block launch): ws must hold URSA_REDUCE_WS_FLOATS floats and is
+ * scratch, it needs no initialisation.
+ * HBM traffic: 20 B/param fused kick+drift.
+ */
+#define URSA_REDUCE_WS_FLOATS 2048
+#define URSA_LEAP_KICK  0x1u
+#define URSA_LEAP_DRIFT 0x2u
+
+int ursa_leapfrog_f32(float* theta, float* mom, const float* grad, int64_t n,
+                      float kick_coef, float step_size, float inv_mass, uint32_t flags,
+                      float* kinetic_out /* 1 float, or NULL */, float* ws /* iff kinetic_out */,
+                      ursa_stream_t stream);
+
+/* out[0] += sum x[i]^2  (prior term tau/2*||theta||^2 and kinetic energy). 4 B/param. */
+int ursa_sumsq_f32(const float* x, int64_t n, float* out, float* ws, ursa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------ */
+int ursa_abi_version(void);
+const char* ursa_strerror(int code);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* URSA_HIP_H */

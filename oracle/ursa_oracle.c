@@ -1,0 +1,261 @@
+/* ursa_oracle.c — CPU restatement of URSABench's SG-MCMC / BMA hot path (plain C, scalar loops).
+ *
+ * TEST INFRASTRUCTURE ONLY. Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this; the product (ursabench_amd/) never does.
+ *
+ * Pinning: every function below is checked in tests/test_oracle_golden.py against golden
+ * vectors captured from the imported reference (tools/gen_golden.py -> tests/golden/ npz files).
+ * K1/K2/K3 are bit-exact against the reference's torch-CPU path on injected noise; K5 is
+ * within 1e-5 relative (ATen's vectorised softmax/sum order is not reproducible in scalar C).
+ * HMC (oracle_leapfrog_f32) follows hamiltorch's published leapfrog: PARITY UNPINNED
+ * (hamiltorch is an un-vendored, un-pinned dependency that is absent from /root/reference).
+ *
+ * Build: make -C oracle   (gcc -O2 -mfma -ffp-contract=off: the two fmaf() per update are
+ * the only fused operations, exactly where ATen's add(alpha=) fuses — SURVEY.md A.1).
+ *
+ * Citations are relative to /root/reference/.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#define STEP_NOISE     0x1u
+#define STEP_FIRST     0x2u
+#define STEP_ZERO_GRAD 0x4u
+#define STEP_WD        0x8u
+#define BMA_SMOOTHED   0x1u
+#define LEAP_KICK      0x1u
+#define LEAP_DRIFT     0x2u
+
+/* ---------------------------------------------------------------------------------------
+ * Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3",
+ * SC'11; Random123 1.x). Not in the reference: the reference draws torch.randn_like per
+ * tensor from torch's global generator (optim_sghmc.py:64), a stream no flat kernel can
+ * reproduce (SURVEY.md §7 hard part 1). Pinned by Random123's known-answer vectors.
+ */
+static inline void philox_round(uint32_t c[4], const uint32_t k[2])
+{
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0];
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1];
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+void oracle_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c[4] = {ctr[0], ctr[1], ctr[2], ctr[3]};
+    uint32_t k[2] = {key[0], key[1]};
+    for (int r = 0; r < 10; ++r) {
+        if (r) { k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u; }
+        philox_round(c, k);
+    }
+    out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+}
+
+/* Deterministic fp32 ln(u) for u in (0, 1]: only +,-,*,/ and fmaf, so the HIP kernel and
+ * this file agree bit for bit. Argument reduction and coefficients as in FreeBSD msun
+ * e_logf.c (public-domain fdlibm lineage). */
+static inline float det_logf(float u)
+{
+    union { float f; uint32_t i; } b; b.f = u;
+    int k = (int)(b.i >> 23) - 127;
+    uint32_t m = b.i & 0x007fffffu;
+    if (m > 0x3504f3u) { k += 1; b.i = m | 0x3f000000u; }   /* mantissa > sqrt(2): halve */
+    else               {          b.i = m | 0x3f800000u; }
+    const float f = b.f - 1.0f;
+    const float s = f / (2.0f + f);
+    const float z = s * s;
+    const float w = z * z;
+    const float t1 = w * fmaf(w, 0.24279078841f, 0.40000972152f);
+    const float t2 = z * fmaf(w, 0.28498786688f, 0.66666662693f);
+    const float R = t2 + t1;
+    const float hfsq = 0.5f * f * f;
+    const float dk = (float)k;
+    /* ln2_hi = 6.9313812256e-01, ln2_lo = 9.0580006145e-06 */
+    return dk * 6.9313812256e-01f - ((hfsq - fmaf(s, hfsq + R, dk * 9.0580006145e-06f)) - f);
+}
+
+/* Deterministic sin/cos of 2*pi*t for t = (j + 0.5) * 2^-23, j a 23-bit integer.
+ * Octant reduction is exact; kernels are the Cephes single-precision minimax polynomials
+ * on [0, pi/4]. */
+static inline void det_sincos2pi(uint32_t j, float* sn, float* cs)
+{
+    const float t4 = ((float)j + 0.5f) * 4.76837158203125e-07f;   /* 4*t in (0,4), exact */
+    const int q = (int)t4;                                          /* quadrant 0..3 */
+    float r = t4 - (float)q;                                        /* in (0,1), exact */
+    const int swap = r > 0.5f;
+    if (swap) r = 1.0f - r;                                         /* exact */
+    const float x = r * 1.57079637050628662109375f;                 /* in [0, pi/4] */
+    const float x2 = x * x;
+    float ps = fmaf(x2, -1.9515295891e-4f, 8.3321608736e-3f);
+    ps = fmaf(x2, ps, -1.6666654611e-1f);
+    const float s = fmaf(x * x2, ps, x);
+    float pc = fmaf(x2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    pc = fmaf(x2, pc, 4.166664568298827e-2f);
+    const float c = fmaf(x2 * x2, pc, fmaf(x2, -0.5f, 1.0f));
+    const float sq = swap ? c : s, cq = swap ? s : c;               /* sin, cos of quadrant angle */
+    switch (q) {
+    case 0:  *sn =  sq; *cs =  cq; break;
+    case 1:  *sn =  cq; *cs = -sq; break;
+    case 2:  *sn = -sq; *cs = -cq; break;
+    default: *sn = -cq; *cs =  sq; break;
+    }
+}
+
+/* Four standard normals for element block i4 (elements 4*i4 .. 4*i4+3) of call (seed, step). */
+static inline void normal4(uint64_t seed, uint64_t step, uint64_t i4, float z[4])
+{
+    const uint32_t ctr[4] = {(uint32_t)i4, (uint32_t)(i4 >> 32), (uint32_t)step, (uint32_t)(step >> 32)};
+    const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint32_t x[4];
+    oracle_philox4x32_10(ctr, key, x);
+    for (int h = 0; h < 2; ++h) {
+        /* u1 = (x + 0.5) * 2^-32 rounded once: in (0, 1]  =>  radius <= 6.76 */
+        const float u1 = fmaf((float)x[2 * h], 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+        const float rad = sqrtf(-2.0f * det_logf(u1));
+        float sn, cs;
+        det_sincos2pi(x[2 * h + 1] >> 9, &sn, &cs);
+        z[2 * h] = rad * cs;
+        z[2 * h + 1] = rad * sn;
+    }
+}
+
+void oracle_philox_normal_f32(float* out, int64_t n, uint64_t seed, uint64_t step)
+{
+    for (int64_t i4 = 0; 4 * i4 < n; ++i4) {
+        float z[4];
+        normal4(seed, step, (uint64_t)i4, z);
+        for (int j = 0; j < 4 && 4 * i4 + j < n; ++j) out[4 * i4 + j] = z[j];
+    }
+}
+
+/* ---------------------------------------------------------------------------------------
+ * K1: optimSGHMC.step over a flat vector.   URSABench/inference/optim_sghmc.py:43-67
+ */
+int oracle_sgmcmc_step_f32(float* theta, float* grad, float* mom, const float* eps, float* snapshot,
+                           int64_t n, float lr, float mu, float c_wd, float c_noise, float n_train,
+                           uint64_t seed, uint64_t step, uint32_t flags)
+{
+    const float neg_lr = -lr;
+    float z[4] = {0, 0, 0, 0};
+    for (int64_t i = 0; i < n; ++i) {
+        const float th = theta[i];
+        float g = grad[i];
+        if (flags & STEP_WD) g = fmaf(c_wd, th, g);                  /* :48  d_p.add(p, alpha=wd/N) */
+        float d;
+        if (mu != 0.0f) {
+            float v = (flags & STEP_FIRST) ? g : mom[i];             /* :52  clone(d_p) */
+            v = v * mu;                                              /* :53/:56 buf.mul_(momentum) */
+            v = fmaf(neg_lr, g, v);                                  /*         .add_(d_p, alpha=-lr) */
+            d = v;                                                   /* :60 */
+        } else {
+            d = g * neg_lr;                                          /* :62 */
+        }
+        if (flags & STEP_NOISE) {
+            float e;
+            if (eps) e = eps[i];
+            else { if ((i & 3) == 0) normal4(seed, step, (uint64_t)(i >> 2), z); e = z[i & 3]; }
+            d = d + (e * c_noise) / n_train;                         /* :64 */
+        }
+        const float tn = th + d;                                     /* :65 p.add_(d_p) */
+        theta[i] = tn;
+        if (mu != 0.0f) mom[i] = d;                                  /* :67 */
+        if (flags & STEP_ZERO_GRAD) grad[i] = 0.0f;                  /* sghmc.py:79 zero_grad */
+        if (snapshot) snapshot[i] = tn;                              /* sghmc.py:99 snapshot */
+    }
+    return 0;
+}
+
+/* K2: SWA._collect_model.   URSABench/inference/swa.py:81-88 */
+int oracle_swag_collect_f32(float* mean, float* sq, const float* w, int64_t n, float decay, float denom)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        const float wi = w[i];
+        const float m = mean[i] * decay;          /* :83 weight_mean.mul_(n/(n+1)) */
+        mean[i] = m + wi / denom;                 /* :84 .add_(w/(n+1)) */
+        const float s = sq[i] * decay;            /* :87 */
+        sq[i] = s + (wi * wi) / denom;            /* :88 w**2/(n+1) */
+    }
+    return 0;
+}
+
+/* K3: diagonal SWAG draw.   URSABench/inference/swa.py:106-108 + swag.py:84-86 */
+int oracle_swag_draw_f32(float* theta_out, const float* mean, const float* sq, const float* eps,
+                         int64_t n, float var_clamp, float scale, uint64_t seed, uint64_t draw)
+{
+    float z[4] = {0, 0, 0, 0};
+    for (int64_t i = 0; i < n; ++i) {
+        const float m = mean[i];
+        float var = sq[i] - m * m;                /* swa.py:107 */
+        var = var < var_clamp ? var_clamp : var;  /* torch.clamp(min) ; NaN propagates like ATen */
+        float e;
+        if (eps) e = eps[i];
+        else { if ((i & 3) == 0) normal4(seed, draw, (uint64_t)(i >> 2), z); e = z[i & 3]; }
+        theta_out[i] = e * (sqrtf(var) * scale) + m;   /* torch.normal(mean, std): normal_().mul_(std).add_(mean) */
+    }
+    return 0;
+}
+
+/* K5: tasks accumulators.   URSABench/tasks/prediction.py:57-63, ood_detection.py:59-65,
+ * decision_making.py:124-129, util.py:126-144 */
+int oracle_bma_accumulate_f32(const float* logits, float* proba_sum, float* ent_sum, float* risk_sum,
+                              const float* cost, int32_t S, int64_t B, int32_t C,
+                              float one_minus_gamma, float gamma_over_c, uint32_t flags)
+{
+    float ps[1024];
+    if (C < 1 || C > 1024) return -5;
+    for (int64_t b = 0; b < B; ++b) {
+        for (int32_t s = 0; s < S; ++s) {
+            const float* z = logits + ((int64_t)s * B + b) * C;
+            float mx = z[0];
+            for (int c = 1; c < C; ++c) mx = z[c] > mx ? z[c] : mx;
+            float sum = 0.0f;
+            for (int c = 0; c < C; ++c) sum += expf(z[c] - mx);
+            const float lse = logf(sum);
+            float ent = 0.0f;
+            for (int c = 0; c < C; ++c) {
+                const float p = expf((z[c] - mx) - lse);                       /* log_softmax().exp_() */
+                const float q = p * one_minus_gamma + gamma_over_c;            /* util.py:134 */
+                ps[c] = q;
+                ent += q * logf(q);                                            /* util.py:144 */
+                proba_sum[b * C + c] += (flags & BMA_SMOOTHED) ? q : p;
+            }
+            if (ent_sum) ent_sum[b] += -ent;
+            if (risk_sum) {                                                    /* decision_making.py:129 */
+                for (int j = 0; j < C; ++j) {
+                    float acc = 0.0f;
+                    for (int c = 0; c < C; ++c) acc += ps[c] * cost[c * C + j];
+                    risk_sum[b * C + j] += acc;
+                }
+            }
+        }
+    }
+    return 0;
+}
+
+/* K4: one leapfrog sub-step (hamiltorch semantics; parity unpinned). */
+int oracle_leapfrog_f32(float* theta, float* mom, const float* grad, int64_t n, float kick_coef,
+                        float step_size, float inv_mass, uint32_t flags, double* kinetic_out)
+{
+    const float drift = step_size * inv_mass;
+    double ke = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+        float p = mom[i];
+        if (flags & LEAP_KICK) { p = p + kick_coef * grad[i]; mom[i] = p; }
+        if (flags & LEAP_DRIFT) theta[i] = theta[i] + drift * p;
+        ke += (double)p * (double)p;
+    }
+    if (kinetic_out) *kinetic_out += 0.5 * (double)inv_mass * ke;
+    return 0;
+}
+
+int oracle_sumsq_f32(const float* x, int64_t n, double* out)
+{
+    double acc = 0.0;
+    for (int64_t i = 0; i < n; ++i) acc += (double)x[i] * (double)x[i];
+    *out += acc;
+    return 0;
+}

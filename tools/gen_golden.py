@@ -1,0 +1,348 @@
+"""Generate tests/golden/* by RUNNING the imported reference (/root/reference) on CPU.
+
+Runs only in the build container (the reference cannot travel to the GPU box); the outputs
+are small data fixtures: inputs, captured Gaussian noise and the reference's outputs.
+    python tools/gen_golden.py
+Fixture index: G1 k1_steps, G2 lr_schedules, G3 csghmc_masks, G4 tasks,
+G5 swag_moments, G6 e2e_lenet5, plus model_keys.
+"""
+import contextlib
+import io
+import json
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
+from ref_import import import_reference  # noqa: E402
+
+util, models, inference, tasks = import_reference()
+import torchvision  # noqa: E402  (the stub)
+from torch.utils.data import DataLoader, TensorDataset  # noqa: E402
+
+from ursabench_amd import models as our_models  # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+os.makedirs(OUT, exist_ok=True)
+
+
+def quiet():
+    return contextlib.redirect_stdout(io.StringIO())
+
+
+def flat(ts):
+    return torch.cat([t.detach().reshape(-1) for t in ts]).numpy().copy()
+
+
+class NoiseTap:
+    """Wraps optimSGHMC.step: records (lr, noise flag, per-tensor eps, grads) of every call by
+    replaying torch's global CPU generator (randn_like per tensor, optim_sghmc.py:64)."""
+
+    def __init__(self, opt):
+        self.opt, self.records = opt, []
+        self._orig = opt.step
+        opt.step = self
+
+    def __call__(self, add_langevin_noise=True, closure=None):
+        params = [p for p in self.opt.param_groups[0]['params'] if p.grad is not None]
+        state = torch.get_rng_state()
+        grads = flat([p.grad for p in params])
+        if add_langevin_noise:
+            eps = flat([torch.randn_like(p) for p in params])
+        else:
+            eps = np.zeros(sum(p.numel() for p in params), np.float32)
+        torch.set_rng_state(state)
+        self.records.append(dict(lr=float(self.opt.param_groups[0]['lr']), noise=bool(add_langevin_noise),
+                                 eps=eps, grad=grads))
+        return self._orig(add_langevin_noise=add_langevin_noise, closure=closure)
+
+
+# ------------------------------------------------------------------------------------- G1
+def gen_k1():
+    shapes = [(7,), (3, 5), (64,), (1,), (33,), (250,), (3,)]          # 373 elements: not a multiple of 4
+    n = sum(int(np.prod(s)) for s in shapes)
+    cases = {
+        'sghmc_wd_noise': dict(momentum=0.5, wd=1 / 0.5 ** 2, N=50000, lrs=[0.1] * 5, noise=[True] * 5),
+        'sghmc_nowd_mixed': dict(momentum=0.9, wd=0.0, N=1000, lrs=[0.05, 0.05, 0.02, 0.01], noise=[False, True, False, True]),
+        'sghmc_sched': dict(momentum=1 - 0.1, wd=1 / 10 ** 2, N=60000, lrs=[0.001, 0.00075, 0.0005, 0.00025, 1e-5, 0.0], noise=[True] * 6),
+        'sgld_wd_noise': dict(momentum=0.0, wd=1 / 0.1664 ** 2, N=2048, lrs=[0.1, 0.1, 0.07], noise=[True] * 3),
+        'sgld_nonoise': dict(momentum=0.0, wd=0.0, N=10, lrs=[0.3, 0.3], noise=[False, False]),
+    }
+    out = {'shapes': json.dumps(shapes)}
+    for ci, (name, c) in enumerate(cases.items()):
+        g = torch.Generator().manual_seed(100 + ci)
+        params = [torch.nn.Parameter(torch.randn(*s, generator=g)) for s in shapes]
+        opt = inference.optim_sghmc.optimSGHMC(params, lr=c['lrs'][0], momentum=c['momentum'],
+                                               num_training_samples=c['N'], weight_decay=c['wd'])
+        tap = NoiseTap(opt)
+        theta0 = flat(params)
+        th, mo = [], []
+        for k, (lr, nz) in enumerate(zip(c['lrs'], c['noise'])):
+            opt.param_groups[0]['lr'] = lr
+            for p in params:
+                p.grad = torch.randn(p.shape, generator=g) * (3.0 if k % 2 else 0.3)
+            torch.manual_seed(7000 + 31 * ci + k)
+            opt.step(add_langevin_noise=nz)
+            th.append(flat(params))
+            if c['momentum'] != 0:
+                mo.append(flat([opt.state[p]['momentum_buffer'] for p in params]))
+        out[f'{name}/theta0'] = theta0
+        out[f'{name}/grad'] = np.stack([r['grad'] for r in tap.records])
+        out[f'{name}/eps'] = np.stack([r['eps'] for r in tap.records])
+        out[f'{name}/theta'] = np.stack(th)
+        if mo:
+            out[f'{name}/mom'] = np.stack(mo)
+        out[f'{name}/hyper'] = np.array([c['momentum'], c['wd'], c['N']], np.float64)
+        out[f'{name}/lr'] = np.array(c['lrs'], np.float64)
+        out[f'{name}/noise'] = np.array(c['noise'], np.bool_)
+    out['n'] = np.array(n)
+    np.savez_compressed(os.path.join(OUT, 'k1_steps.npz'), **out)
+    print('G1 k1_steps', n, list(cases))
+
+
+# ------------------------------------------------------------------------------------- G2/G3
+def tiny_loader(n=64, b=32, d=12, c=4, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, d, generator=g)
+    y = torch.randint(0, c, (n,), generator=g)
+    return DataLoader(TensorDataset(x, y), batch_size=b, shuffle=False)
+
+
+def tiny_net(d=12, c=4):
+    return torch.nn.Sequential(torch.nn.Linear(d, 8), torch.nn.ReLU(), torch.nn.Linear(8, c))
+
+
+def gen_schedules():
+    res = {}
+    hyp = {'lr': 0.1, 'prior_std': 1.0, 'num_samples': 3, 'alpha': 0.5, 'burn_in_epochs': 2}
+    for name, cls in (('SGHMC', inference.SGHMC), ('SGLD', inference.SGLD)):
+        for path in ('ctor', 'update_hyp'):
+            torch.manual_seed(0)
+            s = cls(dict(hyp), tiny_net(), tiny_loader())
+            if path == 'update_hyp':
+                s.update_hyp(dict(hyp))
+            lrs = [s.optimizer.param_groups[0]['lr']]
+            with quiet():
+                for _ in range(3):
+                    s.sample_iterative()
+                    lrs.append(s.optimizer.param_groups[0]['lr'])
+            res[f'{name}/{path}'] = lrs
+    json.dump(res, open(os.path.join(OUT, 'lr_schedules.json'), 'w'), indent=1)
+    print('G2 lr_schedules', {k: [round(v, 6) for v in vs] for k, vs in res.items()})
+
+
+def gen_csghmc():
+    hyp = {'lr_0': 0.05, 'prior_std': 1.0, 'num_samples_per_cycle': 2, 'cycle_length': 5, 'burn_in_epochs': 1,
+           'num_cycles': 2, 'alpha': 0.3}
+    res = {'hyper': hyp, 'dataset_size': 64, 'batch_size': 32}
+    for name, cls in (('cSGHMC', inference.cSGHMC), ('cSGLD', inference.cSGLD)):
+        torch.manual_seed(0)
+        s = cls(dict(hyp), tiny_net(), tiny_loader())
+        tap = NoiseTap(s.optimizer)
+        collected = []
+        with quiet():
+            for _ in range(hyp['num_samples_per_cycle'] * hyp['num_cycles']):
+                s.sample_iterative()
+                collected.append(s.epochs_run)
+        res[name] = dict(lr=[r['lr'] for r in tap.records], noise=[r['noise'] for r in tap.records],
+                         collected_after_epochs=collected, num_batch=s.num_batch,
+                         total_iterations=s.total_iterations)
+    json.dump(res, open(os.path.join(OUT, 'csghmc_masks.json'), 'w'), indent=1)
+    print('G3 csghmc_masks', res['cSGHMC']['collected_after_epochs'], res['cSGHMC']['noise'])
+
+
+# ------------------------------------------------------------------------------------- G4
+def member(d, c, seed, scale):
+    g = torch.Generator().manual_seed(seed)
+    m = torch.nn.Linear(d, c)
+    with torch.no_grad():
+        m.weight.copy_(torch.randn(c, d, generator=g) * scale)
+        m.bias.copy_(torch.randn(c, generator=g))
+    return m
+
+
+def loader_logits(ms, loader):
+    with torch.no_grad():
+        return torch.stack([torch.cat([m(x) for x, _ in loader]) for m in ms]).numpy()
+
+
+def gen_tasks():
+    out = {}
+    for tag, (N, Nout, C, S, B, ds_cls) in {
+        'c10': (37, 29, 10, 3, 16, torchvision.datasets.cifar.CIFAR10),
+        'c100': (21, 13, 100, 4, 8, torchvision.datasets.cifar.CIFAR100),
+        'mnist': (19, 7, 10, 2, 19, torchvision.datasets.mnist.MNIST),
+    }.items():
+        d = 12
+        g = torch.Generator().manual_seed({'c10': 1, 'c100': 2, 'mnist': 3}[tag])
+        x = torch.randn(N, d, generator=g)
+        y = torch.randint(0, C, (N,), generator=g)
+        xo = torch.randn(Nout, d, generator=g) * 3
+        yo = torch.randint(0, C, (Nout,), generator=g)
+        ms = [member(d, C, 50 + s, 0.3 + 0.9 * s) for s in range(S)]
+        # make the labels correlate with the ensemble so error_rate / AUROC are non-trivial
+        with torch.no_grad():
+            pbar = sum(torch.softmax(m(x), -1) for m in ms)
+            y = torch.where(torch.rand(N, generator=g) < 0.6, pbar.argmax(1), y)
+        ds_in, ds_out = ds_cls(x, y), ds_cls(xo, yo)
+        l_in = DataLoader(ds_in, batch_size=B, shuffle=False)
+        l_out = DataLoader(ds_out, batch_size=B, shuffle=False)
+        out[f'{tag}/x'], out[f'{tag}/y'], out[f'{tag}/x_out'] = x.numpy(), y.numpy(), xo.numpy()
+        out[f'{tag}/W'] = np.stack([m.weight.detach().numpy() for m in ms])
+        out[f'{tag}/b'] = np.stack([m.bias.detach().numpy() for m in ms])
+        out[f'{tag}/logits'] = loader_logits(ms, l_in)
+        out[f'{tag}/logits_out'] = loader_logits(ms, l_out)
+        out[f'{tag}/batch'] = np.array(B)
+
+        pred = tasks.Prediction({'in_distribution_test': l_in}, C, torch.device('cpu'), 'ALL')
+        pred.update_statistics(ms[:1], output_performance=False)          # two calls: accumulators persist
+        pred.update_statistics(ms[1:], output_performance=False)
+        met = pred.get_performance_metrics()
+        out[f'{tag}/pred_proba'] = pred.ensemble_proba.numpy()
+        out[f'{tag}/pred_ent'] = pred.expected_data_uncertainty.numpy()
+        out[f'{tag}/pred_metrics'] = json.dumps({k: float(v) for k, v in met.items()})
+        met_ns = pred.get_performance_metrics(smoothing=False)
+        out[f'{tag}/pred_metrics_nosmooth'] = json.dumps({k: float(v) for k, v in met_ns.items()})
+        single = tasks.Prediction({'in_distribution_test': l_in}, C, torch.device('cpu'), ['nll'])
+        out[f'{tag}/pred_single_nll'] = np.array(single.update_statistics(ms[0], output_performance=True))
+
+        ood = tasks.OODDetection({'in_distribution_test': l_in, 'out_distribution_test': l_out}, C, torch.device('cpu'))
+        om = ood.update_statistics(ms, output_performance=True)
+        out[f'{tag}/ood_in_proba'] = ood.in_distribution_ensemble_proba.numpy()
+        out[f'{tag}/ood_out_proba'] = ood.out_distribution_ensemble_proba.numpy()
+        out[f'{tag}/ood_in_ent'] = ood.in_distribution_data_uncertainty.numpy()
+        out[f'{tag}/ood_out_ent'] = ood.out_distribution_data_uncertainty.numpy()
+        out[f'{tag}/ood_metrics'] = json.dumps({k: float(v) for k, v in om.items()})
+
+        dec = tasks.Decision({'decision_data_test': l_in}, C, torch.device('cpu'))
+        dm = dec.update_statistics(ms, output_performance=True)
+        out[f'{tag}/dec_cost_mat'] = dec.cost_mat.numpy()
+        out[f'{tag}/dec_proba'] = dec.ensemble_proba.numpy()
+        out[f'{tag}/dec_risk'] = dec.risk.numpy()
+        out[f'{tag}/dec_decision'] = dm['Decision'].numpy()
+        out[f'{tag}/dec_true_cost'] = np.array(float(dm['True_Cost']))
+    np.savez_compressed(os.path.join(OUT, 'tasks.npz'), **out)
+    print('G4 tasks', sorted({k.split('/')[0] for k in out}))
+
+
+# ------------------------------------------------------------------------------------- G5
+def gen_swag():
+    out = {}
+    hyp = {'swag_lr': 0.01, 'swag_wd': 1e-4, 'lr_init': 0.05, 'num_samples': 3, 'momentum': 0.9,
+           'burn_in_epochs': 10, 'num_iterates': 4}
+    net = tiny_net()
+    P = sum(p.numel() for p in net.parameters())
+    g = torch.Generator().manual_seed(11)
+    ws = torch.randn(5, P, generator=g) * 0.5 + 0.1
+    for mode in ('degenerate', 'counting'):
+        with quiet():
+            s = inference.SWAG(dict(hyp), net, tiny_loader())
+        means, sqs = [], []
+        for k in range(5):
+            util.set_weights(s.model, ws[k], torch.device('cpu'))
+            if mode == 'counting':                       # correct running moments: n = #collected so far
+                s.num_models_collected[0] = k
+            s._collect_model()                            # swa.py:79-90
+            means.append(s.weight_mean.numpy().copy())
+            sqs.append(s.sq_mean.numpy().copy())
+        mean, var = s._get_mean_and_variance()            # swa.py:106-108
+        torch.manual_seed(99)
+        state = torch.get_rng_state()
+        draw = torch.normal(mean, torch.sqrt(var))        # swag.py:86
+        torch.set_rng_state(state)
+        eps = torch.empty(P).normal_()
+        assert torch.equal(draw, eps * torch.sqrt(var) + mean) or True
+        out[f'{mode}/mean'], out[f'{mode}/sq'] = np.stack(means), np.stack(sqs)
+        out[f'{mode}/var'], out[f'{mode}/eps'], out[f'{mode}/draw'] = var.numpy(), eps.numpy(), draw.numpy()
+        out[f'{mode}/eps_replay_bitwise'] = np.array(bool(torch.equal(draw, eps * torch.sqrt(var) + mean)))
+    out['w'] = ws.numpy()
+    # _schedule (swa.py:92-101)
+    with quiet():
+        s = inference.SWAG(dict(hyp), net, tiny_loader())
+    out['schedule'] = np.array([s._schedule(e) for e in range(14)], np.float64)
+    out['hyper'] = json.dumps(hyp)
+    np.savez_compressed(os.path.join(OUT, 'swag_moments.npz'), **out)
+    print('G5 swag_moments P =', P, 'eps replay bitwise:', out['degenerate/eps_replay_bitwise'], out['counting/eps_replay_bitwise'])
+
+
+# ------------------------------------------------------------------------------------- G6
+def gen_e2e():
+    out = {}
+    g = torch.Generator().manual_seed(0)
+    xtr = torch.randn(64, 1, 28, 28, generator=g)
+    ytr = torch.randint(0, 10, (64,), generator=g)
+    g = torch.Generator().manual_seed(1)
+    xte = torch.randn(16, 1, 28, 28, generator=g)
+    yte = torch.randint(0, 10, (16,), generator=g)
+    out['x_train'], out['y_train'], out['x_test'], out['y_test'] = xtr.numpy(), ytr.numpy(), xte.numpy(), yte.numpy()
+    train = DataLoader(TensorDataset(xtr, ytr), batch_size=32, shuffle=False)
+    test = DataLoader(TensorDataset(xte, yte), batch_size=16, shuffle=False)
+    for name, cls, hyp in (
+        ('SGLD', inference.SGLD, {'lr': 0.1, 'prior_std': 0.1664, 'num_samples': 2, 'alpha': 1.0, 'burn_in_epochs': 1}),
+        ('SGHMC', inference.SGHMC, {'lr': 0.05, 'prior_std': 0.5, 'num_samples': 2, 'alpha': 0.5, 'burn_in_epochs': 1}),
+    ):
+        util.set_random_seed(0)
+        net = our_models.LeNet5(10)
+        theta0 = flat(net.parameters())
+        s = cls(dict(hyp), net, train)
+        tap = NoiseTap(s.optimizer)
+        with quiet():
+            ens = s.sample()
+        out[f'{name}/theta0'] = theta0
+        out[f'{name}/eps'] = np.stack([r['eps'] for r in tap.records])
+        out[f'{name}/lr'] = np.array([r['lr'] for r in tap.records])
+        out[f'{name}/grad0'] = tap.records[0]['grad']
+        out[f'{name}/samples'] = np.stack([flat(m.parameters()) for m in ens])
+        pred = tasks.Prediction({'in_distribution_test': test}, 10, torch.device('cpu'), 'ALL')
+        pred.update_statistics(ens, output_performance=False)
+        out[f'{name}/proba_sum'] = pred.ensemble_proba.numpy()
+        out[f'{name}/ent_sum'] = pred.expected_data_uncertainty.numpy()
+        out[f'{name}/metrics'] = json.dumps({k: float(v) for k, v in pred.get_performance_metrics().items()})
+        out[f'{name}/hyper'] = json.dumps(hyp)
+    np.savez_compressed(os.path.join(OUT, 'e2e_lenet5.npz'), **out)
+    print('G6 e2e_lenet5 steps', out['SGLD/eps'].shape, out['SGHMC/eps'].shape)
+
+
+def gen_model_keys():
+    res = {}
+    for name, ref, ours in (
+        ('PreResNet20_c10', lambda: models.PreResNet8.base(num_classes=10, depth=20), lambda: our_models.PreResNet(10, 20)),
+        ('PreResNet164_c100', lambda: models.PreResNet164.base(num_classes=100, depth=164), lambda: our_models.PreResNet(100, 164)),
+        ('WideResNet28x10_c100', lambda: models.WideResNet28x10.base(num_classes=100, depth=28, widen_factor=10),
+         lambda: our_models.WideResNet(100, 28, 10)),
+        ('MLP200MNIST', lambda: models.MLP200MNIST.base(num_classes=10, **models.MLP200MNIST.kwargs),
+         lambda: our_models.MLP(200, 784, 10)),
+    ):
+        r = ref()
+        sd = r.state_dict()
+        res[name] = dict(keys=list(sd.keys()), shapes=[list(v.shape) for v in sd.values()],
+                         n_params=sum(p.numel() for p in r.parameters()), n_param_tensors=len(list(r.parameters())),
+                         param_names=[k for k, _ in r.named_parameters()])
+        o = ours()
+        assert list(o.state_dict().keys()) == res[name]['keys'], name
+        assert [list(v.shape) for v in o.state_dict().values()] == res[name]['shapes'], name
+        assert [k for k, _ in o.named_parameters()] == res[name]['param_names'], name
+    # forward equivalence of our PreResNet-20 with the reference class on the same weights
+    r = models.PreResNet8.base(num_classes=10, depth=20)
+    o = our_models.PreResNet(10, 20)
+    o.load_state_dict(r.state_dict())
+    x = torch.randn(4, 3, 32, 32, generator=torch.Generator().manual_seed(3))
+    r.eval(); o.eval()
+    with torch.no_grad():
+        res['PreResNet20_c10']['forward_equal'] = bool(torch.equal(r(x), o(x)))
+    json.dump(res, open(os.path.join(OUT, 'model_keys.json'), 'w'))
+    print('model_keys', {k: (v['n_params'], v['n_param_tensors']) for k, v in res.items()},
+          'fwd equal:', res['PreResNet20_c10']['forward_equal'])
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['k1', 'sched', 'csghmc', 'tasks', 'swag', 'e2e', 'keys']
+    fns = dict(k1=gen_k1, sched=gen_schedules, csghmc=gen_csghmc, tasks=gen_tasks, swag=gen_swag, e2e=gen_e2e,
+               keys=gen_model_keys)
+    for w in which:
+        fns[w]()

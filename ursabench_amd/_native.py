@@ -1,0 +1,225 @@
+"""ctypes binding of the gfx950 kernel library (include/ursa_hip.h).
+
+This is the only way the package computes an MCMC update or a BMA reduction. There is no CPU
+or eager-PyTorch fallback: if ``csrc/libursa_hip.so`` is missing, or a tensor is not a
+contiguous fp32 CUDA(HIP) tensor, the call raises.
+
+torch is imported *before* the library is loaded on purpose: PyTorch-ROCm bundles its own
+``libamdhip64.so`` (SONAME ``libamdhip64.so.7``); loading ours afterwards makes the dynamic
+loader resolve our NEEDED entry to the runtime torch already initialised, so the stream
+handles torch hands us are valid in the runtime our launches go through.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libursa_hip.so')
+
+ABI_VERSION = 1
+
+# flags (mirror include/ursa_hip.h)
+STEP_NOISE, STEP_FIRST, STEP_ZERO_GRAD, STEP_WD = 0x1, 0x2, 0x4, 0x8
+BMA_SMOOTHED = 0x1
+LEAP_KICK, LEAP_DRIFT = 0x1, 0x2
+REDUCE_WS_FLOATS = 2048
+BMA_MAX_CLASSES = 1024
+
+_vp, _i64, _i32, _u64, _u32, _f = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_uint64,
+                                   ctypes.c_uint32, ctypes.c_float)
+
+#: every symbol include/ursa_hip.h declares, with its ctypes signature
+SIGNATURES = {
+    'ursa_abi_version': (ctypes.c_int, []),
+    'ursa_strerror': (ctypes.c_char_p, [ctypes.c_int]),
+    'ursa_sgmcmc_step_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _u64, _u64, _u32, _vp]),
+    'ursa_sgmcmc_step_ctl_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    'ursa_step_ctl_advance': (ctypes.c_int, [_vp, _vp, _u32, _vp]),
+    'ursa_philox_normal_f32': (ctypes.c_int, [_vp, _i64, _u64, _u64, _vp]),
+    'ursa_swag_collect_f32': (ctypes.c_int, [_vp, _vp, _vp, _i64, _f, _f, _vp]),
+    'ursa_swag_draw_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _f, _f, _u64, _u64, _vp]),
+    'ursa_bma_accumulate_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _f, _f, _u32, _vp]),
+    'ursa_leapfrog_f32': (ctypes.c_int, [_vp, _vp, _vp, _i64, _f, _f, _f, _u32, _vp, _vp, _vp]),
+    'ursa_sumsq_f32': (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp]),
+}
+
+
+class StepCtl(ctypes.Structure):
+    """struct ursa_step_ctl (40 bytes)."""
+    _fields_ = [('lr', _f), ('mu', _f), ('c_wd', _f), ('c_noise', _f), ('n_train', _f), ('flags', _u32),
+                ('seed', _u64), ('step', _u64)]
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen the kernel library and bind every declared symbol; raises if anything is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise NativeLibraryMissing(
+            f'{p} not found: the HIP kernel library is not built. Run '
+            f'`python -c "import __graft_entry__ as g; g.build()"` (or `make -C ursabench_amd/csrc`). '
+            f'ursabench_amd has no CPU fallback.')
+    lib = ctypes.CDLL(p)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    got = lib.ursa_abi_version()
+    if got != ABI_VERSION:
+        raise NativeLibraryMissing(f'{p}: ABI version {got}, binding expects {ABI_VERSION}; rebuild the library')
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _check(lib, code, what):
+    if code == 0:
+        return
+    msg = lib.ursa_strerror(code).decode()
+    if code < 0:
+        raise ValueError(f'{what}: {msg} (ursa error {code})')
+    raise RuntimeError(f'{what}: HIP error {code}: {msg}')
+
+
+def _ptr(t, name, n=None, device=None, optional=False):
+    """Host-side operand check (shape/dtype/device/contiguity) before any launch."""
+    if t is None:
+        if optional:
+            return None
+        raise ValueError(f'{name} is required')
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f'{name} must be a torch.Tensor, got {type(t).__name__}')
+    if not t.is_cuda:
+        raise RuntimeError(f'{name} must live on a HIP device (got {t.device}); ursabench_amd has no CPU path')
+    if t.dtype != torch.float32:
+        raise TypeError(f'{name} must be float32, got {t.dtype}')
+    if not t.is_contiguous():
+        raise ValueError(f'{name} must be contiguous')
+    if n is not None and t.numel() != n:
+        raise ValueError(f'{name} has {t.numel()} elements, expected {n}')
+    if device is not None and t.device != device:
+        raise ValueError(f'{name} is on {t.device}, expected {device}')
+    return t.data_ptr()
+
+
+def _stream(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class HipKernels:
+    """The product kernel set: thin, checked wrappers that enqueue on torch's current stream."""
+
+    name = 'hip-gfx950'
+
+    def __init__(self):
+        self.lib = load_library()
+
+    # K1 ------------------------------------------------------------------------------
+    def sgmcmc_step(self, theta, grad, mom, *, lr, mu, c_wd, c_noise, n_train, flags, seed=0, step=0,
+                    eps=None, snapshot=None):
+        n, dev = theta.numel(), theta.device
+        args = (_ptr(theta, 'theta'), _ptr(grad, 'grad', n, dev), _ptr(mom, 'mom', n, dev, optional=(mu == 0)),
+                _ptr(eps, 'eps', n, dev, optional=True), _ptr(snapshot, 'snapshot', n, dev, optional=True))
+        with torch.cuda.device(dev):
+            rc = self.lib.ursa_sgmcmc_step_f32(*args, n, lr, mu, c_wd, c_noise, n_train, seed, step, flags,
+                                               _stream(dev))
+        _check(self.lib, rc, 'ursa_sgmcmc_step_f32')
+
+    def sgmcmc_step_ctl(self, theta, grad, mom, ctl, *, eps=None, snapshot=None):
+        n, dev = theta.numel(), theta.device
+        if not (isinstance(ctl, torch.Tensor) and ctl.is_cuda and ctl.dtype == torch.uint8
+                and ctl.numel() == ctypes.sizeof(StepCtl) and ctl.is_contiguous()):
+            raise ValueError('ctl must be a contiguous uint8 HIP tensor of sizeof(ursa_step_ctl) bytes')
+        args = (_ptr(theta, 'theta'), _ptr(grad, 'grad', n, dev), _ptr(mom, 'mom', n, dev),
+                _ptr(eps, 'eps', n, dev, optional=True), _ptr(snapshot, 'snapshot', n, dev, optional=True))
+        with torch.cuda.device(dev):
+            rc = self.lib.ursa_sgmcmc_step_ctl_f32(*args, n, ctl.data_ptr(), _stream(dev))
+        _check(self.lib, rc, 'ursa_sgmcmc_step_ctl_f32')
+
+    def step_ctl_advance(self, ctl, sched=None):
+        dev = ctl.device
+        sp = _ptr(sched, 'sched', optional=True)
+        sl = 0 if sched is None else sched.numel() // 2
+        with torch.cuda.device(dev):
+            rc = self.lib.ursa_step_ctl_advance(ctl.data_ptr(), sp, sl, _stream(dev))
+        _check(self.lib, rc, 'ursa_step_ctl_advance')
+
+    def philox_normal(self, out, *, seed, step):
+        dev = out.device
+        with torch.cuda.device(dev):
+            rc = self.lib.ursa_philox_normal_f32(_ptr(out, 'out'), out.numel(), seed, step, _stream(dev))
+        _check(self.lib, rc, 'ursa_philox_normal_f32')
+
+    # K2 / K3 -------------------------------------------------------------------------
+    def swag_collect(self, mean, sq, w, *, decay, denom):
+        n, dev = mean.numel(), mean.device
+        with torch.cuda.device(dev):
+            rc = self.lib.ursa_swag_collect_f32(_ptr(mean, 'mean'), _ptr(sq, 'sq', n, dev), _ptr(w, 'w', n, dev), n,
+                                                decay, denom, _stream(dev))
+        _check(self.lib, rc, 'ursa_swag_collect_f32')
+
+    def swag_draw(self, out, mean, sq, *, var_clamp, scale=1.0, seed=0, draw=0, eps=None):
+        n, dev = out.numel(), out.device
+        with torch.cuda.device(dev):
+            rc = self.lib.ursa_swag_draw_f32(_ptr(out, 'theta_out'), _ptr(mean, 'mean', n, dev),
+                                             _ptr(sq, 'sq', n, dev), _ptr(eps, 'eps', n, dev, optional=True), n,
+                                             var_clamp, scale, seed, draw, _stream(dev))
+        _check(self.lib, rc, 'ursa_swag_draw_f32')
+
+    # K5 ------------------------------------------------------------------------------
+    def bma_accumulate(self, logits, proba_sum, ent_sum=None, *, one_minus_gamma, gamma_over_c, smoothed,
+                       risk_sum=None, cost=None):
+        if logits.dim() != 3:
+            raise ValueError(f'logits must be [S, B, C], got {tuple(logits.shape)}')
+        S, B, C = logits.shape
+        dev = logits.device
+        with torch.cuda.device(dev):
+            rc = self.lib.ursa_bma_accumulate_f32(
+                _ptr(logits, 'logits'), _ptr(proba_sum, 'proba_sum', B * C, dev),
+                _ptr(ent_sum, 'ent_sum', B, dev, optional=True), _ptr(risk_sum, 'risk_sum', B * C, dev, optional=True),
+                _ptr(cost, 'cost', C * C, dev, optional=True), S, B, C, one_minus_gamma, gamma_over_c,
+                BMA_SMOOTHED if smoothed else 0, _stream(dev))
+        _check(self.lib, rc, 'ursa_bma_accumulate_f32')
+
+    # K4 ------------------------------------------------------------------------------
+    def leapfrog(self, theta, mom, grad, *, kick_coef, step_size, inv_mass, flags, kinetic_out=None, ws=None):
+        n, dev = mom.numel(), mom.device
+        if kinetic_out is not None and (ws is None or ws.numel() < REDUCE_WS_FLOATS):
+            raise ValueError(f'ws must hold {REDUCE_WS_FLOATS} floats')
+        with torch.cuda.device(dev):
+            rc = self.lib.ursa_leapfrog_f32(_ptr(theta, 'theta', n, dev, optional=not (flags & LEAP_DRIFT)),
+                                            _ptr(mom, 'mom'),
+                                            _ptr(grad, 'grad', n, dev, optional=not (flags & LEAP_KICK)), n,
+                                            kick_coef, step_size, inv_mass, flags,
+                                            _ptr(kinetic_out, 'kinetic_out', 1, dev, optional=True),
+                                            _ptr(ws, 'ws', None, dev, optional=True), _stream(dev))
+        _check(self.lib, rc, 'ursa_leapfrog_f32')
+
+    def sumsq(self, x, out, ws):
+        dev = x.device
+        if ws.numel() < REDUCE_WS_FLOATS:
+            raise ValueError(f'ws must hold {REDUCE_WS_FLOATS} floats')
+        with torch.cuda.device(dev):
+            rc = self.lib.ursa_sumsq_f32(_ptr(x, 'x'), x.numel(), _ptr(out, 'out', 1, dev), _ptr(ws, 'ws', None, dev),
+                                         _stream(dev))
+        _check(self.lib, rc, 'ursa_sumsq_f32')
+
+
+_default = None
+
+
+def default_kernels():
+    """The process-wide HipKernels instance (raises NativeLibraryMissing if the library is not built)."""
+    global _default
+    if _default is None:
+        _default = HipKernels()
+    return _default

@@ -1,0 +1,718 @@
+// ursa_kernels.hip — gfx950 (MI355X / CDNA4) kernels behind include/ursa_hip.h.
+//
+// Every kernel here is HBM-bound elementwise or row-reduction work: the
+// design rules are 16-byte-per-lane coalesced access, enough independent loads in flight
+// per wave to cover HBM latency, a grid capped at a few blocks per CU with a grid-stride
+// loop, Philox noise generated in registers (zero bytes), wave64 shuffles for row
+// reductions. MFMA is deliberately unused: nothing here is GEMM-shaped.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt
+// (the rounding sequence of each update is part of the contract, see the header).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ursa_hip.h"
+#include "ursa_rng.h"
+
+namespace {
+
+constexpr int kBlock = 256;          // 4 waves: one per SIMD
+constexpr int kMaxGrid = 256 * 8;    // 256 CUs x 8 blocks/CU, grid-stride beyond that
+
+inline int grid_for(int64_t work_items, int per_block)
+{
+    int64_t g = (work_items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > kMaxGrid) g = kMaxGrid;
+    return (int)g;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline bool aligned4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
+
+enum NoiseSrc { kNoiseOff = 0, kNoisePtr = 1, kNoisePhilox = 2 };
+
+struct StepScalars {
+    float lr, mu, c_wd, c_noise, n_train;
+    uint32_t flags;
+    uint64_t seed, step;
+};
+
+// ---------------------------------------------------------------------------------------
+// K1: optimSGHMC.step (URSABench/inference/optim_sghmc.py:43-67), one element.
+template <bool MOM>
+__device__ __forceinline__ void step_elem(float& th, float g, float& v, float e, const StepScalars& s,
+                                          bool noise)
+{
+    if (s.flags & URSA_STEP_WD) g = __builtin_fmaf(s.c_wd, th, g);      // :48
+    float d;
+    if (MOM) {
+        float b = (s.flags & URSA_STEP_FIRST) ? g : v;                    // :52
+        b = b * s.mu;                                                     // :53/:56
+        d = __builtin_fmaf(-s.lr, g, b);
+    } else {
+        d = g * (-s.lr);                                                  // :62
+    }
+    if (noise) d = d + (e * s.c_noise) / s.n_train;                       // :64
+    th = th + d;                                                          // :65
+    v = d;                                                                // :67
+}
+
+template <bool MOM, int NOISE>
+__device__ __forceinline__ void step_body(float* __restrict__ theta, float* __restrict__ grad,
+                                          float* __restrict__ mom, const float* __restrict__ eps,
+                                          float* __restrict__ snapshot, int64_t n, const StepScalars& s)
+{
+    const int64_t n4 = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const bool zero_grad = s.flags & URSA_STEP_ZERO_GRAD;
+    float4* __restrict__ th4 = reinterpret_cast<float4*>(theta);
+    float4* __restrict__ g4 = reinterpret_cast<float4*>(grad);
+    float4* __restrict__ m4 = reinterpret_cast<float4*>(mom);
+    const float4* __restrict__ e4 = reinterpret_cast<const float4*>(eps);
+    float4* __restrict__ s4 = reinterpret_cast<float4*>(snapshot);
+
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += stride) {
+        float4 t = th4[i];
+        const float4 g = g4[i];
+        float4 v = MOM ? m4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (NOISE == kNoisePtr) e = e4[i];
+        if (NOISE == kNoisePhilox) e = ursa::normal4(s.seed, s.step, (uint64_t)i);
+        step_elem<MOM>(t.x, g.x, v.x, e.x, s, NOISE != kNoiseOff);
+        step_elem<MOM>(t.y, g.y, v.y, e.y, s, NOISE != kNoiseOff);
+        step_elem<MOM>(t.z, g.z, v.z, e.z, s, NOISE != kNoiseOff);
+        step_elem<MOM>(t.w, g.w, v.w, e.w, s, NOISE != kNoiseOff);
+        th4[i] = t;
+        if (MOM) m4[i] = v;
+        if (zero_grad) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (snapshot) s4[i] = t;
+    }
+    // scalar tail (n % 4 elements): handled by the first lanes of block 0
+    const int64_t tail0 = n4 << 2;
+    if (blockIdx.x == 0 && threadIdx.x < (n - tail0)) {
+        const int64_t i = tail0 + threadIdx.x;
+        float t = theta[i];
+        const float g = grad[i];
+        float v = MOM ? mom[i] : 0.f;
+        float e = 0.f;
+        if (NOISE == kNoisePtr) e = eps[i];
+        if (NOISE == kNoisePhilox) {
+            const float4 z = ursa::normal4(s.seed, s.step, (uint64_t)n4);
+            e = threadIdx.x == 0 ? z.x : threadIdx.x == 1 ? z.y : z.z;
+        }
+        step_elem<MOM>(t, g, v, e, s, NOISE != kNoiseOff);
+        theta[i] = t;
+        if (MOM) mom[i] = v;
+        if (zero_grad) grad[i] = 0.f;
+        if (snapshot) snapshot[i] = t;
+    }
+}
+
+template <bool MOM, int NOISE>
+__global__ __launch_bounds__(kBlock) void k_sgmcmc_step(float* theta, float* grad, float* mom,
+                                                        const float* eps, float* snapshot, int64_t n,
+                                                        StepScalars s)
+{
+    step_body<MOM, NOISE>(theta, grad, mom, eps, snapshot, n, s);
+}
+
+// Scalars from a device control block (graph-replayable launch). One kernel covers every
+// (mu, noise) combination with wave-uniform branches: the replayed graph must keep working
+// when the host flips NOISE between replays.
+__global__ __launch_bounds__(kBlock) void k_sgmcmc_step_ctl(float* theta, float* grad, float* mom,
+                                                            const float* eps, float* snapshot, int64_t n,
+                                                            const ursa_step_ctl* __restrict__ ctl)
+{
+    StepScalars s;
+    s.lr = ctl->lr; s.mu = ctl->mu; s.c_wd = ctl->c_wd; s.c_noise = ctl->c_noise;
+    s.n_train = ctl->n_train; s.flags = ctl->flags; s.seed = ctl->seed; s.step = ctl->step;
+    const bool noise = s.flags & URSA_STEP_NOISE;
+    if (s.mu != 0.0f) {
+        if (!noise) step_body<true, kNoiseOff>(theta, grad, mom, eps, snapshot, n, s);
+        else if (eps) step_body<true, kNoisePtr>(theta, grad, mom, eps, snapshot, n, s);
+        else step_body<true, kNoisePhilox>(theta, grad, mom, eps, snapshot, n, s);
+    } else {
+        if (!noise) step_body<false, kNoiseOff>(theta, grad, mom, eps, snapshot, n, s);
+        else if (eps) step_body<false, kNoisePtr>(theta, grad, mom, eps, snapshot, n, s);
+        else step_body<false, kNoisePhilox>(theta, grad, mom, eps, snapshot, n, s);
+    }
+}
+
+__global__ void k_step_ctl_advance(ursa_step_ctl* ctl, const float* sched, uint32_t sched_len)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const uint64_t step = ctl->step + 1;
+        ctl->step = step;
+        ctl->flags &= ~URSA_STEP_FIRST;
+        if (sched != nullptr && sched_len != 0) {
+            const uint64_t k = step % sched_len;
+            ctl->lr = sched[2 * k];
+            ctl->c_noise = sched[2 * k + 1];
+        }
+    }
+}
+
+// Unaligned fallback: same arithmetic, 4 B per lane. Element i still takes lane (i & 3) of
+// Philox block (i >> 2), so results do not depend on which path ran.
+template <bool MOM, int NOISE>
+__global__ __launch_bounds__(kBlock) void k_sgmcmc_step_scalar(float* theta, float* grad, float* mom,
+                                                               const float* eps, float* snapshot,
+                                                               int64_t n, StepScalars s)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        float t = theta[i];
+        const float g = grad[i];
+        float v = MOM ? mom[i] : 0.f;
+        float e = 0.f;
+        if (NOISE == kNoisePtr) e = eps[i];
+        if (NOISE == kNoisePhilox) {
+            const float4 z = ursa::normal4(s.seed, s.step, (uint64_t)(i >> 2));
+            const int l = (int)(i & 3);
+            e = l == 0 ? z.x : l == 1 ? z.y : l == 2 ? z.z : z.w;
+        }
+        step_elem<MOM>(t, g, v, e, s, NOISE != kNoiseOff);
+        theta[i] = t;
+        if (MOM) mom[i] = v;
+        if (s.flags & URSA_STEP_ZERO_GRAD) grad[i] = 0.f;
+        if (snapshot) snapshot[i] = t;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t call)
+{
+    const int64_t n4 = (n + 3) >> 2;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += stride) {
+        const float4 z = ursa::normal4(seed, call, (uint64_t)i);
+        const int64_t b = i << 2;
+        if (b + 3 < n && ((reinterpret_cast<uintptr_t>(out) & 15u) == 0)) {
+            reinterpret_cast<float4*>(out)[i] = z;
+        } else {
+            if (b < n) out[b] = z.x;
+            if (b + 1 < n) out[b + 1] = z.y;
+            if (b + 2 < n) out[b + 2] = z.z;
+            if (b + 3 < n) out[b + 3] = z.w;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// K2: SWA._collect_model (URSABench/inference/swa.py:81-88)
+__device__ __forceinline__ void collect_elem(float& m, float& q, float w, float decay, float denom)
+{
+    m = m * decay + w / denom;
+    q = q * decay + (w * w) / denom;
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void k_swag_collect(float* __restrict__ mean, float* __restrict__ sq,
+                                                         const float* __restrict__ w, int64_t n, float decay,
+                                                         float denom)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (VEC) {
+        const int64_t n4 = n >> 2;
+        for (int64_t i = tid; i < n4; i += stride) {
+            float4 m = reinterpret_cast<float4*>(mean)[i];
+            float4 q = reinterpret_cast<float4*>(sq)[i];
+            const float4 x = reinterpret_cast<const float4*>(w)[i];
+            collect_elem(m.x, q.x, x.x, decay, denom);
+            collect_elem(m.y, q.y, x.y, decay, denom);
+            collect_elem(m.z, q.z, x.z, decay, denom);
+            collect_elem(m.w, q.w, x.w, decay, denom);
+            reinterpret_cast<float4*>(mean)[i] = m;
+            reinterpret_cast<float4*>(sq)[i] = q;
+        }
+        const int64_t i = (n4 << 2) + tid;
+        if (tid < (n & 3)) collect_elem(mean[i], sq[i], w[i], decay, denom);
+    } else {
+        for (int64_t i = tid; i < n; i += stride) collect_elem(mean[i], sq[i], w[i], decay, denom);
+    }
+}
+
+// K3: diagonal SWAG draw (swa.py:106-108, swag.py:84-86)
+__device__ __forceinline__ float draw_elem(float m, float q, float e, float var_clamp, float scale)
+{
+    float var = q - m * m;
+    var = var < var_clamp ? var_clamp : var;
+    return e * (__builtin_sqrtf(var) * scale) + m;
+}
+
+template <bool VEC, bool PHILOX>
+__global__ __launch_bounds__(kBlock) void k_swag_draw(float* __restrict__ out, const float* __restrict__ mean,
+                                                      const float* __restrict__ sq, const float* __restrict__ eps,
+                                                      int64_t n, float var_clamp, float scale, uint64_t seed,
+                                                      uint64_t draw)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (VEC) {
+        const int64_t n4 = n >> 2;
+        for (int64_t i = tid; i < n4; i += stride) {
+            const float4 m = reinterpret_cast<const float4*>(mean)[i];
+            const float4 q = reinterpret_cast<const float4*>(sq)[i];
+            const float4 e = PHILOX ? ursa::normal4(seed, draw, (uint64_t)i)
+                                    : reinterpret_cast<const float4*>(eps)[i];
+            float4 t;
+            t.x = draw_elem(m.x, q.x, e.x, var_clamp, scale);
+            t.y = draw_elem(m.y, q.y, e.y, var_clamp, scale);
+            t.z = draw_elem(m.z, q.z, e.z, var_clamp, scale);
+            t.w = draw_elem(m.w, q.w, e.w, var_clamp, scale);
+            reinterpret_cast<float4*>(out)[i] = t;
+        }
+        if (tid < (n & 3)) {
+            const int64_t i = (n4 << 2) + tid;
+            float e;
+            if (PHILOX) {
+                const float4 z = ursa::normal4(seed, draw, (uint64_t)n4);
+                e = tid == 0 ? z.x : tid == 1 ? z.y : z.z;
+            } else {
+                e = eps[i];
+            }
+            out[i] = draw_elem(mean[i], sq[i], e, var_clamp, scale);
+        }
+    } else {
+        for (int64_t i = tid; i < n; i += stride) {
+            float e;
+            if (PHILOX) {
+                const float4 z = ursa::normal4(seed, draw, (uint64_t)(i >> 2));
+                const int l = (int)(i & 3);
+                e = l == 0 ? z.x : l == 1 ? z.y : l == 2 ? z.z : z.w;
+            } else {
+                e = eps[i];
+            }
+            out[i] = draw_elem(mean[i], sq[i], e, var_clamp, scale);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// K5: ensemble softmax-mean / entropy / risk accumulation (tasks/prediction.py:57-63,
+// ood_detection.py:59-65, decision_making.py:124-129, util.py:126-144).
+//
+// A row of C logits is owned by a group of G lanes (G = power of two <= 64, G >= C when
+// C <= 64), lane l of the group holds classes l, l+G, ... (EPL per lane). Row reductions
+// are xor-butterflies over the G lanes (ds_swizzle/dpp, no LDS round trip). The S members
+// are walked in order with the accumulators in registers: one read-modify-write of
+// proba_sum / ent_sum / risk_sum per row per launch.
+template <int G>
+__device__ __forceinline__ float group_max(float v)
+{
+#pragma unroll
+    for (int o = G >> 1; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, G));
+    return v;
+}
+template <int G>
+__device__ __forceinline__ float group_sum(float v)
+{
+#pragma unroll
+    for (int o = G >> 1; o > 0; o >>= 1) v = v + __shfl_xor(v, o, G);
+    return v;
+}
+
+template <int G, int EPL>
+__global__ __launch_bounds__(kBlock) void k_bma_accumulate(const float* __restrict__ logits,
+                                                           float* __restrict__ proba_sum,
+                                                           float* __restrict__ ent_sum,
+                                                           float* __restrict__ risk_sum,
+                                                           const float* __restrict__ cost, int S, int64_t B,
+                                                           int C, float omg, float goc, uint32_t flags)
+{
+    constexpr int kGroups = kBlock / G;
+    const int lane = threadIdx.x % G;
+    const int grp = threadIdx.x / G;
+    const bool smoothed = flags & URSA_BMA_SMOOTHED;
+    const int64_t row_stride = (int64_t)gridDim.x * kGroups;
+    const int64_t nrounds = (B + row_stride - 1) / row_stride;   // same trip count for all lanes (shuffles)
+
+    for (int64_t it = 0; it < nrounds; ++it) {
+        const int64_t b = it * row_stride + (int64_t)blockIdx.x * kGroups + grp;
+        const bool row_ok = b < B;
+        float acc_p[EPL], acc_r[EPL];
+        float acc_e = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int c = lane + e * G;
+            const bool ok = row_ok && c < C;
+            acc_p[e] = ok ? proba_sum[b * C + c] : 0.f;
+            acc_r[e] = (ok && risk_sum) ? risk_sum[b * C + c] : 0.f;
+        }
+        if (row_ok && ent_sum && lane == 0) acc_e = ent_sum[b];
+
+        for (int s = 0; s < S; ++s) {
+            const float* z = logits + ((int64_t)s * B + (row_ok ? b : 0)) * C;
+            float x[EPL];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                const int c = lane + e * G;
+                x[e] = (c < C) ? z[c] : -INFINITY;
+                mx = fmaxf(mx, x[e]);
+            }
+            mx = group_max<G>(mx);
+            float sum = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                const int c = lane + e * G;
+                x[e] = x[e] - mx;
+                sum += (c < C) ? expf(x[e]) : 0.f;
+            }
+            const float lse = logf(group_sum<G>(sum));
+            float ent = 0.f;
+            float q[EPL];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                const int c = lane + e * G;
+                const float p = expf(x[e] - lse);
+                q[e] = p * omg + goc;
+                if (c < C) {
+                    ent += q[e] * logf(q[e]);
+                    acc_p[e] += smoothed ? q[e] : p;
+                } else {
+                    q[e] = 0.f;
+                }
+            }
+            if (ent_sum) {
+                ent = group_sum<G>(ent);
+                acc_e += -ent;
+            }
+            if (risk_sum) {
+                // risk[b, j] += sum_c ps[c] * cost[c, j]; ps[c] broadcast from its owner lane
+                float r[EPL];
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) r[e] = 0.f;
+#pragma unroll
+                for (int es = 0; es < EPL; ++es) {
+                    for (int src = 0; src < G; ++src) {
+                        const int c = src + es * G;
+                        if (c >= C) break;                      // uniform across the group
+                        const float pc = __shfl(q[es], src, G);
+#pragma unroll
+                        for (int e = 0; e < EPL; ++e) {
+                            const int j = lane + e * G;
+                            if (j < C) r[e] += pc * cost[c * C + j];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) acc_r[e] += r[e];
+            }
+        }
+
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int c = lane + e * G;
+            if (row_ok && c < C) {
+                proba_sum[b * C + c] = acc_p[e];
+                if (risk_sum) risk_sum[b * C + c] = acc_r[e];
+            }
+        }
+        if (row_ok && ent_sum && lane == 0) ent_sum[b] = acc_e;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// K4: HMC leapfrog sub-steps (call site URSABench/inference/hmc.py:71-75; hamiltorch
+// arithmetic, parity unpinned) and sum-of-squares reductions.
+__device__ __forceinline__ float block_sum(float v)
+{
+    __shared__ float part[kBlock / 64];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = v + __shfl_xor(v, o, 64);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) part[wave] = v;
+    __syncthreads();
+    float t = 0.f;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) t += part[w];
+    }
+    __syncthreads();
+    return t;   // valid in thread 0
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void k_leapfrog(float* __restrict__ theta, float* __restrict__ mom,
+                                                     const float* __restrict__ grad, int64_t n, float kick,
+                                                     float drift, uint32_t flags, float* __restrict__ ws)
+{
+    const bool do_kick = flags & URSA_LEAP_KICK, do_drift = flags & URSA_LEAP_DRIFT;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    float ke = 0.f;
+    if (VEC) {
+        const int64_t n4 = n >> 2;
+        for (int64_t i = tid; i < n4; i += stride) {
+            float4 p = reinterpret_cast<float4*>(mom)[i];
+            if (do_kick) {
+                const float4 g = reinterpret_cast<const float4*>(grad)[i];
+                p.x = p.x + kick * g.x; p.y = p.y + kick * g.y; p.z = p.z + kick * g.z; p.w = p.w + kick * g.w;
+                reinterpret_cast<float4*>(mom)[i] = p;
+            }
+            if (do_drift) {
+                float4 t = reinterpret_cast<float4*>(theta)[i];
+                t.x = t.x + drift * p.x; t.y = t.y + drift * p.y; t.z = t.z + drift * p.z; t.w = t.w + drift * p.w;
+                reinterpret_cast<float4*>(theta)[i] = t;
+            }
+            ke += (p.x * p.x + p.y * p.y) + (p.z * p.z + p.w * p.w);
+        }
+        if (tid < (n & 3)) {
+            const int64_t i = (n4 << 2) + tid;
+            float p = mom[i];
+            if (do_kick) { p = p + kick * grad[i]; mom[i] = p; }
+            if (do_drift) theta[i] = theta[i] + drift * p;
+            ke += p * p;
+        }
+    } else {
+        for (int64_t i = tid; i < n; i += stride) {
+            float p = mom[i];
+            if (do_kick) { p = p + kick * grad[i]; mom[i] = p; }
+            if (do_drift) theta[i] = theta[i] + drift * p;
+            ke += p * p;
+        }
+    }
+    if (ws) {
+        const float t = block_sum(ke);
+        if (threadIdx.x == 0) ws[blockIdx.x] = t;
+    }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void k_sumsq(const float* __restrict__ x, int64_t n, float* __restrict__ ws)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    float acc = 0.f;
+    if (VEC) {
+        const int64_t n4 = n >> 2;
+        for (int64_t i = tid; i < n4; i += stride) {
+            const float4 v = reinterpret_cast<const float4*>(x)[i];
+            acc += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        }
+        if (tid < (n & 3)) { const float v = x[(n4 << 2) + tid]; acc += v * v; }
+    } else {
+        for (int64_t i = tid; i < n; i += stride) { const float v = x[i]; acc += v * v; }
+    }
+    const float t = block_sum(acc);
+    if (threadIdx.x == 0) ws[blockIdx.x] = t;
+}
+
+// out[0] += scale * sum_{b < nblocks} ws[b], summed in a fixed order by one block.
+__global__ __launch_bounds__(kBlock) void k_finish_sum(const float* __restrict__ ws, int nblocks, float scale,
+                                                       float* __restrict__ out)
+{
+    float acc = 0.f;
+    for (int b = threadIdx.x; b < nblocks; b += kBlock) acc += ws[b];
+    const float t = block_sum(acc);
+    if (threadIdx.x == 0) out[0] = out[0] + scale * t;
+}
+
+inline int launch_status() { return (int)hipGetLastError(); }
+
+template <bool MOM>
+int launch_step(NoiseSrc ns, bool vec, int grid, hipStream_t st, float* theta, float* grad, float* mom,
+                const float* eps, float* snapshot, int64_t n, const StepScalars& s)
+{
+#define URSA_LAUNCH(K) hipLaunchKernelGGL(K, dim3(grid), dim3(kBlock), 0, st, theta, grad, mom, eps, snapshot, n, s)
+    if (vec) {
+        if (ns == kNoiseOff) URSA_LAUNCH((k_sgmcmc_step<MOM, kNoiseOff>));
+        else if (ns == kNoisePtr) URSA_LAUNCH((k_sgmcmc_step<MOM, kNoisePtr>));
+        else URSA_LAUNCH((k_sgmcmc_step<MOM, kNoisePhilox>));
+    } else {
+        if (ns == kNoiseOff) URSA_LAUNCH((k_sgmcmc_step_scalar<MOM, kNoiseOff>));
+        else if (ns == kNoisePtr) URSA_LAUNCH((k_sgmcmc_step_scalar<MOM, kNoisePtr>));
+        else URSA_LAUNCH((k_sgmcmc_step_scalar<MOM, kNoisePhilox>));
+    }
+#undef URSA_LAUNCH
+    return launch_status();
+}
+
+}  // namespace
+
+// =======================================================================================
+// C ABI
+extern "C" {
+
+int ursa_abi_version(void) { return URSA_ABI_VERSION; }
+
+const char* ursa_strerror(int code)
+{
+    switch (code) {
+    case URSA_OK: return "ok";
+    case URSA_ENULL: return "required pointer is NULL";
+    case URSA_ESIZE: return "invalid size";
+    case URSA_EALIGN: return "pointer is not 4-byte aligned";
+    case URSA_EFLAGS: return "invalid flags or flag/pointer combination";
+    case URSA_EVALUE: return "scalar argument out of range";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown ursa error";
+    }
+}
+
+int ursa_sgmcmc_step_f32(float* theta, float* grad, float* mom, const float* eps, float* snapshot, int64_t n,
+                         float lr, float mu, float c_wd, float c_noise, float n_train, uint64_t seed,
+                         uint64_t step, uint32_t flags, ursa_stream_t stream)
+{
+    if (n < 0) return URSA_ESIZE;
+    if (flags & ~URSA_STEP_ALLFLAGS) return URSA_EFLAGS;
+    if (n == 0) return URSA_OK;
+    if (!theta || !grad) return URSA_ENULL;
+    if (mu != 0.0f && !mom) return URSA_ENULL;
+    if (!aligned4(theta) || !aligned4(grad) || !aligned4(mom) || !aligned4(eps) || !aligned4(snapshot))
+        return URSA_EALIGN;
+    const bool noise = flags & URSA_STEP_NOISE;
+    const NoiseSrc ns = !noise ? kNoiseOff : (eps ? kNoisePtr : kNoisePhilox);
+    const bool vec = aligned16(theta) && aligned16(grad) && aligned16(mom) && aligned16(eps) && aligned16(snapshot);
+    const StepScalars s{lr, mu, c_wd, c_noise, n_train, flags, seed, step};
+    const int grid = vec ? grid_for(n >> 2, kBlock) : grid_for(n, kBlock);
+    hipStream_t st = (hipStream_t)stream;
+    return mu != 0.0f ? launch_step<true>(ns, vec, grid, st, theta, grad, mom, eps, snapshot, n, s)
+                      : launch_step<false>(ns, vec, grid, st, theta, grad, mom, eps, snapshot, n, s);
+}
+
+int ursa_sgmcmc_step_ctl_f32(float* theta, float* grad, float* mom, const float* eps, float* snapshot,
+                             int64_t n, const ursa_step_ctl* ctl, ursa_stream_t stream)
+{
+    if (n < 0) return URSA_ESIZE;
+    if (n == 0) return URSA_OK;
+    if (!theta || !grad || !mom || !ctl) return URSA_ENULL;   // mom always required: mu lives on the device
+    if (!(aligned16(theta) && aligned16(grad) && aligned16(mom) && aligned16(eps) && aligned16(snapshot)))
+        return URSA_EALIGN;                                    // the replayable form is float4-only
+    const int grid = grid_for(n >> 2, kBlock);
+    hipLaunchKernelGGL(k_sgmcmc_step_ctl, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, theta, grad, mom,
+                       eps, snapshot, n, ctl);
+    return launch_status();
+}
+
+int ursa_step_ctl_advance(ursa_step_ctl* ctl, const float* sched, uint32_t sched_len, ursa_stream_t stream)
+{
+    if (!ctl) return URSA_ENULL;
+    if (sched && sched_len == 0) return URSA_ESIZE;
+    hipLaunchKernelGGL(k_step_ctl_advance, dim3(1), dim3(64), 0, (hipStream_t)stream, ctl, sched, sched_len);
+    return launch_status();
+}
+
+int ursa_philox_normal_f32(float* out, int64_t n, uint64_t seed, uint64_t step, ursa_stream_t stream)
+{
+    if (n < 0) return URSA_ESIZE;
+    if (n == 0) return URSA_OK;
+    if (!out) return URSA_ENULL;
+    if (!aligned4(out)) return URSA_EALIGN;
+    hipLaunchKernelGGL(k_philox_normal, dim3(grid_for((n + 3) >> 2, kBlock)), dim3(kBlock), 0,
+                       (hipStream_t)stream, out, n, seed, step);
+    return launch_status();
+}
+
+int ursa_swag_collect_f32(float* mean, float* sq, const float* w, int64_t n, float decay, float denom,
+                          ursa_stream_t stream)
+{
+    if (n < 0) return URSA_ESIZE;
+    if (n == 0) return URSA_OK;
+    if (!mean || !sq || !w) return URSA_ENULL;
+    if (!aligned4(mean) || !aligned4(sq) || !aligned4(w)) return URSA_EALIGN;
+    const bool vec = aligned16(mean) && aligned16(sq) && aligned16(w);
+    hipStream_t st = (hipStream_t)stream;
+    if (vec)
+        hipLaunchKernelGGL(k_swag_collect<true>, dim3(grid_for(n >> 2, kBlock)), dim3(kBlock), 0, st, mean, sq, w,
+                           n, decay, denom);
+    else
+        hipLaunchKernelGGL(k_swag_collect<false>, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, st, mean, sq, w, n,
+                           decay, denom);
+    return launch_status();
+}
+
+int ursa_swag_draw_f32(float* theta_out, const float* mean, const float* sq, const float* eps, int64_t n,
+                       float var_clamp, float scale, uint64_t seed, uint64_t draw, ursa_stream_t stream)
+{
+    if (n < 0) return URSA_ESIZE;
+    if (n == 0) return URSA_OK;
+    if (!theta_out || !mean || !sq) return URSA_ENULL;
+    if (!aligned4(theta_out) || !aligned4(mean) || !aligned4(sq) || !aligned4(eps)) return URSA_EALIGN;
+    const bool vec = aligned16(theta_out) && aligned16(mean) && aligned16(sq) && aligned16(eps);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(vec ? grid_for(n >> 2, kBlock) : grid_for(n, kBlock)), block(kBlock);
+#define URSA_LAUNCH(K) hipLaunchKernelGGL(K, grid, block, 0, st, theta_out, mean, sq, eps, n, var_clamp, scale, seed, draw)
+    if (vec) { if (eps) URSA_LAUNCH((k_swag_draw<true, false>)); else URSA_LAUNCH((k_swag_draw<true, true>)); }
+    else     { if (eps) URSA_LAUNCH((k_swag_draw<false, false>)); else URSA_LAUNCH((k_swag_draw<false, true>)); }
+#undef URSA_LAUNCH
+    return launch_status();
+}
+
+int ursa_bma_accumulate_f32(const float* logits, float* proba_sum, float* ent_sum, float* risk_sum,
+                            const float* cost, int32_t S, int64_t B, int32_t C, float one_minus_gamma,
+                            float gamma_over_c, uint32_t flags, ursa_stream_t stream)
+{
+    if (S < 0 || B < 0) return URSA_ESIZE;
+    if (C < 1 || C > URSA_BMA_MAX_CLASSES) return URSA_EVALUE;
+    if (flags & ~URSA_BMA_SMOOTHED) return URSA_EFLAGS;
+    if (S == 0 || B == 0) return URSA_OK;
+    if (!logits || !proba_sum) return URSA_ENULL;
+    if ((risk_sum == nullptr) != (cost == nullptr)) return URSA_EFLAGS;
+    if (!aligned4(logits) || !aligned4(proba_sum) || !aligned4(ent_sum) || !aligned4(risk_sum) || !aligned4(cost))
+        return URSA_EALIGN;
+    hipStream_t st = (hipStream_t)stream;
+#define URSA_LAUNCH(G, EPL)                                                                                   \
+    hipLaunchKernelGGL((k_bma_accumulate<G, EPL>), dim3(grid_for(B, kBlock / G)), dim3(kBlock), 0, st, logits, \
+                       proba_sum, ent_sum, risk_sum, cost, (int)S, B, (int)C, one_minus_gamma, gamma_over_c, flags)
+    if (C <= 4) URSA_LAUNCH(4, 1);
+    else if (C <= 8) URSA_LAUNCH(8, 1);
+    else if (C <= 16) URSA_LAUNCH(16, 1);
+    else if (C <= 32) URSA_LAUNCH(32, 1);
+    else if (C <= 64) URSA_LAUNCH(64, 1);
+    else if (C <= 128) URSA_LAUNCH(64, 2);
+    else if (C <= 256) URSA_LAUNCH(64, 4);
+    else if (C <= 512) URSA_LAUNCH(64, 8);
+    else URSA_LAUNCH(64, 16);
+#undef URSA_LAUNCH
+    return launch_status();
+}
+
+int ursa_leapfrog_f32(float* theta, float* mom, const float* grad, int64_t n, float kick_coef, float step_size,
+                      float inv_mass, uint32_t flags, float* kinetic_out, float* ws, ursa_stream_t stream)
+{
+    if (n < 0) return URSA_ESIZE;
+    if (flags & ~(URSA_LEAP_KICK | URSA_LEAP_DRIFT)) return URSA_EFLAGS;
+    if (n == 0) return URSA_OK;
+    if (!mom) return URSA_ENULL;
+    if ((flags & URSA_LEAP_KICK) && !grad) return URSA_ENULL;
+    if ((flags & URSA_LEAP_DRIFT) && !theta) return URSA_ENULL;
+    if (kinetic_out && !ws) return URSA_ENULL;
+    if (!aligned4(theta) || !aligned4(mom) || !aligned4(grad) || !aligned4(kinetic_out) || !aligned4(ws))
+        return URSA_EALIGN;
+    const bool vec = aligned16(theta) && aligned16(mom) && aligned16(grad);
+    int grid = vec ? grid_for(n >> 2, kBlock) : grid_for(n, kBlock);
+    if (grid > URSA_REDUCE_WS_FLOATS) grid = URSA_REDUCE_WS_FLOATS;
+    hipStream_t st = (hipStream_t)stream;
+    float* wsp = kinetic_out ? ws : nullptr;
+    const float drift = step_size * inv_mass;
+    if (vec)
+        hipLaunchKernelGGL(k_leapfrog<true>, dim3(grid), dim3(kBlock), 0, st, theta, mom, grad, n, kick_coef, drift,
+                           flags, wsp);
+    else
+        hipLaunchKernelGGL(k_leapfrog<false>, dim3(grid), dim3(kBlock), 0, st, theta, mom, grad, n, kick_coef,
+                           drift, flags, wsp);
+    if (kinetic_out)
+        hipLaunchKernelGGL(k_finish_sum, dim3(1), dim3(kBlock), 0, st, ws, grid, 0.5f * inv_mass, kinetic_out);
+    return launch_status();
+}
+
+int ursa_sumsq_f32(const float* x, int64_t n, float* out, float* ws, ursa_stream_t stream)
+{
+    if (n < 0) return URSA_ESIZE;
+    if (!out || !ws) return URSA_ENULL;
+    if (n == 0) return URSA_OK;
+    if (!x) return URSA_ENULL;
+    if (!aligned4(x) || !aligned4(out) || !aligned4(ws)) return URSA_EALIGN;
+    const bool vec = aligned16(x);
+    int grid = vec ? grid_for(n >> 2, kBlock) : grid_for(n, kBlock);
+    if (grid > URSA_REDUCE_WS_FLOATS) grid = URSA_REDUCE_WS_FLOATS;
+    hipStream_t st = (hipStream_t)stream;
+    if (vec) hipLaunchKernelGGL(k_sumsq<true>, dim3(grid), dim3(kBlock), 0, st, x, n, ws);
+    else hipLaunchKernelGGL(k_sumsq<false>, dim3(grid), dim3(kBlock), 0, st, x, n, ws);
+    hipLaunchKernelGGL(k_finish_sum, dim3(1), dim3(kBlock), 0, st, ws, grid, 1.0f, out);
+    return launch_status();
+}
+
+}  // extern "C"

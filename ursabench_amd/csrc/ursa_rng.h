@@ -1,0 +1,104 @@
+// ursa_rng.h — in-register Gaussian noise for the gfx950 kernels.
+//
+// Philox4x32-10 (Salmon et al., SC'11) counter-based generator + Box-Muller. One Philox
+// call yields the four normals of one float4 of the parameter arena, so noise costs no HBM
+// traffic and no LDS: counter = (float4 index, call index), key = seed.
+//
+// The reference draws torch.randn_like per tensor from torch's global generator
+// (URSABench/inference/optim_sghmc.py:64); that stream cannot be reproduced by any flat
+// kernel, so parity with the reference uses the kernels' `eps` input instead, and this
+// stream is pinned (a) by Random123's known-answer vectors and (b) bit for bit against the
+// scalar C restatement in oracle/ursa_oracle.c. To make (b) possible ln / sin / cos are
+// evaluated with +,-,*,/ , sqrt and fma only (all correctly rounded on both sides); the
+// translation unit must be compiled with -ffp-contract=off.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ursa {
+
+struct u32x4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                               uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0;
+        const uint32_t n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return {c0, c1, c2, c3};
+}
+
+// ln(u), u in (0, 1]; fdlibm-style reduction, degree-4 even/odd split in s = f/(2+f).
+__device__ __forceinline__ float det_logf(float u)
+{
+    uint32_t bits = __float_as_uint(u);
+    int k = (int)(bits >> 23) - 127;
+    const uint32_t m = bits & 0x007fffffu;
+    const bool big = m > 0x3504f3u;
+    k += big ? 1 : 0;
+    const float f = __uint_as_float(m | (big ? 0x3f000000u : 0x3f800000u)) - 1.0f;
+    const float s = f / (2.0f + f);
+    const float z = s * s;
+    const float w = z * z;
+    const float t1 = w * __builtin_fmaf(w, 0.24279078841f, 0.40000972152f);
+    const float t2 = z * __builtin_fmaf(w, 0.28498786688f, 0.66666662693f);
+    const float R = t2 + t1;
+    const float hfsq = 0.5f * f * f;
+    const float dk = (float)k;
+    return dk * 6.9313812256e-01f - ((hfsq - __builtin_fmaf(s, hfsq + R, dk * 9.0580006145e-06f)) - f);
+}
+
+// sin, cos of 2*pi*(j + 0.5)*2^-23, j < 2^23. Exact octant reduction + minimax kernels.
+__device__ __forceinline__ void det_sincos2pi(uint32_t j, float& sn, float& cs)
+{
+    const float t4 = ((float)j + 0.5f) * 4.76837158203125e-07f;
+    const int q = (int)t4;
+    float r = t4 - (float)q;
+    const bool swap = r > 0.5f;
+    r = swap ? 1.0f - r : r;
+    const float x = r * 1.57079637050628662109375f;
+    const float x2 = x * x;
+    float ps = __builtin_fmaf(x2, -1.9515295891e-4f, 8.3321608736e-3f);
+    ps = __builtin_fmaf(x2, ps, -1.6666654611e-1f);
+    const float s = __builtin_fmaf(x * x2, ps, x);
+    float pc = __builtin_fmaf(x2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    pc = __builtin_fmaf(x2, pc, 4.166664568298827e-2f);
+    const float c = __builtin_fmaf(x2 * x2, pc, __builtin_fmaf(x2, -0.5f, 1.0f));
+    const float sq = swap ? c : s, cq = swap ? s : c;
+    // quadrant rotation: q=0 (s,c)  q=1 (c,-s)  q=2 (-s,-c)  q=3 (-c,s)
+    const float a = (q & 1) ? cq : sq;
+    const float b = (q & 1) ? sq : cq;
+    sn = (q & 2) ? -a : a;
+    cs = (q == 1 || q == 2) ? -b : b;
+}
+
+// The four N(0,1) draws of arena float4 `i4` in call (seed, call).
+__device__ __forceinline__ float4 normal4(uint64_t seed, uint64_t call, uint64_t i4)
+{
+    const u32x4 x = philox4x32_10((uint32_t)i4, (uint32_t)(i4 >> 32), (uint32_t)call,
+                                  (uint32_t)(call >> 32), (uint32_t)seed, (uint32_t)(seed >> 32));
+    float4 z;
+    {
+        const float u1 = __builtin_fmaf((float)x.x, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+        const float rad = __builtin_sqrtf(-2.0f * det_logf(u1));
+        float sn, cs;
+        det_sincos2pi(x.y >> 9, sn, cs);
+        z.x = rad * cs; z.y = rad * sn;
+    }
+    {
+        const float u1 = __builtin_fmaf((float)x.z, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+        const float rad = __builtin_sqrtf(-2.0f * det_logf(u1));
+        float sn, cs;
+        det_sincos2pi(x.w >> 9, sn, cs);
+        z.z = rad * cs; z.w = rad * sn;
+    }
+    return z;
+}
+
+}  // namespace ursa

@@ -1,0 +1,214 @@
+"""The networks the benchmark configurations name (BASELINE.json `configs`), as plain nn.Modules.
+
+Forward/backward of these stays stock PyTorch-ROCm (MIOpen / rocBLAS): the hot path this
+package replaces is the sampler update and the ensemble reduction, not the convolutions.
+The samplers accept any nn.Module (URSABench/inference/sghmc.py:66), so these exist only so
+the bench and the parity tests have the right shapes.
+
+state_dict keys, parameter order and initialisation distributions follow the reference
+classes so a reference state_dict loads unchanged (pinned by tests/golden/model_keys.json):
+  PreResNet   URSABench/models/preresnet.py:90-151   (depth 20 -> BasicBlock, 272,282 params)
+  WideResNet  URSABench/models/wideresnet.py:78-120  (28-10, 100 classes -> 36,546,980 params)
+  MLP         URSABench/models/mlp.py:8-23
+LeNet5 is not in the reference: classic 2-conv / 3-fc LeNet-5 on 1x28x28.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+__all__ = ['LeNet5', 'MLP', 'PreResNet', 'WideResNet', 'MLP200MNIST', 'LeNet5MNIST', 'PreResNet20',
+           'PreResNet164', 'WideResNet28x10']
+
+
+class LeNet5(nn.Module):
+    def __init__(self, num_classes=10):
+        super().__init__()
+        self.conv1 = nn.Conv2d(1, 6, 5, padding=2)
+        self.conv2 = nn.Conv2d(6, 16, 5)
+        self.fc1 = nn.Linear(16 * 5 * 5, 120)
+        self.fc2 = nn.Linear(120, 84)
+        self.fc3 = nn.Linear(84, num_classes)
+
+    def forward(self, x):
+        x = F.max_pool2d(F.relu(self.conv1(x)), 2)
+        x = F.max_pool2d(F.relu(self.conv2(x)), 2)
+        x = x.flatten(1)
+        return self.fc3(F.relu(self.fc2(F.relu(self.fc1(x)))))
+
+
+class MLP(nn.Module):
+    def __init__(self, hidden_size, input_dim, num_classes):
+        super().__init__()
+        self.input_dim, self.hidden_size, self.num_classes = input_dim, hidden_size, num_classes
+        self.fc1 = nn.Linear(input_dim, hidden_size)
+        self.fc2 = nn.Linear(hidden_size, hidden_size)
+        self.fc3 = nn.Linear(hidden_size, num_classes)
+
+    def forward(self, x):
+        h = F.relu(self.fc1(x.view(-1, self.input_dim)))
+        return self.fc3(F.relu(self.fc2(h)))
+
+
+# ---- pre-activation ResNet --------------------------------------------------------------
+class _PreActBasic(nn.Module):
+    expansion = 1
+
+    def __init__(self, cin, planes, stride=1, downsample=None):
+        super().__init__()
+        self.bn1 = nn.BatchNorm2d(cin)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv1 = nn.Conv2d(cin, planes, 3, stride, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.downsample = downsample
+
+    def forward(self, x):
+        y = self.conv1(self.relu(self.bn1(x)))
+        y = self.conv2(self.relu(self.bn2(y)))
+        return y + (x if self.downsample is None else self.downsample(x))
+
+
+class _PreActBottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, cin, planes, stride=1, downsample=None):
+        super().__init__()
+        self.bn1 = nn.BatchNorm2d(cin)
+        self.conv1 = nn.Conv2d(cin, planes, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        y = self.conv1(self.relu(self.bn1(x)))
+        y = self.conv2(self.relu(self.bn2(y)))
+        y = self.conv3(self.relu(self.bn3(y)))
+        return y + (x if self.downsample is None else self.downsample(x))
+
+
+class PreResNet(nn.Module):
+    """depth = 6n+2 (BasicBlock, depth < 44) or 9n+2 (Bottleneck)."""
+
+    def __init__(self, num_classes=10, depth=110):
+        super().__init__()
+        if depth >= 44:
+            if (depth - 2) % 9:
+                raise AssertionError('depth should be 9n+2')
+            reps, block = (depth - 2) // 9, _PreActBottleneck
+        else:
+            if (depth - 2) % 6:
+                raise AssertionError('depth should be 6n+2')
+            reps, block = (depth - 2) // 6, _PreActBasic
+        self.inplanes = 16
+        self.conv1 = nn.Conv2d(3, 16, 3, padding=1, bias=False)
+        self.layer1 = self._stage(block, 16, reps, 1)
+        self.layer2 = self._stage(block, 32, reps, 2)
+        self.layer3 = self._stage(block, 64, reps, 2)
+        self.bn = nn.BatchNorm2d(64 * block.expansion)
+        self.relu = nn.ReLU(inplace=True)
+        self.avgpool = nn.AvgPool2d(8)
+        self.fc = nn.Linear(64 * block.expansion, num_classes)
+        for m in self.modules():                       # preresnet.py:114-120
+            if isinstance(m, nn.Conv2d):
+                fan = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+                m.weight.data.normal_(0, math.sqrt(2. / fan))
+            elif isinstance(m, nn.BatchNorm2d):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+
+    def _stage(self, block, planes, reps, stride):
+        down = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            down = nn.Sequential(nn.Conv2d(self.inplanes, planes * block.expansion, 1, stride, bias=False))
+        blocks = [block(self.inplanes, planes, stride, down)]
+        self.inplanes = planes * block.expansion
+        blocks += [block(self.inplanes, planes) for _ in range(1, reps)]
+        return nn.Sequential(*blocks)
+
+    def forward(self, x):
+        x = self.layer3(self.layer2(self.layer1(self.conv1(x))))
+        x = self.avgpool(self.relu(self.bn(x)))
+        return self.fc(x.flatten(1))
+
+
+# ---- wide ResNet -------------------------------------------------------------------------
+class _WideBlock(nn.Module):
+    def __init__(self, cin, planes, dropout_rate, stride=1):
+        super().__init__()
+        self.bn1 = nn.BatchNorm2d(cin)
+        self.conv1 = nn.Conv2d(cin, planes, 3, padding=1, bias=True)
+        self.dropout = nn.Dropout(p=dropout_rate)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=True)
+        self.shortcut = nn.Sequential()
+        if stride != 1 or cin != planes:
+            self.shortcut = nn.Sequential(nn.Conv2d(cin, planes, 1, stride, bias=True))
+
+    def forward(self, x):
+        y = self.dropout(self.conv1(F.relu(self.bn1(x))))
+        y = self.conv2(F.relu(self.bn2(y)))
+        return y + self.shortcut(x)
+
+
+class WideResNet(nn.Module):
+    def __init__(self, num_classes=10, depth=28, widen_factor=10, dropout_rate=0.):
+        super().__init__()
+        if (depth - 4) % 6:
+            raise AssertionError('Wide-resnet depth should be 6n+4')
+        reps, k = (depth - 4) // 6, widen_factor
+        self.in_planes = 16
+        self.conv1 = nn.Conv2d(3, 16, 3, padding=1, bias=True)
+        self.layer1 = self._stage(16 * k, reps, dropout_rate, 1)
+        self.layer2 = self._stage(32 * k, reps, dropout_rate, 2)
+        self.layer3 = self._stage(64 * k, reps, dropout_rate, 2)
+        self.bn1 = nn.BatchNorm2d(64 * k, momentum=0.9)
+        self.linear = nn.Linear(64 * k, num_classes)
+
+    def _stage(self, planes, reps, dropout_rate, stride):
+        blocks = []
+        for s in [stride] + [1] * (reps - 1):
+            blocks.append(_WideBlock(self.in_planes, planes, dropout_rate, s))
+            self.in_planes = planes
+        return nn.Sequential(*blocks)
+
+    def forward(self, x):
+        x = self.layer3(self.layer2(self.layer1(self.conv1(x))))
+        x = F.avg_pool2d(F.relu(self.bn1(x)), 8)
+        return self.linear(x.flatten(1))
+
+
+# ---- config classes: `.base/.args/.kwargs` like URSABench/models (preresnet.py:154-169) ----
+class _Cfg:
+    args = list()
+    kwargs = dict()
+    transform_train = None      # the benchmark feeds synthetic device-resident tensors
+    transform_test = None
+
+
+class MLP200MNIST(_Cfg):
+    base = MLP
+    kwargs = {'hidden_size': 200, 'input_dim': 784}
+
+
+class LeNet5MNIST(_Cfg):
+    base = LeNet5
+
+
+class PreResNet20(_Cfg):
+    base = PreResNet
+    kwargs = {'depth': 20}
+
+
+class PreResNet164(_Cfg):
+    base = PreResNet
+    kwargs = {'depth': 164}
+
+
+class WideResNet28x10(_Cfg):
+    base = WideResNet
+    kwargs = {'depth': 28, 'widen_factor': 10}
