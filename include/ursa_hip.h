@@ -72,12 +72,14 @@ int ursa_sgmcmc_step_f32(float* theta, float* grad, float* mom /* NULL iff mu ==
 /* Same update with the per-step scalars read from a DEVICE control block, so the launch
  * can sit inside a captured hipGraph and be replayed while lr / step / flags change.
  * ursa_step_ctl_advance (1 thread) does step += 1, clears FIRST, and if `sched` != NULL
- * loads (lr, c_noise) = sched[step % sched_len] — the per-iteration cyclical schedule of
- * csghmc.py:64-72 precomputed by the host in float64 and rounded once. */
+ * loads (lr, c_noise) = sched[(step - sched_base) % sched_len] — the per-iteration cyclical
+ * schedule of csghmc.py:64-72 precomputed by the host in float64 and rounded once; the host
+ * sets sched_base = step when it uploads an epoch's table. `step` is also the Philox call
+ * index, so it only ever grows. */
 typedef struct ursa_step_ctl {
     float lr, mu, c_wd, c_noise, n_train;
     uint32_t flags;
-    uint64_t seed, step;
+    uint64_t seed, step, sched_base;
 } ursa_step_ctl;
 
 int ursa_sgmcmc_step_ctl_f32(float* theta, float* grad, float* mom, const float* eps,

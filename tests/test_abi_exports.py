@@ -1,0 +1,55 @@
+"""CPU: the C-ABI library loads and exports every symbol include/ursa_hip.h declares
+(no compute calls without a GPU)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, 'include', 'ursa_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(ursa_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from ursabench_amd import _native
+    if not os.path.exists(_native.LIB_PATH):
+        pytest.fail(f'{_native.LIB_PATH} is not built: run __graft_entry__.build()')
+    lib = _native.load_library()
+    declared = _declared_symbols()
+    assert len(declared) >= 11
+    for sym in declared:
+        assert hasattr(lib, sym), f'{sym} declared in include/ursa_hip.h but not exported'
+    assert sorted(_native.SIGNATURES) == declared, 'binding table and header disagree'
+    assert lib.ursa_abi_version() == _native.ABI_VERSION
+    assert lib.ursa_strerror(-1).decode() == 'required pointer is NULL'
+
+
+def test_argument_errors_do_not_need_a_gpu():
+    """Argument validation happens before any launch, so it can be exercised on CPU."""
+    from ursabench_amd import _native
+    lib = _native.load_library()
+    assert lib.ursa_sgmcmc_step_f32(None, None, None, None, None, -1, 0, 0, 0, 0, 1, 0, 0, 0, None) == -2   # ESIZE
+    assert lib.ursa_sgmcmc_step_f32(None, None, None, None, None, 8, 0, 0, 0, 0, 1, 0, 0, 0, None) == -1    # ENULL
+    assert lib.ursa_sgmcmc_step_f32(None, None, None, None, None, 8, 0, 0, 0, 0, 1, 0, 0, 0x100, None) == -4  # EFLAGS
+    assert lib.ursa_sgmcmc_step_f32(None, None, None, None, None, 0, 0, 0, 0, 0, 1, 0, 0, 0, None) == 0     # n == 0: no-op
+    assert lib.ursa_bma_accumulate_f32(None, None, None, None, None, 1, 1, 0, 0, 0, 0, None) == -5           # C out of range
+    assert lib.ursa_bma_accumulate_f32(None, None, None, None, None, 1, 1, 2000, 0, 0, 0, None) == -5
+
+
+def test_wrappers_refuse_cpu_tensors():
+    import torch
+    from ursabench_amd import _native
+    k = _native.default_kernels()
+    t = torch.zeros(8)
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        k.sgmcmc_step(t, t.clone(), t.clone(), lr=0.1, mu=0.5, c_wd=0.0, c_noise=0.1, n_train=10.0, flags=0)
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from ursabench_amd import _native
+    with pytest.raises(_native.NativeLibraryMissing, match='no CPU fallback'):
+        _native.load_library(str(tmp_path / 'nope.so'))

@@ -1,0 +1,289 @@
+"""GPU parity tests proper: every kernel, called through the C ABI (ctypes -> libursa_hip.so),
+against the CPU oracle on the same seeded inputs and against the committed golden vectors
+captured from the reference. Bit-exact for the elementwise kernels (K1, K2, K3, Philox noise,
+leapfrog); 1e-5 relative (north_star's fp32 tolerance) for the softmax/entropy reductions."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def K():
+    from ursabench_amd import _native
+    assert torch.cuda.is_available(), 'gpu tests need a HIP device'
+    return _native.default_kernels()
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def test_philox_normal_bitwise_vs_oracle(K):
+    for n, seed, step in ((1, 1, 0), (3, 2, 1), (4, 3, 2), (1027, 0xdeadbeefcafe, 2 ** 40 + 5), (1 << 20, 42, 3)):
+        out = torch.empty(n, device='cuda')
+        K.philox_normal(out, seed=seed, step=step)
+        assert np.array_equal(host(out), O.philox_normal(n, seed, step)), (n, seed, step)
+    # unaligned output pointer (scalar store path)
+    buf = torch.empty(1030, device='cuda')
+    K.philox_normal(buf[1:1028], seed=9, step=9)
+    assert np.array_equal(host(buf[1:1028]), O.philox_normal(1027, 9, 9))
+
+
+K1_CASES = ['sghmc_wd_noise', 'sghmc_nowd_mixed', 'sghmc_sched', 'sgld_wd_noise', 'sgld_nonoise']
+
+
+@pytest.mark.parametrize('case', K1_CASES)
+@pytest.mark.parametrize('offset', [0, 1])          # 0: float4 path; 1: misaligned -> 4-byte path
+def test_k1_bitwise_vs_reference_golden(K, golden_dir, case, offset):
+    g = np.load(os.path.join(golden_dir, 'k1_steps.npz'))
+    momentum, wd, N = g[f'{case}/hyper']
+    n = int(g['n'])
+
+    def slot(a=None):
+        buf = torch.zeros(n + 8, device='cuda')
+        v = buf[offset:offset + n]
+        if a is not None:
+            v.copy_(dev(a))
+        return v
+
+    theta = slot(g[f'{case}/theta0'])
+    mom = slot() if momentum != 0 else None
+    for k, lr in enumerate(g[f'{case}/lr']):
+        flags = (O.STEP_NOISE if g[f'{case}/noise'][k] else 0) | (O.STEP_WD if wd != 0 else 0)
+        if k == 0 and momentum != 0:
+            flags |= O.STEP_FIRST
+        K.sgmcmc_step(theta, slot(g[f'{case}/grad'][k]), mom, eps=slot(g[f'{case}/eps'][k]), flags=flags,
+                      **O.step_scalars(float(lr), float(momentum), float(wd), N))
+        assert np.array_equal(host(theta), g[f'{case}/theta'][k]), (case, k)
+        if momentum != 0:
+            assert np.array_equal(host(mom), g[f'{case}/mom'][k]), (case, k)
+
+
+@pytest.mark.parametrize('n', [1, 2, 3, 4, 5, 63, 64, 255, 1024, 272282, 1 << 22])
+@pytest.mark.parametrize('mu', [0.0, 0.9])
+def test_k1_bitwise_vs_oracle_all_modes(K, n, mu):
+    rng = np.random.default_rng(n * 7 + int(mu * 10))
+    th0, gr0, mo0 = (rng.standard_normal(n).astype(np.float32) for _ in range(3))
+    eps = rng.standard_normal(n).astype(np.float32)
+    sc = O.step_scalars(0.05, mu, 4.0, 50000)
+    for flags, use_eps, fuse in ((0, False, False), (O.STEP_NOISE | O.STEP_WD, True, False),
+                                 (O.STEP_NOISE | O.STEP_WD, False, True), (O.STEP_NOISE | O.STEP_FIRST, False, False),
+                                 (O.STEP_WD | O.STEP_ZERO_GRAD, False, True)):
+        a = [th0.copy(), gr0.copy(), mo0.copy() if mu else None]
+        snap_o = np.empty_like(th0) if fuse else None
+        if fuse:
+            flags |= O.STEP_ZERO_GRAD
+        O.sgmcmc_step(a[0], a[1], a[2], eps=eps.copy() if use_eps else None, snapshot=snap_o, flags=flags,
+                      seed=1234567, step=77, **sc)
+        b = [dev(th0), dev(gr0), dev(mo0) if mu else None]
+        snap_d = torch.empty(n, device='cuda') if fuse else None
+        K.sgmcmc_step(b[0], b[1], b[2], eps=dev(eps) if use_eps else None, snapshot=snap_d, flags=flags,
+                      seed=1234567, step=77, **sc)
+        assert np.array_equal(host(b[0]), a[0]), (n, mu, flags)
+        assert np.array_equal(host(b[1]), a[1]), (n, mu, flags)
+        if mu:
+            assert np.array_equal(host(b[2]), a[2]), (n, mu, flags)
+        if fuse:
+            assert np.array_equal(host(snap_d), snap_o)
+
+
+def test_k1_trajectory_bitwise_philox(K):
+    """20 steps in production (Philox) mode: the GPU trajectory equals the oracle's bit for bit."""
+    n = 61706
+    rng = np.random.default_rng(5)
+    th, mo = rng.standard_normal(n).astype(np.float32), np.zeros(n, np.float32)
+    dth, dmo = dev(th), dev(mo)
+    for k in range(20):
+        gr = rng.standard_normal(n).astype(np.float32)
+        sc = O.step_scalars(0.1 * (1 - k / 40), 0.5, 4.0, 50000)
+        flags = O.STEP_NOISE | O.STEP_WD | (O.STEP_FIRST if k == 0 else 0)
+        O.sgmcmc_step(th, gr.copy(), mo, flags=flags, seed=3, step=k, **sc)
+        K.sgmcmc_step(dth, dev(gr), dmo, flags=flags, seed=3, step=k, **sc)
+    assert np.array_equal(host(dth), th) and np.array_equal(host(dmo), mo)
+
+
+def _ctl_tensor(**kw):
+    import ctypes
+    from ursabench_amd._native import StepCtl
+    c = StepCtl(**kw)
+    return torch.frombuffer(bytearray(bytes(c)), dtype=torch.uint8).cuda()
+
+
+def test_k1_ctl_variant_and_advance(K):
+    """Device-control-block launch (graph-replayable) == the scalar-argument launch; advance walks the
+    (lr, c_noise) schedule table and clears FIRST."""
+    import ctypes
+    from ursabench_amd._native import StepCtl
+    n = 4096 + 4
+    rng = np.random.default_rng(11)
+    th0, mo0 = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
+    lrs = [0.1, 0.07, 0.03]
+    sched = np.array([[lr, np.sqrt(2 * (1 - 0.5) * lr)] for lr in lrs], np.float32)
+    a = [dev(th0), dev(mo0)]
+    b = [dev(th0), dev(mo0)]
+    sc0 = O.step_scalars(lrs[0], 0.5, 4.0, 1000)
+    ctl = _ctl_tensor(lr=sc0['lr'], mu=0.5, c_wd=sc0['c_wd'], c_noise=float(sched[0, 1]), n_train=1000.0,
+                      flags=O.STEP_NOISE | O.STEP_WD | O.STEP_FIRST | O.STEP_ZERO_GRAD, seed=99, step=0)
+    dsched = dev(sched)
+    for k in range(5):
+        gr = rng.standard_normal(n).astype(np.float32)
+        ga, gb = dev(gr), dev(gr)
+        flags = O.STEP_NOISE | O.STEP_WD | O.STEP_ZERO_GRAD | (O.STEP_FIRST if k == 0 else 0)
+        lr, cn = sched[k % 3]
+        K.sgmcmc_step(a[0], ga, a[1], lr=float(lr), mu=0.5, c_wd=sc0['c_wd'], c_noise=float(cn), n_train=1000.0,
+                      flags=flags, seed=99, step=k)
+        K.sgmcmc_step_ctl(b[0], gb, b[1], ctl)
+        K.step_ctl_advance(ctl, dsched)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and not gb.any(), k
+    back = StepCtl.from_buffer_copy(bytes(ctl.cpu().numpy()))
+    assert back.step == 5 and not (back.flags & O.STEP_FIRST) and back.lr == sched[5 % 3, 0]
+
+
+@pytest.mark.parametrize('mode', ['degenerate', 'counting'])
+def test_k2_k3_bitwise_vs_reference_golden(K, golden_dir, mode):
+    g = np.load(os.path.join(golden_dir, 'swag_moments.npz'))
+    w = g['w']
+    mean, sq = torch.zeros(w.shape[1], device='cuda'), torch.zeros(w.shape[1], device='cuda')
+    for k in range(w.shape[0]):
+        n = k if mode == 'counting' else 0
+        K.swag_collect(mean, sq, dev(w[k]), decay=n / (n + 1.0), denom=n + 1.0)
+        assert np.array_equal(host(mean), g[f'{mode}/mean'][k]) and np.array_equal(host(sq), g[f'{mode}/sq'][k])
+    out = torch.empty_like(mean)
+    K.swag_draw(out, mean, sq, var_clamp=1e-30, eps=dev(g[f'{mode}/eps']))
+    assert np.array_equal(host(out), g[f'{mode}/draw'])
+
+
+@pytest.mark.parametrize('n', [1, 7, 1000, 36546980 // 16 + 3])
+def test_k2_k3_bitwise_vs_oracle(K, n):
+    rng = np.random.default_rng(n)
+    mean, w = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
+    sq = (mean ** 2 + rng.random(n).astype(np.float32) * 0.1).astype(np.float32)
+    sq[::5] = mean[::5] ** 2 - 0.01                                  # negative variance -> clamp
+    dm, ds = dev(mean), dev(sq)
+    O.swag_collect(mean, sq, w, decay=3 / 4.0, denom=4.0)
+    K.swag_collect(dm, ds, dev(w), decay=3 / 4.0, denom=4.0)
+    assert np.array_equal(host(dm), mean) and np.array_equal(host(ds), sq)
+    for eps in (None, rng.standard_normal(n).astype(np.float32)):
+        o, d = np.empty(n, np.float32), torch.empty(n, device='cuda')
+        O.swag_draw(o, mean, sq, var_clamp=1e-30, scale=0.5, seed=8, draw=2, eps=eps)
+        K.swag_draw(d, dm, ds, var_clamp=1e-30, scale=0.5, seed=8, draw=2, eps=None if eps is None else dev(eps))
+        assert np.array_equal(host(d), o)
+
+
+@pytest.mark.parametrize('tag', ['c10', 'c100', 'mnist'])
+def test_k5_vs_reference_golden(K, golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, 'tasks.npz'))
+    z, zo = g[f'{tag}/logits'], g[f'{tag}/logits_out']
+    S, N, C = z.shape
+    gam = dict(one_minus_gamma=1 - 1e-4, gamma_over_c=1e-4 * 1 / C)
+    rtol = 1e-5
+    p, e = torch.zeros(N, C, device='cuda'), torch.zeros(N, device='cuda')
+    K.bma_accumulate(dev(z[:1]), p, e, smoothed=False, **gam)
+    K.bma_accumulate(dev(z[1:]), p, e, smoothed=False, **gam)
+    np.testing.assert_allclose(host(p), g[f'{tag}/pred_proba'], rtol=rtol, atol=1e-9)
+    np.testing.assert_allclose(host(e), g[f'{tag}/pred_ent'], rtol=rtol, atol=1e-7)
+    for zz, kp, ke in ((z, 'ood_in_proba', 'ood_in_ent'), (zo, 'ood_out_proba', 'ood_out_ent')):
+        p, e = torch.zeros(zz.shape[1], C, device='cuda'), torch.zeros(zz.shape[1], device='cuda')
+        K.bma_accumulate(dev(zz), p, e, smoothed=True, **gam)
+        np.testing.assert_allclose(host(p), g[f'{tag}/{kp}'], rtol=rtol, atol=1e-9)
+        np.testing.assert_allclose(host(e), g[f'{tag}/{ke}'], rtol=rtol, atol=1e-7)
+    p, r = torch.zeros(N, C, device='cuda'), torch.zeros(N, C, device='cuda')
+    K.bma_accumulate(dev(z), p, None, smoothed=True, risk_sum=r, cost=dev(g[f'{tag}/dec_cost_mat']), **gam)
+    np.testing.assert_allclose(host(p), g[f'{tag}/dec_proba'], rtol=rtol, atol=1e-9)
+    np.testing.assert_allclose(host(r), g[f'{tag}/dec_risk'], rtol=rtol, atol=1e-7)
+    assert np.array_equal(host(r / S).argmin(1), g[f'{tag}/dec_decision'])
+
+
+@pytest.mark.parametrize('S,B,C', [(1, 1, 1), (2, 5, 2), (3, 100, 3), (4, 1000, 10), (2, 333, 17), (3, 257, 64),
+                                   (30, 512, 100), (2, 65, 129), (2, 40, 1000), (1, 3, 1024), (5, 10000, 10)])
+def test_k5_vs_oracle_shapes(K, S, B, C):
+    rng = np.random.default_rng(S * 1000 + C)
+    z = (rng.standard_normal((S, B, C)) * 4).astype(np.float32)
+    z[0, 0, :] = 50.0 * rng.standard_normal(C)                       # a very peaked row
+    cost = rng.random((C, C)).astype(np.float32)
+    gam = dict(one_minus_gamma=1 - 1e-4, gamma_over_c=1e-4 * 1 / C)
+    for smoothed, risk in ((False, False), (True, True)):
+        p0 = rng.random((B, C)).astype(np.float32)                    # accumulate on top of existing sums
+        e0 = rng.random(B).astype(np.float32)
+        r0 = rng.random((B, C)).astype(np.float32)
+        po, eo, ro = p0.copy(), e0.copy(), r0.copy()
+        O.bma_accumulate(z, po, eo, smoothed=smoothed, risk_sum=ro if risk else None, cost=cost if risk else None, **gam)
+        pd, ed, rd = dev(p0), dev(e0), dev(r0)
+        K.bma_accumulate(dev(z), pd, ed, smoothed=smoothed, risk_sum=rd if risk else None,
+                         cost=dev(cost) if risk else None, **gam)
+        np.testing.assert_allclose(host(pd), po, rtol=1e-5, atol=1e-8)
+        np.testing.assert_allclose(host(ed), eo, rtol=1e-5, atol=1e-6)
+        if risk:
+            np.testing.assert_allclose(host(rd), ro, rtol=1e-5, atol=1e-6)
+        else:
+            assert np.array_equal(host(rd), r0)
+    # property at full size: probabilities of each member sum to one => row sums grow by exactly S
+    p = torch.zeros(B, C, device='cuda')
+    K.bma_accumulate(dev(z), p, None, smoothed=False, **gam)
+    np.testing.assert_allclose(host(p.sum(1)), np.full(B, S, np.float32), rtol=2e-6)
+
+
+def test_k5_empty_and_errors(K):
+    p = torch.zeros(4, 10, device='cuda')
+    K.bma_accumulate(torch.zeros(0, 4, 10, device='cuda'), p, None, one_minus_gamma=0.9999, gamma_over_c=1e-5, smoothed=False)
+    assert not p.any()
+    with pytest.raises(ValueError):
+        K.bma_accumulate(torch.zeros(1, 4, 10, device='cuda'), p, None, one_minus_gamma=0.9999, gamma_over_c=1e-5,
+                         smoothed=True, risk_sum=torch.zeros(4, 10, device='cuda'))        # risk without cost
+    with pytest.raises(ValueError):
+        K.bma_accumulate(torch.zeros(1, 4, 2000, device='cuda'), torch.zeros(4, 2000, device='cuda'), None,
+                         one_minus_gamma=0.9999, gamma_over_c=1e-5, smoothed=True)          # C too large
+    with pytest.raises(ValueError):
+        K.bma_accumulate(torch.zeros(1, 5, 10, device='cuda'), p, None, one_minus_gamma=0.9999, gamma_over_c=1e-5,
+                         smoothed=True)                                                      # shape mismatch
+
+
+@pytest.mark.parametrize('n', [1, 5, 1023, 1726388])
+def test_k4_leapfrog_vs_oracle(K, n):
+    rng = np.random.default_rng(n)
+    th, p, g = (rng.standard_normal(n).astype(np.float32) for _ in range(3))
+    dth, dp, dg = dev(th), dev(p), dev(g)
+    ws = torch.empty(2048, device='cuda')
+    ke = torch.zeros(1, device='cuda')
+    k_o = O.leapfrog(th, p, g, kick_coef=0.5e-3, step_size=1e-3, inv_mass=2.0, flags=O.LEAP_KICK | O.LEAP_DRIFT,
+                     want_kinetic=True)
+    K.leapfrog(dth, dp, dg, kick_coef=0.5e-3, step_size=1e-3, inv_mass=2.0, flags=O.LEAP_KICK | O.LEAP_DRIFT,
+               kinetic_out=ke, ws=ws)
+    assert np.array_equal(host(dth), th) and np.array_equal(host(dp), p)
+    np.testing.assert_allclose(float(ke), k_o, rtol=2e-6)
+    out = torch.zeros(1, device='cuda')
+    K.sumsq(dth, out, ws)
+    np.testing.assert_allclose(float(out), O.sumsq(th), rtol=2e-6)
+    # deterministic reduction: same bits on a second launch
+    out2 = torch.zeros(1, device='cuda')
+    K.sumsq(dth, out2, ws)
+    assert torch.equal(out, out2)
+
+
+def test_k1_roofline_sized_properties(K):
+    """Full-size arena (2^26 elements, > Infinity Cache): size-independent properties.
+    (a) noise off, wd off, mu=0: theta' == theta - lr*g exactly (linearity);
+    (b) Philox noise statistics over the whole arena; (c) ZERO_GRAD leaves grad all-zero."""
+    n = 1 << 26
+    th = torch.randn(n, device='cuda')
+    g = torch.randn(n, device='cuda')
+    ref = th + g * (-0.125)
+    K.sgmcmc_step(th, g, None, lr=0.125, mu=0.0, c_wd=0.0, c_noise=0.0, n_train=1.0, flags=0)
+    assert torch.equal(th, ref)
+    th.zero_(); g.zero_()
+    K.sgmcmc_step(th, g, None, lr=0.5, mu=0.0, c_wd=0.0, c_noise=1.0, n_train=1.0, flags=O.STEP_NOISE | O.STEP_ZERO_GRAD,
+                  seed=7, step=1)
+    assert abs(float(th.mean())) < 1e-3 and abs(float(th.std()) - 1) < 1e-3 and not g.any()
+    assert float(th.abs().max()) < 6.8
+    assert np.array_equal(host(th[:4096]), O.philox_normal(4096, 7, 1))

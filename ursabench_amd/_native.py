@@ -46,9 +46,9 @@ SIGNATURES = {
 
 
 class StepCtl(ctypes.Structure):
-    """struct ursa_step_ctl (40 bytes)."""
+    """struct ursa_step_ctl (48 bytes)."""
     _fields_ = [('lr', _f), ('mu', _f), ('c_wd', _f), ('c_noise', _f), ('n_train', _f), ('flags', _u32),
-                ('seed', _u64), ('step', _u64)]
+                ('seed', _u64), ('step', _u64), ('sched_base', _u64)]
 
 
 class NativeLibraryMissing(RuntimeError):
@@ -136,11 +136,11 @@ class HipKernels:
 
     def sgmcmc_step_ctl(self, theta, grad, mom, ctl, *, eps=None, snapshot=None):
         n, dev = theta.numel(), theta.device
+        args = (_ptr(theta, 'theta'), _ptr(grad, 'grad', n, dev), _ptr(mom, 'mom', n, dev),
+                _ptr(eps, 'eps', n, dev, optional=True), _ptr(snapshot, 'snapshot', n, dev, optional=True))
         if not (isinstance(ctl, torch.Tensor) and ctl.is_cuda and ctl.dtype == torch.uint8
                 and ctl.numel() == ctypes.sizeof(StepCtl) and ctl.is_contiguous()):
             raise ValueError('ctl must be a contiguous uint8 HIP tensor of sizeof(ursa_step_ctl) bytes')
-        args = (_ptr(theta, 'theta'), _ptr(grad, 'grad', n, dev), _ptr(mom, 'mom', n, dev),
-                _ptr(eps, 'eps', n, dev, optional=True), _ptr(snapshot, 'snapshot', n, dev, optional=True))
         with torch.cuda.device(dev):
             rc = self.lib.ursa_sgmcmc_step_ctl_f32(*args, n, ctl.data_ptr(), _stream(dev))
         _check(self.lib, rc, 'ursa_sgmcmc_step_ctl_f32')

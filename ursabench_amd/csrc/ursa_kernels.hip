@@ -146,7 +146,7 @@ __global__ void k_step_ctl_advance(ursa_step_ctl* ctl, const float* sched, uint3
         ctl->step = step;
         ctl->flags &= ~URSA_STEP_FIRST;
         if (sched != nullptr && sched_len != 0) {
-            const uint64_t k = step % sched_len;
+            const uint64_t k = (step - ctl->sched_base) % sched_len;
             ctl->lr = sched[2 * k];
             ctl->c_noise = sched[2 * k + 1];
         }

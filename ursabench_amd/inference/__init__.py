@@ -1,0 +1,6 @@
+"""Sampler namespace: classes are looked up by attribute name, `getattr(inference, name)`
+(URSABench/experiment.py:74), exactly like URSABench/inference/__init__.py:1-11."""
+from .optim_sghmc import optimSGHMC  # noqa: F401
+from .inference_base import _Inference  # noqa: F401
+from .sghmc import SGHMC, SGLD  # noqa: F401
+from .csghmc import cSGHMC, cSGLD  # noqa: F401

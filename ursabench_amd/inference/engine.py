@@ -1,0 +1,90 @@
+"""The chain engine: one minibatch step = forward + loss + backward (stock PyTorch-ROCm:
+MIOpen / rocBLAS) + ONE fused gfx950 update launch, optionally captured once into a hipGraph
+and replayed for every full-size batch of the epoch.
+
+Replaces the hot loop of URSABench/inference/sghmc.py:72-86 (and csghmc.py:80-93). What is
+removed relative to the reference: 8 launches per parameter tensor per step (488 for
+PreResNet-20), `optimizer.zero_grad()` (fused into the update), the per-step host sync
+`loss.item()` (sghmc.py:82; the loss is accumulated on the device) and every host-side launch
+gap (graph replay). Per-step scalars (lr, noise scale, noise on/off, Philox counter) live in a
+48-byte device control block so the captured graph stays valid while they change.
+"""
+import torch
+
+
+class ChainEngine:
+    WARMUP_STEPS = 3
+
+    def __init__(self, model, optimizer, loss_criterion, device, use_graph=None):
+        self.model, self.opt, self.crit = model, optimizer, loss_criterion
+        self.device = torch.device(device)
+        if use_graph is None:
+            use_graph = self.device.type == 'cuda'
+        if use_graph and self.device.type != 'cuda':
+            raise ValueError('hipGraph capture needs a HIP device')
+        self.use_graph = use_graph
+        self.loss_acc = torch.zeros((), device=self.device)     # sum_i loss_i * batch_i, on device
+        self._graph = None
+        self._static = None
+        self._eager_full_steps = 0
+        self.stats = dict(graph_replays=0, eager_steps=0, captures=0)
+
+    def invalidate(self):
+        self._graph, self._static, self._eager_full_steps = None, None, 0
+
+    def _train_step(self, x, y, eps=None):
+        logits = self.model(x)
+        loss = self.crit(logits, y)
+        loss.backward()
+        self.loss_acc += loss.detach() * x.shape[0]
+        self.opt.ctl_step(eps=eps)
+
+    def _capture(self, x, y):
+        self._static = (torch.empty_like(x), torch.empty_like(y))
+        self._static[0].copy_(x)
+        self._static[1].copy_(y)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._train_step(*self._static)
+        self._graph = g
+        self.stats['captures'] += 1
+
+    def run_epoch(self, loader, add_langevin_noise, sched=None, eps_per_step=None):
+        """One pass over `loader`. Returns the number of examples seen; self.loss_acc holds the
+        summed loss (read it with .item() only when debugging: that is the one host sync)."""
+        self.model.train()
+        self.loss_acc.zero_()
+        self.opt.ctl_begin(add_langevin_noise, sched)
+        full = getattr(loader, 'batch_size', None)
+        seen = steps = 0
+        graph_ok = self.use_graph and eps_per_step is None
+        for bi, (x, y) in enumerate(loader):
+            x = x.to(self.device, non_blocking=True)
+            y = y.to(self.device, non_blocking=True)
+            b = x.shape[0]
+            if graph_ok and b == full:
+                if self._graph is None and self._eager_full_steps >= self.WARMUP_STEPS:
+                    self._capture(x, y)            # records the step; the replay below executes it
+                if self._graph is not None:
+                    if self._static[0].shape != x.shape:
+                        raise RuntimeError(f'batch shape changed {tuple(self._static[0].shape)} -> {tuple(x.shape)}')
+                    self._static[0].copy_(x)
+                    self._static[1].copy_(y)
+                    self._graph.replay()
+                    self.stats['graph_replays'] += 1
+                else:
+                    # warm-up steps are real steps, run on a side stream as capture will be
+                    s = torch.cuda.Stream(self.device)
+                    s.wait_stream(torch.cuda.current_stream(self.device))
+                    with torch.cuda.stream(s):
+                        self._train_step(x, y)
+                    torch.cuda.current_stream(self.device).wait_stream(s)
+                    self._eager_full_steps += 1
+                    self.stats['eager_steps'] += 1
+            else:
+                self._train_step(x, y, None if eps_per_step is None else eps_per_step(steps))
+                self.stats['eager_steps'] += 1
+            seen += b
+            steps += 1
+        self.opt.ctl_end(steps)
+        return seen

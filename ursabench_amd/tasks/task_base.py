@@ -1,0 +1,114 @@
+"""_Task base (URSABench/tasks/task_base.py:4-20) + the device-resident ensemble evaluator all
+three tasks share."""
+import torch
+import torch.distributed as dist
+
+from .. import _native
+
+GAMMA = 1e-4   # util.central_smoothing default (util.py:126)
+
+
+class _Task:
+    def __init__(self, data_loader=None, num_classes=None, device=torch.device('cpu')):
+        self.data_loader = data_loader
+        self.num_classes = num_classes
+        self.device = device
+
+    def reset(self):
+        raise NotImplementedError
+
+    def update_statistics(self, model, output_performance=False):
+        raise NotImplementedError
+
+    def ensemble_update_statistics(self, model_list, output_performance=False):
+        raise NotImplementedError
+
+    def get_performance_metrics(self):
+        raise NotImplementedError
+
+
+def as_member_list(models):
+    """prediction.py:38-48 — a module or a list of modules; anything else is NotImplementedError."""
+    if isinstance(models, list):
+        if not all(isinstance(m, torch.nn.Module) for m in models):
+            raise NotImplementedError
+        return models
+    if isinstance(models, torch.nn.Module):
+        return [models]
+    raise NotImplementedError
+
+
+class EnsembleAccumulator:
+    """sum_s softmax / entropy / risk over ensemble members for one data loader.
+
+    Reference loop (prediction.py:52-64): for every (batch, member): move ALL weights host->device,
+    forward, softmax twice, two D2H copies, CPU `+=`, move the weights back. Here: members stay in
+    HBM, the S logit blocks of a batch land in one [S, B, C] slab and ONE launch of
+    `ursa_bma_accumulate_f32` folds them into device accumulators; the host sees the result once,
+    after an optional all-reduce across ranks (one process per GPU, members sharded over ranks).
+    """
+
+    def __init__(self, loader, num_classes, device, kernels, smoothed, with_entropy=True, cost=None):
+        self.loader, self.C, self.device = loader, int(num_classes), device
+        self.K = kernels if kernels is not None else _native.default_kernels()
+        self.smoothed, self.cost = smoothed, cost
+        self.N = len(loader.dataset)
+        self.with_entropy = with_entropy
+        self._slabs = {}
+        self.reset(entropy_too=True)
+
+    def reset(self, entropy_too=True):
+        self.proba = torch.zeros(self.N, self.C, device=self.device)
+        if entropy_too or not hasattr(self, 'ent'):
+            self.ent = torch.zeros(self.N, device=self.device) if self.with_entropy else None
+        self.risk = torch.zeros(self.N, self.C, device=self.device) if self.cost is not None else None
+
+    @torch.no_grad()
+    def accumulate(self, members):
+        S = len(members)
+        for m in members:
+            m.to(self.device)          # no-op for bank-resident members; moves foreign CPU models once
+            m.eval()
+        start = 0
+        for x, _ in self.loader:
+            b = len(x)
+            x = x.to(self.device, non_blocking=True)
+            slab = self._slabs.get((S, b))
+            if slab is None:
+                slab = self._slabs[(S, b)] = torch.empty(S, b, self.C, device=self.device)
+            for s, m in enumerate(members):
+                z = m(x)
+                if z.shape != (b, self.C):
+                    raise ValueError(f'member {s} returned logits {tuple(z.shape)}, expected {(b, self.C)}')
+                slab[s].copy_(z)
+            self.K.bma_accumulate(slab, self.proba[start:start + b],
+                                  None if self.ent is None else self.ent[start:start + b],
+                                  one_minus_gamma=1 - GAMMA, gamma_over_c=GAMMA * 1 / self.C, smoothed=self.smoothed,
+                                  risk_sum=None if self.risk is None else self.risk[start:start + b], cost=self.cost)
+            start += b
+
+    def reduced(self, count, group=None):
+        """(proba_sum, ent_sum, risk_sum, total member count) summed over ranks: ONE all-reduce of
+        the concatenated fp32 accumulators over RCCL/xGMI (gloo on CPU), + the count."""
+        parts = [self.proba.reshape(-1)]
+        if self.ent is not None:
+            parts.append(self.ent)
+        if self.risk is not None:
+            parts.append(self.risk.reshape(-1))
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            buf = torch.cat(parts + [torch.tensor([float(count)], device=self.device)])
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+            count = int(round(buf[-1].item()))
+            buf = buf[:-1]
+        else:
+            buf = torch.cat(parts)
+        nc = self.N * self.C
+        proba = buf[:nc].view(self.N, self.C)
+        off = nc
+        ent = risk = None
+        if self.ent is not None:
+            ent = buf[off:off + self.N]
+            off += self.N
+        if self.risk is not None:
+            risk = buf[off:off + nc].view(self.N, self.C)
+        return proba, ent, risk, count

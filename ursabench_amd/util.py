@@ -1,0 +1,119 @@
+"""Host helpers the hot path needs, with the semantics of URSABench/util.py (file:line cited
+per function). Everything here is plumbing; the arithmetic lives in the HIP kernels."""
+import random
+import time
+
+import numpy as np
+import torch
+from torch.nn import CrossEntropyLoss
+from torch.nn.modules.batchnorm import _BatchNorm
+
+_random_seed = None
+
+
+def set_random_seed(seed=None):
+    """util.py:20-29 — seeds python, numpy, torch (and the HIP generator). The samplers read
+    torch.initial_seed() at construction as the Philox key of their chain."""
+    global _random_seed
+    if seed is None:
+        seed = int((time.time() * 1e6) % 1e8)
+    _random_seed = seed
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed(seed)
+
+
+def get_loss_criterion(loss='multi_class_linear_output', **kwargs):
+    """util.py:80-89 — mean-reduced cross entropy is the only supported likelihood."""
+    if loss != 'multi_class_linear_output':
+        raise NotImplementedError
+    return CrossEntropyLoss(**kwargs)
+
+
+def reset_model(model):
+    """util.py:92-107 — reset_parameters() on TOP-LEVEL children only (nested blocks are not
+    re-initialised: a reference quirk callers rely on for timing, kept). In place, so arena
+    views stay valid."""
+    if not isinstance(model, torch.nn.Module):
+        raise NotImplementedError
+    for _, child in model.named_children():
+        fn = getattr(child, 'reset_parameters', None)
+        if fn is not None:
+            fn()
+    return model
+
+
+def flatten(lst):
+    """util.py:163-169."""
+    return torch.cat([t.contiguous().view(-1, 1) for t in lst]).view(-1)
+
+
+def set_weights(model, vector, device=None):
+    """util.py:172-176."""
+    off = 0
+    for p in model.parameters():
+        n = p.numel()
+        p.data.copy_(vector[off:off + n].view(p.size()).to(device))
+        off += n
+
+
+def adjust_learning_rate(optimizer, lr):
+    """util.py:179-182."""
+    for g in optimizer.param_groups:
+        g['lr'] = lr
+    return lr
+
+
+def central_smoothing(proba, gamma=1e-4):
+    """util.py:126-134 (host version, used only by the metric surface on [N, C] means)."""
+    return (1 - gamma) * proba + gamma * 1 / (proba.shape[1])
+
+
+def compute_predictive_entropy(proba):
+    """util.py:137-144."""
+    return -(proba * torch.log(proba)).sum(dim=-1)
+
+
+def check_bn(model):
+    """util.py:185-193."""
+    return any(isinstance(m, _BatchNorm) for m in model.modules())
+
+
+def bn_update(loader, model, subset=None, device=None, **kwargs):
+    """util.py:212-247 — reset BN statistics and re-estimate them with one train-mode pass using
+    the cumulative-average momentum b/(n+b). The reference hard-codes input.cuda() (:236); here
+    the batch goes to the model's own device. Statistics are reset IN PLACE (the reference
+    re-assigns the buffers, :198-199) so member-bank views stay valid."""
+    bns = [m for m in model.modules() if isinstance(m, _BatchNorm)]
+    if not bns:
+        return
+    if device is None:
+        device = next(model.parameters()).device
+    was_training = model.training
+    model.train()
+    momenta = {}
+    for m in bns:
+        m.running_mean.zero_()
+        m.running_var.fill_(1)
+        momenta[m] = m.momentum
+    n = 0
+    num_batches = len(loader)
+    with torch.no_grad():
+        it = iter(loader)
+        if subset is not None:
+            num_batches = int(num_batches * subset)
+        for bi, (x, _) in enumerate(it):
+            if subset is not None and bi >= num_batches:
+                break
+            x = x.to(device, non_blocking=True)
+            b = x.size(0)
+            mom = b / (n + b)
+            for m in bns:
+                m.momentum = mom
+            model(x, **kwargs)
+            n += b
+    for m in bns:
+        m.momentum = momenta[m]
+    model.train(was_training)
