@@ -1,0 +1,239 @@
+"""Headline benchmark: posterior-samples/sec (+ BMA-predictions/sec) for PreResNet-20 / CIFAR-10-
+shaped synthetic data, SGHMC, one chain per GPU (BASELINE.json configs[1]; configs[2] at N > 1).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one posterior sample: one epoch of ceil(50000/128) = 391 minibatch updates
+(forward + backward in stock PyTorch-ROCm, then ONE fused gfx950 update launch) followed by a
+device-to-device snapshot into the member bank (URSABench/inference/sghmc.py:65-101; protocol of
+URSABench/time_script.py:89-114: burn-in 0). W untimed samples, then exactly K timed samples
+bracketed by barrier + synchronize; rank 0 prints ONE JSON line. value = samples of ALL ranks /
+max-over-ranks time. After the timed region the K-member ensemble of every rank is evaluated on
+the 10,000-row test set (Prediction.update_statistics + one all-reduce): `bma_preds_per_s`.
+
+Extra objects: `roofline` (the update kernel, HIP events on its own stream, same launch as the
+workload's) and `cpu_baseline` (the torch-CPU port of the reference path, oracle/torch_cpu_path.py,
+timed on this box's host cores on a bounded sample; rank 0, N = 1 only).
+"""
+import argparse
+import importlib.util
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); measured float4 copy ceiling: 6290
+HBM_COPY_GBPS = 6290.0
+
+# C2 hyper-parameters: URSABench/hyperparams/ResNet50CIFAR10/sghmc_hyperparams.json (no PreResNet-20
+# file exists in the reference), burn-in forced to 0 as time_script.py:89-90 does.
+HYP = {'lr': 0.1, 'prior_std': 0.5, 'alpha': 0.5, 'burn_in_epochs': 0}
+N_TRAIN, N_TEST, BATCH, CLASSES = 50000, 10000, 128, 10
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3, help='timed posterior samples per chain (time_script S=3)')
+    ap.add_argument('--warmup', type=int, default=1, help='untimed posterior samples per chain')
+    ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-steps', type=int, default=200, help='minibatch steps of the CPU port to time')
+    ap.add_argument('--large-n', type=int, default=1 << 26, help='elements of the roofline-sized K1 launch')
+    return ap.parse_args()
+
+
+def event_time_ms(fn, iters, stream, graph_batch=0):
+    """Average duration of one fn() launch, HIP events recorded on `stream` (the stream the kernel is
+    launched on). With graph_batch > 0 the launches are captured `graph_batch` at a time into a
+    hipGraph and the replay is timed, so the host's per-launch Python/ctypes cost (~10 us) is not
+    what is measured; the figure then is kernel duration + the ~1.5 us dependent-kernel boundary."""
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if graph_batch:
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(graph_batch):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        reps = max(1, iters // graph_batch)
+        s = torch.cuda.current_stream()
+        a.record(s)
+        for _ in range(reps):
+            g.replay()
+        b.record(s)
+        b.synchronize()
+        return a.elapsed_time(b) / (reps * graph_batch)
+    with torch.cuda.stream(stream):
+        for _ in range(5):
+            fn()
+        a.record(stream)
+        for _ in range(iters):
+            fn()
+        b.record(stream)
+    b.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+def roofline_block(sampler, large_n):
+    """Dominant kernel = the fused update (k_sgmcmc_step_ctl): identical launch to the one inside
+    the timed region (same arena, same control block), timed with HIP events on the stream it is
+    launched on. Algorithmic bytes: SGHMC 20 B/param (theta, grad, mom read; theta, mom written)
+    + 4 B/param for the fused gradient zeroing = 24 B x arena elements per launch."""
+    opt, arena = sampler.optimizer, sampler.arena
+    K = opt.kernels
+    stream = torch.cuda.current_stream()
+    opt.ctl_begin(True)
+    ms = event_time_ms(lambda: K.sgmcmc_step_ctl(arena.theta, arena.grad, arena.mom, opt._ctl), 2048, stream,
+                       graph_batch=256)
+    bytes_per_launch = 24 * arena.n
+    achieved = bytes_per_launch / (ms * 1e-3) / 1e9
+    out = {'bound': 'hbm', 'kernel': 'k_sgmcmc_step_ctl', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS,
+           'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': None,
+           'bytes_per_launch': bytes_per_launch, 'us_per_launch': round(ms * 1e3, 3),
+           'note': 'workload-sized launch (6.6 MB of state, L2/Infinity-Cache resident, one float4 per lane): '
+                   'latency-bound; us_per_launch is a 256-launch hipGraph replay / 256 and includes the '
+                   '~1.5 us kernel boundary; see roofline_large for the HBM-sized launch of the same arithmetic'}
+    # the same arithmetic at a working set beyond the 256 MiB Infinity Cache
+    n = large_n
+    th, g, m = (torch.randn(n, device='cuda') for _ in range(3))
+    sc = dict(lr=HYP['lr'], mu=1 - HYP['alpha'], c_wd=(1 / HYP['prior_std'] ** 2) / N_TRAIN, c_noise=0.3,
+              n_train=float(N_TRAIN), seed=1, step=1)
+    ms_l = event_time_ms(lambda: K.sgmcmc_step(th, g, m, flags=0x1 | 0x4 | 0x8, **sc), 30, stream)
+    ach_l = 24 * n / (ms_l * 1e-3) / 1e9
+    large = {'kernel': 'k_sgmcmc_step<mom,philox>', 'elements': n, 'achieved': round(ach_l, 1), 'peak': HBM_PEAK_GBPS,
+             'unit': 'GB/s', 'frac': round(ach_l / HBM_PEAK_GBPS, 4), 'frac_of_measured_copy_ceiling':
+             round(ach_l / HBM_COPY_GBPS, 4), 'us_per_launch': round(ms_l * 1e3, 2), 'bytes_per_launch': 24 * n}
+    del th, g, m
+    return out, large
+
+
+def cpu_baseline_block(steps):
+    """Reference CPU path (port): PreResNet-20 forward/backward + per-tensor torch update loop on
+    this box's host cores, `steps` minibatch steps of the same workload; extrapolated to
+    posterior-samples/s = 1 / (391 x seconds-per-step)."""
+    spec = importlib.util.spec_from_file_location('torch_cpu_path', os.path.join(ROOT, 'oracle', 'torch_cpu_path.py'))
+    port = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(port)
+    from ursabench_amd import models
+    torch.manual_seed(0)
+    # probed on the GPU box (256 logical CPUs, tools/cpu_threads_probe.py): 8/16/32/64/128 threads ->
+    # 76/50/76/222/1119 ms per forward+backward; 16 is the fastest, more threads only add sync cost
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    net = models.PreResNet(CLASSES, 20)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((steps + 3) * BATCH, 3, 32, 32, generator=g)
+    y = torch.randint(0, CLASSES, (len(x),), generator=g)
+    batches = [(x[i:i + BATCH], y[i:i + BATCH]) for i in range(0, len(x), BATCH)]
+    kw = dict(lr=HYP['lr'], momentum=1 - HYP['alpha'], weight_decay=1 / HYP['prior_std'] ** 2,
+              num_training_samples=N_TRAIN)
+    state = {}
+    port.sghmc_epoch(net, batches[:3], state, **kw)                       # warm up
+    n, secs = port.sghmc_epoch(net, batches[3:], state, **kw)
+    steps_per_sample = (N_TRAIN + BATCH - 1) // BATCH
+    return {'value': round(1.0 / (steps_per_sample * secs / n), 5), 'unit': 'posterior-samples/s',
+            'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'{n} minibatch steps (B={BATCH}) of PreResNet-20 SGHMC on torch-CPU '
+                      f'({secs:.1f} s, {1e3 * secs / n:.1f} ms/step), extrapolated to {steps_per_sample} steps/sample',
+            'ms_per_minibatch_step': round(1e3 * secs / n, 2)}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    if world != a.gpus:
+        raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a HIP device (no CPU fallback)')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)        # RCCL over xGMI
+
+    from ursabench_amd import inference, models, tasks, util
+    from ursabench_amd.data import synthetic
+
+    util.set_random_seed(rank)                                 # chain c uses seed c (experiment.py:170)
+    train = synthetic(N_TRAIN, (3, 32, 32), CLASSES, seed=0, device=dev, batch_size=BATCH)
+    test = synthetic(N_TEST, (3, 32, 32), CLASSES, seed=1, device=dev, batch_size=BATCH)
+    net = models.PreResNet(CLASSES, 20).to(dev)
+    hyp = dict(HYP, num_samples=a.steps + a.warmup)
+    sampler = inference.SGHMC(hyp, net, train, device=dev, use_graph=not a.no_graph)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        sampler.sample_iterative()
+    barrier()
+    t0 = time.perf_counter()
+    ensemble = [sampler.sample_iterative() for _ in range(a.steps)]       # EXACTLY K timed steps
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+
+    # ---- BMA predictive over the test set: members sharded over ranks, one all-reduce -------------
+    pred = tasks.Prediction({'in_distribution_test': test}, CLASSES, dev, 'ALL')
+    pred.update_statistics(ensemble[:1], output_performance=False)        # warm up MIOpen eval-mode kernels
+    pred.reset()
+    barrier()
+    t1 = time.perf_counter()
+    pred.update_statistics(ensemble, output_performance=False)
+    barrier()
+    dt_bma = time.perf_counter() - t1
+    if world > 1:
+        t = torch.tensor([dt_bma], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_bma = t.item()
+    metrics = pred.get_performance_metrics()
+    members = pred.num_samples_collected
+
+    if rank == 0:
+        roof, roof_large = roofline_block(sampler, a.large_n)
+        steps_per_sample = len(train)
+        line = {
+            'metric': 'posterior-samples/sec (PreResNet-20 SGHMC, 1 chain per GPU); bma_preds_per_s beside it',
+            'value': round(world * a.steps / dt, 4), 'unit': 'posterior-samples/s', 'n_gpus': world, 'steps': a.steps,
+            'warmup': a.warmup, 'ms_per_step': round(1e3 * dt / a.steps, 2), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'PreResNet-20 / CIFAR-10-shaped synthetic, SGHMC 1 chain per GPU '
+                                   '(BASELINE configs[1]; configs[2] when n_gpus > 1)', 'n_train': N_TRAIN,
+                       'n_test': N_TEST, 'batch': BATCH, 'minibatch_steps_per_sample': steps_per_sample,
+                       'params': sampler.arena.num_parameters, 'hyper': HYP, 'chains': world,
+                       'hip_graph': not a.no_graph, 'sharding': 'one independent chain per rank; members stay on '
+                       'their rank; one RCCL all-reduce of [N*C + N] fp32 for the predictive'},
+            'minibatch_steps_per_s': round(world * a.steps * steps_per_sample / dt, 1),
+            'bma_preds_per_s': round(N_TEST / dt_bma, 1), 'bma_members': members,
+            'bma_member_forwards_per_s': round(members * N_TEST / dt_bma, 1),
+            'bma_nll': round(float(metrics['nll']), 5),
+            'engine': sampler.engine.stats,
+            'roofline': roof, 'roofline_large': roof_large,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline_block(a.cpu_steps)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
