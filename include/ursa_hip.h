@@ -61,7 +61,14 @@ typedef void* ursa_stream_t; /* hipStream_t */
 #define URSA_STEP_FIRST     0x2u
 #define URSA_STEP_ZERO_GRAD 0x4u
 #define URSA_STEP_WD        0x8u
-#define URSA_STEP_ALLFLAGS  0xFu
+/* SGD mode: torch.optim.SGD(momentum, weight_decay) as used by the SWA/SWAG trajectory
+ * (URSABench/inference/swa.py:41-42, swag.py:55-70), dampening 0, no nesterov, no noise:
+ *     g~ = WD ? fmaf(c_wd, theta, g) : g          (c_wd = weight_decay itself here)
+ *     mu != 0:  b = FIRST ? g~ : mom * mu + g~ ;  mom = b        mu == 0:  b = g~
+ *     theta = fmaf(-lr, b, theta)
+ */
+#define URSA_STEP_SGD       0x10u
+#define URSA_STEP_ALLFLAGS  0x1Fu
 
 int ursa_sgmcmc_step_f32(float* theta, float* grad, float* mom /* NULL iff mu == 0 */,
                          const float* eps /* NULL => Philox */, float* snapshot /* or NULL */,

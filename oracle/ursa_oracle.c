@@ -23,6 +23,7 @@
 #define STEP_FIRST     0x2u
 #define STEP_ZERO_GRAD 0x4u
 #define STEP_WD        0x8u
+#define STEP_SGD       0x10u
 #define BMA_SMOOTHED   0x1u
 #define LEAP_KICK      0x1u
 #define LEAP_DRIFT     0x2u
@@ -145,6 +146,17 @@ int oracle_sgmcmc_step_f32(float* theta, float* grad, float* mom, const float* e
         const float th = theta[i];
         float g = grad[i];
         if (flags & STEP_WD) g = fmaf(c_wd, th, g);                  /* :48  d_p.add(p, alpha=wd/N) */
+        if (flags & STEP_SGD) {
+            /* torch.optim.SGD single-tensor update (the SWA/SWAG trajectory, swa.py:41-42):
+             * buf = FIRST ? clone(g~) : buf.mul_(mu).add_(g~);  p.add_(buf, alpha=-lr) */
+            float b = g;
+            if (mu != 0.0f) { b = (flags & STEP_FIRST) ? g : mom[i] * mu + g; mom[i] = b; }
+            const float ts = fmaf(neg_lr, b, th);
+            theta[i] = ts;
+            if (flags & STEP_ZERO_GRAD) grad[i] = 0.0f;
+            if (snapshot) snapshot[i] = ts;
+            continue;
+        }
         float d;
         if (mu != 0.0f) {
             float v = (flags & STEP_FIRST) ? g : mom[i];             /* :52  clone(d_p) */

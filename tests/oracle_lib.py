@@ -11,7 +11,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _L = ctypes.CDLL(os.path.join(ROOT, 'oracle', 'liboracle.so'))
 
-STEP_NOISE, STEP_FIRST, STEP_ZERO_GRAD, STEP_WD = 1, 2, 4, 8
+STEP_NOISE, STEP_FIRST, STEP_ZERO_GRAD, STEP_WD, STEP_SGD = 1, 2, 4, 8, 16
 BMA_SMOOTHED = 1
 LEAP_KICK, LEAP_DRIFT = 1, 2
 

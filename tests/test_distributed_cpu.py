@@ -1,0 +1,94 @@
+"""CPU, world_size 2, gloo: the N > 1 path. Members are sharded over ranks, every rank reduces its
+own members over the full test set, ONE all-reduce produces the predictive on every rank; it must
+equal the single-process result over all members."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _members(C=10, d=12, S=5):
+    out = []
+    for s in range(S):
+        g = torch.Generator().manual_seed(100 + s)
+        m = torch.nn.Linear(d, C)
+        with torch.no_grad():
+            m.weight.copy_(torch.randn(C, d, generator=g) * (0.5 + s))
+            m.bias.copy_(torch.randn(C, generator=g))
+        out.append(m)
+    return out
+
+
+def _loaders():
+    from torch.utils.data import DataLoader, TensorDataset
+    g = torch.Generator().manual_seed(7)
+    x, y = torch.randn(45, 12, generator=g), torch.randint(0, 10, (45,), generator=g)
+    xo = torch.randn(23, 12, generator=g) * 3
+    mk = lambda a, b: DataLoader(TensorDataset(a, b), batch_size=16, shuffle=False)
+    return mk(x, y), mk(xo, torch.zeros(23, dtype=torch.long))
+
+
+def _evaluate(members, group_ok):
+    from ursabench_amd import tasks
+    from ursabench_amd.tasks.decision_making import CIFAR10_cost
+    from oracle_kernels import OracleKernels
+    l_in, l_out = _loaders()
+    dev = torch.device('cpu')
+    pred = tasks.Prediction({'in_distribution_test': l_in}, 10, dev, 'ALL', kernels=OracleKernels())
+    pred.update_statistics(members, output_performance=False)
+    ood = tasks.OODDetection({'in_distribution_test': l_in, 'out_distribution_test': l_out}, 10, dev, kernels=OracleKernels())
+    om = ood.update_statistics(members, output_performance=True)
+    dec = tasks.Decision({'decision_data_test': l_in}, 10, dev, cost_mat=CIFAR10_cost(10), kernels=OracleKernels())
+    dm = dec.update_statistics(members, output_performance=True)
+    return dict(proba=pred.ensemble_proba.numpy(), ent=pred.expected_data_uncertainty.numpy(),
+                count=pred.num_samples_collected, metrics=pred.get_performance_metrics(), ood=om,
+                risk=dec.risk.numpy(), decision=dm['Decision'].numpy(), ood_count=ood.num_samples_collected)
+
+
+def _worker(rank, world, port, outdir):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    from ursabench_amd.distributed import init_from_env, shard
+    r, w, dev = init_from_env('cpu')
+    assert (r, w) == (rank, world) and dist.is_initialized() and dist.get_backend() == 'gloo'
+    mine = shard(_members(), rank, world)            # 5 members over 2 ranks: 3 + 2
+    res = _evaluate(mine, True)
+    np.savez(os.path.join(outdir, f'rank{rank}.npz'), proba=res['proba'], ent=res['ent'], risk=res['risk'],
+             decision=res['decision'], count=res['count'], nll=res['metrics']['nll'],
+             auroc=res['ood']['model_uncertainty_auroc'], ood_count=res['ood_count'], n_local=len(mine))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_member_sharded_bma_equals_single_process(tmp_path):
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    ref = _evaluate(_members(), False)              # this process: no process group, all 5 members
+    r0, r1 = (np.load(tmp_path / f'rank{r}.npz') for r in (0, 1))
+    assert int(r0['n_local']) == 3 and int(r1['n_local']) == 2
+    for r in (r0, r1):                              # every rank holds the full predictive
+        assert int(r['count']) == 5 and int(r['ood_count']) == 5
+        np.testing.assert_allclose(r['proba'], ref['proba'], rtol=2e-6, atol=1e-7)   # summation order differs
+        np.testing.assert_allclose(r['ent'], ref['ent'], rtol=2e-6, atol=1e-6)
+        np.testing.assert_allclose(r['risk'], ref['risk'], rtol=2e-6, atol=1e-6)
+        assert np.array_equal(r['decision'], ref['decision'])
+        assert float(r['nll']) == pytest.approx(ref['metrics']['nll'], rel=1e-5)
+        assert float(r['auroc']) == pytest.approx(ref['ood']['model_uncertainty_auroc'], abs=1e-9)
+    assert np.array_equal(r0['proba'], r1['proba'])
+
+
+def test_shard_and_seed_helpers():
+    from ursabench_amd.distributed import chain_seed, shard
+    assert shard(range(30), 7, 8) == [7, 15, 23] and sum(len(shard(range(30), r, 8)) for r in range(8)) == 30
+    assert [chain_seed(0, r) for r in range(3)] == [0, 1, 2]

@@ -287,3 +287,21 @@ def test_k1_roofline_sized_properties(K):
     assert abs(float(th.mean())) < 1e-3 and abs(float(th.std()) - 1) < 1e-3 and not g.any()
     assert float(th.abs().max()) < 6.8
     assert np.array_equal(host(th[:4096]), O.philox_normal(4096, 7, 1))
+
+
+@pytest.mark.parametrize('case', ['sgd_mom_wd', 'sgd_mom_nowd', 'sgd_plain_wd'])
+def test_sgd_mode_bitwise_vs_torch_sgd_golden(K, golden_dir, case):
+    g = np.load(os.path.join(golden_dir, 'sgd_steps.npz'))
+    momentum, wd = g[f'{case}/hyper']
+    theta = dev(g[f'{case}/theta0'])
+    mom = torch.zeros_like(theta) if momentum != 0 else None
+    for k, lr in enumerate(g[f'{case}/lr']):
+        flags = O.STEP_SGD | (O.STEP_WD if wd != 0 else 0) | (O.STEP_FIRST if (k == 0 and momentum != 0) else 0)
+        K.sgmcmc_step(theta, dev(g[f'{case}/grad'][k]), mom, lr=float(lr), mu=float(momentum), c_wd=float(wd),
+                      c_noise=0.0, n_train=1.0, flags=flags)
+        assert np.array_equal(host(theta), g[f'{case}/theta'][k]), (case, k)
+        if momentum != 0:
+            assert np.array_equal(host(mom), g[f'{case}/mom'][k]), (case, k)
+    with pytest.raises(ValueError):
+        K.sgmcmc_step(theta, theta.clone(), mom, lr=0.1, mu=float(momentum), c_wd=0.0, c_noise=0.0, n_train=1.0,
+                      flags=O.STEP_SGD | O.STEP_NOISE)

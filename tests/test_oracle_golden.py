@@ -147,3 +147,19 @@ def test_k4_leapfrog_physics():
     np.testing.assert_allclose(-pb, p0, atol=2e-5)
     ke = O.leapfrog(th0.copy(), p0.copy(), None, kick_coef=0.0, step_size=0.0, inv_mass=2.0, flags=0, want_kinetic=True)
     np.testing.assert_allclose(ke, 0.5 * 2.0 * float((p0.astype(np.float64) ** 2).sum()), rtol=1e-12)
+
+
+@pytest.mark.parametrize('case', ['sgd_mom_wd', 'sgd_mom_nowd', 'sgd_plain_wd'])
+def test_sgd_mode_bitwise_vs_torch_sgd(golden_dir, case):
+    """The SWA/SWAG trajectory optimizer (torch.optim.SGD, swa.py:41-42) as a K1 mode."""
+    g = np.load(os.path.join(golden_dir, 'sgd_steps.npz'))
+    momentum, wd = g[f'{case}/hyper']
+    theta = g[f'{case}/theta0'].copy()
+    mom = np.zeros_like(theta) if momentum != 0 else None
+    for k, lr in enumerate(g[f'{case}/lr']):
+        flags = O.STEP_SGD | (O.STEP_WD if wd != 0 else 0) | (O.STEP_FIRST if (k == 0 and momentum != 0) else 0)
+        O.sgmcmc_step(theta, g[f'{case}/grad'][k].copy(), mom, lr=float(lr), mu=float(momentum), c_wd=float(wd),
+                      c_noise=0.0, n_train=1.0, flags=flags)
+        assert np.array_equal(theta, g[f'{case}/theta'][k]), (case, k)
+        if momentum != 0:
+            assert np.array_equal(mom, g[f'{case}/mom'][k]), (case, k)

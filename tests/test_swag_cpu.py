@@ -1,0 +1,94 @@
+"""CPU: SWA / SWAG host logic through the oracle kernel set against the reference's own runs (G8),
+in bug-compatible mode; the corrected mode against first principles."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+from torch.utils.data import DataLoader, TensorDataset
+
+import ursabench_amd.inference as inference
+from oracle_kernels import OracleKernels
+from test_samplers_cpu import tiny_loader, tiny_net
+
+
+def bn_net():
+    return torch.nn.Sequential(torch.nn.Conv2d(1, 4, 3), torch.nn.BatchNorm2d(4), torch.nn.ReLU(),
+                               torch.nn.Flatten(), torch.nn.Linear(4 * 4 * 4, 4))
+
+
+def bn_loader(n=64, b=32, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return DataLoader(TensorDataset(torch.randn(n, 1, 6, 6, generator=g), torch.randint(0, 4, (n,), generator=g)),
+                      batch_size=b, shuffle=False)
+
+
+def flat(ps):
+    return torch.cat([p.detach().reshape(-1) for p in ps]).numpy()
+
+
+@pytest.mark.parametrize('tag', ['mlp', 'bn'])
+@pytest.mark.parametrize('cls_name', ['SWAG', 'SWA'])
+def test_swag_swa_bug_compatible_vs_reference(golden_dir, tag, cls_name):
+    g = np.load(os.path.join(golden_dir, 'swag_e2e.npz'))
+    hyp = json.loads(str(g['hyper']))
+    torch.manual_seed(0)
+    net = (tiny_net if tag == 'mlp' else bn_net)()
+    assert np.array_equal(flat(net.parameters()), g[f'{tag}/{cls_name}/theta0'])
+    loader = (tiny_loader if tag == 'mlp' else bn_loader)()
+    s = getattr(inference, cls_name)(dict(hyp), net, loader, kernels=OracleKernels(), use_graph=False)
+    ens = s.sample(num_samples=2)
+    assert s.epochs_run == int(g[f'{tag}/{cls_name}/epochs_run'])
+    assert np.array_equal(s.num_models_collected.numpy(), g[f'{tag}/{cls_name}/n_collected'])
+    # the SGD trajectory, the moments and the (degenerate) samples are the reference's, bit for bit
+    assert np.array_equal(flat(s.model.parameters()), g[f'{tag}/{cls_name}/live_theta'])
+    assert np.array_equal(s.weight_mean.numpy(), g[f'{tag}/{cls_name}/weight_mean'])
+    assert np.array_equal(s.sq_mean.numpy(), g[f'{tag}/{cls_name}/sq_mean'])
+    assert (ens[0] is ens[1]) == bool(g[f'{tag}/{cls_name}/same_object'])
+    for m, ref, refb in zip(ens, g[f'{tag}/{cls_name}/samples'], g[f'{tag}/{cls_name}/sample_buffers']):
+        assert np.array_equal(flat(m.parameters()), ref)
+        if refb.size:                                    # BatchNorm statistics after bn_update (util.py:212-247)
+            got = torch.cat([b.detach().float().reshape(-1) for b in m.buffers()]).numpy()
+            np.testing.assert_allclose(got, refb, rtol=1e-6, atol=1e-7)
+
+
+def test_swag_schedule_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'swag_moments.npz'))
+    hyp = json.loads(str(g['hyper']))
+    s = inference.SWAG(dict(hyp), tiny_net(), tiny_loader(), kernels=OracleKernels(), use_graph=False)
+    assert [s._schedule(e) for e in range(14)] == list(g['schedule'])
+
+
+def test_swag_corrected_mode_is_a_real_diagonal_gaussian():
+    """reference_quirks=False: moments average the collected iterates, draws differ and follow
+    N(mean, var) with our Philox stream."""
+    hyp = {'swag_lr': 0.01, 'swag_wd': 1e-4, 'lr_init': 0.05, 'num_samples': 3, 'momentum': 0.9,
+           'burn_in_epochs': 1, 'num_iterates': 3}
+    torch.manual_seed(0)
+    K = OracleKernels()
+    s = inference.SWAG(dict(hyp), tiny_net(), tiny_loader(), kernels=K, use_graph=False, reference_quirks=False)
+    iterates = []
+    orig = s._collect_model
+
+    def tap():
+        iterates.append(s.arena.flatten().clone())
+        orig()
+    s._collect_model = tap
+    ens = s.sample()
+    W = torch.stack(iterates).double()
+    assert s.num_models_collected.item() == 3 and len(iterates) == 3
+    np.testing.assert_allclose(s.weight_mean.numpy(), W.mean(0).numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(s.sq_mean.numpy(), (W ** 2).mean(0).numpy(), rtol=1e-5, atol=1e-7)
+    mean, var = s._get_mean_and_variance()
+    thetas = [flat(m.parameters()) for m in ens]
+    assert not np.array_equal(thetas[0], thetas[1])
+    import oracle_lib as O
+    idx = s.arena.layout.gather_index('cpu').numpy()
+    for d, th in enumerate(thetas):
+        eps = O.philox_normal(s.arena.n, s.seed, d)[idx]
+        np.testing.assert_allclose(th, eps * np.sqrt(var.numpy()) + mean.numpy(), rtol=1e-6, atol=1e-7)
+    with pytest.raises(NotImplementedError):
+        s.sample_iterative(full_cov=True)
+    s.update_hyp(dict(hyp))
+    assert s.num_models_collected.item() == 0 and not s._mean.any() and s.burnt_in is False

@@ -105,6 +105,38 @@ def gen_k1():
     print('G1 k1_steps', n, list(cases))
 
 
+def gen_sgd():
+    """G7: torch.optim.SGD(momentum, weight_decay) — the optimizer the reference's SWA/SWAG trajectory
+    uses (swa.py:41-42) — on CPU, caller-provided gradients."""
+    shapes = [(7,), (3, 5), (64,), (1,), (33,), (250,), (3,)]
+    out = {'shapes': json.dumps(shapes)}
+    cases = {'sgd_mom_wd': dict(momentum=0.9, wd=5e-4, lrs=[0.05, 0.05, 0.03, 0.01, 0.01]),
+             'sgd_mom_nowd': dict(momentum=0.1, wd=0.0, lrs=[0.001, 0.001, 0.002]),
+             'sgd_plain_wd': dict(momentum=0.0, wd=1e-3, lrs=[0.1, 0.05])}
+    for ci, (name, c) in enumerate(cases.items()):
+        g = torch.Generator().manual_seed(300 + ci)
+        params = [torch.nn.Parameter(torch.randn(*s, generator=g)) for s in shapes]
+        opt = torch.optim.SGD(params, lr=c['lrs'][0], momentum=c['momentum'], weight_decay=c['wd'])
+        out[f'{name}/theta0'] = flat(params)
+        grads, th, mo = [], [], []
+        for lr in c['lrs']:
+            opt.param_groups[0]['lr'] = lr
+            for p in params:
+                p.grad = torch.randn(p.shape, generator=g)
+            grads.append(flat([p.grad for p in params]))
+            opt.step()
+            th.append(flat(params))
+            if c['momentum'] != 0:
+                mo.append(flat([opt.state[p]['momentum_buffer'] for p in params]))
+        out[f'{name}/grad'], out[f'{name}/theta'] = np.stack(grads), np.stack(th)
+        if mo:
+            out[f'{name}/mom'] = np.stack(mo)
+        out[f'{name}/hyper'] = np.array([c['momentum'], c['wd']], np.float64)
+        out[f'{name}/lr'] = np.array(c['lrs'], np.float64)
+    np.savez_compressed(os.path.join(OUT, 'sgd_steps.npz'), **out)
+    print('G7 sgd_steps', list(cases))
+
+
 # ------------------------------------------------------------------------------------- G2/G3
 def tiny_loader(n=64, b=32, d=12, c=4, seed=0):
     g = torch.Generator().manual_seed(seed)
@@ -270,6 +302,46 @@ def gen_swag():
     print('G5 swag_moments P =', P, 'eps replay bitwise:', out['degenerate/eps_replay_bitwise'], out['counting/eps_replay_bitwise'])
 
 
+def bn_net():
+    return torch.nn.Sequential(torch.nn.Conv2d(1, 4, 3), torch.nn.BatchNorm2d(4), torch.nn.ReLU(),
+                               torch.nn.Flatten(), torch.nn.Linear(4 * 4 * 4, 4))
+
+
+def bn_loader(n=64, b=32, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return DataLoader(TensorDataset(torch.randn(n, 1, 6, 6, generator=g), torch.randint(0, 4, (n,), generator=g)),
+                      batch_size=b, shuffle=False)
+
+
+def gen_swag_e2e():
+    """G8: the reference's SWAG / SWA run end to end on CPU (torch SGD trajectory, CPU moments,
+    degenerate draw, bn_update), on an MLP and on a small conv+BatchNorm net."""
+    out = {}
+    hyp = {'swag_lr': 0.01, 'swag_wd': 1e-4, 'lr_init': 0.05, 'num_samples': 2, 'momentum': 0.9,
+           'burn_in_epochs': 2, 'num_iterates': 2}
+    out['hyper'] = json.dumps(hyp)
+    for tag, mk_net, mk_loader in (('mlp', tiny_net, tiny_loader), ('bn', bn_net, bn_loader)):
+        for cls_name in ('SWAG', 'SWA'):
+            torch.manual_seed(0)
+            net = mk_net()
+            out[f'{tag}/{cls_name}/theta0'] = flat(net.parameters())
+            with quiet():
+                s = getattr(inference, cls_name)(dict(hyp), net, mk_loader())
+                ens = s.sample(num_samples=2)
+            out[f'{tag}/{cls_name}/weight_mean'] = s.weight_mean.numpy().copy()
+            out[f'{tag}/{cls_name}/sq_mean'] = s.sq_mean.numpy().copy()
+            out[f'{tag}/{cls_name}/n_collected'] = s.num_models_collected.numpy().copy()
+            out[f'{tag}/{cls_name}/epochs_run'] = np.array(s.epochs_run)
+            out[f'{tag}/{cls_name}/live_theta'] = flat(s.model.parameters())
+            out[f'{tag}/{cls_name}/samples'] = np.stack([flat(m.parameters()) for m in ens])
+            bufs = [torch.cat([b.detach().float().reshape(-1) for b in m.buffers()]).numpy() if list(m.buffers())
+                    else np.zeros(0, np.float32) for m in ens]
+            out[f'{tag}/{cls_name}/sample_buffers'] = np.stack(bufs)
+            out[f'{tag}/{cls_name}/same_object'] = np.array(ens[0] is ens[1])
+    np.savez_compressed(os.path.join(OUT, 'swag_e2e.npz'), **out)
+    print('G8 swag_e2e', {k: v.shape for k, v in out.items() if k.endswith('samples')})
+
+
 # ------------------------------------------------------------------------------------- G6
 def gen_e2e():
     out = {}
@@ -341,8 +413,8 @@ def gen_model_keys():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['k1', 'sched', 'csghmc', 'tasks', 'swag', 'e2e', 'keys']
-    fns = dict(k1=gen_k1, sched=gen_schedules, csghmc=gen_csghmc, tasks=gen_tasks, swag=gen_swag, e2e=gen_e2e,
+    which = sys.argv[1:] or ['k1', 'sgd', 'sched', 'csghmc', 'tasks', 'swag', 'swag_e2e', 'e2e', 'keys']
+    fns = dict(k1=gen_k1, sgd=gen_sgd, swag_e2e=gen_swag_e2e, sched=gen_schedules, csghmc=gen_csghmc, tasks=gen_tasks, swag=gen_swag, e2e=gen_e2e,
                keys=gen_model_keys)
     for w in which:
         fns[w]()

@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libursa_hip.so')
 ABI_VERSION = 1
 
 # flags (mirror include/ursa_hip.h)
-STEP_NOISE, STEP_FIRST, STEP_ZERO_GRAD, STEP_WD = 0x1, 0x2, 0x4, 0x8
+STEP_NOISE, STEP_FIRST, STEP_ZERO_GRAD, STEP_WD, STEP_SGD = 0x1, 0x2, 0x4, 0x8, 0x10
 BMA_SMOOTHED = 0x1
 LEAP_KICK, LEAP_DRIFT = 0x1, 0x2
 REDUCE_WS_FLOATS = 2048

@@ -45,6 +45,15 @@ __device__ __forceinline__ void step_elem(float& th, float g, float& v, float e,
                                           bool noise)
 {
     if (s.flags & URSA_STEP_WD) g = __builtin_fmaf(s.c_wd, th, g);      // :48
+    if (s.flags & URSA_STEP_SGD) {                                        // torch.optim.SGD (swa.py:41-42)
+        float b = g;
+        if (MOM) {
+            b = (s.flags & URSA_STEP_FIRST) ? g : v * s.mu + g;
+            v = b;
+        }
+        th = __builtin_fmaf(-s.lr, b, th);
+        return;
+    }
     float d;
     if (MOM) {
         float b = (s.flags & URSA_STEP_FIRST) ? g : v;                    // :52
@@ -557,6 +566,7 @@ int ursa_sgmcmc_step_f32(float* theta, float* grad, float* mom, const float* eps
 {
     if (n < 0) return URSA_ESIZE;
     if (flags & ~URSA_STEP_ALLFLAGS) return URSA_EFLAGS;
+    if ((flags & URSA_STEP_SGD) && (flags & URSA_STEP_NOISE)) return URSA_EFLAGS;
     if (n == 0) return URSA_OK;
     if (!theta || !grad) return URSA_ENULL;
     if (mu != 0.0f && !mom) return URSA_ENULL;

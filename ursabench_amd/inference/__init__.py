@@ -4,3 +4,6 @@ from .optim_sghmc import optimSGHMC  # noqa: F401
 from .inference_base import _Inference  # noqa: F401
 from .sghmc import SGHMC, SGLD  # noqa: F401
 from .csghmc import cSGHMC, cSGLD  # noqa: F401
+from .flat_sgd import FlatSGD  # noqa: F401
+from .swag import SWA, SWAG  # noqa: F401
+from .hmc import HMC  # noqa: F401

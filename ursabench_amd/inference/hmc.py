@@ -1,0 +1,153 @@
+"""HMC — drop-in for URSABench/inference/hmc.py:23-85.
+
+The reference delegates all arithmetic to `hamiltorch.sample_model` (hmc.py:71-75), an
+un-vendored, un-pinned dependency that is absent from /root/reference: PARITY UNPINNED. This file
+restates hamiltorch's published sampler: full-batch log posterior
+log p = -sum CE - tau/2 ||theta||^2 (the Normal prior's constants cancel in the accept test and
+are dropped), momentum ~ N(0, mass), leapfrog with a half kick, L x (drift, kick) and a final
+half-kick correction, Metropolis accept on H = -log p + 1/2 p^T M^-1 p. Forward/backward are stock
+PyTorch-ROCm over the whole training set held on the device (hmc.py:44-50); the leapfrog
+sub-steps and both energy reductions are the K4 kernels on the flat arena.
+
+The returned trajectory follows hamiltorch's layout: the initial position, then the L positions of
+every proposal (a rejected proposal repeats the previous L), thinned exactly like hmc.py:80 —
+`samples[burn*L::L]`. Only the positions that thinning selects are kept in HBM.
+"""
+import math
+
+import torch
+
+from .. import _native
+from ..arena import FlatArena, MemberBank
+from ..util import reset_model
+from .inference_base import _Inference
+
+
+class HMC(_Inference):
+    def __init__(self, hyperparameters, model=None, train_loader=None, model_loss='multi_class_linear_output',
+                 device=torch.device('cpu'), *, kernels=None, seed=None):
+        super().__init__(hyperparameters, model, train_loader, device)
+        if hyperparameters == None:  # noqa: E711  (hmc.py:32-34)
+            hyperparameters = {'step_size': 0.001, 'num_samples': 10, 'L': 1, 'tau': 0.1, 'burn': -1, 'mass': 1.0}
+        self._read_hyp(hyperparameters)
+        self.model_loss = model_loss
+        if model_loss != 'multi_class_linear_output':
+            raise NotImplementedError
+        xs, ys = [], []
+        for data, target in train_loader:                       # hmc.py:44-50: the whole set, on the device
+            xs.append(data.clone().to(device))
+            ys.append(target.clone().to(device))
+        self.x, self.y = torch.cat(xs), torch.cat(ys)
+        self.model = model.to(device) if isinstance(model, torch.nn.Module) else model
+        self.kernels = kernels if kernels is not None else _native.default_kernels()
+        self.seed = int(torch.initial_seed() if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
+        self.arena = None
+        self._proposals = 0
+        self.accepted = 0
+
+    def _read_hyp(self, h):
+        self.step_size = h['step_size']
+        self.num_samples = h['num_samples']
+        self.L = h['L']
+        self.tau = h['tau']
+        self.burn = h['burn']
+        self.mass = h['mass']
+
+    def update_hyp(self, hyperparameters):
+        self._read_hyp(hyperparameters)
+        self.model = reset_model(self.model)
+
+    # ---- pieces --------------------------------------------------------------------------------
+    def _bind(self):
+        if self.arena is None:
+            a = self.arena = FlatArena(self.model.parameters(), module=self.model)
+            dev = a.device
+            self.bank = MemberBank(a)
+            self._p = torch.zeros(a.n, device=dev)
+            self._glogp = torch.zeros(a.n, device=dev)
+            self._mask = torch.zeros(a.n, device=dev)
+            self._mask[a.layout.gather_index(dev)] = 1.0
+            self._ws = torch.zeros(_native.REDUCE_WS_FLOATS, device=dev)
+            self._acc = torch.zeros(1, device=dev)
+            self._crit = torch.nn.CrossEntropyLoss(reduction='sum')
+
+    def _neg_logp_and_grad(self):
+        """U(theta) = sum CE + tau/2 ||theta||^2 (device scalar) and grad log p in self._glogp."""
+        a = self.arena
+        a.grad.zero_()
+        nll = self._crit(self.model(self.x), self.y.long().view(-1))
+        nll.backward()
+        with torch.no_grad():
+            torch.add(a.grad, a.theta, alpha=self.tau, out=self._glogp)
+            self._glogp.neg_()
+            self._acc.zero_()
+            self.kernels.sumsq(a.theta, self._acc, self._ws)
+            return nll.detach() + 0.5 * self.tau * self._acc[0]
+
+    def _kinetic(self):
+        self._acc.zero_()
+        self.kernels.leapfrog(None, self._p, None, kick_coef=0.0, step_size=0.0, inv_mass=1.0 / self.mass, flags=0,
+                              kinetic_out=self._acc, ws=self._ws)
+        return self._acc[0].clone()
+
+    def sample(self, debug=False):
+        if not isinstance(self.model, torch.nn.Module):
+            raise NotImplementedError
+        self._bind()
+        a, K, L, eps, inv_mass = self.arena, self.kernels, self.L, self.step_size, 1.0 / self.mass
+        total = L * self.num_samples + 1
+        wanted = set(range(total)[self.burn * L::L])                    # what hmc.py:80 will select
+        kept = {}
+
+        def keep(idx):
+            if idx in wanted:
+                kept[idx] = self.bank.snapshot(self.model)
+
+        self.model.train()      # hamiltorch runs the functional model in its current (training) mode
+        keep(0)
+        prev_positions = None
+        for n in range(self.num_samples):
+            theta0 = a.theta.clone()
+            fb0 = None if a.fbuf is None else a.fbuf.clone()
+            K.philox_normal(self._p, seed=self.seed, step=self._proposals)
+            self._p.mul_(self._mask).mul_(math.sqrt(self.mass))
+            self._proposals += 1
+            U0 = self._neg_logp_and_grad()
+            H0 = U0 + self._kinetic()
+            K.leapfrog(None, self._p, self._glogp, kick_coef=0.5 * eps, step_size=eps, inv_mass=inv_mass,
+                       flags=_native.LEAP_KICK)
+            positions = []
+            for l in range(L):
+                K.leapfrog(a.theta, self._p, None, kick_coef=0.0, step_size=eps, inv_mass=inv_mass,
+                           flags=_native.LEAP_DRIFT)
+                U1 = self._neg_logp_and_grad()
+                K.leapfrog(None, self._p, self._glogp, kick_coef=eps, step_size=eps, inv_mass=inv_mass,
+                           flags=_native.LEAP_KICK)
+                idx = n * L + l + 1
+                if idx in wanted:
+                    positions.append((idx, self.bank.snapshot(self.model)))
+            K.leapfrog(None, self._p, self._glogp, kick_coef=-0.5 * eps, step_size=eps, inv_mass=inv_mass,
+                       flags=_native.LEAP_KICK)
+            H1 = U1 + self._kinetic()
+            rho = min(0.0, float(H0 - H1))                  # the one host sync per proposal (MH test)
+            if debug:
+                print({'proposal': n, 'H0': float(H0), 'H1': float(H1), 'rho': rho})
+            if math.isfinite(rho) and rho >= math.log(torch.rand(1).item()):
+                self.accepted += 1
+                for idx, m in positions:
+                    kept[idx] = m
+                prev_positions = {idx - n * L: m for idx, m in positions}
+            else:                                           # reject: restore, repeat the previous L positions
+                a.theta.copy_(theta0)
+                if fb0 is not None:
+                    a.fbuf.copy_(fb0)
+                for l in range(1, L + 1):
+                    idx = n * L + l
+                    if idx in wanted:
+                        if prev_positions is not None and l in prev_positions:
+                            kept[idx] = prev_positions[l]
+                        else:
+                            kept[idx] = self.bank.snapshot(self.model)
+        if len(kept) != len(wanted):
+            print('Warning, thinning of sampling not aligned as reject occured in first sample.')
+        return [kept[i] for i in sorted(kept)]
