@@ -124,7 +124,9 @@ def test_csghmc_on_gpu_walks_the_device_schedule():
     assert len(ens) == 1 and s.epochs_run == 3 and s.engine.stats['graph_replays'] > 0
     from ursabench_amd._native import StepCtl
     c = StepCtl.from_buffer_copy(bytes(s.optimizer._ctl.cpu().numpy()))
-    assert c.step == 27 and np.float32(s.lr) == np.float32(s._epoch_table()[-1, 0])
+    assert c.step == 27
+    want = s._adjust_learning_rate(s.optimizer, s.epochs_run - 1, len(s.train_loader) - 1)   # last iteration run
+    assert s.lr == pytest.approx(want) and s.optimizer.param_groups[0]['lr'] == pytest.approx(want)
     assert np.isfinite(flat_params(ens[0]).cpu().numpy()).all()
 
 
@@ -153,3 +155,74 @@ def test_bma_full_size_properties():
     b.update_statistics([m2], output_performance=False)
     assert torch.equal(a.ensemble_proba, b.ensemble_proba) and a.num_samples_collected == b.num_samples_collected == 2
     assert torch.equal(a.expected_data_uncertainty, b.expected_data_uncertainty)
+
+
+def test_swag_on_gpu_both_modes():
+    hyp = {'swag_lr': 0.01, 'swag_wd': 1e-4, 'lr_init': 0.05, 'num_samples': 3, 'momentum': 0.9,
+           'burn_in_epochs': 1, 'num_iterates': 2}
+    torch.manual_seed(0)
+    train = synthetic(512 + 40, (3, 32, 32), 10, seed=0, device=DEV, batch_size=128)
+    # bug-compatible (reference) mode: every "sample" is the last SGD iterate + a BN refresh
+    s = inference.SWAG(dict(hyp), models.PreResNet(10, 8).to(DEV), train, device=DEV)
+    ens = s.sample()
+    live = s.arena.flatten()
+    assert s.num_models_collected.item() == 0 and s.epochs_run == 3 and s.engine.stats['graph_replays'] > 0
+    assert all(torch.equal(flat_params(m), live) for m in ens)
+    assert torch.equal(s.weight_mean, live)
+    np.testing.assert_allclose(s.sq_mean.cpu().numpy(), (live * live).cpu().numpy(), rtol=1e-6)
+    bn = dict(ens[0].named_buffers())
+    assert float(bn['bn.running_var'].min()) > 0 and not torch.equal(bn['bn.running_mean'], torch.zeros_like(bn['bn.running_mean']))
+    # corrected mode: real moments, distinct draws that follow our Philox stream through K3
+    s2 = inference.SWAG(dict(hyp), models.PreResNet(10, 8).to(DEV), train, device=DEV, reference_quirks=False, seed=9)
+    ens2 = s2.sample()
+    assert s2.num_models_collected.item() == 2
+    assert not torch.equal(flat_params(ens2[0]), flat_params(ens2[1]))
+    mean, var = s2._get_mean_and_variance()
+    idx = s2.arena.layout.gather_index('cpu').numpy()
+    for d, m in enumerate(ens2):
+        eps = O.philox_normal(s2.arena.n, 9, d)[idx]
+        np.testing.assert_allclose(flat_params(m).cpu().numpy(), eps * np.sqrt(var.cpu().numpy()) + mean.cpu().numpy(),
+                                   rtol=1e-6, atol=1e-7)
+
+
+def test_flat_sgd_equals_torch_sgd_on_gpu():
+    torch.manual_seed(0)
+    a, b = models.PreResNet(10, 8).to(DEV), models.PreResNet(10, 8).to(DEV)
+    b.load_state_dict(a.state_dict())
+    oa = inference.FlatSGD(a.parameters(), lr=0.05, momentum=0.9, weight_decay=5e-4)
+    ob = torch.optim.SGD(b.parameters(), lr=0.05, momentum=0.9, weight_decay=5e-4)
+    x = torch.randn(64, 3, 32, 32, device=DEV)
+    y = torch.randint(0, 10, (64,), device=DEV)
+    torch.backends.cudnn.deterministic = True
+    try:
+        for k in range(3):
+            for net, opt in ((a, oa), (b, ob)):
+                opt.zero_grad()
+                torch.nn.functional.cross_entropy(net(x), y).backward()
+                opt.step()
+    finally:
+        torch.backends.cudnn.deterministic = False
+    np.testing.assert_allclose(flat_params(a).cpu().numpy(), flat_params(b).cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_hmc_on_gpu_small():
+    torch.manual_seed(0)
+    train = synthetic(256, (1, 28, 28), 10, seed=0, device=DEV, batch_size=128)
+    s = inference.HMC({'step_size': 1e-4, 'num_samples': 3, 'L': 2, 'tau': 1.0, 'burn': 0, 'mass': 1.0},
+                      models.LeNet5(10).to(DEV), train, device=DEV, seed=4)
+    out = s.sample()
+    assert len(out) == 4 and s.accepted == 3 and s.x.shape[0] == 256
+    th = [flat_params(m) for m in out]
+    assert all(torch.isfinite(t).all() for t in th) and not torch.equal(th[0], th[-1])
+
+
+def test_compute_val_loss_matches_torch():
+    torch.manual_seed(0)
+    train = synthetic(256, (1, 28, 28), 10, seed=0, device=DEV, batch_size=128)
+    val = synthetic(200, (1, 28, 28), 10, seed=2, device=DEV, batch_size=64)
+    s = inference.SGLD({'lr': 0.01, 'prior_std': 1.0, 'num_samples': 1, 'alpha': 1.0, 'burn_in_epochs': 0},
+                       models.LeNet5(10).to(DEV), train, device=DEV)
+    got = s.compute_val_loss(val)
+    with torch.no_grad():
+        ref = torch.nn.functional.cross_entropy(s.model(val.dataset.x), val.dataset.y).item()
+    assert got == pytest.approx(ref, rel=1e-5)
