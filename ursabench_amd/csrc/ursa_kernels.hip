@@ -1,10 +1,17 @@
 // ursa_kernels.hip — gfx950 (MI355X / CDNA4) kernels behind include/ursa_hip.h.
 //
 // Every kernel here is HBM-bound elementwise or row-reduction work: the
-// design rules are 16-byte-per-lane coalesced access, enough independent loads in flight
-// per wave to cover HBM latency, a grid capped at a few blocks per CU with a grid-stride
-// loop, Philox noise generated in registers (zero bytes), wave64 shuffles for row
-// reductions. MFMA is deliberately unused: nothing here is GEMM-shaped.
+// design rules are 16-byte-per-lane coalesced access, Philox noise generated in registers
+// (zero bytes), wave64 shuffles for row reductions. MFMA is deliberately unused: nothing
+// here is GEMM-shaped.
+//
+// Launch shape of the streaming kernels (measured, tools/exp/k1_variants.hip, random data,
+// interleaved A/B in one process): ONE float4 per thread, 512-thread blocks, grid =
+// ceil(n4/512), no grid-stride loop. At 2^26 elements (805 MB of state) that runs the fused
+// update at 6.36 TB/s (6.61 with non-temporal accesses) against 4.76 TB/s for the textbook
+// "2048 blocks + grid-stride" shape: many short blocks keep every HBM channel busy and let
+// the dispatcher balance the 8 XCDs. Non-temporal loads/stores are used only when the state
+// exceeds ~2x the 256 MiB Infinity Cache (they cost 3-15 % on cache-resident state).
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt
 // (the rounding sequence of each update is part of the contract, see the header).
@@ -16,8 +23,38 @@
 
 namespace {
 
-constexpr int kBlock = 256;          // 4 waves: one per SIMD
-constexpr int kMaxGrid = 256 * 8;    // 256 CUs x 8 blocks/CU, grid-stride beyond that
+constexpr int kBlock = 256;          // reductions / row kernels: 4 waves, one per SIMD
+constexpr int kMaxGrid = 256 * 8;    // grid-stride kernels (reductions): 256 CUs x 8 blocks/CU
+constexpr int kSBlock = 512;         // streaming kernels: one float4 per thread
+constexpr int64_t kNtBytes = 512ll << 20;   // state larger than this streams past the Infinity Cache
+
+inline int sgrid(int64_t items)      // one item per thread
+{
+    int64_t g = (items + kSBlock - 1) / kSBlock;
+    return (int)(g < 1 ? 1 : g);
+}
+
+template <bool NT>
+__device__ __forceinline__ float4 ld4(const float4* p)
+{
+    if (NT) {
+        float4 r;
+        r.x = __builtin_nontemporal_load(&p->x); r.y = __builtin_nontemporal_load(&p->y);
+        r.z = __builtin_nontemporal_load(&p->z); r.w = __builtin_nontemporal_load(&p->w);
+        return r;
+    }
+    return *p;
+}
+template <bool NT>
+__device__ __forceinline__ void st4(float4* p, const float4& v)
+{
+    if (NT) {
+        __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y);
+        __builtin_nontemporal_store(v.z, &p->z); __builtin_nontemporal_store(v.w, &p->w);
+    } else {
+        *p = v;
+    }
+}
 
 inline int grid_for(int64_t work_items, int per_block)
 {
@@ -67,13 +104,12 @@ __device__ __forceinline__ void step_elem(float& th, float g, float& v, float e,
     v = d;                                                                // :67
 }
 
-template <bool MOM, int NOISE>
+template <bool MOM, int NOISE, bool NT>
 __device__ __forceinline__ void step_body(float* __restrict__ theta, float* __restrict__ grad,
                                           float* __restrict__ mom, const float* __restrict__ eps,
                                           float* __restrict__ snapshot, int64_t n, const StepScalars& s)
 {
     const int64_t n4 = n >> 2;
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
     const bool zero_grad = s.flags & URSA_STEP_ZERO_GRAD;
     float4* __restrict__ th4 = reinterpret_cast<float4*>(theta);
     float4* __restrict__ g4 = reinterpret_cast<float4*>(grad);
@@ -81,70 +117,72 @@ __device__ __forceinline__ void step_body(float* __restrict__ theta, float* __re
     const float4* __restrict__ e4 = reinterpret_cast<const float4*>(eps);
     float4* __restrict__ s4 = reinterpret_cast<float4*>(snapshot);
 
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += stride) {
-        float4 t = th4[i];
-        const float4 g = g4[i];
-        float4 v = MOM ? m4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t i = (int64_t)blockIdx.x * kSBlock + threadIdx.x;      // one float4 per thread
+    if (i < n4) {
+        float4 t = ld4<NT>(th4 + i);
+        const float4 g = ld4<NT>(g4 + i);
+        float4 v = MOM ? ld4<NT>(m4 + i) : make_float4(0.f, 0.f, 0.f, 0.f);
         float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (NOISE == kNoisePtr) e = e4[i];
+        if (NOISE == kNoisePtr) e = ld4<NT>(e4 + i);
         if (NOISE == kNoisePhilox) e = ursa::normal4(s.seed, s.step, (uint64_t)i);
         step_elem<MOM>(t.x, g.x, v.x, e.x, s, NOISE != kNoiseOff);
         step_elem<MOM>(t.y, g.y, v.y, e.y, s, NOISE != kNoiseOff);
         step_elem<MOM>(t.z, g.z, v.z, e.z, s, NOISE != kNoiseOff);
         step_elem<MOM>(t.w, g.w, v.w, e.w, s, NOISE != kNoiseOff);
-        th4[i] = t;
-        if (MOM) m4[i] = v;
-        if (zero_grad) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (snapshot) s4[i] = t;
+        st4<NT>(th4 + i, t);
+        if (MOM) st4<NT>(m4 + i, v);
+        if (zero_grad) st4<NT>(g4 + i, make_float4(0.f, 0.f, 0.f, 0.f));
+        if (snapshot) st4<NT>(s4 + i, t);
     }
     // scalar tail (n % 4 elements): handled by the first lanes of block 0
     const int64_t tail0 = n4 << 2;
     if (blockIdx.x == 0 && threadIdx.x < (n - tail0)) {
-        const int64_t i = tail0 + threadIdx.x;
-        float t = theta[i];
-        const float g = grad[i];
-        float v = MOM ? mom[i] : 0.f;
+        const int64_t j = tail0 + threadIdx.x;
+        float t = theta[j];
+        const float g = grad[j];
+        float v = MOM ? mom[j] : 0.f;
         float e = 0.f;
-        if (NOISE == kNoisePtr) e = eps[i];
+        if (NOISE == kNoisePtr) e = eps[j];
         if (NOISE == kNoisePhilox) {
             const float4 z = ursa::normal4(s.seed, s.step, (uint64_t)n4);
             e = threadIdx.x == 0 ? z.x : threadIdx.x == 1 ? z.y : z.z;
         }
         step_elem<MOM>(t, g, v, e, s, NOISE != kNoiseOff);
-        theta[i] = t;
-        if (MOM) mom[i] = v;
-        if (zero_grad) grad[i] = 0.f;
-        if (snapshot) snapshot[i] = t;
+        theta[j] = t;
+        if (MOM) mom[j] = v;
+        if (zero_grad) grad[j] = 0.f;
+        if (snapshot) snapshot[j] = t;
     }
 }
 
-template <bool MOM, int NOISE>
-__global__ __launch_bounds__(kBlock) void k_sgmcmc_step(float* theta, float* grad, float* mom,
-                                                        const float* eps, float* snapshot, int64_t n,
-                                                        StepScalars s)
+template <bool MOM, int NOISE, bool NT>
+__global__ __launch_bounds__(kSBlock) void k_sgmcmc_step(float* theta, float* grad, float* mom,
+                                                         const float* eps, float* snapshot, int64_t n,
+                                                         StepScalars s)
 {
-    step_body<MOM, NOISE>(theta, grad, mom, eps, snapshot, n, s);
+    step_body<MOM, NOISE, NT>(theta, grad, mom, eps, snapshot, n, s);
 }
 
 // Scalars from a device control block (graph-replayable launch). One kernel covers every
 // (mu, noise) combination with wave-uniform branches: the replayed graph must keep working
 // when the host flips NOISE between replays.
-__global__ __launch_bounds__(kBlock) void k_sgmcmc_step_ctl(float* theta, float* grad, float* mom,
-                                                            const float* eps, float* snapshot, int64_t n,
-                                                            const ursa_step_ctl* __restrict__ ctl)
+template <bool NT>
+__global__ __launch_bounds__(kSBlock) void k_sgmcmc_step_ctl(float* theta, float* grad, float* mom,
+                                                             const float* eps, float* snapshot, int64_t n,
+                                                             const ursa_step_ctl* __restrict__ ctl)
 {
     StepScalars s;
     s.lr = ctl->lr; s.mu = ctl->mu; s.c_wd = ctl->c_wd; s.c_noise = ctl->c_noise;
     s.n_train = ctl->n_train; s.flags = ctl->flags; s.seed = ctl->seed; s.step = ctl->step;
     const bool noise = s.flags & URSA_STEP_NOISE;
     if (s.mu != 0.0f) {
-        if (!noise) step_body<true, kNoiseOff>(theta, grad, mom, eps, snapshot, n, s);
-        else if (eps) step_body<true, kNoisePtr>(theta, grad, mom, eps, snapshot, n, s);
-        else step_body<true, kNoisePhilox>(theta, grad, mom, eps, snapshot, n, s);
+        if (!noise) step_body<true, kNoiseOff, NT>(theta, grad, mom, eps, snapshot, n, s);
+        else if (eps) step_body<true, kNoisePtr, NT>(theta, grad, mom, eps, snapshot, n, s);
+        else step_body<true, kNoisePhilox, NT>(theta, grad, mom, eps, snapshot, n, s);
     } else {
-        if (!noise) step_body<false, kNoiseOff>(theta, grad, mom, eps, snapshot, n, s);
-        else if (eps) step_body<false, kNoisePtr>(theta, grad, mom, eps, snapshot, n, s);
-        else step_body<false, kNoisePhilox>(theta, grad, mom, eps, snapshot, n, s);
+        if (!noise) step_body<false, kNoiseOff, NT>(theta, grad, mom, eps, snapshot, n, s);
+        else if (eps) step_body<false, kNoisePtr, NT>(theta, grad, mom, eps, snapshot, n, s);
+        else step_body<false, kNoisePhilox, NT>(theta, grad, mom, eps, snapshot, n, s);
     }
 }
 
@@ -189,21 +227,20 @@ __global__ __launch_bounds__(kBlock) void k_sgmcmc_step_scalar(float* theta, flo
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t call)
+__global__ __launch_bounds__(kSBlock) void k_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t call)
 {
     const int64_t n4 = (n + 3) >> 2;
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += stride) {
-        const float4 z = ursa::normal4(seed, call, (uint64_t)i);
-        const int64_t b = i << 2;
-        if (b + 3 < n && ((reinterpret_cast<uintptr_t>(out) & 15u) == 0)) {
-            reinterpret_cast<float4*>(out)[i] = z;
-        } else {
-            if (b < n) out[b] = z.x;
-            if (b + 1 < n) out[b + 1] = z.y;
-            if (b + 2 < n) out[b + 2] = z.z;
-            if (b + 3 < n) out[b + 3] = z.w;
-        }
+    const int64_t i = (int64_t)blockIdx.x * kSBlock + threadIdx.x;
+    if (i >= n4) return;
+    const float4 z = ursa::normal4(seed, call, (uint64_t)i);
+    const int64_t b = i << 2;
+    if (b + 3 < n && ((reinterpret_cast<uintptr_t>(out) & 15u) == 0)) {
+        reinterpret_cast<float4*>(out)[i] = z;
+    } else {
+        if (b < n) out[b] = z.x;
+        if (b + 1 < n) out[b + 1] = z.y;
+        if (b + 2 < n) out[b + 2] = z.z;
+        if (b + 3 < n) out[b + 3] = z.w;
     }
 }
 
@@ -215,31 +252,37 @@ __device__ __forceinline__ void collect_elem(float& m, float& q, float w, float 
     q = q * decay + (w * w) / denom;
 }
 
-template <bool VEC>
-__global__ __launch_bounds__(kBlock) void k_swag_collect(float* __restrict__ mean, float* __restrict__ sq,
-                                                         const float* __restrict__ w, int64_t n, float decay,
-                                                         float denom)
+template <bool NT>
+__global__ __launch_bounds__(kSBlock) void k_swag_collect_v(float* __restrict__ mean, float* __restrict__ sq,
+                                                            const float* __restrict__ w, int64_t n, float decay,
+                                                            float denom)
+{
+    const int64_t n4 = n >> 2;
+    const int64_t i = (int64_t)blockIdx.x * kSBlock + threadIdx.x;
+    if (i < n4) {
+        float4 m = ld4<NT>(reinterpret_cast<const float4*>(mean) + i);
+        float4 q = ld4<NT>(reinterpret_cast<const float4*>(sq) + i);
+        const float4 x = ld4<NT>(reinterpret_cast<const float4*>(w) + i);
+        collect_elem(m.x, q.x, x.x, decay, denom);
+        collect_elem(m.y, q.y, x.y, decay, denom);
+        collect_elem(m.z, q.z, x.z, decay, denom);
+        collect_elem(m.w, q.w, x.w, decay, denom);
+        st4<NT>(reinterpret_cast<float4*>(mean) + i, m);
+        st4<NT>(reinterpret_cast<float4*>(sq) + i, q);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t j = (n4 << 2) + threadIdx.x;
+        collect_elem(mean[j], sq[j], w[j], decay, denom);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_swag_collect_s(float* __restrict__ mean, float* __restrict__ sq,
+                                                           const float* __restrict__ w, int64_t n, float decay,
+                                                           float denom)
 {
     const int64_t stride = (int64_t)gridDim.x * kBlock;
-    const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (VEC) {
-        const int64_t n4 = n >> 2;
-        for (int64_t i = tid; i < n4; i += stride) {
-            float4 m = reinterpret_cast<float4*>(mean)[i];
-            float4 q = reinterpret_cast<float4*>(sq)[i];
-            const float4 x = reinterpret_cast<const float4*>(w)[i];
-            collect_elem(m.x, q.x, x.x, decay, denom);
-            collect_elem(m.y, q.y, x.y, decay, denom);
-            collect_elem(m.z, q.z, x.z, decay, denom);
-            collect_elem(m.w, q.w, x.w, decay, denom);
-            reinterpret_cast<float4*>(mean)[i] = m;
-            reinterpret_cast<float4*>(sq)[i] = q;
-        }
-        const int64_t i = (n4 << 2) + tid;
-        if (tid < (n & 3)) collect_elem(mean[i], sq[i], w[i], decay, denom);
-    } else {
-        for (int64_t i = tid; i < n; i += stride) collect_elem(mean[i], sq[i], w[i], decay, denom);
-    }
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
+        collect_elem(mean[i], sq[i], w[i], decay, denom);
 }
 
 // K3: diagonal SWAG draw (swa.py:106-108, swag.py:84-86)
@@ -250,51 +293,56 @@ __device__ __forceinline__ float draw_elem(float m, float q, float e, float var_
     return e * (__builtin_sqrtf(var) * scale) + m;
 }
 
-template <bool VEC, bool PHILOX>
-__global__ __launch_bounds__(kBlock) void k_swag_draw(float* __restrict__ out, const float* __restrict__ mean,
-                                                      const float* __restrict__ sq, const float* __restrict__ eps,
-                                                      int64_t n, float var_clamp, float scale, uint64_t seed,
-                                                      uint64_t draw)
+template <bool PHILOX, bool NT>
+__global__ __launch_bounds__(kSBlock) void k_swag_draw_v(float* __restrict__ out, const float* __restrict__ mean,
+                                                         const float* __restrict__ sq, const float* __restrict__ eps,
+                                                         int64_t n, float var_clamp, float scale, uint64_t seed,
+                                                         uint64_t draw)
+{
+    const int64_t n4 = n >> 2;
+    const int64_t i = (int64_t)blockIdx.x * kSBlock + threadIdx.x;
+    if (i < n4) {
+        const float4 m = ld4<NT>(reinterpret_cast<const float4*>(mean) + i);
+        const float4 q = ld4<NT>(reinterpret_cast<const float4*>(sq) + i);
+        const float4 e = PHILOX ? ursa::normal4(seed, draw, (uint64_t)i)
+                                : ld4<NT>(reinterpret_cast<const float4*>(eps) + i);
+        float4 t;
+        t.x = draw_elem(m.x, q.x, e.x, var_clamp, scale);
+        t.y = draw_elem(m.y, q.y, e.y, var_clamp, scale);
+        t.z = draw_elem(m.z, q.z, e.z, var_clamp, scale);
+        t.w = draw_elem(m.w, q.w, e.w, var_clamp, scale);
+        st4<NT>(reinterpret_cast<float4*>(out) + i, t);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t j = (n4 << 2) + threadIdx.x;
+        float e;
+        if (PHILOX) {
+            const float4 z = ursa::normal4(seed, draw, (uint64_t)n4);
+            e = threadIdx.x == 0 ? z.x : threadIdx.x == 1 ? z.y : z.z;
+        } else {
+            e = eps[j];
+        }
+        out[j] = draw_elem(mean[j], sq[j], e, var_clamp, scale);
+    }
+}
+
+template <bool PHILOX>
+__global__ __launch_bounds__(kBlock) void k_swag_draw_s(float* __restrict__ out, const float* __restrict__ mean,
+                                                        const float* __restrict__ sq, const float* __restrict__ eps,
+                                                        int64_t n, float var_clamp, float scale, uint64_t seed,
+                                                        uint64_t draw)
 {
     const int64_t stride = (int64_t)gridDim.x * kBlock;
-    const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (VEC) {
-        const int64_t n4 = n >> 2;
-        for (int64_t i = tid; i < n4; i += stride) {
-            const float4 m = reinterpret_cast<const float4*>(mean)[i];
-            const float4 q = reinterpret_cast<const float4*>(sq)[i];
-            const float4 e = PHILOX ? ursa::normal4(seed, draw, (uint64_t)i)
-                                    : reinterpret_cast<const float4*>(eps)[i];
-            float4 t;
-            t.x = draw_elem(m.x, q.x, e.x, var_clamp, scale);
-            t.y = draw_elem(m.y, q.y, e.y, var_clamp, scale);
-            t.z = draw_elem(m.z, q.z, e.z, var_clamp, scale);
-            t.w = draw_elem(m.w, q.w, e.w, var_clamp, scale);
-            reinterpret_cast<float4*>(out)[i] = t;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        float e;
+        if (PHILOX) {
+            const float4 z = ursa::normal4(seed, draw, (uint64_t)(i >> 2));
+            const int l = (int)(i & 3);
+            e = l == 0 ? z.x : l == 1 ? z.y : l == 2 ? z.z : z.w;
+        } else {
+            e = eps[i];
         }
-        if (tid < (n & 3)) {
-            const int64_t i = (n4 << 2) + tid;
-            float e;
-            if (PHILOX) {
-                const float4 z = ursa::normal4(seed, draw, (uint64_t)n4);
-                e = tid == 0 ? z.x : tid == 1 ? z.y : z.z;
-            } else {
-                e = eps[i];
-            }
-            out[i] = draw_elem(mean[i], sq[i], e, var_clamp, scale);
-        }
-    } else {
-        for (int64_t i = tid; i < n; i += stride) {
-            float e;
-            if (PHILOX) {
-                const float4 z = ursa::normal4(seed, draw, (uint64_t)(i >> 2));
-                const int l = (int)(i & 3);
-                e = l == 0 ? z.x : l == 1 ? z.y : l == 2 ? z.z : z.w;
-            } else {
-                e = eps[i];
-            }
-            out[i] = draw_elem(mean[i], sq[i], e, var_clamp, scale);
-        }
+        out[i] = draw_elem(mean[i], sq[i], e, var_clamp, scale);
     }
 }
 
@@ -443,6 +491,36 @@ __device__ __forceinline__ float block_sum(float v)
     return t;   // valid in thread 0
 }
 
+// Streaming form (no energy wanted): one float4 per thread like K1.
+__global__ __launch_bounds__(kSBlock) void k_leapfrog_v(float* __restrict__ theta, float* __restrict__ mom,
+                                                        const float* __restrict__ grad, int64_t n, float kick,
+                                                        float drift, uint32_t flags)
+{
+    const bool do_kick = flags & URSA_LEAP_KICK, do_drift = flags & URSA_LEAP_DRIFT;
+    const int64_t n4 = n >> 2;
+    const int64_t i = (int64_t)blockIdx.x * kSBlock + threadIdx.x;
+    if (i < n4) {
+        float4 p = reinterpret_cast<float4*>(mom)[i];
+        if (do_kick) {
+            const float4 g = reinterpret_cast<const float4*>(grad)[i];
+            p.x = p.x + kick * g.x; p.y = p.y + kick * g.y; p.z = p.z + kick * g.z; p.w = p.w + kick * g.w;
+            reinterpret_cast<float4*>(mom)[i] = p;
+        }
+        if (do_drift) {
+            float4 t = reinterpret_cast<float4*>(theta)[i];
+            t.x = t.x + drift * p.x; t.y = t.y + drift * p.y; t.z = t.z + drift * p.z; t.w = t.w + drift * p.w;
+            reinterpret_cast<float4*>(theta)[i] = t;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t j = (n4 << 2) + threadIdx.x;
+        float p = mom[j];
+        if (do_kick) { p = p + kick * grad[j]; mom[j] = p; }
+        if (do_drift) theta[j] = theta[j] + drift * p;
+    }
+}
+
+// Grid-stride form: also used when the kinetic energy is wanted (bounded number of block partials).
 template <bool VEC>
 __global__ __launch_bounds__(kBlock) void k_leapfrog(float* __restrict__ theta, float* __restrict__ mom,
                                                      const float* __restrict__ grad, int64_t n, float kick,
@@ -522,18 +600,26 @@ __global__ __launch_bounds__(kBlock) void k_finish_sum(const float* __restrict__
 inline int launch_status() { return (int)hipGetLastError(); }
 
 template <bool MOM>
-int launch_step(NoiseSrc ns, bool vec, int grid, hipStream_t st, float* theta, float* grad, float* mom,
+int launch_step(NoiseSrc ns, bool vec, bool nt, hipStream_t st, float* theta, float* grad, float* mom,
                 const float* eps, float* snapshot, int64_t n, const StepScalars& s)
 {
-#define URSA_LAUNCH(K) hipLaunchKernelGGL(K, dim3(grid), dim3(kBlock), 0, st, theta, grad, mom, eps, snapshot, n, s)
+#define URSA_LAUNCH(K, G, B) hipLaunchKernelGGL(K, dim3(G), dim3(B), 0, st, theta, grad, mom, eps, snapshot, n, s)
     if (vec) {
-        if (ns == kNoiseOff) URSA_LAUNCH((k_sgmcmc_step<MOM, kNoiseOff>));
-        else if (ns == kNoisePtr) URSA_LAUNCH((k_sgmcmc_step<MOM, kNoisePtr>));
-        else URSA_LAUNCH((k_sgmcmc_step<MOM, kNoisePhilox>));
+        const int grid = sgrid(n >> 2);
+        if (nt) {
+            if (ns == kNoiseOff) URSA_LAUNCH((k_sgmcmc_step<MOM, kNoiseOff, true>), grid, kSBlock);
+            else if (ns == kNoisePtr) URSA_LAUNCH((k_sgmcmc_step<MOM, kNoisePtr, true>), grid, kSBlock);
+            else URSA_LAUNCH((k_sgmcmc_step<MOM, kNoisePhilox, true>), grid, kSBlock);
+        } else {
+            if (ns == kNoiseOff) URSA_LAUNCH((k_sgmcmc_step<MOM, kNoiseOff, false>), grid, kSBlock);
+            else if (ns == kNoisePtr) URSA_LAUNCH((k_sgmcmc_step<MOM, kNoisePtr, false>), grid, kSBlock);
+            else URSA_LAUNCH((k_sgmcmc_step<MOM, kNoisePhilox, false>), grid, kSBlock);
+        }
     } else {
-        if (ns == kNoiseOff) URSA_LAUNCH((k_sgmcmc_step_scalar<MOM, kNoiseOff>));
-        else if (ns == kNoisePtr) URSA_LAUNCH((k_sgmcmc_step_scalar<MOM, kNoisePtr>));
-        else URSA_LAUNCH((k_sgmcmc_step_scalar<MOM, kNoisePhilox>));
+        const int grid = grid_for(n, kBlock);
+        if (ns == kNoiseOff) URSA_LAUNCH((k_sgmcmc_step_scalar<MOM, kNoiseOff>), grid, kBlock);
+        else if (ns == kNoisePtr) URSA_LAUNCH((k_sgmcmc_step_scalar<MOM, kNoisePtr>), grid, kBlock);
+        else URSA_LAUNCH((k_sgmcmc_step_scalar<MOM, kNoisePhilox>), grid, kBlock);
     }
 #undef URSA_LAUNCH
     return launch_status();
@@ -576,10 +662,10 @@ int ursa_sgmcmc_step_f32(float* theta, float* grad, float* mom, const float* eps
     const NoiseSrc ns = !noise ? kNoiseOff : (eps ? kNoisePtr : kNoisePhilox);
     const bool vec = aligned16(theta) && aligned16(grad) && aligned16(mom) && aligned16(eps) && aligned16(snapshot);
     const StepScalars s{lr, mu, c_wd, c_noise, n_train, flags, seed, step};
-    const int grid = vec ? grid_for(n >> 2, kBlock) : grid_for(n, kBlock);
+    const bool nt = n * (int64_t)(mu != 0.0f ? 12 : 8) > kNtBytes;       // theta + grad (+ mom) past the cache
     hipStream_t st = (hipStream_t)stream;
-    return mu != 0.0f ? launch_step<true>(ns, vec, grid, st, theta, grad, mom, eps, snapshot, n, s)
-                      : launch_step<false>(ns, vec, grid, st, theta, grad, mom, eps, snapshot, n, s);
+    return mu != 0.0f ? launch_step<true>(ns, vec, nt, st, theta, grad, mom, eps, snapshot, n, s)
+                      : launch_step<false>(ns, vec, nt, st, theta, grad, mom, eps, snapshot, n, s);
 }
 
 int ursa_sgmcmc_step_ctl_f32(float* theta, float* grad, float* mom, const float* eps, float* snapshot,
@@ -590,9 +676,13 @@ int ursa_sgmcmc_step_ctl_f32(float* theta, float* grad, float* mom, const float*
     if (!theta || !grad || !mom || !ctl) return URSA_ENULL;   // mom always required: mu lives on the device
     if (!(aligned16(theta) && aligned16(grad) && aligned16(mom) && aligned16(eps) && aligned16(snapshot)))
         return URSA_EALIGN;                                    // the replayable form is float4-only
-    const int grid = grid_for(n >> 2, kBlock);
-    hipLaunchKernelGGL(k_sgmcmc_step_ctl, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, theta, grad, mom,
-                       eps, snapshot, n, ctl);
+    const int grid = sgrid(n >> 2);
+    if (n * 12ll > kNtBytes)
+        hipLaunchKernelGGL(k_sgmcmc_step_ctl<true>, dim3(grid), dim3(kSBlock), 0, (hipStream_t)stream, theta, grad,
+                           mom, eps, snapshot, n, ctl);
+    else
+        hipLaunchKernelGGL(k_sgmcmc_step_ctl<false>, dim3(grid), dim3(kSBlock), 0, (hipStream_t)stream, theta, grad,
+                           mom, eps, snapshot, n, ctl);
     return launch_status();
 }
 
@@ -610,8 +700,8 @@ int ursa_philox_normal_f32(float* out, int64_t n, uint64_t seed, uint64_t step, 
     if (n == 0) return URSA_OK;
     if (!out) return URSA_ENULL;
     if (!aligned4(out)) return URSA_EALIGN;
-    hipLaunchKernelGGL(k_philox_normal, dim3(grid_for((n + 3) >> 2, kBlock)), dim3(kBlock), 0,
-                       (hipStream_t)stream, out, n, seed, step);
+    hipLaunchKernelGGL(k_philox_normal, dim3(sgrid((n + 3) >> 2)), dim3(kSBlock), 0, (hipStream_t)stream, out, n,
+                       seed, step);
     return launch_status();
 }
 
@@ -624,12 +714,15 @@ int ursa_swag_collect_f32(float* mean, float* sq, const float* w, int64_t n, flo
     if (!aligned4(mean) || !aligned4(sq) || !aligned4(w)) return URSA_EALIGN;
     const bool vec = aligned16(mean) && aligned16(sq) && aligned16(w);
     hipStream_t st = (hipStream_t)stream;
-    if (vec)
-        hipLaunchKernelGGL(k_swag_collect<true>, dim3(grid_for(n >> 2, kBlock)), dim3(kBlock), 0, st, mean, sq, w,
-                           n, decay, denom);
+    if (vec && n * 12ll > kNtBytes)
+        hipLaunchKernelGGL(k_swag_collect_v<true>, dim3(sgrid(n >> 2)), dim3(kSBlock), 0, st, mean, sq, w, n, decay,
+                           denom);
+    else if (vec)
+        hipLaunchKernelGGL(k_swag_collect_v<false>, dim3(sgrid(n >> 2)), dim3(kSBlock), 0, st, mean, sq, w, n, decay,
+                           denom);
     else
-        hipLaunchKernelGGL(k_swag_collect<false>, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, st, mean, sq, w, n,
-                           decay, denom);
+        hipLaunchKernelGGL(k_swag_collect_s, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, st, mean, sq, w, n, decay,
+                           denom);
     return launch_status();
 }
 
@@ -642,10 +735,12 @@ int ursa_swag_draw_f32(float* theta_out, const float* mean, const float* sq, con
     if (!aligned4(theta_out) || !aligned4(mean) || !aligned4(sq) || !aligned4(eps)) return URSA_EALIGN;
     const bool vec = aligned16(theta_out) && aligned16(mean) && aligned16(sq) && aligned16(eps);
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid(vec ? grid_for(n >> 2, kBlock) : grid_for(n, kBlock)), block(kBlock);
+    const bool nt = n * 12ll > kNtBytes;
+    const dim3 grid(vec ? sgrid(n >> 2) : grid_for(n, kBlock)), block(vec ? kSBlock : kBlock);
 #define URSA_LAUNCH(K) hipLaunchKernelGGL(K, grid, block, 0, st, theta_out, mean, sq, eps, n, var_clamp, scale, seed, draw)
-    if (vec) { if (eps) URSA_LAUNCH((k_swag_draw<true, false>)); else URSA_LAUNCH((k_swag_draw<true, true>)); }
-    else     { if (eps) URSA_LAUNCH((k_swag_draw<false, false>)); else URSA_LAUNCH((k_swag_draw<false, true>)); }
+    if (vec && nt) { if (eps) URSA_LAUNCH((k_swag_draw_v<false, true>)); else URSA_LAUNCH((k_swag_draw_v<true, true>)); }
+    else if (vec)  { if (eps) URSA_LAUNCH((k_swag_draw_v<false, false>)); else URSA_LAUNCH((k_swag_draw_v<true, false>)); }
+    else           { if (eps) URSA_LAUNCH((k_swag_draw_s<false>)); else URSA_LAUNCH((k_swag_draw_s<true>)); }
 #undef URSA_LAUNCH
     return launch_status();
 }
@@ -697,7 +792,10 @@ int ursa_leapfrog_f32(float* theta, float* mom, const float* grad, int64_t n, fl
     hipStream_t st = (hipStream_t)stream;
     float* wsp = kinetic_out ? ws : nullptr;
     const float drift = step_size * inv_mass;
-    if (vec)
+    if (vec && !kinetic_out)
+        hipLaunchKernelGGL(k_leapfrog_v, dim3(sgrid(n >> 2)), dim3(kSBlock), 0, st, theta, mom, grad, n, kick_coef,
+                           drift, flags);
+    else if (vec)
         hipLaunchKernelGGL(k_leapfrog<true>, dim3(grid), dim3(kBlock), 0, st, theta, mom, grad, n, kick_coef, drift,
                            flags, wsp);
     else
