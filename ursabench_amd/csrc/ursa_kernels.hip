@@ -355,20 +355,59 @@ __global__ __launch_bounds__(kBlock) void k_swag_draw_s(float* __restrict__ out,
 // are xor-butterflies over the G lanes (ds_swizzle/dpp, no LDS round trip). The S members
 // are walked in order with the accumulators in registers: one read-modify-write of
 // proba_sum / ent_sum / risk_sum per row per launch.
-template <int G>
-__device__ __forceinline__ float group_max(float v)
+// exp(x) for x <= 0: 2^(x*log2e) on v_exp_f32 with the product's rounding error folded back in
+// (hi/lo split of log2 e): 1-2 ulp, 6 instructions instead of ocml expf's ~15.
+__device__ __forceinline__ float exp_nonpos(float x)
 {
-#pragma unroll
-    for (int o = G >> 1; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, G));
+    const float t = x * 1.44269502162933349609375f;
+    float r = __builtin_fmaf(x, 1.44269502162933349609375f, -t);
+    r = __builtin_fmaf(x, 1.925963033500011e-08f, r);
+    const float e = __builtin_amdgcn_exp2f(t);
+    return __builtin_fmaf(e, r * 0.693147182464599609375f, e);
+}
+// ln(q) for normal q > 0 on v_log_f32 (<= 2 ulp)
+__device__ __forceinline__ float ln_pos(float q) { return __builtin_amdgcn_logf(q) * 0.693147182464599609375f; }
+
+// Lane-group reductions on the VALU only (no LDS round trip, no s_waitcnt): xor butterflies inside
+// a quad (DPP quad_perm), then row_half_mirror / row_mirror inside a 16-lane row; across rows
+// v_readlane of one lane per row. Every lane of the group ends with the same bits (the combining
+// order is a fixed tree). ds_bpermute-based __shfl_xor spent
+// 63 % of this kernel's wave-cycles in s_waitcnt (rocprofv3 SQ_WAIT_ANY, profiles/).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+struct OpMax { __device__ __forceinline__ float operator()(float a, float b) const { return fmaxf(a, b); } };
+struct OpSum { __device__ __forceinline__ float operator()(float a, float b) const { return a + b; } };
+
+template <int G, class Op>
+__device__ __forceinline__ float group_reduce(float v, Op op)
+{
+    if (G >= 2) v = op(v, dpp_mov<0xB1>(v));        // quad_perm [1,0,3,2]
+    if (G >= 4) v = op(v, dpp_mov<0x4E>(v));        // quad_perm [2,3,0,1]
+    if (G >= 8) v = op(v, dpp_mov<0x141>(v));       // row_half_mirror
+    if (G >= 16) v = op(v, dpp_mov<0x140>(v));      // row_mirror
+    // Across 16-lane rows: every lane of a row now holds its row's result, so four v_readlane pull
+    // the row results into SGPRs and two/three more ops combine them. (gfx950's v_permlane16/32_swap
+    // would do it in fewer instructions, but the builtin's second result is mis-lowered by ROCm 7.2's
+    // hipcc — both halves alias one register: tools/exp/dpp_probe.hip.)
+    if (G >= 32) {
+        const int iv = __builtin_bit_cast(int, v);
+        const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0));
+        const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+        const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32));
+        const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+        const float lo = op(r0, r1), hi = op(r2, r3);
+        if (G >= 64) v = op(lo, hi);
+        else v = (threadIdx.x & 32) ? hi : lo;
+    }
     return v;
 }
 template <int G>
-__device__ __forceinline__ float group_sum(float v)
-{
-#pragma unroll
-    for (int o = G >> 1; o > 0; o >>= 1) v = v + __shfl_xor(v, o, G);
-    return v;
-}
+__device__ __forceinline__ float group_max(float v) { return group_reduce<G>(v, OpMax()); }
+template <int G>
+__device__ __forceinline__ float group_sum(float v) { return group_reduce<G>(v, OpSum()); }
 
 template <int G, int EPL>
 __global__ __launch_bounds__(kBlock) void k_bma_accumulate(const float* __restrict__ logits,
@@ -399,63 +438,82 @@ __global__ __launch_bounds__(kBlock) void k_bma_accumulate(const float* __restri
         }
         if (row_ok && ent_sum && lane == 0) acc_e = ent_sum[b];
 
-        for (int s = 0; s < S; ++s) {
-            const float* z = logits + ((int64_t)s * B + (row_ok ? b : 0)) * C;
-            float x[EPL];
-            float mx = -INFINITY;
+        // Members are walked in order, U at a time: the U x EPL loads of a chunk are issued before any
+        // of its arithmetic, and the U softmax chains are independent so the compiler interleaves
+        // their shuffle reductions. Arithmetic per element is ~13 VALU instructions: e = exp(x - max)
+        // through v_exp_f32 with a compensated exponent (1-2 ulp), p = e / sum (one IEEE reciprocal per
+        // row instead of the reference's second exp), ln q through v_log_f32. The kernel is
+        // VALU-throughput-bound, not HBM-bound, at C <= 100.
+        constexpr int U = EPL <= 2 ? 8 : EPL <= 4 ? 4 : EPL <= 8 ? 2 : 1;
+        const int64_t row_off = (row_ok ? b : 0) * (int64_t)C;
+        for (int s0 = 0; s0 < S; s0 += U) {
+            float xs[U][EPL];
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) {
-                const int c = lane + e * G;
-                x[e] = (c < C) ? z[c] : -INFINITY;
-                mx = fmaxf(mx, x[e]);
-            }
-            mx = group_max<G>(mx);
-            float sum = 0.f;
+            for (int u = 0; u < U; ++u) {
+                const int sm = (s0 + u < S) ? s0 + u : S - 1;
+                const float* z = logits + (int64_t)sm * B * C + row_off;
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) {
-                const int c = lane + e * G;
-                x[e] = x[e] - mx;
-                sum += (c < C) ? expf(x[e]) : 0.f;
-            }
-            const float lse = logf(group_sum<G>(sum));
-            float ent = 0.f;
-            float q[EPL];
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) {
-                const int c = lane + e * G;
-                const float p = expf(x[e] - lse);
-                q[e] = p * omg + goc;
-                if (c < C) {
-                    ent += q[e] * logf(q[e]);
-                    acc_p[e] += smoothed ? q[e] : p;
-                } else {
-                    q[e] = 0.f;
+                for (int e = 0; e < EPL; ++e) {
+                    const int c = lane + e * G;
+                    const float v = z[c < C ? c : C - 1];       // unconditional load (clamped index): a guarded
+                    xs[u][e] = (c < C) ? v : -INFINITY;         // load becomes a branch and serialises the batch
                 }
             }
-            if (ent_sum) {
-                ent = group_sum<G>(ent);
-                acc_e += -ent;
+            float pu[U][EPL], qu[U][EPL], entu[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float mx = -INFINITY;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) mx = fmaxf(mx, xs[u][e]);
+                mx = group_max<G>(mx);
+                float sum = 0.f;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) {
+                    const int c = lane + e * G;
+                    pu[u][e] = (c < C) ? exp_nonpos(xs[u][e] - mx) : 0.f;
+                    sum += pu[u][e];
+                }
+                const float inv = 1.0f / group_sum<G>(sum);
+                float ent = 0.f;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) {
+                    const int c = lane + e * G;
+                    const float p = pu[u][e] * inv;
+                    const float q = p * omg + goc;
+                    pu[u][e] = p;
+                    qu[u][e] = (c < C) ? q : 0.f;
+                    ent += (c < C) ? q * ln_pos(q) : 0.f;
+                }
+                entu[u] = ent_sum ? group_sum<G>(ent) : 0.f;
             }
-            if (risk_sum) {
-                // risk[b, j] += sum_c ps[c] * cost[c, j]; ps[c] broadcast from its owner lane
-                float r[EPL];
+            // fold the chunk into the accumulators in member order (same order as the reference's `+=`)
 #pragma unroll
-                for (int e = 0; e < EPL; ++e) r[e] = 0.f;
+            for (int u = 0; u < U; ++u) {
+                const bool live = s0 + u < S;                // uniform across the wave
 #pragma unroll
-                for (int es = 0; es < EPL; ++es) {
-                    for (int src = 0; src < G; ++src) {
-                        const int c = src + es * G;
-                        if (c >= C) break;                      // uniform across the group
-                        const float pc = __shfl(q[es], src, G);
+                for (int e = 0; e < EPL; ++e) acc_p[e] += live ? (smoothed ? qu[u][e] : pu[u][e]) : 0.f;
+                acc_e += live ? -entu[u] : 0.f;
+                if (risk_sum && live) {
+                    // risk[b, j] += sum_c ps[c] * cost[c, j]; ps[c] broadcast from its owner lane
+                    float r[EPL];
 #pragma unroll
-                        for (int e = 0; e < EPL; ++e) {
-                            const int j = lane + e * G;
-                            if (j < C) r[e] += pc * cost[c * C + j];
+                    for (int e = 0; e < EPL; ++e) r[e] = 0.f;
+#pragma unroll
+                    for (int es = 0; es < EPL; ++es) {
+                        for (int src = 0; src < G; ++src) {
+                            const int c = src + es * G;
+                            if (c >= C) break;                      // uniform across the group
+                            const float pc = __shfl(qu[u][es], src, G);
+#pragma unroll
+                            for (int e = 0; e < EPL; ++e) {
+                                const int j = lane + e * G;
+                                if (j < C) r[e] += pc * cost[c * C + j];
+                            }
                         }
                     }
-                }
 #pragma unroll
-                for (int e = 0; e < EPL; ++e) acc_r[e] += r[e];
+                    for (int e = 0; e < EPL; ++e) acc_r[e] += r[e];
+                }
             }
         }
 
