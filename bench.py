@@ -46,6 +46,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=1, help='untimed posterior samples per chain')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--force-dist', action='store_true', help='join an RCCL process group even when WORLD_SIZE is 1')
     ap.add_argument('--cpu-steps', type=int, default=200, help='minibatch steps of the CPU port to time')
     ap.add_argument('--large-n', type=int, default=1 << 26, help='elements of the roofline-sized K1 launch')
     return ap.parse_args()
@@ -86,6 +87,19 @@ def event_time_ms(fn, iters, stream, graph_batch=0):
     return a.elapsed_time(b) / iters
 
 
+def pmc_traffic(elements):
+    """HBM bytes per launch of the update kernel from PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate
+    rocprofv3 --pmc passes, tools/pmc_collect.sh): PMC needs the profiler, so the figure is the committed
+    measurement in profiles/ for a launch of exactly this size, or None."""
+    path = os.path.join(ROOT, 'profiles', 'r01_k1_pmc.json')
+    if not os.path.exists(path):
+        return None
+    for v in json.load(open(path))['kernels'].values():
+        if v['elements'] == elements:
+            return v['hbm_bytes_per_launch_corrected']
+    return None
+
+
 def roofline_block(sampler, large_n):
     """Dominant kernel = the fused update (k_sgmcmc_step_ctl): identical launch to the one inside
     the timed region (same arena, same control block), timed with HIP events on the stream it is
@@ -99,8 +113,9 @@ def roofline_block(sampler, large_n):
                        graph_batch=256)
     bytes_per_launch = 24 * arena.n
     achieved = bytes_per_launch / (ms * 1e-3) / 1e9
+    traffic = pmc_traffic(arena.n)
     out = {'bound': 'hbm', 'kernel': 'k_sgmcmc_step_ctl', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS,
-           'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': None,
+           'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': traffic,
            'bytes_per_launch': bytes_per_launch, 'us_per_launch': round(ms * 1e3, 3),
            'note': 'workload-sized launch (6.6 MB of state, L2/Infinity-Cache resident, one float4 per lane): '
                    'latency-bound; us_per_launch is a 256-launch hipGraph replay / 256 and includes the '
@@ -114,7 +129,8 @@ def roofline_block(sampler, large_n):
     ach_l = 24 * n / (ms_l * 1e-3) / 1e9
     large = {'kernel': 'k_sgmcmc_step<mom,philox>', 'elements': n, 'achieved': round(ach_l, 1), 'peak': HBM_PEAK_GBPS,
              'unit': 'GB/s', 'frac': round(ach_l / HBM_PEAK_GBPS, 4), 'frac_of_measured_copy_ceiling':
-             round(ach_l / HBM_COPY_GBPS, 4), 'us_per_launch': round(ms_l * 1e3, 2), 'bytes_per_launch': 24 * n}
+             round(ach_l / HBM_COPY_GBPS, 4), 'us_per_launch': round(ms_l * 1e3, 2), 'bytes_per_launch': 24 * n,
+             'traffic': pmc_traffic(n)}
     del th, g, m
     return out, large
 
@@ -160,8 +176,10 @@ def main():
         raise SystemExit('bench.py needs a HIP device (no CPU fallback)')
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
-        dist.init_process_group('nccl', device_id=dev)        # RCCL over xGMI
+    if world > 1 or a.force_dist:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)      # RCCL over xGMI
 
     from ursabench_amd import inference, models, tasks, util
     from ursabench_amd.data import synthetic
@@ -173,8 +191,10 @@ def main():
     hyp = dict(HYP, num_samples=a.steps + a.warmup)
     sampler = inference.SGHMC(hyp, net, train, device=dev, use_graph=not a.no_graph)
 
+    use_dist = dist.is_initialized()
+
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -185,7 +205,7 @@ def main():
     ensemble = [sampler.sample_iterative() for _ in range(a.steps)]       # EXACTLY K timed steps
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
@@ -199,7 +219,7 @@ def main():
     pred.update_statistics(ensemble, output_performance=False)
     barrier()
     dt_bma = time.perf_counter() - t1
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt_bma], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt_bma = t.item()
@@ -230,7 +250,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline_block(a.cpu_steps)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

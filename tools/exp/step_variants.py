@@ -1,0 +1,68 @@
+"""What does a PreResNet-20 B=128 training step cost under hipGraph replay, and which host-side
+choices move it? (fp32, MI355X). Prints ms/step for several variants."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from ursabench_amd import models
+
+dev = torch.device('cuda')
+crit = torch.nn.CrossEntropyLoss()
+
+
+def bench(name, channels_last=False, benchmark=False, grads_none=False, no_nbt=False, flat_grad_views=False, steps=200):
+    torch.backends.cudnn.benchmark = benchmark
+    torch.manual_seed(0)
+    net = models.PreResNet(10, 20).to(dev)
+    x = torch.randn(128, 3, 32, 32, device=dev)
+    y = torch.randint(0, 10, (128,), device=dev)
+    if channels_last:
+        net = net.to(memory_format=torch.channels_last)
+        x = x.contiguous(memory_format=torch.channels_last)
+    if no_nbt:
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.num_batches_tracked = None
+    params = list(net.parameters())
+    if flat_grad_views:
+        n = sum(p.numel() for p in params)
+        flat = torch.zeros(n, device=dev)
+        off = 0
+        for p in params:
+            p.grad = flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+    net.train()
+
+    def step():
+        loss = crit(net(x), y)
+        loss.backward()
+        if grads_none:
+            for p in params:
+                p.grad = None
+        elif flat_grad_views:
+            flat.zero_()
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step()
+    for _ in range(10):
+        g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        g.replay()
+    torch.cuda.synchronize()
+    print(f'{name:55s} {(time.perf_counter() - t0) / steps * 1e3:7.3f} ms/step', flush=True)
+
+
+bench('grads accumulate into flat views (+memset)   [current]', flat_grad_views=True)
+bench('grads=None after step (no AccumulateGrad adds)', grads_none=True)
+bench('grads=None + no num_batches_tracked', grads_none=True, no_nbt=True)
+bench('grads=None + cudnn.benchmark', grads_none=True, benchmark=True)
+bench('grads=None + channels_last', grads_none=True, channels_last=True)
+bench('grads=None + channels_last + benchmark + no nbt', grads_none=True, channels_last=True, benchmark=True, no_nbt=True)

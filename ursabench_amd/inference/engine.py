@@ -44,7 +44,9 @@ class ChainEngine:
         self._static[0].copy_(x)
         self._static[1].copy_(y)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread_local: RCCL's watchdog thread (one process per GPU jobs) may touch the HIP runtime while
+        # this thread captures; only this thread's calls belong to the capture
+        with torch.cuda.graph(g, capture_error_mode='thread_local'):
             self._train_step(*self._static)
         self._graph = g
         self.stats['captures'] += 1
