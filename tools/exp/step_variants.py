@@ -9,7 +9,7 @@ dev = torch.device('cuda')
 crit = torch.nn.CrossEntropyLoss()
 
 
-def bench(name, channels_last=False, benchmark=False, grads_none=False, no_nbt=False, flat_grad_views=False, steps=200):
+def bench(name, channels_last=False, benchmark=False, grads_none=False, no_nbt=False, flat_grad_views=False, pack=None, steps=200):
     torch.backends.cudnn.benchmark = benchmark
     torch.manual_seed(0)
     net = models.PreResNet(10, 20).to(dev)
@@ -30,11 +30,25 @@ def bench(name, channels_last=False, benchmark=False, grads_none=False, no_nbt=F
         for p in params:
             p.grad = flat[off:off + p.numel()].view_as(p)
             off += p.numel()
+    if pack:
+        n = sum(p.numel() for p in params)
+        flat = torch.zeros(n, device=dev)
+        views, off = [], 0
+        for p in params:
+            views.append(flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
     net.train()
 
     def step():
         loss = crit(net(x), y)
         loss.backward()
+        if pack == 'foreach_copy':
+            torch._foreach_copy_(views, [p.grad for p in params])
+        elif pack == 'foreach_add':
+            torch._foreach_add_(views, [p.grad for p in params])
+            flat.mul_(0.0)       # stands in for the fused re-zeroing in K1
+        elif pack == 'cat':
+            torch.cat([p.grad.reshape(-1) for p in params], out=flat)
         if grads_none:
             for p in params:
                 p.grad = None
@@ -60,9 +74,8 @@ def bench(name, channels_last=False, benchmark=False, grads_none=False, no_nbt=F
     print(f'{name:55s} {(time.perf_counter() - t0) / steps * 1e3:7.3f} ms/step', flush=True)
 
 
-bench('grads accumulate into flat views (+memset)   [current]', flat_grad_views=True)
-bench('grads=None after step (no AccumulateGrad adds)', grads_none=True)
-bench('grads=None + no num_batches_tracked', grads_none=True, no_nbt=True)
-bench('grads=None + cudnn.benchmark', grads_none=True, benchmark=True)
-bench('grads=None + channels_last', grads_none=True, channels_last=True)
-bench('grads=None + channels_last + benchmark + no nbt', grads_none=True, channels_last=True, benchmark=True, no_nbt=True)
+bench('grads accumulate into flat views (+memset)   [old]', flat_grad_views=True)
+bench('grads=None (no packing at all)', grads_none=True)
+bench('grads=None + _foreach_copy_ into flat', grads_none=True, pack='foreach_copy')
+bench('grads=None + _foreach_add_ into zeroed flat', grads_none=True, pack='foreach_add')
+bench('grads=None + torch.cat(out=flat)', grads_none=True, pack='cat')

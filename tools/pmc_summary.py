@@ -20,6 +20,6 @@ for k in fetch:
     n = {68608: 273408}.get(grid, grid * 4)
     out['kernels'][k] = {'launches': nf[k], 'FETCH_SIZE_KiB': fetch[k], 'WRITE_SIZE_KiB': write.get(k),
                          'hbm_bytes_per_launch_corrected': int((2 * fetch[k] + write.get(k, 0)) * 1024),
-                         'algorithmic_bytes_per_launch': 24 * n, 'elements': n}
+                         'algorithmic_bytes_per_launch': 20 * n, 'elements': n}
 json.dump(out, open(sys.argv[3], 'w'), indent=1)
 print(json.dumps(out, indent=1))

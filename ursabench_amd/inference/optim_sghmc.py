@@ -53,6 +53,7 @@ class optimSGHMC(Optimizer):
         self._step = 0                 # Philox call index == number of updates applied so far
         self._ctl = None               # device control block (graph-replayable stepping)
         self._sched = None             # device (lr, c_noise) table for per-iteration schedules
+        self.ctl_zero_grad = True      # control-block stepping re-zeroes the flat gradient (fused)
 
     def __setstate__(self, state):
         super().__setstate__(state)
@@ -120,7 +121,8 @@ class optimSGHMC(Optimizer):
         sc = self._scalars(group, add_langevin_noise, 0)
         a.ensure_mom()
         c = _native.StepCtl(lr=sc['lr'], mu=sc['mu'], c_wd=sc['c_wd'], c_noise=sc['c_noise'], n_train=sc['n_train'],
-                            flags=sc['flags'] | _native.STEP_ZERO_GRAD, seed=self.seed, step=self._step,
+                            flags=sc['flags'] | (_native.STEP_ZERO_GRAD if self.ctl_zero_grad else 0), seed=self.seed,
+                            step=self._step,
                             sched_base=self._step)
         if sched is not None:
             c.lr, c.c_noise = float(sched[0, 0]), float(sched[0, 1])

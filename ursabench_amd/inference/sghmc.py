@@ -52,8 +52,7 @@ class _ChainSampler(_Inference):
         self.optimizer = optimSGHMC(params=self.model.parameters(), lr=lr, momentum=momentum,
                                     num_training_samples=self.dataset_size, weight_decay=weight_decay,
                                     kernels=self._kernels, arena=self.arena, seed=seed)
-        self.engine.opt = self.optimizer
-        self.engine.invalidate()
+        self.engine.set_optimizer(self.optimizer)
 
     def _snapshot(self):
         return self.bank.snapshot(self.model)

@@ -112,8 +112,7 @@ class SWA(_Inference):
         self.swag_model = reset_model(self.swag_model)
         self.optimizer = FlatSGD(params=self.model.parameters(), lr=self.lr_init, momentum=self.momentum,
                                  weight_decay=self.swag_wd, kernels=self._kernels, arena=self.arena, seed=self.seed)
-        self.engine.opt = self.optimizer
-        self.engine.invalidate()
+        self.engine.set_optimizer(self.optimizer)
 
     # -- the three SWA primitives ------------------------------------------------------------
     def _collect_model(self):
