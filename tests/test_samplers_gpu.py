@@ -219,3 +219,32 @@ def test_compute_val_loss_matches_torch():
     with torch.no_grad():
         ref = torch.nn.functional.cross_entropy(s.model(val.dataset.x), val.dataset.y).item()
     assert got == pytest.approx(ref, rel=1e-5)
+
+
+def test_bma_graph_replay_equals_eager_member_forwards():
+    """Bank-resident members are evaluated through one hipGraph-captured twin; foreign modules (here:
+    deep copies, which lose the bank handle) eagerly. Same accumulators either way."""
+    import copy
+    torch.manual_seed(0)
+    train = synthetic(512, (3, 32, 32), 10, seed=0, device=DEV, batch_size=128)
+    test = synthetic(1000, (3, 32, 32), 10, seed=1, device=DEV, batch_size=128)     # ragged last batch: 104
+    s = inference.SGHMC({'lr': 0.05, 'prior_std': 0.5, 'num_samples': 3, 'alpha': 0.5, 'burn_in_epochs': 0},
+                        models.PreResNet(10, 8).to(DEV), train, device=DEV)
+    ens = s.sample()
+    a = tasks.Prediction({'in_distribution_test': test}, 10, DEV, 'ALL')
+    a.update_statistics(ens, output_performance=False)
+    assert len(a._acc._twins) == 1 and len(next(iter(a._acc._twins.values()))['graphs']) == 2
+    foreign = []
+    for m in ens:
+        c = copy.deepcopy(m)
+        del c._ursa_bank
+        foreign.append(c)
+    b = tasks.Prediction({'in_distribution_test': test}, 10, DEV, 'ALL')
+    b.update_statistics(foreign, output_performance=False)
+    assert len(b._acc._twins) == 0
+    np.testing.assert_allclose(a.ensemble_proba.numpy(), b.ensemble_proba.numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(a.expected_data_uncertainty.numpy(), b.expected_data_uncertainty.numpy(), rtol=1e-5, atol=1e-6)
+    # the twin must not alias a member: evaluating leaves every member's weights untouched
+    w = [m._ursa_row.clone() for m in ens]
+    a.update_statistics(ens[:2], output_performance=False)
+    assert all(torch.equal(x, m._ursa_row) for x, m in zip(w, ens))

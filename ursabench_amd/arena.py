@@ -193,6 +193,7 @@ class MemberBank:
                 mod._buffers[name] = fviews[full] if full in fviews else iviews[full]
         m.train(like.training)
         m._ursa_row = row            # flat handle for hosts that want the member without the module
+        m._ursa_bank = self
         return m
 
     def snapshot(self, like):
