@@ -1,0 +1,46 @@
+"""Synthetic stand-ins for URSABench/datasets.py `loaders(...)` (datasets.py:138-261): same return
+shape — `({'train': loader, 'test': loader}, num_classes)` — with device-resident synthetic tensors of
+the named dataset's shape (there is no network on the benchmark boxes, and the hot path does not
+depend on pixel values). x ~ N(0,1) (OOD sets: shifted and scaled), y ~ U{0..C-1}."""
+import torch
+
+from .data import DeviceLoader, TensorSet
+
+# name -> (sample shape, classes, train size, test size)
+SHAPES = {
+    'MNIST': ((1, 28, 28), 10, 60000, 10000), 'FashionMNIST': ((1, 28, 28), 10, 60000, 10000),
+    'KMNIST': ((1, 28, 28), 10, 60000, 10000), 'CIFAR10': ((3, 32, 32), 10, 50000, 10000),
+    'CIFAR100': ((3, 32, 32), 100, 50000, 10000), 'SVHN': ((3, 32, 32), 10, 73257, 10000),   # test cut to 10k: datasets.py:76-77
+    'STL10': ((3, 32, 32), 10, 5000, 8000),
+}
+
+
+def _named_dataset_cls(name):
+    # tasks.Decision picks its cost matrix from the dataset class NAME (decision_making.py:90-97 uses
+    # torchvision class identity)
+    return type(name, (TensorSet,), {})
+
+
+def loaders(dataset, path=None, batch_size=128, num_workers=0, transform_train=None, transform_test=None,
+            use_validation=False, val_size=0.2, split_classes=None, shuffle_train=True, imbalance=False,
+            device='cuda', train_size=None, test_size=None, seed=0, **kwargs):
+    if dataset not in SHAPES:
+        raise NotImplementedError(dataset)
+    shape, classes, n_train, n_test = SHAPES[dataset]
+    n_train, n_test = train_size or n_train, test_size or n_test
+    cls = _named_dataset_cls(dataset)
+    ood = dataset in ('FashionMNIST', 'KMNIST', 'SVHN', 'STL10')
+    out = {}
+    for split, n, s in (('train', n_train, seed), ('test', n_test, seed + 1)):
+        g = torch.Generator().manual_seed(s + (1000 if ood else 0))
+        x = torch.randn((n,) + shape, generator=g)
+        if ood:
+            x = x * 2.0 + 0.5
+        y = torch.randint(0, classes, (n,), generator=g)
+        if split == 'train' and use_validation:
+            n_val = int(n * val_size)
+            out['train'] = DeviceLoader(x[:-n_val].to(device), y[:-n_val].to(device), batch_size, shuffle_train, s, cls)
+            out['test'] = DeviceLoader(x[-n_val:].to(device), y[-n_val:].to(device), batch_size, False, s, cls)
+            return out, classes
+        out[split] = DeviceLoader(x.to(device), y.to(device), batch_size, shuffle_train and split == 'train', s, cls)
+    return out, classes

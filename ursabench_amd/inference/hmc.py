@@ -25,7 +25,7 @@ from .inference_base import _Inference
 
 class HMC(_Inference):
     def __init__(self, hyperparameters, model=None, train_loader=None, model_loss='multi_class_linear_output',
-                 device=torch.device('cpu'), *, kernels=None, seed=None):
+                 device=torch.device('cpu'), *, kernels=None, seed=None, use_graph=None):
         super().__init__(hyperparameters, model, train_loader, device)
         if hyperparameters == None:  # noqa: E711  (hmc.py:32-34)
             hyperparameters = {'step_size': 0.001, 'num_samples': 10, 'L': 1, 'tau': 0.1, 'burn': -1, 'mass': 1.0}
@@ -42,6 +42,8 @@ class HMC(_Inference):
         self.kernels = kernels if kernels is not None else _native.default_kernels()
         self.seed = int(torch.initial_seed() if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
         self.arena = None
+        self.use_graph = (torch.device(device).type == 'cuda') if use_graph is None else use_graph
+        self._graph, self._evals, self._u = None, 0, None
         self._proposals = 0
         self.accepted = 0
 
@@ -56,6 +58,7 @@ class HMC(_Inference):
     def update_hyp(self, hyperparameters):
         self._read_hyp(hyperparameters)
         self.model = reset_model(self.model)
+        self._graph, self._evals = None, 0          # tau is baked into the captured graph
 
     # ---- pieces --------------------------------------------------------------------------------
     def _bind(self):
@@ -71,8 +74,8 @@ class HMC(_Inference):
             self._acc = torch.zeros(1, device=dev)
             self._crit = torch.nn.CrossEntropyLoss(reduction='sum')
 
-    def _neg_logp_and_grad(self):
-        """U(theta) = sum CE + tau/2 ||theta||^2 (device scalar) and grad log p in self._glogp."""
+    def _eval_potential(self):
+        """U(theta) = sum CE + tau/2 ||theta||^2 into self._u and grad log p into self._glogp."""
         a = self.arena
         a.grad.zero_()
         nll = self._crit(self.model(self.x), self.y.long().view(-1))
@@ -82,7 +85,31 @@ class HMC(_Inference):
             self._glogp.neg_()
             self._acc.zero_()
             self.kernels.sumsq(a.theta, self._acc, self._ws)
-            return nll.detach() + 0.5 * self.tau * self._acc[0]
+            self._u.copy_(nll.detach() + 0.5 * self.tau * self._acc[0])
+
+    def _neg_logp_and_grad(self):
+        """One full-batch forward/backward + prior. The inputs never change (hmc.py:44-50 holds the whole
+        training set on the device), so after two eager evaluations the whole thing — ~3,000 launches for
+        PreResNet-164 — is captured once into a hipGraph and replayed for every leapfrog step."""
+        if self._u is None:
+            self._u = torch.zeros((), device=self.arena.device)
+        if self.use_graph and self._graph is None and self._evals >= 2:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                self._eval_potential()
+            self._graph = g
+        if self._graph is not None:
+            self._graph.replay()
+        elif self.use_graph:
+            side = torch.cuda.Stream(self.arena.device)
+            side.wait_stream(torch.cuda.current_stream(self.arena.device))
+            with torch.cuda.stream(side):
+                self._eval_potential()
+            torch.cuda.current_stream(self.arena.device).wait_stream(side)
+        else:
+            self._eval_potential()
+        self._evals += 1
+        return self._u.clone()
 
     def _kinetic(self):
         self._acc.zero_()

@@ -25,6 +25,17 @@ def set_random_seed(seed=None):
         torch.cuda.manual_seed(seed)
 
 
+def silent(fn):
+    """util.py:40-50 — run fn with stdout discarded (the timing harness silences the samplers' prints)."""
+    import contextlib
+    import io
+
+    def silent_fn(*args, **kwargs):
+        with contextlib.redirect_stdout(io.StringIO()):
+            return fn(*args, **kwargs)
+    return silent_fn
+
+
 def get_loss_criterion(loss='multi_class_linear_output', **kwargs):
     """util.py:80-89 — mean-reduced cross entropy is the only supported likelihood."""
     if loss != 'multi_class_linear_output':
