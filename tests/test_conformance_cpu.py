@@ -1,0 +1,67 @@
+"""CPU: call sequences of the reference's callers against our classes (oracle kernel set):
+hyper-optimisation (`_HypOpt.inference_step`, URSABench/hyperopt/hyper_optimization.py:51-73), the SGD
+baseline sampler, member-bank checkpoints."""
+import numpy as np
+import pytest
+import torch
+
+import ursabench_amd.inference as inference
+from ursabench_amd import checkpoint, tasks
+from oracle_kernels import OracleKernels
+from test_samplers_cpu import tiny_loader, tiny_net
+
+
+def test_hyperopt_call_sequence():
+    """update_hyp -> reset -> sample -> update_statistics(output_performance=True) returns a float, twice,
+    with the sampler restarting from a re-initialised model each time."""
+    K = OracleKernels()
+    hyp = {'lr': 0.05, 'prior_std': 1.0, 'num_samples': 2, 'alpha': 0.5, 'burn_in_epochs': 1}
+    sampler = inference.SGHMC(dict(hyp), tiny_net(), tiny_loader(), kernels=K, use_graph=False)
+    obj = tasks.Prediction({'in_distribution_test': tiny_loader(seed=3)}, 4, torch.device('cpu'), ['nll'], kernels=K)
+    vals = []
+    for lr in (0.05, 0.01):
+        sampler.update_hyp(dict(hyp, lr=lr))
+        obj.reset()
+        samples = sampler.sample()
+        v = obj.update_statistics(samples, output_performance=True)
+        assert isinstance(v, float) and np.isfinite(v) and obj.num_samples_collected == 2
+        vals.append(v)
+    assert vals[0] != vals[1]
+    for name in ('SGLD', 'SGHMC', 'cSGLD', 'cSGHMC', 'SWA', 'SWAG', 'HMC', 'SGD', 'MCdropout', 'optimSGHMC'):
+        assert hasattr(inference, name)
+    with pytest.raises(NotImplementedError):
+        inference.MCdropout(None)
+
+
+def test_sgd_baseline_sampler():
+    K = OracleKernels()
+    s = inference.SGD({'lr': 0.1, 'epochs': 2, 'momentum': 0.9, 'weight_decay': 1e-3}, tiny_net(), tiny_loader(),
+                      kernels=K, use_graph=False)
+    out = s.sample(num_samples=2)
+    assert out[0] is out[1] is s.model and len(K.step_log) == 3 * 2      # epochs+1 epochs once, then nothing
+    assert all(f & 16 for _, _, f, _ in K.step_log)                       # SGD mode, no Langevin noise
+    assert s.optimizer.param_groups[0]['lr'] == pytest.approx(0.1 / 100)  # cosine to eta_min = lr/100
+
+
+def test_member_bank_checkpoint_roundtrip(tmp_path):
+    K = OracleKernels()
+    net = torch.nn.Sequential(torch.nn.Linear(12, 8), torch.nn.BatchNorm1d(8), torch.nn.ReLU(), torch.nn.Linear(8, 4))
+    s = inference.SGHMC({'lr': 0.05, 'prior_std': 1.0, 'num_samples': 3, 'alpha': 0.5, 'burn_in_epochs': 0}, net,
+                        tiny_loader(), kernels=K, use_graph=False)
+    ens = s.sample()
+    p = str(tmp_path / 'ens.pt')
+    checkpoint.save_ensemble(ens, p)
+    back = checkpoint.load_ensemble(p, net)
+    assert len(back) == 3
+    x = torch.randn(5, 12)
+    for a, b in zip(ens, back):
+        a.eval(); b.eval()
+        assert torch.equal(a(x), b(x))
+        assert all(torch.equal(u, v) for u, v in zip(a.state_dict().values(), b.state_dict().values()))
+    sds = checkpoint.to_state_dicts(ens)
+    fresh = torch.nn.Sequential(torch.nn.Linear(12, 8), torch.nn.BatchNorm1d(8), torch.nn.ReLU(), torch.nn.Linear(8, 4))
+    fresh.load_state_dict(sds[1])
+    fresh.eval()
+    assert torch.equal(fresh(x), ens[1](x))
+    with pytest.raises(ValueError):
+        checkpoint.save_ensemble([net], p)

@@ -7,3 +7,4 @@ from .csghmc import cSGHMC, cSGLD  # noqa: F401
 from .flat_sgd import FlatSGD  # noqa: F401
 from .swag import SWA, SWAG  # noqa: F401
 from .hmc import HMC  # noqa: F401
+from .sgd import SGD, MCdropout  # noqa: F401
