@@ -64,6 +64,12 @@ inline int grid_for(int64_t work_items, int per_block)
     return (int)g;
 }
 
+inline int bma_grid(int64_t rows, int rows_per_block)      // one block per row tile, no cap below 2^20 blocks
+{
+    int64_t g = (rows + rows_per_block - 1) / rows_per_block;
+    return (int)(g < 1 ? 1 : g > (1 << 20) ? (1 << 20) : g);
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline bool aligned4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
 
@@ -417,40 +423,43 @@ __global__ __launch_bounds__(kBlock) void k_bma_accumulate(const float* __restri
                                                            const float* __restrict__ cost, int S, int64_t B,
                                                            int C, float omg, float goc, uint32_t flags)
 {
-    constexpr int kGroups = kBlock / G;
-    const int lane = threadIdx.x % G;
-    const int grp = threadIdx.x / G;
+    // A block owns 64/G rows. Its 4 waves split the S members into 4 contiguous ranges (4x the
+    // parallelism of one-wave-per-row: B = 10^4 rows are only 2,500 waves otherwise, 2.4 per SIMD), each
+    // wave sums its range in member order in registers, and wave 0 folds the partial sums in wave order
+    // into the global accumulators: ((acc + P0) + P1) + P2) + P3 — a fixed, reproducible order.
+    constexpr int kRows = 64 / G;
+    constexpr int kWaves = kBlock / 64;
+    constexpr int kVals = 2 * EPL + 1;                       // proba[EPL], risk[EPL], entropy
+    __shared__ float part[kWaves - 1][kVals][64];
+    const int wave = threadIdx.x >> 6, wl = threadIdx.x & 63;
+    const int lane = wl % G, grp = wl / G;
     const bool smoothed = flags & URSA_BMA_SMOOTHED;
-    const int64_t row_stride = (int64_t)gridDim.x * kGroups;
-    const int64_t nrounds = (B + row_stride - 1) / row_stride;   // same trip count for all lanes (shuffles)
+    const int s_per = (S + kWaves - 1) / kWaves;
+    const int s_lo = wave * s_per < S ? wave * s_per : S;
+    const int s_hi = s_lo + s_per < S ? s_lo + s_per : S;
+    const int64_t row_stride = (int64_t)gridDim.x * kRows;
+    const int64_t nrounds = (B + row_stride - 1) / row_stride;   // same trip count for every wave (barriers)
 
     for (int64_t it = 0; it < nrounds; ++it) {
-        const int64_t b = it * row_stride + (int64_t)blockIdx.x * kGroups + grp;
+        const int64_t b = it * row_stride + (int64_t)blockIdx.x * kRows + grp;
         const bool row_ok = b < B;
         float acc_p[EPL], acc_r[EPL];
         float acc_e = 0.f;
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            const int c = lane + e * G;
-            const bool ok = row_ok && c < C;
-            acc_p[e] = ok ? proba_sum[b * C + c] : 0.f;
-            acc_r[e] = (ok && risk_sum) ? risk_sum[b * C + c] : 0.f;
-        }
-        if (row_ok && ent_sum && lane == 0) acc_e = ent_sum[b];
+        for (int e = 0; e < EPL; ++e) acc_p[e] = acc_r[e] = 0.f;
 
-        // Members are walked in order, U at a time: the U x EPL loads of a chunk are issued before any
-        // of its arithmetic, and the U softmax chains are independent so the compiler interleaves
-        // their shuffle reductions. Arithmetic per element is ~13 VALU instructions: e = exp(x - max)
-        // through v_exp_f32 with a compensated exponent (1-2 ulp), p = e / sum (one IEEE reciprocal per
-        // row instead of the reference's second exp), ln q through v_log_f32. The kernel is
-        // VALU-throughput-bound, not HBM-bound, at C <= 100.
-        constexpr int U = EPL <= 2 ? 8 : EPL <= 4 ? 4 : EPL <= 8 ? 2 : 1;
+        // Members are walked in order, U at a time: the U x EPL loads of a chunk are issued before any of
+        // its arithmetic, and the U softmax chains are independent so the compiler interleaves their
+        // reductions. Arithmetic per element is ~13 VALU instructions: e = exp(x - max) through v_exp_f32
+        // with a compensated exponent (1-2 ulp), p = e / sum (one IEEE reciprocal per row instead of the
+        // reference's second exp), ln q through v_log_f32.
+        constexpr int U = EPL <= 2 ? 8 : EPL <= 4 ? 4 : EPL <= 8 ? 2 : 1;     // U * EPL <= 16 logits in flight per lane
         const int64_t row_off = (row_ok ? b : 0) * (int64_t)C;
-        for (int s0 = 0; s0 < S; s0 += U) {
+        for (int s0 = s_lo; s0 < s_hi; s0 += U) {
             float xs[U][EPL];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int sm = (s0 + u < S) ? s0 + u : S - 1;
+                const int sm = (s0 + u < s_hi) ? s0 + u : s_hi - 1;
                 const float* z = logits + (int64_t)sm * B * C + row_off;
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) {
@@ -486,10 +495,10 @@ __global__ __launch_bounds__(kBlock) void k_bma_accumulate(const float* __restri
                 }
                 entu[u] = ent_sum ? group_sum<G>(ent) : 0.f;
             }
-            // fold the chunk into the accumulators in member order (same order as the reference's `+=`)
+            // fold the chunk into this wave's partial sums in member order
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const bool live = s0 + u < S;                // uniform across the wave
+                const bool live = s0 + u < s_hi;             // uniform across the wave
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) acc_p[e] += live ? (smoothed ? qu[u][e] : pu[u][e]) : 0.f;
                 acc_e += live ? -entu[u] : 0.f;
@@ -517,15 +526,40 @@ __global__ __launch_bounds__(kBlock) void k_bma_accumulate(const float* __restri
             }
         }
 
+        if (wave > 0) {
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            const int c = lane + e * G;
-            if (row_ok && c < C) {
-                proba_sum[b * C + c] = acc_p[e];
-                if (risk_sum) risk_sum[b * C + c] = acc_r[e];
+            for (int e = 0; e < EPL; ++e) {
+                part[wave - 1][e][wl] = acc_p[e];
+                part[wave - 1][EPL + e][wl] = acc_r[e];
+            }
+            part[wave - 1][2 * EPL][wl] = acc_e;
+        }
+        __syncthreads();
+        if (wave == 0 && row_ok) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                const int c = lane + e * G;
+                if (c < C) {
+                    float p = proba_sum[b * C + c] + acc_p[e];
+#pragma unroll
+                    for (int w = 0; w < kWaves - 1; ++w) p += part[w][e][wl];
+                    proba_sum[b * C + c] = p;
+                    if (risk_sum) {
+                        float r = risk_sum[b * C + c] + acc_r[e];
+#pragma unroll
+                        for (int w = 0; w < kWaves - 1; ++w) r += part[w][EPL + e][wl];
+                        risk_sum[b * C + c] = r;
+                    }
+                }
+            }
+            if (ent_sum && lane == 0) {
+                float en = ent_sum[b] + acc_e;
+#pragma unroll
+                for (int w = 0; w < kWaves - 1; ++w) en += part[w][2 * EPL][wl];
+                ent_sum[b] = en;
             }
         }
-        if (row_ok && ent_sum && lane == 0) ent_sum[b] = acc_e;
+        __syncthreads();
     }
 }
 
@@ -817,15 +851,19 @@ int ursa_bma_accumulate_f32(const float* logits, float* proba_sum, float* ent_su
         return URSA_EALIGN;
     hipStream_t st = (hipStream_t)stream;
 #define URSA_LAUNCH(G, EPL)                                                                                   \
-    hipLaunchKernelGGL((k_bma_accumulate<G, EPL>), dim3(grid_for(B, kBlock / G)), dim3(kBlock), 0, st, logits, \
+    hipLaunchKernelGGL((k_bma_accumulate<G, EPL>), dim3(bma_grid(B, 64 / G)), dim3(kBlock), 0, st, logits, \
                        proba_sum, ent_sum, risk_sum, cost, (int)S, B, (int)C, one_minus_gamma, gamma_over_c, flags)
+    // Rows are owned by 16-lane groups whenever C <= 256: the three row reductions are then pure DPP
+    // (no cross-row step) and one DPP instruction serves the 4 rows of the wave at once; more classes per
+    // lane also means more independent exp/log work per lane. Measured at S=30, B=1e4, C=100:
+    // <64 lanes, 2 per lane> 103 us, <16 lanes, 8 per lane> see DESIGN.md.
     if (C <= 4) URSA_LAUNCH(4, 1);
     else if (C <= 8) URSA_LAUNCH(8, 1);
     else if (C <= 16) URSA_LAUNCH(16, 1);
-    else if (C <= 32) URSA_LAUNCH(32, 1);
-    else if (C <= 64) URSA_LAUNCH(64, 1);
-    else if (C <= 128) URSA_LAUNCH(64, 2);
-    else if (C <= 256) URSA_LAUNCH(64, 4);
+    else if (C <= 32) URSA_LAUNCH(16, 2);
+    else if (C <= 64) URSA_LAUNCH(16, 4);
+    else if (C <= 128) URSA_LAUNCH(16, 8);
+    else if (C <= 256) URSA_LAUNCH(16, 16);
     else if (C <= 512) URSA_LAUNCH(64, 8);
     else URSA_LAUNCH(64, 16);
 #undef URSA_LAUNCH
