@@ -51,7 +51,14 @@ class ChainEngine:
         for p in self._params:
             p.grad = None
         loss.backward()
-        torch._foreach_copy_(self._grad_views, [p.grad for p in self._params])
+        grads = [p.grad for p in self._params]
+        if any(g is None for g in grads):
+            # a parameter that received no gradient keeps a zero slot (the reference skips such tensors
+            # altogether, optim_sghmc.py:44-45; here they still see prior + noise)
+            pairs = [(v, g) for v, g in zip(self._grad_views, grads) if g is not None]
+            torch._foreach_copy_([v for v, _ in pairs], [g for _, g in pairs])
+        else:
+            torch._foreach_copy_(self._grad_views, grads)
         for p in self._params:
             p.grad = None
         self.loss_acc += loss.detach() * x.shape[0]
