@@ -55,6 +55,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--force-dist', action='store_true', help='join an RCCL process group even when WORLD_SIZE is 1')
     ap.add_argument('--cpu-steps', type=int, default=200, help='minibatch steps of the CPU port to time')
+    ap.add_argument('--ref-style-steps', type=int, default=150, help='eager reference-style GPU steps to time (0: skip)')
     ap.add_argument('--large-n', type=int, default=1 << 26, help='elements of the roofline-sized K1 launch')
     return ap.parse_args()
 
@@ -172,6 +173,65 @@ def cpu_baseline_block(steps):
             'ms_per_minibatch_step': round(1e3 * secs / n, 2)}
 
 
+def reference_style_gpu_block(steps, dev):
+    """Informational: the REFERENCE'S execution pattern on this same GPU (stock torch ops only, written out
+    here — not the product, not the oracle): eager forward/backward, per-parameter-tensor update with 8 small
+    ops each (optim_sghmc.py:43-67), `loss.item()` every step (sghmc.py:82) and a `deepcopy(model.cpu())`
+    per sample (sghmc.py:99). Extrapolated to posterior-samples/s like the CPU baseline."""
+    import copy
+    import math
+    from ursabench_amd import models
+    torch.manual_seed(0)
+    net = models.PreResNet(CLASSES, 20).to(dev)
+    crit = torch.nn.CrossEntropyLoss()
+    params = list(net.parameters())
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(8 * BATCH, 3, 32, 32, generator=g).to(dev)
+    y = torch.randint(0, CLASSES, (8 * BATCH,), generator=g).to(dev)
+    lr, mu, wd = HYP['lr'], 1 - HYP['alpha'], 1 / HYP['prior_std'] ** 2
+    state = {}
+
+    def step(k):
+        i = (k % 8) * BATCH
+        logits = net(x[i:i + BATCH])
+        for p in params:
+            p.grad = None
+        loss = crit(logits, y[i:i + BATCH])
+        loss.backward()
+        total = loss.item() * BATCH
+        with torch.no_grad():
+            for p in params:
+                d_p = p.grad.add(p, alpha=wd / N_TRAIN)
+                buf = state.get(p)
+                if buf is None:
+                    buf = torch.clone(d_p).detach()
+                buf.mul_(mu).add_(d_p, alpha=-lr)
+                d_p = buf.add(torch.randn_like(buf) * math.sqrt(2 * (1 - mu) * lr) / N_TRAIN)
+                p.add_(d_p)
+                state[p] = d_p
+        return total
+
+    net.train()
+    for k in range(10):
+        step(k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(k)
+    torch.cuda.synchronize()
+    t_step = (time.perf_counter() - t0) / steps
+    t0 = time.perf_counter()
+    snap = copy.deepcopy(net.cpu())
+    net.to(dev)
+    torch.cuda.synchronize()
+    t_snap = time.perf_counter() - t0
+    del snap
+    per_sample = ((N_TRAIN + BATCH - 1) // BATCH) * t_step + t_snap
+    return {'value': round(1.0 / per_sample, 4), 'unit': 'posterior-samples/s', 'kind': 'reference-style eager loop, same GPU',
+            'ms_per_minibatch_step': round(1e3 * t_step, 3), 'ms_snapshot_via_cpu': round(1e3 * t_snap, 2),
+            'sample': f'{steps} eager minibatch steps, extrapolated'}
+
+
 def main():
     a = parse()
     rank = int(os.environ.get('RANK', 0))
@@ -254,6 +314,8 @@ def main():
             'engine': sampler.engine.stats,
             'roofline': roof, 'roofline_large': roof_large,
         }
+        if world == 1 and a.ref_style_steps > 0:
+            line['reference_style_gpu'] = reference_style_gpu_block(a.ref_style_steps, dev)
         if world == 1 and not a.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline_block(a.cpu_steps)
         print(json.dumps(line), flush=True)

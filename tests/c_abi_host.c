@@ -1,0 +1,77 @@
+/* A plain-C host for the C ABI (include/ursa_hip.h): no Python, no torch. Allocates with the HIP
+ * runtime, runs the fused update (Philox noise, momentum, weight decay, fused grad zeroing) and the
+ * BMA reduction through libursa_hip.so and checks them against the CPU oracle (liboracle.so).
+ * Built and run by tests/test_c_abi_host.py on the GPU box:
+ *   gcc -D__HIP_PLATFORM_AMD__ tests/c_abi_host.c -Iinclude -I/opt/rocm/include -Lursabench_amd/csrc -lursa_hip
+ *       -Loracle -loracle -L/opt/rocm/lib -lamdhip64 -lm
+ */
+#include <hip/hip_runtime_api.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "ursa_hip.h"
+
+int oracle_sgmcmc_step_f32(float*, float*, float*, const float*, float*, int64_t, float, float, float, float, float,
+                           uint64_t, uint64_t, uint32_t);
+int oracle_bma_accumulate_f32(const float*, float*, float*, float*, const float*, int32_t, int64_t, int32_t, float,
+                              float, uint32_t);
+
+#define CHECK(x) do { int rc_ = (x); if (rc_) { printf("FAIL %s -> %d (%s)\n", #x, rc_, ursa_strerror(rc_)); return 1; } } while (0)
+
+static float frand(unsigned* s) { *s = *s * 1664525u + 1013904223u; return ((*s >> 8) / 8388608.0f) - 1.0f; }
+
+int main(void)
+{
+    if (ursa_abi_version() != URSA_ABI_VERSION) { printf("FAIL abi version\n"); return 1; }
+    const int64_t n = 61706 + 3;                 /* not a multiple of 4: exercises the scalar tail */
+    const size_t bytes = (size_t)n * sizeof(float);
+    float *th = malloc(bytes), *gr = malloc(bytes), *mo = malloc(bytes), *back = malloc(bytes);
+    unsigned seed = 12345u;
+    for (int64_t i = 0; i < n; ++i) { th[i] = frand(&seed); gr[i] = 3.0f * frand(&seed); mo[i] = 0.1f * frand(&seed); }
+    float *dth, *dgr, *dmo;
+    CHECK(hipMalloc((void**)&dth, bytes)); CHECK(hipMalloc((void**)&dgr, bytes)); CHECK(hipMalloc((void**)&dmo, bytes));
+    CHECK(hipMemcpy(dth, th, bytes, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(dgr, gr, bytes, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(dmo, mo, bytes, hipMemcpyHostToDevice));
+    hipStream_t st;
+    CHECK(hipStreamCreate(&st));
+    const uint32_t flags = URSA_STEP_NOISE | URSA_STEP_WD | URSA_STEP_ZERO_GRAD;
+    for (int k = 0; k < 3; ++k) {                /* three steps: device vs oracle trajectories must stay bit-equal */
+        CHECK(ursa_sgmcmc_step_f32(dth, dgr, dmo, NULL, NULL, n, 0.05f, 0.9f, 4.0f / 50000.0f, 0.1f, 50000.0f, 77u,
+                                   (uint64_t)k, flags, st));
+        oracle_sgmcmc_step_f32(th, gr, mo, NULL, NULL, n, 0.05f, 0.9f, 4.0f / 50000.0f, 0.1f, 50000.0f, 77u, (uint64_t)k,
+                               flags);
+        for (int64_t i = 0; i < n; ++i) gr[i] = frand(&seed);
+        CHECK(hipStreamSynchronize(st));
+        CHECK(hipMemcpy(dgr, gr, bytes, hipMemcpyHostToDevice));
+    }
+    CHECK(hipMemcpy(back, dth, bytes, hipMemcpyDeviceToHost));
+    if (memcmp(back, th, bytes)) { printf("FAIL theta differs from the oracle\n"); return 1; }
+    CHECK(hipMemcpy(back, dmo, bytes, hipMemcpyDeviceToHost));
+    if (memcmp(back, mo, bytes)) { printf("FAIL momentum differs from the oracle\n"); return 1; }
+
+    /* BMA reduction: S=5 members, B=777 rows, C=10 classes */
+    const int S = 5, C = 10; const int64_t B = 777;
+    const size_t zb = (size_t)S * B * C * sizeof(float), pb = (size_t)B * C * sizeof(float), eb = (size_t)B * sizeof(float);
+    float *z = malloc(zb), *p = calloc(B * C, sizeof(float)), *e = calloc(B, sizeof(float)), *pd = malloc(pb), *ed = malloc(eb);
+    for (size_t i = 0; i < (size_t)S * B * C; ++i) z[i] = 4.0f * frand(&seed);
+    float *dz, *dp, *de;
+    CHECK(hipMalloc((void**)&dz, zb)); CHECK(hipMalloc((void**)&dp, pb)); CHECK(hipMalloc((void**)&de, eb));
+    CHECK(hipMemcpy(dz, z, zb, hipMemcpyHostToDevice)); CHECK(hipMemset(dp, 0, pb)); CHECK(hipMemset(de, 0, eb));
+    const float omg = (float)(1 - 1e-4), goc = (float)(1e-4 / C);
+    CHECK(ursa_bma_accumulate_f32(dz, dp, de, NULL, NULL, S, B, C, omg, goc, 0, st));
+    CHECK(hipStreamSynchronize(st));
+    oracle_bma_accumulate_f32(z, p, e, NULL, NULL, S, B, C, omg, goc, 0);
+    CHECK(hipMemcpy(pd, dp, pb, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(ed, de, eb, hipMemcpyDeviceToHost));
+    double worst = 0;
+    for (int64_t i = 0; i < B * C; ++i) { double r = fabs(pd[i] - p[i]) / (fabs(p[i]) + 1e-8); if (r > worst) worst = r; }
+    for (int64_t i = 0; i < B; ++i) { double r = fabs(ed[i] - e[i]) / (fabs(e[i]) + 1e-6); if (r > worst) worst = r; }
+    if (worst > 1e-5) { printf("FAIL bma relative error %g\n", worst); return 1; }
+    /* argument errors come back as codes, not crashes */
+    if (ursa_sgmcmc_step_f32(NULL, NULL, NULL, NULL, NULL, 8, 0, 0, 0, 0, 1, 0, 0, 0, st) != URSA_ENULL) { printf("FAIL enull\n"); return 1; }
+    if (ursa_bma_accumulate_f32(dz, dp, de, NULL, NULL, S, B, 5000, omg, goc, 0, st) != URSA_EVALUE) { printf("FAIL evalue\n"); return 1; }
+    printf("C-ABI host OK: K1 bit-equal to the oracle over 3 steps (n=%lld), K5 max relative error %.2e\n", (long long)n, worst);
+    return 0;
+}
