@@ -166,8 +166,21 @@ def cpu_baseline_block(steps):
     port.sghmc_epoch(net, batches[:3], state, **kw)                       # warm up
     n, secs = port.sghmc_epoch(net, batches[3:], state, **kw)
     steps_per_sample = (N_TRAIN + BATCH - 1) // BATCH
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)                                              # the scalar figure, on a few steps
+    n1, secs1 = port.sghmc_epoch(net, batches[3:3 + max(4, steps // 20)], state, **kw)
+    torch.set_num_threads(threads)
+    cpu_model = 'unknown'
+    try:
+        for ln in open('/proc/cpuinfo'):
+            if ln.startswith('model name'):
+                cpu_model = ln.split(':', 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {'value': round(1.0 / (steps_per_sample * secs / n), 5), 'unit': 'posterior-samples/s',
-            'cores': torch.get_num_threads(), 'kind': 'port',
+            'cores': threads, 'kind': 'port', 'cpu_model': cpu_model, 'logical_cpus': os.cpu_count(),
+            'value_1_thread': round(1.0 / (steps_per_sample * secs1 / n1), 5),
             'sample': f'{n} minibatch steps (B={BATCH}) of PreResNet-20 SGHMC on torch-CPU '
                       f'({secs:.1f} s, {1e3 * secs / n:.1f} ms/step), extrapolated to {steps_per_sample} steps/sample',
             'ms_per_minibatch_step': round(1e3 * secs / n, 2)}

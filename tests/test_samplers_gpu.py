@@ -248,3 +248,57 @@ def test_bma_graph_replay_equals_eager_member_forwards():
     w = [m._ursa_row.clone() for m in ens]
     a.update_statistics(ens[:2], output_performance=False)
     assert all(torch.equal(x, m._ursa_row) for x, m in zip(w, ens))
+
+
+def _rccl_worker(rank, world, port, q):
+    try:
+        _rccl_worker_body(rank, world, port, q)
+    except BaseException as exc:          # surface the failure instead of letting the parent time out
+        import traceback
+        q.put(('error', traceback.format_exc()))
+        raise
+
+
+def _rccl_worker_body(rank, world, port, q):
+    import os
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    from ursabench_amd import inference, models, tasks
+    from ursabench_amd.data import synthetic
+    from ursabench_amd.distributed import init_from_env
+    r, w, dev = init_from_env('cuda')                 # world size 1: leaves the process group alone
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    assert dist.is_initialized() and dist.get_backend() == 'nccl'
+    torch.manual_seed(0)
+    train = synthetic(640, (3, 32, 32), 10, seed=0, device=dev, batch_size=128)
+    test = synthetic(300, (3, 32, 32), 10, seed=1, device=dev, batch_size=128)
+    s = inference.SGHMC({'lr': 0.05, 'prior_std': 0.5, 'num_samples': 2, 'alpha': 0.5, 'burn_in_epochs': 0},
+                        models.PreResNet(10, 8).to(dev), train, device=dev)      # hipGraph capture with RCCL alive
+    ens = s.sample()
+    pred = tasks.Prediction({'in_distribution_test': test}, 10, dev, 'ALL')
+    pred.update_statistics(ens, output_performance=False)                        # all-reduce over RCCL
+    q.put((pred.num_samples_collected, float(pred.ensemble_proba.sum()), s.engine.stats['graph_replays']))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_process_group_with_graph_capture_world_size_1():
+    """One process per GPU over RCCL (backend 'nccl'): on a 1-GPU box the world is 1, which still exercises
+    process-group init, hipGraph capture beside RCCL's watchdog thread, and the predictive all-reduce."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(0, 1, port, q))
+    p.start()
+    res = q.get(timeout=180)
+    p.join(timeout=60)
+    assert res[0] != 'error', res[1]
+    count, total, replays = res
+    assert p.exitcode == 0 and count == 2 and replays > 0
+    assert total == pytest.approx(2 * 300, rel=1e-5)         # every member's probabilities sum to 1 per row

@@ -175,7 +175,7 @@ class EnsembleAccumulator:
             parts.append(self.ent)
         if self.risk is not None:
             parts.append(self.risk.reshape(-1))
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if dist.is_available() and dist.is_initialized():       # also at world size 1: the collective is then a no-op
             buf = torch.cat(parts + [torch.tensor([float(count)], device=self.device)])
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
             count = int(round(buf[-1].item()))
