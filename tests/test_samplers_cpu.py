@@ -179,3 +179,50 @@ def test_end_to_end_lenet5_vs_reference(golden_dir, name):
         got = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).numpy()
         np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-7)
     assert [l for l, *_ in s._kernels.step_log] == [np.float32(v) for v in g[f'{name}/lr']]
+
+
+def _preresnet8_inputs(g):
+    """Regenerate the fixture's inputs (tools/gen_golden.py gen_e2e_preresnet) and verify the checksum."""
+    gen = torch.Generator().manual_seed(0)
+    xtr, ytr = torch.randn(256, 3, 32, 32, generator=gen), torch.randint(0, 10, (256,), generator=gen)
+    gen = torch.Generator().manual_seed(1)
+    xte, yte = torch.randn(64, 3, 32, 32, generator=gen), torch.randint(0, 10, (64,), generator=gen)
+    chk = [float(xtr.double().sum()), float(ytr.sum()), float(xte.double().sum()), float(yte.sum())]
+    assert chk == list(g['input_checksum']), 'torch CPU generator stream differs from the one the fixture was made with'
+    return (DataLoader(TensorDataset(xtr, ytr), batch_size=128), DataLoader(TensorDataset(xte, yte), batch_size=64))
+
+
+def _load_preresnet8(g):
+    net = models.PreResNet(10, 8)
+    with torch.no_grad():
+        off = 0
+        for p in net.parameters():
+            p.copy_(torch.tensor(g['theta0'][off:off + p.numel()]).view_as(p))
+            off += p.numel()
+        off = 0
+        for b in net.buffers():
+            b.copy_(torch.tensor(g['buffers0'][off:off + b.numel()]).view_as(b).to(b.dtype))
+            off += b.numel()
+    return net
+
+
+def test_end_to_end_preresnet8_vs_reference(golden_dir):
+    """The reference's SGHMC on its own PreResNet (BatchNorm buffers included) replayed on CPU through the
+    oracle kernel set: samples, BN statistics and the Prediction accumulators match."""
+    from ursabench_amd import tasks
+    g = np.load(os.path.join(golden_dir, 'e2e_preresnet8.npz'))
+    hyp = json.loads(str(g['hyper']))
+    train, test = _preresnet8_inputs(g)
+    K = OracleKernels()
+    s = inference.SGHMC(dict(hyp), _load_preresnet8(g), train, kernels=K, use_graph=False)
+    s.eps_provider = lambda k: pad_eps(s.arena, g['eps'][k])
+    ens = s.sample()
+    for m, ref, refb in zip(ens, g['samples'], g['sample_buffers']):
+        got = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).numpy()
+        np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-7)
+        gotb = torch.cat([b.detach().float().reshape(-1) for b in m.buffers()]).numpy()
+        np.testing.assert_allclose(gotb, refb, rtol=1e-5, atol=1e-7)
+    pred = tasks.Prediction({'in_distribution_test': test}, 10, torch.device('cpu'), 'ALL', kernels=K)
+    pred.update_statistics(ens, output_performance=False)
+    np.testing.assert_allclose(pred.ensemble_proba.numpy(), g['proba_sum'], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(pred.expected_data_uncertainty.numpy(), g['ent_sum'], rtol=1e-5, atol=1e-6)

@@ -302,3 +302,27 @@ def test_rccl_process_group_with_graph_capture_world_size_1():
     count, total, replays = res
     assert p.exitcode == 0 and count == 2 and replays > 0
     assert total == pytest.approx(2 * 300, rel=1e-5)         # every member's probabilities sum to 1 per row
+
+
+def test_end_to_end_preresnet8_vs_reference_on_gpu(golden_dir):
+    """BASELINE configs[1]'s network family (PreResNet, BatchNorm) and sampler (SGHMC): the reference's CPU run
+    replayed on the GPU with its captured noise. north_star's criterion — fp32 predictive probabilities
+    within 1e-5 relative of the reference CPU path — on 64 test rows after 4 noisy SGHMC steps."""
+    from test_samplers_cpu import _load_preresnet8, _preresnet8_inputs
+    g = np.load(os.path.join(golden_dir, 'e2e_preresnet8.npz'))
+    hyp = json.loads(str(g['hyper']))
+    train, test = _preresnet8_inputs(g)
+    s = inference.SGHMC(dict(hyp), _load_preresnet8(g), train, device=DEV)
+
+    def eps(k):
+        e = torch.zeros(s.arena.n, device=DEV)
+        e[s.arena.layout.gather_index(DEV)] = torch.tensor(g['eps'][k], device=DEV)
+        return e
+    s.eps_provider = eps
+    ens = s.sample()
+    for m, ref in zip(ens, g['samples']):
+        np.testing.assert_allclose(flat_params(m).cpu().numpy(), ref, rtol=1e-4, atol=2e-5)
+    pred = tasks.Prediction({'in_distribution_test': test}, 10, DEV, 'ALL')
+    pred.update_statistics(ens, output_performance=False)
+    np.testing.assert_allclose(pred.ensemble_proba.numpy(), g['proba_sum'], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(pred.expected_data_uncertainty.numpy(), g['ent_sum'], rtol=1e-5, atol=1e-6)

@@ -380,6 +380,41 @@ def gen_e2e():
     print('G6 e2e_lenet5 steps', out['SGLD/eps'].shape, out['SGHMC/eps'].shape)
 
 
+def gen_e2e_preresnet():
+    """G9: the reference's SGHMC on its own PreResNet class (depth 8: same blocks as the PreResNet-20 of
+    BASELINE configs[1], a third of the parameters so the captured noise stays small), CPU, 2 samples x 2
+    minibatch steps, then its Prediction task on 64 test rows."""
+    out = {}
+    g = torch.Generator().manual_seed(0)
+    xtr, ytr = torch.randn(256, 3, 32, 32, generator=g), torch.randint(0, 10, (256,), generator=g)
+    g = torch.Generator().manual_seed(1)
+    xte, yte = torch.randn(64, 3, 32, 32, generator=g), torch.randint(0, 10, (64,), generator=g)
+    # inputs are regenerated by the tests from the same CPU generators (same torch build => same values); only a
+    # checksum travels
+    out['input_checksum'] = np.array([float(xtr.double().sum()), float(ytr.sum()), float(xte.double().sum()), float(yte.sum())])
+    train = DataLoader(TensorDataset(xtr, ytr), batch_size=128, shuffle=False)
+    test = DataLoader(TensorDataset(xte, yte), batch_size=64, shuffle=False)
+    hyp = {'lr': 0.05, 'prior_std': 0.5, 'num_samples': 2, 'alpha': 0.5, 'burn_in_epochs': 0}
+    util.set_random_seed(0)
+    net = models.PreResNet8.base(num_classes=10, depth=8)
+    out['theta0'] = flat(net.parameters())
+    out['buffers0'] = torch.cat([b.detach().float().reshape(-1) for b in net.buffers()]).numpy()
+    s = inference.SGHMC(dict(hyp), net, train)
+    tap = NoiseTap(s.optimizer)
+    with quiet():
+        ens = s.sample()
+    out['eps'] = np.stack([r['eps'] for r in tap.records])
+    out['samples'] = np.stack([flat(m.parameters()) for m in ens])
+    out['sample_buffers'] = np.stack([torch.cat([b.detach().float().reshape(-1) for b in m.buffers()]).numpy() for m in ens])
+    pred = tasks.Prediction({'in_distribution_test': test}, 10, torch.device('cpu'), 'ALL')
+    pred.update_statistics(ens, output_performance=False)
+    out['proba_sum'], out['ent_sum'] = pred.ensemble_proba.numpy(), pred.expected_data_uncertainty.numpy()
+    out['metrics'] = json.dumps({k: float(v) for k, v in pred.get_performance_metrics().items()})
+    out['hyper'] = json.dumps(hyp)
+    np.savez_compressed(os.path.join(OUT, 'e2e_preresnet8.npz'), **out)
+    print('G9 e2e_preresnet8 steps', out['eps'].shape)
+
+
 def gen_model_keys():
     res = {}
     for name, ref, ours in (
@@ -413,8 +448,8 @@ def gen_model_keys():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['k1', 'sgd', 'sched', 'csghmc', 'tasks', 'swag', 'swag_e2e', 'e2e', 'keys']
-    fns = dict(k1=gen_k1, sgd=gen_sgd, swag_e2e=gen_swag_e2e, sched=gen_schedules, csghmc=gen_csghmc, tasks=gen_tasks, swag=gen_swag, e2e=gen_e2e,
+    which = sys.argv[1:] or ['k1', 'sgd', 'sched', 'csghmc', 'tasks', 'swag', 'swag_e2e', 'e2e', 'e2e_preresnet', 'keys']
+    fns = dict(k1=gen_k1, sgd=gen_sgd, swag_e2e=gen_swag_e2e, e2e_preresnet=gen_e2e_preresnet, sched=gen_schedules, csghmc=gen_csghmc, tasks=gen_tasks, swag=gen_swag, e2e=gen_e2e,
                keys=gen_model_keys)
     for w in which:
         fns[w]()
