@@ -52,6 +52,8 @@ def parse():
     ap.add_argument('--steps', type=int, default=3, help='timed posterior samples per chain (time_script S=3)')
     ap.add_argument('--warmup', type=int, default=1, help='untimed posterior samples per chain')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
+    ap.add_argument('--chains-per-gpu', type=int, default=1, help='>1: ChainGroup (parallel graph branches); the headline config is 1')
+    ap.add_argument('--multi-chain-probe', type=int, default=4, help='chains of the informational multi-chain run at N=1 (0: skip)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--force-dist', action='store_true', help='join an RCCL process group even when WORLD_SIZE is 1')
     ap.add_argument('--cpu-steps', type=int, default=200, help='minibatch steps of the CPU port to time')
@@ -186,6 +188,21 @@ def cpu_baseline_block(steps):
             'ms_per_minibatch_step': round(1e3 * secs / n, 2)}
 
 
+def multi_chain_block(k, make_chain, inference):
+    """Informational (NOT the headline config, which is one chain per GPU): K independent chains on this one
+    GPU stepped as K parallel branches of one hipGraph (inference/chain_group.py). One untimed sample per
+    chain, then one timed."""
+    group = inference.ChainGroup([make_chain(100 + c) for c in range(k)])
+    group.sample_iterative()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    group.sample_iterative()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {'chains_per_gpu': k, 'value': round(k / dt, 4), 'unit': 'posterior-samples/s (aggregate over the chains)',
+            'ms_per_lockstep_round': round(1e3 * dt / len(group.loader), 3), 'engine': group.stats}
+
+
 def reference_style_gpu_block(steps, dev):
     """Informational: the REFERENCE'S execution pattern on this same GPU (stock torch ops only, written out
     here — not the product, not the oracle): eager forward/backward, per-parameter-tensor update with 8 small
@@ -264,12 +281,22 @@ def main():
     from ursabench_amd import inference, models, tasks, util
     from ursabench_amd.data import synthetic
 
-    util.set_random_seed(rank)                                 # chain c uses seed c (experiment.py:170)
     train = synthetic(N_TRAIN, (3, 32, 32), CLASSES, seed=0, device=dev, batch_size=BATCH)
     test = synthetic(N_TEST, (3, 32, 32), CLASSES, seed=1, device=dev, batch_size=BATCH)
-    net = models.PreResNet(CLASSES, 20).to(dev)
     hyp = dict(HYP, num_samples=a.steps + a.warmup)
-    sampler = inference.SGHMC(hyp, net, train, device=dev, use_graph=not a.no_graph)
+    kpg = max(1, a.chains_per_gpu)
+
+    def make_chain(c):
+        util.set_random_seed(c)                                # chain c uses seed c (experiment.py:170)
+        return inference.SGHMC(dict(hyp), models.PreResNet(CLASSES, 20).to(dev), train, device=dev,
+                               use_graph=not a.no_graph)
+
+    chains = [make_chain(rank * kpg + k) for k in range(kpg)]
+    sampler = chains[0]
+    group = inference.ChainGroup(chains, use_graph=not a.no_graph) if kpg > 1 else None
+
+    def one_sample():                                          # one posterior sample from every local chain
+        return group.sample_iterative() if group is not None else [sampler.sample_iterative()]
 
     use_dist = dist.is_initialized()
 
@@ -279,10 +306,10 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(a.warmup):
-        sampler.sample_iterative()
+        one_sample()
     barrier()
     t0 = time.perf_counter()
-    ensemble = [sampler.sample_iterative() for _ in range(a.steps)]       # EXACTLY K timed steps
+    ensemble = [m for _ in range(a.steps) for m in one_sample()]          # EXACTLY K timed steps (per chain)
     barrier()
     dt = time.perf_counter() - t0
     if use_dist:
@@ -311,22 +338,24 @@ def main():
         steps_per_sample = len(train)
         line = {
             'metric': 'posterior-samples/sec (PreResNet-20 SGHMC, 1 chain per GPU); bma_preds_per_s beside it',
-            'value': round(world * a.steps / dt, 4), 'unit': 'posterior-samples/s', 'n_gpus': world, 'steps': a.steps,
+            'value': round(world * kpg * a.steps / dt, 4), 'unit': 'posterior-samples/s', 'n_gpus': world, 'steps': a.steps,
             'warmup': a.warmup, 'ms_per_step': round(1e3 * dt / a.steps, 2), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'PreResNet-20 / CIFAR-10-shaped synthetic, SGHMC 1 chain per GPU '
                                    '(BASELINE configs[1]; configs[2] when n_gpus > 1)', 'n_train': N_TRAIN,
                        'n_test': N_TEST, 'batch': BATCH, 'minibatch_steps_per_sample': steps_per_sample,
-                       'params': sampler.arena.num_parameters, 'hyper': HYP, 'chains': world,
+                       'params': sampler.arena.num_parameters, 'hyper': HYP, 'chains': world * kpg, 'chains_per_gpu': kpg,
                        'hip_graph': not a.no_graph, 'sharding': 'one independent chain per rank; members stay on '
                        'their rank; one RCCL all-reduce of [N*C + N] fp32 for the predictive'},
-            'minibatch_steps_per_s': round(world * a.steps * steps_per_sample / dt, 1),
+            'minibatch_steps_per_s': round(world * kpg * a.steps * steps_per_sample / dt, 1),
             'bma_preds_per_s': round(N_TEST / dt_bma, 1), 'bma_members': members,
             'bma_member_forwards_per_s': round(members * N_TEST / dt_bma, 1),
             'bma_nll': round(float(metrics['nll']), 5),
-            'engine': sampler.engine.stats,
+            'engine': group.stats if group is not None else sampler.engine.stats,
             'roofline': roof, 'roofline_large': roof_large,
         }
+        if world == 1 and kpg == 1 and a.multi_chain_probe > 1:
+            line['multi_chain_per_gpu'] = multi_chain_block(a.multi_chain_probe, make_chain, inference)
         if world == 1 and a.ref_style_steps > 0:
             line['reference_style_gpu'] = reference_style_gpu_block(a.ref_style_steps, dev)
         if world == 1 and not a.no_cpu_baseline:

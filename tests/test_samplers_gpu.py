@@ -326,3 +326,23 @@ def test_end_to_end_preresnet8_vs_reference_on_gpu(golden_dir):
     pred.update_statistics(ens, output_performance=False)
     np.testing.assert_allclose(pred.ensemble_proba.numpy(), g['proba_sum'], rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(pred.expected_data_uncertainty.numpy(), g['ent_sum'], rtol=1e-5, atol=1e-6)
+
+
+def test_chain_group_parallel_branches_match_single_chains():
+    """K chains as K parallel branches of one hipGraph: each chain ends where it ends when run alone (up to
+    MIOpen's atomics-level nondeterminism), the branches really are captured together, chains differ."""
+    from ursabench_amd import util
+    hyp = {'lr': 0.05, 'prior_std': 0.5, 'num_samples': 1, 'alpha': 0.5, 'burn_in_epochs': 1}
+    train = synthetic(1024 + 40, (3, 32, 32), 10, seed=0, device=DEV, batch_size=128)
+
+    def make(k):
+        util.set_random_seed(k)
+        return inference.SGHMC(dict(hyp), models.PreResNet(10, 8).to(DEV), train, device=DEV)
+    alone = [make(k).sample()[0] for k in range(3)]
+    group = inference.ChainGroup([make(k) for k in range(3)])
+    together = [c[0] for c in group.sample()]
+    assert group.stats['captures'] == 1 and group.stats['graph_replays'] > 0
+    for a, b in zip(alone, together):
+        np.testing.assert_allclose(flat_params(a).cpu().numpy(), flat_params(b).cpu().numpy(), rtol=2e-3, atol=3e-4)
+    assert not torch.equal(flat_params(together[0]), flat_params(together[1]))
+    assert all(s.optimizer._step == 18 for s in group.samplers)

@@ -8,3 +8,4 @@ from .flat_sgd import FlatSGD  # noqa: F401
 from .swag import SWA, SWAG  # noqa: F401
 from .hmc import HMC  # noqa: F401
 from .sgd import SGD, MCdropout  # noqa: F401
+from .chain_group import ChainGroup  # noqa: F401

@@ -82,25 +82,27 @@ class cSGHMC(_ChainSampler):
         self.lr = rows[-1][0]                       # what the reference leaves in self.lr / param_groups
         return torch.tensor(rows, dtype=torch.float32)
 
-    def sample_iterative(self, val_loader=None, debug_val_loss=False, wandb_debug=False):
-        if not isinstance(self.model, torch.nn.Module):
-            raise NotImplementedError
+    def _epochs(self, val_loader=None, debug_val_loss=False, wandb_debug=False):
+        """Epoch generator (see SGHMC._epochs): runs epochs until one falls in the collecting tail of a cycle
+        (csghmc.py:77-111)."""
         while True:
             noise = (self.epochs_run % self.cycle_length) + 1 > (self.cycle_length - self.burn_in_epochs
                                                                  - self.num_samples_per_cycle)
             table = self._epoch_table()
-            first_lr = float(table[0, 0])
-            self.optimizer.param_groups[0]['lr'] = first_lr     # ctl_begin reads the epoch's first lr from here
-            base = self.optimizer._step
-            eps = None if self.eps_provider is None else (lambda k: self.eps_provider(base + k))
-            seen = self.engine.run_epoch(self.train_loader, bool(noise), sched=table, eps_per_step=eps)
+            self.optimizer.param_groups[0]['lr'] = float(table[0, 0])   # ctl_begin reads the epoch's first lr here
+            seen = yield bool(noise), table
             self.optimizer.param_groups[0]['lr'] = self.lr
             self.epochs_run += 1
             print('Epoch: ', self.epochs_run, ' lr: ', self.lr)
             if debug_val_loss:
                 self._debug_metrics(val_loader, seen, None, wandb_debug)
             if ((self.epochs_run - 1) % self.cycle_length) >= (self.cycle_length - self.num_samples_per_cycle):
-                return self._snapshot()
+                return
+
+    def sample_iterative(self, val_loader=None, debug_val_loss=False, wandb_debug=False):
+        if not isinstance(self.model, torch.nn.Module):
+            raise NotImplementedError
+        return self._drive(self._epochs(val_loader, debug_val_loss, wandb_debug))
 
     def sample(self, num_samples=None, val_loader=None, debug_val_loss=False, wandb_debug=False):
         if num_samples is None:

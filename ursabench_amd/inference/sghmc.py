@@ -57,6 +57,23 @@ class _ChainSampler(_Inference):
     def _snapshot(self):
         return self.bank.snapshot(self.model)
 
+    def _eps_for_epoch(self):
+        if self.eps_provider is None:
+            return None
+        base = self.optimizer._step
+        return lambda k: self.eps_provider(base + k)
+
+    def _drive(self, epochs):
+        """Run one sampler's epoch generator on its own engine and snapshot when it is exhausted."""
+        try:
+            noise, sched = next(epochs)
+            while True:
+                seen = self.engine.run_epoch(self.train_loader, noise, sched=sched, eps_per_step=self._eps_for_epoch())
+                noise, sched = epochs.send(seen)
+        except StopIteration:
+            pass
+        return self._snapshot()
+
     def _debug_metrics(self, val_loader, seen, extra=None, wandb_debug=False):
         metrics = {'train_loss': self.engine.loss_acc.item() / self.dataset_size,
                    'val_loss': self.compute_val_loss(val_loader)}
@@ -105,9 +122,9 @@ class SGHMC(_ChainSampler):
                                                      T_max=self.burn_in_epochs + self.num_samples,
                                                      eta_min=self.lr_final)
 
-    def sample_iterative(self, val_loader=None, debug_val_loss=False, wandb_debug=False):
-        if not isinstance(self.model, torch.nn.Module):
-            raise NotImplementedError
+    def _epochs(self, val_loader=None, debug_val_loss=False, wandb_debug=False):
+        """The epochs of the next sample as a generator: yields (noise, schedule table) for the driver to
+        run, receives the number of examples seen, does the end-of-epoch bookkeeping (sghmc.py:67-98)."""
         if self.burnt_in is False:
             epochs = self.burn_in_epochs + 1
             self.burnt_in = True
@@ -115,17 +132,15 @@ class SGHMC(_ChainSampler):
             epochs = 1
         for epoch in range(epochs):
             noise = bool(epoch > 0.8 * epochs or self.burnt_in)          # sghmc.py:83 (always True)
-            seen = self.engine.run_epoch(self.train_loader, noise, eps_per_step=self._eps_for_epoch())
+            seen = yield noise, None
             self.optimizer_scheduler.step()
             if debug_val_loss:
                 self._debug_metrics(val_loader, seen, {'lr': self.optimizer_scheduler.get_last_lr()}, wandb_debug)
-        return self._snapshot()
 
-    def _eps_for_epoch(self):
-        if self.eps_provider is None:
-            return None
-        base = self.optimizer._step
-        return lambda k: self.eps_provider(base + k)
+    def sample_iterative(self, val_loader=None, debug_val_loss=False, wandb_debug=False):
+        if not isinstance(self.model, torch.nn.Module):
+            raise NotImplementedError
+        return self._drive(self._epochs(val_loader, debug_val_loss, wandb_debug))
 
     def sample(self, num_samples=None, val_loader=None, debug_val_loss=False, wandb_debug=False):
         if num_samples is None:

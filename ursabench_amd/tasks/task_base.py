@@ -91,24 +91,24 @@ class EnsembleAccumulator:
         self.risk = torch.zeros(self.N, self.C, device=self.device) if self.cost is not None else None
 
     # -- member forwards ---------------------------------------------------------------------
-    def _resident_twin(self, members):
-        """Members that came out of one MemberBank share a layout: evaluate them through ONE module
-        whose tensors view a persistent row (copy member row -> twin row, 1 MB device-to-device) so
-        the forward can be captured once per batch shape into a hipGraph and replayed for every
-        (batch, member). Returns None for foreign modules (eager forwards then)."""
+    def _resident_twin(self, member):
+        """A member that came out of a MemberBank is evaluated through that bank's *twin*: ONE module
+        whose tensors view a persistent row (copy member row -> twin row, 1 MB device-to-device) so the
+        forward is captured once per batch shape into a hipGraph and replayed for every (batch, member).
+        Members of several chains (several banks) get one twin per bank. Returns None for foreign
+        modules (eager forward then)."""
         if self.device.type != 'cuda' or not self.use_graph:
             return None
-        bank = getattr(members[0], '_ursa_bank', None)
-        if bank is None or any(getattr(m, '_ursa_bank', None) is not bank or getattr(m, '_ursa_row', None) is None
-                               for m in members):
+        bank = getattr(member, '_ursa_bank', None)
+        if bank is None or getattr(member, '_ursa_row', None) is None:
             return None
         twin = self._twins.get(id(bank))
         if twin is None:
             row, irow = bank.new_row()
-            row.copy_(members[0]._ursa_row)
+            row.copy_(member._ursa_row)
             for dst, (k, _) in zip(irow, bank.arena.ibufs):
-                dst.copy_(dict(members[0].named_buffers())[k])
-            mod = bank.materialise(row, irow, members[0])
+                dst.copy_(dict(member.named_buffers())[k])
+            mod = bank.materialise(row, irow, member)
             mod.eval()
             _prefer_aten_batchnorm_in_eval(mod)
             twin = self._twins[id(bank)] = dict(row=row, mod=mod, graphs={}, bank=bank)
@@ -138,7 +138,7 @@ class EnsembleAccumulator:
         for m in members:
             m.to(self.device)          # no-op for bank-resident members; moves foreign CPU models once
             m.eval()
-        twin = self._resident_twin(members)
+        twins = [self._resident_twin(m) for m in members]
         start = 0
         for x, _ in self.loader:
             b = len(x)
@@ -146,21 +146,21 @@ class EnsembleAccumulator:
             slab = self._slabs.get((S, b))
             if slab is None:
                 slab = self._slabs[(S, b)] = torch.empty(S, b, self.C, device=self.device)
-            if twin is not None:
-                graph, sx, out = self._twin_forward(twin, x)
-                if out.shape != (b, self.C):
-                    raise ValueError(f'members return logits {tuple(out.shape)}, expected {(b, self.C)}')
-                sx.copy_(x)
-                for s, m in enumerate(members):
+            fed = set()
+            for s, (m, twin) in enumerate(zip(members, twins)):
+                if twin is not None:
+                    graph, sx, out = self._twin_forward(twin, x)
+                    if id(twin) not in fed:                 # the batch goes into each twin's static input once
+                        sx.copy_(x)
+                        fed.add(id(twin))
                     twin['row'].copy_(m._ursa_row)
                     graph.replay()
-                    slab[s].copy_(out)
-            else:
-                for s, m in enumerate(members):
+                    z = out
+                else:
                     z = m(x)
-                    if z.shape != (b, self.C):
-                        raise ValueError(f'member {s} returned logits {tuple(z.shape)}, expected {(b, self.C)}')
-                    slab[s].copy_(z)
+                if z.shape != (b, self.C):
+                    raise ValueError(f'member {s} returned logits {tuple(z.shape)}, expected {(b, self.C)}')
+                slab[s].copy_(z)
             self.K.bma_accumulate(slab, self.proba[start:start + b],
                                   None if self.ent is None else self.ent[start:start + b],
                                   one_minus_gamma=1 - GAMMA, gamma_over_c=GAMMA * 1 / self.C, smoothed=self.smoothed,
