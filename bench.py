@@ -127,7 +127,7 @@ def roofline_block(sampler, large_n):
     out = {'bound': 'hbm', 'kernel': 'k_sgmcmc_step_ctl', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS,
            'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': traffic,
            'bytes_per_launch': bytes_per_launch, 'us_per_launch': round(ms * 1e3, 3),
-           'note': 'workload-sized launch (6.6 MB of state, L2/Infinity-Cache resident, one float4 per lane): '
+           'note': 'workload-sized launch (5.5 MB of state, L2/Infinity-Cache resident, one float4 per lane): '
                    'latency-bound; us_per_launch is a 256-launch hipGraph replay / 256 and includes the '
                    '~1.5 us kernel boundary; see roofline_large for the HBM-sized launch of the same arithmetic'}
     # the same arithmetic at a working set beyond the 256 MiB Infinity Cache

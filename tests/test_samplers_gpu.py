@@ -248,6 +248,10 @@ def test_bma_graph_replay_equals_eager_member_forwards():
     w = [m._ursa_row.clone() for m in ens]
     a.update_statistics(ens[:2], output_performance=False)
     assert all(torch.equal(x, m._ursa_row) for x, m in zip(w, ens))
+    # 3 members on 4 lanes, then 6 members (two lane groups, second one partial)
+    c = tasks.Prediction({'in_distribution_test': test}, 10, DEV, 'ALL')
+    c.update_statistics(ens + ens, output_performance=False)
+    np.testing.assert_allclose(c.ensemble_proba.numpy(), 2 * b.ensemble_proba.numpy(), rtol=1e-5, atol=1e-7)
 
 
 def _rccl_worker(rank, world, port, q):

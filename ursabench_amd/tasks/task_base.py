@@ -91,12 +91,15 @@ class EnsembleAccumulator:
         self.risk = torch.zeros(self.N, self.C, device=self.device) if self.cost is not None else None
 
     # -- member forwards ---------------------------------------------------------------------
+    LANES = 4      # member forwards evaluated concurrently (parallel branches of one hipGraph)
+
     def _resident_twin(self, member):
-        """A member that came out of a MemberBank is evaluated through that bank's *twin*: ONE module
-        whose tensors view a persistent row (copy member row -> twin row, 1 MB device-to-device) so the
-        forward is captured once per batch shape into a hipGraph and replayed for every (batch, member).
-        Members of several chains (several banks) get one twin per bank. Returns None for foreign
-        modules (eager forward then)."""
+        """A member that came out of a MemberBank is evaluated through that bank's *twin*: LANES modules
+        whose tensors view persistent rows (copy member row -> lane row, 1 MB device-to-device), so the
+        forwards are captured once per batch shape into ONE hipGraph with LANES parallel branches and
+        replayed for every (batch, group of LANES members): small-network forwards leave most CUs idle,
+        independent branches overlap (same effect as inference/chain_group.py). Members of several chains
+        (several banks) get one twin per bank. Returns None for foreign modules (eager forward then)."""
         if self.device.type != 'cuda' or not self.use_graph:
             return None
         bank = getattr(member, '_ursa_bank', None)
@@ -104,32 +107,45 @@ class EnsembleAccumulator:
             return None
         twin = self._twins.get(id(bank))
         if twin is None:
-            row, irow = bank.new_row()
-            row.copy_(member._ursa_row)
-            for dst, (k, _) in zip(irow, bank.arena.ibufs):
-                dst.copy_(dict(member.named_buffers())[k])
-            mod = bank.materialise(row, irow, member)
-            mod.eval()
-            _prefer_aten_batchnorm_in_eval(mod)
-            twin = self._twins[id(bank)] = dict(row=row, mod=mod, graphs={}, bank=bank)
+            rows, mods = [], []
+            for _ in range(self.LANES):
+                row, irow = bank.new_row()
+                row.copy_(member._ursa_row)
+                for dst, (k, _) in zip(irow, bank.arena.ibufs):
+                    dst.copy_(dict(member.named_buffers())[k])
+                mod = bank.materialise(row, irow, member)
+                mod.eval()
+                _prefer_aten_batchnorm_in_eval(mod)
+                rows.append(row)
+                mods.append(mod)
+            twin = self._twins[id(bank)] = dict(rows=rows, mods=mods, graphs={}, bank=bank)
         return twin
 
-    def _twin_forward(self, twin, x):
-        """Replay (capture on first use) the twin's eval forward for this batch shape."""
+    def _twin_graph(self, twin, x):
+        """(graph, static input, per-lane outputs) for this batch shape; captured on first use."""
         key = tuple(x.shape)
         g = twin['graphs'].get(key)
         if g is None:
             sx = torch.empty_like(x)
             sx.copy_(x)
-            side = torch.cuda.Stream(self.device)
-            side.wait_stream(torch.cuda.current_stream(self.device))
-            with torch.cuda.stream(side):
-                twin['mod'](sx)                                  # warm-up outside capture (MIOpen search)
-            torch.cuda.current_stream(self.device).wait_stream(side)
+            cur = torch.cuda.current_stream(self.device)
+            side = [torch.cuda.Stream(self.device) for _ in twin['mods']]
+            side[0].wait_stream(cur)
+            with torch.cuda.stream(side[0]):
+                for m in twin['mods']:
+                    m(sx)                                        # warm-up outside capture (MIOpen search)
+            cur.wait_stream(side[0])
             graph = torch.cuda.CUDAGraph()
+            outs = []
             with torch.cuda.graph(graph, capture_error_mode='thread_local'):
-                out = twin['mod'](sx)
-            g = twin['graphs'][key] = (graph, sx, out)
+                cap = torch.cuda.current_stream(self.device)
+                for m, st in zip(twin['mods'], side):            # fork: one branch per lane
+                    st.wait_stream(cap)
+                    with torch.cuda.stream(st):
+                        outs.append(m(sx))
+                for st in side:                                  # join
+                    cap.wait_stream(st)
+            g = twin['graphs'][key] = (graph, sx, outs)
         return g
 
     @torch.no_grad()
@@ -138,7 +154,14 @@ class EnsembleAccumulator:
         for m in members:
             m.to(self.device)          # no-op for bank-resident members; moves foreign CPU models once
             m.eval()
-        twins = [self._resident_twin(m) for m in members]
+        # plan: per twin, the member indices it serves in groups of LANES; the rest run eagerly
+        by_twin, eager = {}, []
+        for s, m in enumerate(members):
+            twin = self._resident_twin(m)
+            if twin is None:
+                eager.append(s)
+            else:
+                by_twin.setdefault(id(twin), (twin, []))[1].append(s)
         start = 0
         for x, _ in self.loader:
             b = len(x)
@@ -146,18 +169,20 @@ class EnsembleAccumulator:
             slab = self._slabs.get((S, b))
             if slab is None:
                 slab = self._slabs[(S, b)] = torch.empty(S, b, self.C, device=self.device)
-            fed = set()
-            for s, (m, twin) in enumerate(zip(members, twins)):
-                if twin is not None:
-                    graph, sx, out = self._twin_forward(twin, x)
-                    if id(twin) not in fed:                 # the batch goes into each twin's static input once
-                        sx.copy_(x)
-                        fed.add(id(twin))
-                    twin['row'].copy_(m._ursa_row)
-                    graph.replay()
-                    z = out
-                else:
-                    z = m(x)
+            for twin, idxs in by_twin.values():
+                graph, sx, outs = self._twin_graph(twin, x)
+                if outs[0].shape != (b, self.C):
+                    raise ValueError(f'members return logits {tuple(outs[0].shape)}, expected {(b, self.C)}')
+                sx.copy_(x)
+                for g0 in range(0, len(idxs), self.LANES):
+                    group = idxs[g0:g0 + self.LANES]
+                    for lane, s in enumerate(group):
+                        twin['rows'][lane].copy_(members[s]._ursa_row)
+                    graph.replay()                               # unused lanes recompute a stale member: ignored
+                    for lane, s in enumerate(group):
+                        slab[s].copy_(outs[lane])
+            for s in eager:
+                z = members[s](x)
                 if z.shape != (b, self.C):
                     raise ValueError(f'member {s} returned logits {tuple(z.shape)}, expected {(b, self.C)}')
                 slab[s].copy_(z)
