@@ -73,7 +73,7 @@ def event_time_ms(fn, iters, stream, graph_batch=0):
             fn()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode='thread_local'):     # RCCL's watchdog thread may be alive
             for _ in range(graph_batch):
                 fn()
         g.replay()
@@ -337,12 +337,13 @@ def main():
         roof, roof_large = roofline_block(sampler, a.large_n)
         steps_per_sample = len(train)
         line = {
-            'metric': 'posterior-samples/sec (PreResNet-20 SGHMC, 1 chain per GPU); bma_preds_per_s beside it',
+            'metric': f'posterior-samples/sec (PreResNet-20 SGHMC, {kpg} chain{"s" if kpg > 1 else ""} per GPU); '
+                      'bma_preds_per_s beside it',
             'value': round(world * kpg * a.steps / dt, 4), 'unit': 'posterior-samples/s', 'n_gpus': world, 'steps': a.steps,
             'warmup': a.warmup, 'ms_per_step': round(1e3 * dt / a.steps, 2), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'PreResNet-20 / CIFAR-10-shaped synthetic, SGHMC 1 chain per GPU '
-                                   '(BASELINE configs[1]; configs[2] when n_gpus > 1)', 'n_train': N_TRAIN,
+            'config': {'workload': f'PreResNet-20 / CIFAR-10-shaped synthetic, SGHMC {kpg} chain(s) per GPU '
+                                   '(BASELINE configs[1] at 1 chain, 1 GPU; configs[2] when n_gpus > 1)', 'n_train': N_TRAIN,
                        'n_test': N_TEST, 'batch': BATCH, 'minibatch_steps_per_sample': steps_per_sample,
                        'params': sampler.arena.num_parameters, 'hyper': HYP, 'chains': world * kpg, 'chains_per_gpu': kpg,
                        'hip_graph': not a.no_graph, 'sharding': 'one independent chain per rank; members stay on '
