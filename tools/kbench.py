@@ -48,6 +48,7 @@ def main():
     for n in (a.n, 272282):
         th, g, m, snap = (torch.randn(n, device='cuda') for _ in range(4))
         eps = torch.randn(n, device='cuda')
+        ws, acc = torch.zeros(2048, device='cuda'), torch.zeros(1, device='cuda')
         sc = dict(lr=1e-3, c_wd=8e-5, c_noise=0.03, n_train=50000.0, seed=1)
         cases = {
             'k1_sghmc_philox': (20, lambda: K.sgmcmc_step(th, g, m, mu=0.5, flags=0x1 | 0x8, step=3, **sc)),
@@ -58,6 +59,10 @@ def main():
             'k1_sgld_philox': (12, lambda: K.sgmcmc_step(th, g, None, mu=0.0, flags=0x1 | 0x8, step=3, **sc)),
             'k2_swag_collect': (20, lambda: K.swag_collect(th, m, g, decay=0.75, denom=4.0)),
             'k3_swag_draw_philox': (12, lambda: K.swag_draw(snap, th, m, var_clamp=1e-30, seed=1, draw=2)),
+            'k4_leapfrog_kick_drift': (20, lambda: K.leapfrog(th, m, g, kick_coef=1e-4, step_size=2e-4, inv_mass=1.0, flags=0x3)),
+            'k4_leapfrog_kick_drift_kinetic': (20, lambda: K.leapfrog(th, m, g, kick_coef=1e-4, step_size=2e-4, inv_mass=1.0,
+                                                                   flags=0x3, kinetic_out=acc, ws=ws)),
+            'k4_sumsq': (4, lambda: K.sumsq(th, acc, ws)),
             'philox_normal_fill': (4, lambda: K.philox_normal(snap, seed=1, step=2)),
             'torch_copy_(ref)': (8, lambda: snap.copy_(th)),
         }
