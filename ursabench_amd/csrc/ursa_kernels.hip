@@ -26,6 +26,7 @@ namespace {
 constexpr int kBlock = 256;          // reductions / row kernels: 4 waves, one per SIMD
 constexpr int kMaxGrid = 256 * 8;    // grid-stride kernels (reductions): 256 CUs x 8 blocks/CU
 constexpr int kSBlock = 512;         // streaming kernels: one float4 per thread
+constexpr int64_t kMaxElems = 1ll << 40;    // keeps ceil(n/2048) blocks inside a 31-bit grid
 constexpr int64_t kNtBytes = 512ll << 20;   // state larger than this streams past the Infinity Cache
 
 inline int sgrid(int64_t items)      // one item per thread
@@ -742,7 +743,7 @@ int ursa_sgmcmc_step_f32(float* theta, float* grad, float* mom, const float* eps
                          float lr, float mu, float c_wd, float c_noise, float n_train, uint64_t seed,
                          uint64_t step, uint32_t flags, ursa_stream_t stream)
 {
-    if (n < 0) return URSA_ESIZE;
+    if (n < 0 || n > kMaxElems) return URSA_ESIZE;
     if (flags & ~URSA_STEP_ALLFLAGS) return URSA_EFLAGS;
     if ((flags & URSA_STEP_SGD) && (flags & URSA_STEP_NOISE)) return URSA_EFLAGS;
     if (n == 0) return URSA_OK;
@@ -763,7 +764,7 @@ int ursa_sgmcmc_step_f32(float* theta, float* grad, float* mom, const float* eps
 int ursa_sgmcmc_step_ctl_f32(float* theta, float* grad, float* mom, const float* eps, float* snapshot,
                              int64_t n, const ursa_step_ctl* ctl, ursa_stream_t stream)
 {
-    if (n < 0) return URSA_ESIZE;
+    if (n < 0 || n > kMaxElems) return URSA_ESIZE;
     if (n == 0) return URSA_OK;
     if (!theta || !grad || !mom || !ctl) return URSA_ENULL;   // mom always required: mu lives on the device
     if (!(aligned16(theta) && aligned16(grad) && aligned16(mom) && aligned16(eps) && aligned16(snapshot)))
@@ -788,7 +789,7 @@ int ursa_step_ctl_advance(ursa_step_ctl* ctl, const float* sched, uint32_t sched
 
 int ursa_philox_normal_f32(float* out, int64_t n, uint64_t seed, uint64_t step, ursa_stream_t stream)
 {
-    if (n < 0) return URSA_ESIZE;
+    if (n < 0 || n > kMaxElems) return URSA_ESIZE;
     if (n == 0) return URSA_OK;
     if (!out) return URSA_ENULL;
     if (!aligned4(out)) return URSA_EALIGN;
@@ -800,7 +801,7 @@ int ursa_philox_normal_f32(float* out, int64_t n, uint64_t seed, uint64_t step, 
 int ursa_swag_collect_f32(float* mean, float* sq, const float* w, int64_t n, float decay, float denom,
                           ursa_stream_t stream)
 {
-    if (n < 0) return URSA_ESIZE;
+    if (n < 0 || n > kMaxElems) return URSA_ESIZE;
     if (n == 0) return URSA_OK;
     if (!mean || !sq || !w) return URSA_ENULL;
     if (!aligned4(mean) || !aligned4(sq) || !aligned4(w)) return URSA_EALIGN;
@@ -821,7 +822,7 @@ int ursa_swag_collect_f32(float* mean, float* sq, const float* w, int64_t n, flo
 int ursa_swag_draw_f32(float* theta_out, const float* mean, const float* sq, const float* eps, int64_t n,
                        float var_clamp, float scale, uint64_t seed, uint64_t draw, ursa_stream_t stream)
 {
-    if (n < 0) return URSA_ESIZE;
+    if (n < 0 || n > kMaxElems) return URSA_ESIZE;
     if (n == 0) return URSA_OK;
     if (!theta_out || !mean || !sq) return URSA_ENULL;
     if (!aligned4(theta_out) || !aligned4(mean) || !aligned4(sq) || !aligned4(eps)) return URSA_EALIGN;
@@ -873,7 +874,7 @@ int ursa_bma_accumulate_f32(const float* logits, float* proba_sum, float* ent_su
 int ursa_leapfrog_f32(float* theta, float* mom, const float* grad, int64_t n, float kick_coef, float step_size,
                       float inv_mass, uint32_t flags, float* kinetic_out, float* ws, ursa_stream_t stream)
 {
-    if (n < 0) return URSA_ESIZE;
+    if (n < 0 || n > kMaxElems) return URSA_ESIZE;
     if (flags & ~(URSA_LEAP_KICK | URSA_LEAP_DRIFT)) return URSA_EFLAGS;
     if (n == 0) return URSA_OK;
     if (!mom) return URSA_ENULL;
@@ -904,7 +905,7 @@ int ursa_leapfrog_f32(float* theta, float* mom, const float* grad, int64_t n, fl
 
 int ursa_sumsq_f32(const float* x, int64_t n, float* out, float* ws, ursa_stream_t stream)
 {
-    if (n < 0) return URSA_ESIZE;
+    if (n < 0 || n > kMaxElems) return URSA_ESIZE;
     if (!out || !ws) return URSA_ENULL;
     if (n == 0) return URSA_OK;
     if (!x) return URSA_ENULL;
