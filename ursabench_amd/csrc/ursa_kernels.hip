@@ -416,7 +416,7 @@ __device__ __forceinline__ float group_max(float v) { return group_reduce<G>(v, 
 template <int G>
 __device__ __forceinline__ float group_sum(float v) { return group_reduce<G>(v, OpSum()); }
 
-template <int G, int EPL>
+template <int G, int EPL, bool RISK>
 __global__ __launch_bounds__(kBlock) void k_bma_accumulate(const float* __restrict__ logits,
                                                            float* __restrict__ proba_sum,
                                                            float* __restrict__ ent_sum,
@@ -428,9 +428,11 @@ __global__ __launch_bounds__(kBlock) void k_bma_accumulate(const float* __restri
     // parallelism of one-wave-per-row: B = 10^4 rows are only 2,500 waves otherwise, 2.4 per SIMD), each
     // wave sums its range in member order in registers, and wave 0 folds the partial sums in wave order
     // into the global accumulators: ((acc + P0) + P1) + P2) + P3 — a fixed, reproducible order.
+    // RISK (Decision's expected-cost accumulator) is a template flag so Prediction/OOD do not carry its
+    // registers: <16 lanes, 8 classes per lane> needs 122 VGPRs with it (4 waves/SIMD), half without.
     constexpr int kRows = 64 / G;
     constexpr int kWaves = kBlock / 64;
-    constexpr int kVals = 2 * EPL + 1;                       // proba[EPL], risk[EPL], entropy
+    constexpr int kVals = (RISK ? 2 : 1) * EPL + 1;          // proba[EPL], (risk[EPL]), entropy
     __shared__ float part[kWaves - 1][kVals][64];
     const int wave = threadIdx.x >> 6, wl = threadIdx.x & 63;
     const int lane = wl % G, grp = wl / G;
@@ -444,16 +446,18 @@ __global__ __launch_bounds__(kBlock) void k_bma_accumulate(const float* __restri
     for (int64_t it = 0; it < nrounds; ++it) {
         const int64_t b = it * row_stride + (int64_t)blockIdx.x * kRows + grp;
         const bool row_ok = b < B;
-        float acc_p[EPL], acc_r[EPL];
+        float acc_p[EPL], acc_r[RISK ? EPL : 1];
         float acc_e = 0.f;
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) acc_p[e] = acc_r[e] = 0.f;
+        for (int e = 0; e < EPL; ++e) acc_p[e] = 0.f;
+#pragma unroll
+        for (int e = 0; e < (RISK ? EPL : 1); ++e) acc_r[e] = 0.f;
 
         // Members are walked in order, U at a time: the U x EPL loads of a chunk are issued before any of
-        // its arithmetic, and the U softmax chains are independent so the compiler interleaves their
-        // reductions. Arithmetic per element is ~13 VALU instructions: e = exp(x - max) through v_exp_f32
-        // with a compensated exponent (1-2 ulp), p = e / sum (one IEEE reciprocal per row instead of the
-        // reference's second exp), ln q through v_log_f32.
+        // its arithmetic. Arithmetic per element is ~13 VALU instructions: e = exp(x - max) through
+        // v_exp_f32 with a compensated exponent (1-2 ulp), p = e / sum (one IEEE reciprocal per row instead
+        // of the reference's second exp), ln q through v_log_f32. Each member is folded into the wave's
+        // partial sums as soon as it is computed (member order).
         constexpr int U = EPL <= 2 ? 8 : EPL <= 4 ? 4 : EPL <= 8 ? 2 : 1;     // U * EPL <= 16 logits in flight per lane
         const int64_t row_off = (row_ok ? b : 0) * (int64_t)C;
         for (int s0 = s_lo; s0 < s_hi; s0 += U) {
@@ -469,9 +473,9 @@ __global__ __launch_bounds__(kBlock) void k_bma_accumulate(const float* __restri
                     xs[u][e] = (c < C) ? v : -INFINITY;         // load becomes a branch and serialises the batch
                 }
             }
-            float pu[U][EPL], qu[U][EPL], entu[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
+                const bool live = s0 + u < s_hi;                // uniform across the wave
                 float mx = -INFINITY;
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) mx = fmaxf(mx, xs[u][e]);
@@ -480,49 +484,45 @@ __global__ __launch_bounds__(kBlock) void k_bma_accumulate(const float* __restri
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) {
                     const int c = lane + e * G;
-                    pu[u][e] = (c < C) ? exp_nonpos(xs[u][e] - mx) : 0.f;
-                    sum += pu[u][e];
+                    xs[u][e] = (c < C) ? exp_nonpos(xs[u][e] - mx) : 0.f;
+                    sum += xs[u][e];
                 }
                 const float inv = 1.0f / group_sum<G>(sum);
                 float ent = 0.f;
+                float qv[RISK ? EPL : 1];
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) {
                     const int c = lane + e * G;
-                    const float p = pu[u][e] * inv;
-                    const float q = p * omg + goc;
-                    pu[u][e] = p;
-                    qu[u][e] = (c < C) ? q : 0.f;
+                    const float p = xs[u][e] * inv;
+                    const float q = (c < C) ? p * omg + goc : 0.f;
                     ent += (c < C) ? q * ln_pos(q) : 0.f;
+                    acc_p[e] += live ? (smoothed ? q : p) : 0.f;
+                    if (RISK) qv[e] = q;
                 }
-                entu[u] = ent_sum ? group_sum<G>(ent) : 0.f;
-            }
-            // fold the chunk into this wave's partial sums in member order
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const bool live = s0 + u < s_hi;             // uniform across the wave
-#pragma unroll
-                for (int e = 0; e < EPL; ++e) acc_p[e] += live ? (smoothed ? qu[u][e] : pu[u][e]) : 0.f;
-                acc_e += live ? -entu[u] : 0.f;
-                if (risk_sum && live) {
+                if (ent_sum) {
+                    const float en = group_sum<G>(ent);
+                    acc_e += live ? -en : 0.f;
+                }
+                if (RISK && live) {
                     // risk[b, j] += sum_c ps[c] * cost[c, j]; ps[c] broadcast from its owner lane
-                    float r[EPL];
+                    float r[RISK ? EPL : 1];
 #pragma unroll
-                    for (int e = 0; e < EPL; ++e) r[e] = 0.f;
+                    for (int e = 0; e < (RISK ? EPL : 1); ++e) r[e] = 0.f;
 #pragma unroll
-                    for (int es = 0; es < EPL; ++es) {
+                    for (int es = 0; es < (RISK ? EPL : 1); ++es) {
                         for (int src = 0; src < G; ++src) {
                             const int c = src + es * G;
                             if (c >= C) break;                      // uniform across the group
-                            const float pc = __shfl(qu[u][es], src, G);
+                            const float pc = __shfl(qv[es], src, G);
 #pragma unroll
-                            for (int e = 0; e < EPL; ++e) {
+                            for (int e = 0; e < (RISK ? EPL : 1); ++e) {
                                 const int j = lane + e * G;
                                 if (j < C) r[e] += pc * cost[c * C + j];
                             }
                         }
                     }
 #pragma unroll
-                    for (int e = 0; e < EPL; ++e) acc_r[e] += r[e];
+                    for (int e = 0; e < (RISK ? EPL : 1); ++e) acc_r[e] += r[e];
                 }
             }
         }
@@ -531,9 +531,9 @@ __global__ __launch_bounds__(kBlock) void k_bma_accumulate(const float* __restri
 #pragma unroll
             for (int e = 0; e < EPL; ++e) {
                 part[wave - 1][e][wl] = acc_p[e];
-                part[wave - 1][EPL + e][wl] = acc_r[e];
+                if (RISK) part[wave - 1][EPL + e][wl] = acc_r[e];
             }
-            part[wave - 1][2 * EPL][wl] = acc_e;
+            part[wave - 1][kVals - 1][wl] = acc_e;
         }
         __syncthreads();
         if (wave == 0 && row_ok) {
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(kBlock) void k_bma_accumulate(const float* __restri
 #pragma unroll
                     for (int w = 0; w < kWaves - 1; ++w) p += part[w][e][wl];
                     proba_sum[b * C + c] = p;
-                    if (risk_sum) {
+                    if (RISK) {
                         float r = risk_sum[b * C + c] + acc_r[e];
 #pragma unroll
                         for (int w = 0; w < kWaves - 1; ++w) r += part[w][EPL + e][wl];
@@ -556,7 +556,7 @@ __global__ __launch_bounds__(kBlock) void k_bma_accumulate(const float* __restri
             if (ent_sum && lane == 0) {
                 float en = ent_sum[b] + acc_e;
 #pragma unroll
-                for (int w = 0; w < kWaves - 1; ++w) en += part[w][2 * EPL][wl];
+                for (int w = 0; w < kWaves - 1; ++w) en += part[w][kVals - 1][wl];
                 ent_sum[b] = en;
             }
         }
@@ -851,9 +851,17 @@ int ursa_bma_accumulate_f32(const float* logits, float* proba_sum, float* ent_su
     if (!aligned4(logits) || !aligned4(proba_sum) || !aligned4(ent_sum) || !aligned4(risk_sum) || !aligned4(cost))
         return URSA_EALIGN;
     hipStream_t st = (hipStream_t)stream;
-#define URSA_LAUNCH(G, EPL)                                                                                   \
-    hipLaunchKernelGGL((k_bma_accumulate<G, EPL>), dim3(bma_grid(B, 64 / G)), dim3(kBlock), 0, st, logits, \
-                       proba_sum, ent_sum, risk_sum, cost, (int)S, B, (int)C, one_minus_gamma, gamma_over_c, flags)
+#define URSA_LAUNCH(G, EPL)                                                                                     \
+    do {                                                                                                        \
+        if (risk_sum)                                                                                           \
+            hipLaunchKernelGGL((k_bma_accumulate<G, EPL, true>), dim3(bma_grid(B, 64 / G)), dim3(kBlock), 0, st, \
+                               logits, proba_sum, ent_sum, risk_sum, cost, (int)S, B, (int)C, one_minus_gamma,  \
+                               gamma_over_c, flags);                                                            \
+        else                                                                                                    \
+            hipLaunchKernelGGL((k_bma_accumulate<G, EPL, false>), dim3(bma_grid(B, 64 / G)), dim3(kBlock), 0, st, \
+                               logits, proba_sum, ent_sum, risk_sum, cost, (int)S, B, (int)C, one_minus_gamma,  \
+                               gamma_over_c, flags);                                                            \
+    } while (0)
     // Rows are owned by 16-lane groups whenever C <= 256: the three row reductions are then pure DPP
     // (no cross-row step) and one DPP instruction serves the 4 rows of the wave at once; more classes per
     // lane also means more independent exp/log work per lane. Measured at S=30, B=1e4, C=100:
