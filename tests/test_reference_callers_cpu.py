@@ -55,3 +55,31 @@ def test_reference_random_search_drives_our_sampler_and_task():
     assert len(objs) == 3 and all(isinstance(o, float) for o in objs) and len(search.time) == 3
     assert float(best_obj) == pytest.approx(max(objs), rel=1e-6) and set(best) == set(hyps[0])
     assert all(1e-3 <= float(h['lr']) <= 1e-1 for h in hyps)
+
+
+def test_reference_tasks_accept_our_members_and_agree_with_ours():
+    """Members returned by our sampler (bank views) go through the REFERENCE'S Prediction task
+    (model.to(device) / .eval() / model.to('cpu') per batch) and give the same accumulators as ours."""
+    import numpy as np
+    import ursabench_amd.inference as inference
+    from ursabench_amd import tasks
+    from oracle_kernels import OracleKernels
+    from test_samplers_cpu import tiny_loader, tiny_net
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    from ref_import import import_reference
+    _, _, _, ref_tasks = import_reference()
+    K = OracleKernels()
+    s = inference.SGHMC({'lr': 0.05, 'prior_std': 1.0, 'num_samples': 3, 'alpha': 0.5, 'burn_in_epochs': 0},
+                        tiny_net(), tiny_loader(), kernels=K, use_graph=False)
+    ens = s.sample()
+    test = tiny_loader(n=50, b=16, seed=9)
+    theirs = ref_tasks.Prediction({'in_distribution_test': test}, 4, torch.device('cpu'), 'ALL')
+    theirs.update_statistics(ens, output_performance=False)
+    ours = tasks.Prediction({'in_distribution_test': test}, 4, torch.device('cpu'), 'ALL', kernels=K)
+    ours.update_statistics(ens, output_performance=False)
+    np.testing.assert_allclose(ours.ensemble_proba.numpy(), theirs.ensemble_proba.numpy(), rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(ours.expected_data_uncertainty.numpy(), theirs.expected_data_uncertainty.numpy(), rtol=1e-5, atol=1e-7)
+    a, b = ours.get_performance_metrics(), theirs.get_performance_metrics()
+    assert list(a) == list(b)
+    for k in a:
+        assert a[k] == pytest.approx(b[k], rel=2e-5, abs=1e-7, nan_ok=True), k
