@@ -62,7 +62,7 @@ def run(args, device=None, kernels=None):
             hyp = DEFAULTS[method]
         hyp = prepare(method, hyp, args.samples)
         t = torch.zeros(args.trials)
-        for k in range(args.trials):
+        for k in range(-1 if getattr(args, 'discard_first', False) else 0, args.trials):
             model = model_cfg.base(*model_cfg.args, num_classes=num_classes, **model_cfg.kwargs).to(device)
             sampler = getattr(inference, method)(hyperparameters=hyp, model=model, train_loader=loaders['train'],
                                                  device=device, **kw)
@@ -73,7 +73,8 @@ def run(args, device=None, kernels=None):
             fn()
             if device.type == 'cuda':
                 torch.cuda.synchronize(device)
-            t[k] = time.perf_counter() - t0
+            if k >= 0:                       # k = -1: the discarded trial that pays MIOpen's one-time solver search
+                t[k] = time.perf_counter() - t0
         timer[method + '_mean'], timer[method + '_std'] = float(t.mean()), float(t.std()) if args.trials > 1 else 0.0
         print(method, 'time for', args.samples, 'samples:', timer[method + '_mean'], '+-', timer[method + '_std'])
     with open(args.save_path + '.json', 'w') as f:
@@ -95,6 +96,8 @@ def main(argv=None):
     p.add_argument('--trials', type=int, default=10)      # T = 10 (time_script.py:74)
     p.add_argument('--train_size', type=int, default=None)
     p.add_argument('--test_size', type=int, default=None)
+    p.add_argument('--discard_first', action='store_true',
+                   help='run one extra, untimed trial per method first (MIOpen searches its solvers once per process)')
     run(p.parse_args(argv))
 
 
