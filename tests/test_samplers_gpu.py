@@ -311,7 +311,8 @@ def test_rccl_process_group_with_graph_capture_world_size_1():
 def test_end_to_end_preresnet8_vs_reference_on_gpu(golden_dir):
     """BASELINE configs[1]'s network family (PreResNet, BatchNorm) and sampler (SGHMC): the reference's CPU run
     replayed on the GPU with its captured noise. north_star's criterion — fp32 predictive probabilities
-    within 1e-5 relative of the reference CPU path — on 64 test rows after 4 noisy SGHMC steps."""
+    within 1e-5 relative of the reference CPU path — on 64 test rows after 4 noisy SGHMC steps (measured:
+    3.1e-6 max relative error on the probabilities, 2.1e-7 on the entropies; tools/exp/parity_margin.py)."""
     from test_samplers_cpu import _load_preresnet8, _preresnet8_inputs
     g = np.load(os.path.join(golden_dir, 'e2e_preresnet8.npz'))
     hyp = json.loads(str(g['hyper']))
