@@ -133,6 +133,17 @@ void oracle_philox_normal_f32(float* out, int64_t n, uint64_t seed, uint64_t ste
     }
 }
 
+/* elements [start, start+count) of the same stream (start must be a multiple of 4): lets the tests check the
+ * far end of a > 2^31-element arena without generating all of it on the CPU */
+void oracle_philox_normal_range_f32(float* out, int64_t start, int64_t count, uint64_t seed, uint64_t step)
+{
+    for (int64_t k = 0; k < count; k += 4) {
+        float z[4];
+        normal4(seed, step, (uint64_t)((start + k) >> 2), z);
+        for (int j = 0; j < 4 && k + j < count; ++j) out[k + j] = z[j];
+    }
+}
+
 /* ---------------------------------------------------------------------------------------
  * K1: optimSGHMC.step over a flat vector.   URSABench/inference/optim_sghmc.py:43-67
  */

@@ -20,6 +20,8 @@ _vp, _i64, _i32, _u64, _u32, _f = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
 _L.oracle_sgmcmc_step_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _u64, _u64, _u32]
 _L.oracle_philox_normal_f32.argtypes = [_vp, _i64, _u64, _u64]
 _L.oracle_philox_normal_f32.restype = None
+_L.oracle_philox_normal_range_f32.argtypes = [_vp, _i64, _i64, _u64, _u64]
+_L.oracle_philox_normal_range_f32.restype = None
 _L.oracle_philox4x32_10.restype = None
 _L.oracle_swag_collect_f32.argtypes = [_vp, _vp, _vp, _i64, _f, _f]
 _L.oracle_swag_draw_f32.argtypes = [_vp, _vp, _vp, _vp, _i64, _f, _f, _u64, _u64]
@@ -46,6 +48,13 @@ def philox4x32_10(ctr, key):
 def philox_normal(n, seed, step):
     out = np.empty(n, np.float32)
     _L.oracle_philox_normal_f32(_p(out), n, seed, step)
+    return out
+
+
+def philox_normal_range(start, count, seed, step):
+    assert start % 4 == 0
+    out = np.empty(count, np.float32)
+    _L.oracle_philox_normal_range_f32(_p(out), start, count, seed, step)
     return out
 
 

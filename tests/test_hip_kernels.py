@@ -305,3 +305,23 @@ def test_sgd_mode_bitwise_vs_torch_sgd_golden(K, golden_dir, case):
     with pytest.raises(ValueError):
         K.sgmcmc_step(theta, theta.clone(), mom, lr=0.1, mu=float(momentum), c_wd=0.0, c_noise=0.0, n_train=1.0,
                       flags=O.STEP_SGD | O.STEP_NOISE)
+
+
+def test_k1_beyond_2_31_elements(K):
+    """Maximum-size edge: an arena of 2^31 + 4100 elements (17 GB of theta + grad): 64-bit indexing in the
+    grid/element arithmetic and in the Philox counter. Noise-only SGLD update on zeros => theta is the noise
+    stream itself; both ends are compared with the oracle bit for bit, the bulk statistically."""
+    n = (1 << 31) + 4100
+    free, _ = torch.cuda.mem_get_info()
+    if free < 3 * n * 4:
+        pytest.skip('needs 26 GB of free HBM')
+    th = torch.zeros(n, device='cuda')
+    g = torch.zeros(n, device='cuda')
+    K.sgmcmc_step(th, g, None, lr=0.5, mu=0.0, c_wd=0.0, c_noise=1.0, n_train=1.0, flags=O.STEP_NOISE, seed=21, step=5)
+    assert np.array_equal(host(th[:4096]), O.philox_normal_range(0, 4096, 21, 5))
+    tail0 = ((1 << 31) - 8)
+    assert np.array_equal(host(th[tail0:]), O.philox_normal_range(tail0, n - tail0, 21, 5))      # crosses 2^31, scalar tail
+    m, sd = float(th.mean()), float(th.std())
+    assert abs(m) < 2e-4 and abs(sd - 1) < 2e-4 and float(th.abs().max()) < 6.8
+    # the two halves of the arena are different streams (no 32-bit wrap of the counter)
+    assert not torch.equal(th[:4096], th[(1 << 31):(1 << 31) + 4096])
