@@ -325,3 +325,22 @@ def test_k1_beyond_2_31_elements(K):
     assert abs(m) < 2e-4 and abs(sd - 1) < 2e-4 and float(th.abs().max()) < 6.8
     # the two halves of the arena are different streams (no 32-bit wrap of the counter)
     assert not torch.equal(th[:4096], th[(1 << 31):(1 << 31) + 4096])
+
+
+def test_k5_many_rows_grid_loop(K):
+    """More row tiles than the grid cap (2^20 blocks of 4 rows): the kernel's outer loop over row tiles.
+    Property at full size: every member's probabilities sum to one, so row sums grow by exactly S; the first
+    and last rows are compared with the oracle."""
+    S, B, C = 2, (1 << 22) + 5, 10
+    z = torch.randn(S, B, C, device='cuda') * 3
+    p, e = torch.zeros(B, C, device='cuda'), torch.zeros(B, device='cuda')
+    gam = dict(one_minus_gamma=1 - 1e-4, gamma_over_c=1e-4 * 1 / C)
+    K.bma_accumulate(z, p, e, smoothed=False, **gam)
+    rs = p.sum(1)
+    assert float((rs - S).abs().max()) < 1e-5 and float(e.min()) > 0
+    for sl in (slice(0, 64), slice(B - 64, B)):
+        zo = np.ascontiguousarray(host(z[:, sl]))
+        po, eo = np.zeros((64, C), np.float32), np.zeros(64, np.float32)
+        O.bma_accumulate(zo, po, eo, smoothed=False, **gam)
+        np.testing.assert_allclose(host(p[sl]), po, rtol=1e-5, atol=1e-8)
+        np.testing.assert_allclose(host(e[sl]), eo, rtol=1e-5, atol=1e-6)
