@@ -344,3 +344,24 @@ def test_k5_many_rows_grid_loop(K):
         O.bma_accumulate(zo, po, eo, smoothed=False, **gam)
         np.testing.assert_allclose(host(p[sl]), po, rtol=1e-5, atol=1e-8)
         np.testing.assert_allclose(host(e[sl]), eo, rtol=1e-5, atol=1e-6)
+
+
+def test_k2_k3_full_size_properties(K):
+    """WideResNet-28-10 size (36,546,980 parameters, BASELINE configs[3]). Properties: collecting the SAME
+    iterate twice (n = 0, then n = 1) leaves mean = w and sq = w*w exactly (halves add back exactly in fp32);
+    with zero variance the draw is the mean up to the 1e-30 clamp; a unit-variance draw follows our Philox
+    stream at both ends of the vector."""
+    n = 36546980
+    w = torch.randn(n, device='cuda')
+    mean, sq = torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda')
+    K.swag_collect(mean, sq, w, decay=0.0, denom=1.0)
+    K.swag_collect(mean, sq, w, decay=1 / 2.0, denom=2.0)
+    assert torch.equal(mean, w) and torch.equal(sq, w * w)
+    out = torch.empty(n, device='cuda')
+    K.swag_draw(out, mean, sq, var_clamp=1e-30, seed=3, draw=0)
+    assert float((out - mean).abs().max()) < 1e-13
+    K.swag_draw(out, torch.zeros_like(mean), torch.ones_like(sq), var_clamp=1e-30, seed=3, draw=1)
+    assert np.array_equal(host(out[:1024]), O.philox_normal_range(0, 1024, 3, 1))
+    t0 = (n // 4) * 4 - 1024
+    assert np.array_equal(host(out[t0:]), O.philox_normal_range(t0, n - t0, 3, 1))
+    assert abs(float(out.std()) - 1) < 1e-3
