@@ -23,12 +23,8 @@ def _prefer_aten_batchnorm_in_eval(module):
             def forward(x, _inner=inner, _m=m):
                 if _m.training:
                     return _inner(x)
-                prev = torch.backends.cudnn.enabled
-                torch._C._set_cudnn_enabled(False)
-                try:
+                with torch.backends.cudnn.flags(enabled=False):      # restored on exit, also on error
                     return _inner(x)
-                finally:
-                    torch._C._set_cudnn_enabled(prev)
             m.forward = forward
             m._ursa_bn_wrapped = True
 
