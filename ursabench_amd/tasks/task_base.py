@@ -23,8 +23,13 @@ def _prefer_aten_batchnorm_in_eval(module):
             def forward(x, _inner=inner, _m=m):
                 if _m.training:
                     return _inner(x)
-                with torch.backends.cudnn.flags(enabled=False):      # restored on exit, also on error
+                # what torch.backends.cudnn.flags(enabled=False) does, minus its MIOpen "benchmark limit" warning
+                prev = torch.backends.cudnn.enabled
+                torch._C._set_cudnn_enabled(False)
+                try:
                     return _inner(x)
+                finally:
+                    torch._C._set_cudnn_enabled(prev)
             m.forward = forward
             m._ursa_bn_wrapped = True
 
