@@ -226,3 +226,26 @@ def test_end_to_end_preresnet8_vs_reference(golden_dir):
     pred.update_statistics(ens, output_performance=False)
     np.testing.assert_allclose(pred.ensemble_proba.numpy(), g['proba_sum'], rtol=1e-5, atol=1e-8)
     np.testing.assert_allclose(pred.expected_data_uncertainty.numpy(), g['ent_sum'], rtol=1e-5, atol=1e-6)
+
+
+def test_tied_weights_survive_snapshots():
+    """A parameter registered under two names (weight tying) is one arena slot and one view per member."""
+    class Tied(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.enc = torch.nn.Linear(12, 12, bias=False)
+            self.dec = torch.nn.Linear(12, 12, bias=False)
+            self.dec.weight = self.enc.weight
+            self.out = torch.nn.Linear(12, 4)
+
+        def forward(self, x):
+            return self.out(self.dec(torch.relu(self.enc(x))))
+
+    s = inference.SGHMC({'lr': 0.05, 'prior_std': 1.0, 'num_samples': 2, 'alpha': 0.5, 'burn_in_epochs': 0},
+                        Tied(), tiny_loader(), kernels=OracleKernels(), use_graph=False)
+    assert s.arena.num_parameters == 12 * 12 + 12 * 4 + 4
+    ens = s.sample()
+    for m in ens:
+        assert m.enc.weight.data_ptr() == m.dec.weight.data_ptr()
+        assert torch.isfinite(m(torch.randn(3, 12))).all()
+    assert not torch.equal(ens[0].enc.weight, ens[1].enc.weight)

@@ -177,6 +177,9 @@ class MemberBank:
         m = copy.deepcopy(self._skeleton)
         a = self.arena
         pviews = dict(zip(a.param_names, a.layout.views(self.theta_of(row))))
+        by_id = {id(p): pviews[n] for n, p in zip(a.param_names, a.params)}
+        for n, p in like.named_parameters(remove_duplicate=False):       # tied weights: every alias -> one view
+            pviews.setdefault(n, by_id[id(p)])
         fviews = dict(zip(a.fbuf_layout.names, a.fbuf_layout.views(row[a.layout.padded:])))
         iviews = {k: t for t, (k, _) in zip(irow, a.ibufs)}
         req = {k: p.requires_grad for k, p in like.named_parameters()}
