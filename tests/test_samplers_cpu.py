@@ -249,3 +249,29 @@ def test_tied_weights_survive_snapshots():
         assert m.enc.weight.data_ptr() == m.dec.weight.data_ptr()
         assert torch.isfinite(m(torch.randn(3, 12))).all()
     assert not torch.equal(ens[0].enc.weight, ens[1].enc.weight)
+
+
+def test_tensors_without_gradient_are_skipped_like_the_reference():
+    """optim_sghmc.py:44-45: `if p.grad is None: continue` — a frozen / unused tensor gets no prior pull and
+    no noise, in the sampler engine and in the drop-in optimizer alike; a stale arena gradient is never re-applied."""
+    torch.manual_seed(0)
+    net = tiny_net()
+    net[0].weight.requires_grad_(False)
+    frozen0 = net[0].weight.detach().clone()
+    s = inference.SGHMC({'lr': 0.05, 'prior_std': 1.0, 'num_samples': 2, 'alpha': 0.5, 'burn_in_epochs': 0},
+                        net, tiny_loader(), kernels=OracleKernels(), use_graph=False)
+    ens = s.sample()
+    assert torch.equal(net[0].weight, frozen0) and torch.equal(ens[1][0].weight, frozen0)
+    assert not torch.equal(ens[0][2].weight, ens[1][2].weight)
+    # drop-in use: backward, step, then Module.zero_grad() (sets .grad to None), then a step with NO backward
+    params = [torch.nn.Parameter(torch.randn(5)), torch.nn.Parameter(torch.randn(7))]
+    opt = inference.optimSGHMC(params, lr=0.1, momentum=0.5, num_training_samples=10, weight_decay=1.0, kernels=OracleKernels())
+    (params[0].sum() * 2 + params[1].sum() * 3).backward()
+    opt.step(add_langevin_noise=False)
+    after1 = [p.detach().clone() for p in params]
+    for p in params:
+        p.grad = None
+    (params[0] ** 2).sum().backward()                       # params[1] receives no gradient this time
+    opt.step(add_langevin_noise=True)
+    assert torch.equal(params[1], after1[1]) and not torch.equal(params[0], after1[0])
+    assert float(opt.arena.grad_views[1].abs().sum()) == 0  # the previous step's gradient is gone, not re-applied

@@ -92,9 +92,19 @@ class FlatArena:
                 for (k, b), v in zip(fl, self.fbuf_layout.views(self.fbuf)):
                     v.copy_(b)
                     b.data = v
-            self.param_names = [k for k, _ in module.named_parameters()]
+            # names by parameter identity (the optimizer may have been given any subset / order of
+            # module.parameters()); a tied parameter has several names: all of them -> its one slot
+            names_of = {}
+            for k, p in module.named_parameters(remove_duplicate=False):
+                names_of.setdefault(id(p), []).append(k)
+            missing = [i for i, p in enumerate(params) if id(p) not in names_of]
+            if missing:
+                raise ValueError(f'parameters {missing} of the arena do not belong to the module given as module=')
+            self.param_names = [names_of[id(p)][0] for p in params]
+            self.param_aliases = {alias: names_of[id(p)][0] for p in params for alias in names_of[id(p)][1:]}
         else:
             self.param_names = [str(i) for i in range(len(params))]
+            self.param_aliases = {}
 
     # -- reference-compatible flat vectors -------------------------------------------------
     @property
@@ -129,10 +139,26 @@ class FlatArena:
                     v.copy_(p.detach())
                     p.data = v
                 if p.grad is None:
+                    gv.zero_()               # "no gradient": never re-apply the previous step's (optim_sghmc.py:44-45)
                     p.grad = gv
                 elif p.grad.data_ptr() != gv.data_ptr():
                     gv.copy_(p.grad)
                     p.grad = gv
+
+    def stash(self, indices):
+        """Copies of the theta (and momentum) slices of the given tensors, to undo a flat update on them."""
+        L = self.layout
+        spans = [(L.offsets[i], L.offsets[i] + L.numels[i]) for i in indices]
+        return [(lo, hi, self.theta[lo:hi].clone(), None if self.mom is None else self.mom[lo:hi].clone())
+                for lo, hi in spans]
+
+    def unstash(self, kept, snapshot=None):
+        for lo, hi, th, mo in kept:
+            self.theta[lo:hi].copy_(th)
+            if mo is not None:
+                self.mom[lo:hi].copy_(mo)
+            if snapshot is not None:
+                snapshot[lo:hi].copy_(th)
 
     def grads_bound(self):
         return all(p.grad is not None and p.grad.data_ptr() == gv.data_ptr()
@@ -177,9 +203,8 @@ class MemberBank:
         m = copy.deepcopy(self._skeleton)
         a = self.arena
         pviews = dict(zip(a.param_names, a.layout.views(self.theta_of(row))))
-        by_id = {id(p): pviews[n] for n, p in zip(a.param_names, a.params)}
-        for n, p in like.named_parameters(remove_duplicate=False):       # tied weights: every alias -> one view
-            pviews.setdefault(n, by_id[id(p)])
+        for alias, canonical in a.param_aliases.items():                 # tied weights: every alias -> one view
+            pviews[alias] = pviews[canonical]
         fviews = dict(zip(a.fbuf_layout.names, a.fbuf_layout.views(row[a.layout.padded:])))
         iviews = {k: t for t, (k, _) in zip(irow, a.ibufs)}
         req = {k: p.requires_grad for k, p in like.named_parameters()}
@@ -196,6 +221,7 @@ class MemberBank:
                 mod._buffers[name] = fviews[full] if full in fviews else iviews[full]
         m.train(like.training)
         m._ursa_row = row            # flat handle for hosts that want the member without the module
+        m._ursa_irow = irow
         m._ursa_bank = self
         return m
 

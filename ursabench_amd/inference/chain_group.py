@@ -25,11 +25,15 @@ class ChainGroup:
             raise TypeError('ChainGroup takes SGLD/SGHMC/cSGLD/cSGHMC sampler objects')
         if len({type(s) for s in samplers}) != 1 or len({id(s.train_loader) for s in samplers}) != 1:
             raise ValueError('the chains of a group must be of one sampler class and share one train loader')
+        seeds = [s.optimizer.seed for s in samplers]
+        if len(set(seeds)) != len(seeds):
+            raise ValueError(f'chains of a group share a Philox key {seeds}: they would draw bit-identical noise on the '
+                             'same minibatches. Construct them with distinct seed= (or util.set_random_seed between them)')
         self.samplers = samplers
         self.loader = samplers[0].train_loader
         self.device = torch.device(samplers[0].device)
         self.use_graph = (self.device.type == 'cuda') if use_graph is None else use_graph
-        self._graph, self._static, self._warm = None, None, 0
+        self._graph, self._static, self._warm, self._captured_with = None, None, 0, None
         self.stats = dict(graph_replays=0, eager_rounds=0, captures=0)
 
     def __len__(self):
@@ -55,13 +59,23 @@ class ChainGroup:
             for st in side:                                  # join
                 cap.wait_stream(st)
         self._graph = g
+        self._captured_with = self._device_state()
         self.stats['captures'] += 1
+
+    def _device_state(self):
+        """What a captured round bakes in per chain: the optimizer object and the addresses of its control
+        block, schedule table and momentum buffer."""
+        ptr = lambda t: None if t is None else t.data_ptr()
+        return [(id(s.optimizer), ptr(s.optimizer._ctl), ptr(s.optimizer._sched), ptr(s.arena.mom)) for s in self.samplers]
 
     def _run_epoch(self, plans):
         for s, (noise, sched) in zip(self.samplers, plans):
             s.model.train()
             s.engine.loss_acc.zero_()
             s.optimizer.ctl_begin(noise, sched)
+        if self._graph is not None and self._device_state() != self._captured_with:
+            # update_hyp on a member rebuilt its optimizer: the captured round would step the old one
+            self._graph, self._static, self._warm, self._captured_with = None, None, 0, None
         full = getattr(self.loader, 'batch_size', None)
         seen = steps = 0
         for x, y in self.loader:

@@ -20,7 +20,7 @@ from .sghmc import _ChainSampler
 class cSGHMC(_ChainSampler):
 
     def __init__(self, hyperparameters, model=None, train_loader=None, model_loss='multi_class_linear_output',
-                 device=torch.device('cpu'), *, kernels=None, use_graph=None):
+                 device=torch.device('cpu'), *, kernels=None, use_graph=None, seed=None):
         if hyperparameters == None:  # noqa: E711  (csghmc.py:17-19)
             hyperparameters = {'lr_0': 0.001000, 'prior_std': 10.1000, 'num_samples_per_cycle': 5, 'cycle_length': 20,
                                'burn_in_epochs': 5, 'num_cycles': 10, 'alpha': 1., }
@@ -31,7 +31,7 @@ class cSGHMC(_ChainSampler):
         # float, and over-counts by one (csghmc.py:30-31): kept, it shifts the restart points
         self.num_batch = max(1, len(train_loader.dataset) / self.batch_size + 1)
         self._setup_chain(model, train_loader, model_loss, device, kernels, use_graph, lr=self.lr_0,
-                          momentum=1 - self.alpha, weight_decay=1 / (self.prior_std ** 2))
+                          momentum=1 - self.alpha, weight_decay=1 / (self.prior_std ** 2), seed=seed)
         self.burnt_in = False
         self.epochs_run = 0
         self.dataloader_batch_size = self.train_loader.batch_size

@@ -52,17 +52,23 @@ class ChainEngine:
             p.grad = None
         loss.backward()
         grads = [p.grad for p in self._params]
+        keep = None
         if any(g is None for g in grads):
-            # a parameter that received no gradient keeps a zero slot (the reference skips such tensors
-            # altogether, optim_sghmc.py:44-45; here they still see prior + noise)
+            # a parameter that received no gradient (frozen / unused layer) is skipped by the reference
+            # altogether (optim_sghmc.py:44-45): no prior pull, no noise. The flat launch covers it, so its
+            # theta / momentum slices are copied aside and put back (device-to-device, part of the capture).
             pairs = [(v, g) for v, g in zip(self._grad_views, grads) if g is not None]
             torch._foreach_copy_([v for v, _ in pairs], [g for _, g in pairs])
+            if getattr(self.opt, 'skip_grad_none', True):
+                keep = self.opt.arena.stash([i for i, g in enumerate(grads) if g is None])
         else:
             torch._foreach_copy_(self._grad_views, grads)
         for p in self._params:
             p.grad = None
         self.loss_acc += loss.detach() * x.shape[0]
         self.opt.ctl_step(eps=eps)
+        if keep is not None:
+            self.opt.arena.unstash(keep)
 
     def _capture(self, x, y):
         self._static = (torch.empty_like(x), torch.empty_like(y))

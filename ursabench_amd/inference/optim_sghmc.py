@@ -54,6 +54,7 @@ class optimSGHMC(Optimizer):
         self._ctl = None               # device control block (graph-replayable stepping)
         self._sched = None             # device (lr, c_noise) table for per-iteration schedules
         self.ctl_zero_grad = True      # control-block stepping re-zeroes the flat gradient (fused)
+        self.skip_grad_none = True     # reference semantics for tensors whose .grad is None (optim_sghmc.py:44-45)
 
     def __setstate__(self, state):
         super().__setstate__(state)
@@ -63,6 +64,18 @@ class optimSGHMC(Optimizer):
     @property
     def arena(self):
         return self.arenas[0]
+
+    def adopt_device_state(self, old):
+        """This optimizer replaces `old` over the same arena (update_hyp): take over its device control
+        block and schedule table — a hipGraph captured with `old` holds their addresses, and dropping
+        them would hand those addresses back to the caching allocator (use-after-free on replay) — and
+        continue its Philox call counter (same key: a restart at 0 would replay the same noise)."""
+        if old.arena is not self.arena:
+            raise ValueError('adopt_device_state: the two optimizers do not share an arena')
+        self._ctl, self._sched = old._ctl, old._sched
+        old._ctl = old._sched = None
+        if old.seed == self.seed:
+            self._step = old._step
 
     def zero_grad(self, set_to_none=False):
         """One memset of the flat gradient buffer (the grads are arena views and must survive)."""
@@ -101,12 +114,18 @@ class optimSGHMC(Optimizer):
                 loss = closure()
         for gi, group in enumerate(self.param_groups):
             a = self.arenas[gi]
+            # tensors without a gradient are skipped by the reference (optim_sghmc.py:44-45): the flat launch
+            # covers them, so their theta / momentum slices are put back afterwards (rare: frozen layers)
+            skipped = [i for i, p in enumerate(a.params) if p.grad is None] if self.skip_grad_none else []
             a.rebind()
             sc = self._scalars(group, add_langevin_noise, gi)
             mom = a.ensure_mom() if sc['mu'] != 0 else None
+            keep = a.stash(skipped) if skipped else None
             seed = (self.seed ^ (gi * _GROUP_SALT)) & 0xFFFFFFFFFFFFFFFF
             self.kernels.sgmcmc_step(a.theta, a.grad, mom, seed=seed, step=self._step,
                                      eps=eps if gi == 0 else None, snapshot=snapshot if gi == 0 else None, **sc)
+            if keep is not None:
+                a.unstash(keep, snapshot if gi == 0 else None)
             if sc['mu'] != 0 and not self._has_mom[gi]:
                 self._register_momentum_views(gi)
         self._step += 1

@@ -27,9 +27,14 @@ except Exception:                      # pragma: no cover
 class _ChainSampler(_Inference):
     """What SGHMC/SGLD/cSGHMC/cSGLD share: arena-backed optimizer, engine, member bank."""
 
-    def _setup_chain(self, model, train_loader, model_loss, device, kernels, use_graph, lr, momentum, weight_decay):
+    def _setup_chain(self, model, train_loader, model_loss, device, kernels, use_graph, lr, momentum, weight_decay,
+                     seed=None):
+        """seed: the chain's Philox key. None = torch.initial_seed() at construction (what
+        util.set_random_seed set, experiment.py:170) — build chains that must be independent with distinct
+        seed= values or a set_random_seed call between them; ChainGroup refuses equal keys."""
         if not isinstance(model, torch.nn.Module):
             raise NotImplementedError
+        self.seed = int(torch.initial_seed() if seed is None else seed)
         self.model_loss = model_loss
         self.model = model.to(device)
         self.train_loader = train_loader
@@ -38,7 +43,7 @@ class _ChainSampler(_Inference):
         self._kernels = kernels
         self.optimizer = optimSGHMC(params=self.model.parameters(), lr=lr, momentum=momentum,
                                     num_training_samples=self.dataset_size, weight_decay=weight_decay,
-                                    kernels=kernels, module=self.model)
+                                    kernels=kernels, module=self.model, seed=self.seed)
         self.arena = self.optimizer.arena
         self.loss_criterion = get_loss_criterion(loss=model_loss)
         self.engine = ChainEngine(self.model, self.optimizer, self.loss_criterion, device, use_graph)
@@ -46,12 +51,15 @@ class _ChainSampler(_Inference):
         self.eps_provider = None        # callable(step_in_epoch) -> flat eps tensor: parity runs only
 
     def _new_optimizer(self, lr, momentum, weight_decay):
-        """update_hyp rebuilds the optimizer (sghmc.py:57-58); the arena (and so every captured
-        graph address) is reused, the momentum buffer restarts from the first-step rule."""
-        seed = torch.initial_seed()
+        """update_hyp rebuilds the optimizer (sghmc.py:57-58); the arena, the device control block and
+        the schedule table (so every address a captured graph may hold) are reused, the momentum buffer
+        restarts from the first-step rule. The chain keeps its Philox key and the call counter carries
+        over, so a hyper-optimisation trial never replays the noise of the previous one."""
+        old = self.optimizer
         self.optimizer = optimSGHMC(params=self.model.parameters(), lr=lr, momentum=momentum,
                                     num_training_samples=self.dataset_size, weight_decay=weight_decay,
-                                    kernels=self._kernels, arena=self.arena, seed=seed)
+                                    kernels=self._kernels, arena=self.arena, seed=self.seed)
+        self.optimizer.adopt_device_state(old)
         self.engine.set_optimizer(self.optimizer)
 
     def _snapshot(self):
@@ -86,7 +94,7 @@ class _ChainSampler(_Inference):
 class SGHMC(_ChainSampler):
 
     def __init__(self, hyperparameters, model=None, train_loader=None, model_loss='multi_class_linear_output',
-                 device=torch.device('cpu'), *, kernels=None, use_graph=None):
+                 device=torch.device('cpu'), *, kernels=None, use_graph=None, seed=None):
         """hyperparameters: {'lr', 'prior_std', 'num_samples', 'alpha', 'burn_in_epochs'} (sghmc.py:28-32)."""
         if hyperparameters == None:  # noqa: E711  (reference default, sghmc.py:23-25)
             hyperparameters = {'lr': 0.001, 'prior_std': 10, 'num_samples': 2, 'alpha': 0.1, 'burn_in_epochs': 10}
@@ -97,7 +105,7 @@ class SGHMC(_ChainSampler):
         self.alpha = hyperparameters['alpha']
         self.burn_in_epochs = hyperparameters['burn_in_epochs']
         self._setup_chain(model, train_loader, model_loss, device, kernels, use_graph, lr=self.lr,
-                          momentum=1 - self.alpha, weight_decay=1 / (self.prior_std ** 2))
+                          momentum=1 - self.alpha, weight_decay=1 / (self.prior_std ** 2), seed=seed)
         self.burnt_in = False
         self.epochs_run = 0
         self.lr_final = self.lr / 2

@@ -48,7 +48,8 @@ def decision_cost(D, y_true, cost_mat=None):
 
 
 class Decision(_Task):
-    def __init__(self, dataloader, num_classes, device, *, cost_mat=None, kernels=None, process_group=None):
+    def __init__(self, dataloader, num_classes, device, *, cost_mat=None, kernels=None, process_group=None,
+                 acc_kw=None):
         super().__init__(dataloader, num_classes, device)
         self.data_loader = dataloader['decision_data_test']
         self.num_classes = num_classes
@@ -63,17 +64,18 @@ class Decision(_Task):
             cost_mat = maker(self.num_classes)
         self.cost_mat = cost_mat.float().cpu()
         self._acc = EnsembleAccumulator(self.data_loader, num_classes, device, kernels, smoothed=True,
-                                        with_entropy=False, cost=self.cost_mat.to(device).contiguous())
+                                        with_entropy=False, cost=self.cost_mat.to(device).contiguous(), **(acc_kw or {}))
         self.reset()
 
     def _publish(self):
-        p, _, r, n = self._acc.reduced(self._local_count, self.process_group)
-        self.ensemble_proba, self.risk, self.num_samples_collected = p.cpu(), r.cpu(), n
+        p, _, r, n = self._acc.reduced(self._local_count, self.process_group)   # update_statistics only
+        self.ensemble_proba, self.risk, self.num_samples_collected = p, r, n
 
     def reset(self):
         self._local_count = 0
+        self.num_samples_collected = 0
         self._acc.reset()
-        self._publish()
+        self.ensemble_proba, _, self.risk = self._acc.local()
 
     def update_statistics(self, models, output_performance=True, smoothing=True):
         members = as_member_list(models)

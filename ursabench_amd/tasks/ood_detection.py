@@ -13,22 +13,23 @@ __all__ = ['OODDetection']
 
 class OODDetection(_Task):
     def __init__(self, data_loader=None, num_classes=None, device=torch.device('cpu'), *, kernels=None,
-                 process_group=None):
+                 process_group=None, acc_kw=None):
         super().__init__(data_loader, num_classes, device)
         self.in_distribution_loader = data_loader['in_distribution_test']
         self.out_distribution_loader = data_loader['out_distribution_test']
         self.num_classes = num_classes
         self.device = device
         self.process_group = process_group
-        self._in = EnsembleAccumulator(self.in_distribution_loader, num_classes, device, kernels, smoothed=True)
-        self._out = EnsembleAccumulator(self.out_distribution_loader, num_classes, device, kernels, smoothed=True)
+        self._in = EnsembleAccumulator(self.in_distribution_loader, num_classes, device, kernels, smoothed=True, **(acc_kw or {}))
+        self._out = EnsembleAccumulator(self.out_distribution_loader, num_classes, device, kernels, smoothed=True, **(acc_kw or {}))
         self.reset()
 
     def _publish(self):
+        """Collectives (one per loader) happen here, i.e. in update_statistics only."""
         p, e, _, n = self._in.reduced(self._local_count, self.process_group)
-        self.in_distribution_ensemble_proba, self.in_distribution_data_uncertainty = p.cpu(), e.cpu()
+        self.in_distribution_ensemble_proba, self.in_distribution_data_uncertainty = p, e
         p, e, _, _ = self._out.reduced(self._local_count, self.process_group)
-        self.out_distribution_ensemble_proba, self.out_distribution_data_uncertainty = p.cpu(), e.cpu()
+        self.out_distribution_ensemble_proba, self.out_distribution_data_uncertainty = p, e
         self.num_samples_collected = n
 
     def reset(self):
@@ -39,7 +40,9 @@ class OODDetection(_Task):
         self.out_distribution_total_uncertainty = None
         self.in_distribution_model_uncertainty = None
         self.out_distribution_model_uncertainty = None
-        self._publish()
+        self.num_samples_collected = 0
+        self.in_distribution_ensemble_proba, self.in_distribution_data_uncertainty, _ = self._in.local()
+        self.out_distribution_ensemble_proba, self.out_distribution_data_uncertainty, _ = self._out.local()
 
     def update_statistics(self, models, output_performance=True):
         members = as_member_list(models)

@@ -23,7 +23,8 @@ class Prediction(_Task):
                              'misclass_total_uncertainty_aucpr', 'misclass_confidence_auroc',
                              'misclass_confidence_aucpr']
 
-    def __init__(self, dataloader, num_classes, device, metric_list, *, kernels=None, process_group=None):
+    def __init__(self, dataloader, num_classes, device, metric_list, *, kernels=None, process_group=None,
+                 acc_kw=None):
         super().__init__(dataloader, num_classes, device)
         self.data_loader = dataloader['in_distribution_test']
         self.num_classes = num_classes
@@ -34,19 +35,21 @@ class Prediction(_Task):
         self.required_metric_list = self.supported_metric_list if metric_list == 'ALL' else metric_list
         assert all(metric in self.supported_metric_list for metric in self.required_metric_list)
         self.targets = torch.cat([y.cpu() for _, y in self.data_loader])       # prediction.py:28-31
-        self._acc = EnsembleAccumulator(self.data_loader, num_classes, device, kernels, smoothed=False)
-        self._publish()
+        self._acc = EnsembleAccumulator(self.data_loader, num_classes, device, kernels, smoothed=False, **(acc_kw or {}))
+        self.ensemble_proba, self.expected_data_uncertainty, _ = self._acc.local()      # zeros; no collective here
 
     def _publish(self):
-        proba, ent, _, count = self._acc.reduced(self._local_count, self.process_group)
-        self.ensemble_proba = proba.cpu()
-        self.expected_data_uncertainty = ent.cpu()
-        self.num_samples_collected = count
+        """The one collective of the path (see EnsembleAccumulator.reduced): update_statistics only."""
+        self.ensemble_proba, self.expected_data_uncertainty, _, self.num_samples_collected = \
+            self._acc.reduced(self._local_count, self.process_group)
 
     def reset(self):
+        """prediction.py:33-35: clears the probabilities and the count, NOT expected_data_uncertainty
+        (neither the public tensor nor the accumulator behind it). Local: no collective."""
         self._local_count = 0
+        self.num_samples_collected = 0
         self._acc.reset(entropy_too=False)
-        self._publish()
+        self.ensemble_proba = torch.zeros_like(self.ensemble_proba)
 
     def update_statistics(self, models, output_performance=True, smoothing=True):
         members = as_member_list(models)

@@ -12,24 +12,20 @@ def _prefer_aten_batchnorm_in_eval(module):
     """Inference-mode BatchNorm through MIOpen (`MIOpenBatchNormFwdInferSpatialEst`) takes 39 us per
     layer on a [128,16,32,32] fp32 activation — 58 % of a PreResNet-20 eval forward — against 6 us for
     ATen's own `batch_norm_transform_input_kernel` (tools/exp/bn_probe.py; training-mode BN is the
-    other way round, so only eval is redirected). ATen picks the backend from the process-global
-    cudnn/MIOpen switch, so it is flipped around each BatchNorm call of OUR twin module only (host
-    side, i.e. at graph-capture time) and always restored."""
+    other way round, so only eval is redirected). `torch.batch_norm` picks its backend from the
+    process-global cudnn/MIOpen switch; `torch.native_batch_norm` IS the ATen kernel, so the eval
+    forward of OUR twin's BatchNorm layers calls that directly: no global state is touched (RCCL
+    watchdog / ChainGroup threads may be alive) and no private API is used."""
     from torch.nn.modules.batchnorm import _BatchNorm
     for m in module.modules():
         if isinstance(m, _BatchNorm) and not hasattr(m, '_ursa_bn_wrapped'):
             inner = m.forward
 
             def forward(x, _inner=inner, _m=m):
-                if _m.training:
+                if _m.training or _m.running_mean is None or not x.is_cuda:
                     return _inner(x)
-                # what torch.backends.cudnn.flags(enabled=False) does, minus its MIOpen "benchmark limit" warning
-                prev = torch.backends.cudnn.enabled
-                torch._C._set_cudnn_enabled(False)
-                try:
-                    return _inner(x)
-                finally:
-                    torch._C._set_cudnn_enabled(prev)
+                return torch.native_batch_norm(x, _m.weight, _m.bias, _m.running_mean, _m.running_var, False, 0.0,
+                                               _m.eps)[0]
             m.forward = forward
             m._ursa_bn_wrapped = True
 
@@ -74,10 +70,16 @@ class EnsembleAccumulator:
     after an optional all-reduce across ranks (one process per GPU, members sharded over ranks).
     """
 
-    def __init__(self, loader, num_classes, device, kernels, smoothed, with_entropy=True, cost=None, use_graph=True):
+    def __init__(self, loader, num_classes, device, kernels, smoothed, with_entropy=True, cost=None, use_graph=None,
+                 use_twin=None):
         self.loader, self.C, self.device = loader, int(num_classes), torch.device(device)
-        self.use_graph = use_graph
+        on_hip = self.device.type == 'cuda'
+        self.use_graph = on_hip if use_graph is None else bool(use_graph)
+        if self.use_graph and not on_hip:
+            raise ValueError('hipGraph capture needs a HIP device')
+        self.use_twin = on_hip if use_twin is None else bool(use_twin)
         self._twins = {}
+        self.stats = dict(captures=0, twin_forwards=0, eager_forwards=0)
         self.K = kernels if kernels is not None else _native.default_kernels()
         self.smoothed, self.cost = smoothed, cost
         self.N = len(loader.dataset)
@@ -97,63 +99,92 @@ class EnsembleAccumulator:
     def _resident_twin(self, member):
         """A member that came out of a MemberBank is evaluated through that bank's *twin*: LANES modules
         whose tensors view persistent rows (copy member row -> lane row, 1 MB device-to-device), so the
-        forwards are captured once per batch shape into ONE hipGraph with LANES parallel branches and
-        replayed for every (batch, group of LANES members): small-network forwards leave most CUs idle,
-        independent branches overlap (same effect as inference/chain_group.py). Members of several chains
-        (several banks) get one twin per bank. Returns None for foreign modules (eager forward then)."""
-        if self.device.type != 'cuda' or not self.use_graph:
+        forwards are captured once per (batch shape, lanes in use) into ONE hipGraph with parallel
+        branches and replayed for every (batch, group of LANES members): small-network forwards leave
+        most CUs idle, independent branches overlap (same effect as inference/chain_group.py). Members
+        of several chains (several banks) get one twin per bank. Returns None for foreign modules
+        (eager forward then). `use_twin` None: only on a HIP device (on a CPU tensor the row copy buys
+        nothing); the CPU test-suite forces it on with use_graph=False to cover this logic."""
+        if not self.use_twin:
             return None
         bank = getattr(member, '_ursa_bank', None)
-        if bank is None or getattr(member, '_ursa_row', None) is None:
+        row = getattr(member, '_ursa_row', None)
+        if bank is None or row is None or row.device != self.device:
             return None
         twin = self._twins.get(id(bank))
         if twin is None:
-            rows, mods = [], []
+            rows, irows, mods = [], [], []
             for _ in range(self.LANES):
-                row, irow = bank.new_row()
-                row.copy_(member._ursa_row)
-                for dst, (k, _) in zip(irow, bank.arena.ibufs):
-                    dst.copy_(dict(member.named_buffers())[k])
-                mod = bank.materialise(row, irow, member)
+                lane_row, lane_irow = bank.new_row()
+                lane_row.copy_(row)
+                mod = bank.materialise(lane_row, lane_irow, member)
                 mod.eval()
                 _prefer_aten_batchnorm_in_eval(mod)
-                rows.append(row)
+                rows.append(lane_row)
+                irows.append(lane_irow)
                 mods.append(mod)
-            twin = self._twins[id(bank)] = dict(rows=rows, mods=mods, graphs={}, bank=bank)
+            twin = self._twins[id(bank)] = dict(rows=rows, irows=irows, mods=mods, runners={}, inputs={}, bank=bank)
         return twin
 
-    def _twin_graph(self, twin, x):
-        """(graph, static input, per-lane outputs) for this batch shape; captured on first use."""
-        key = tuple(x.shape)
-        g = twin['graphs'].get(key)
-        if g is None:
-            sx = torch.empty_like(x)
-            sx.copy_(x)
+    @staticmethod
+    def _load_lane(twin, lane, member):
+        """member -> lane: the flat row and the integer buffers (BatchNorm num_batches_tracked: unused
+        by an eval forward, copied so that the lane IS the member)."""
+        twin['rows'][lane].copy_(member._ursa_row)
+        src = getattr(member, '_ursa_irow', None)
+        if src is not None:
+            for dst, s in zip(twin['irows'][lane], src):
+                dst.copy_(s)
+
+    def _twin_runner(self, twin, x, lanes):
+        """(run, static input, per-lane outputs) for this batch shape and number of lanes in use;
+        with use_graph the forwards are captured on first use and `run` replays the graph."""
+        key = (tuple(x.shape), lanes)
+        r = twin['runners'].get(key)
+        if r is not None:
+            return r
+        mods = twin['mods'][:lanes]
+        sx = twin['inputs'].get(tuple(x.shape))                  # one static input per batch shape, shared by
+        if sx is None:                                           # the runners of every lane count
+            sx = twin['inputs'][tuple(x.shape)] = torch.empty_like(x)
+        sx.copy_(x)
+        if not self.use_graph:
+            outs = [m(sx) for m in mods]
+
+            def run(_mods=mods, _sx=sx, _outs=outs):
+                for m, o in zip(_mods, _outs):
+                    o.copy_(m(_sx))
+        else:
             cur = torch.cuda.current_stream(self.device)
-            side = [torch.cuda.Stream(self.device) for _ in twin['mods']]
+            side = [torch.cuda.Stream(self.device) for _ in mods]
             side[0].wait_stream(cur)
             with torch.cuda.stream(side[0]):
-                for m in twin['mods']:
+                for m in mods:
                     m(sx)                                        # warm-up outside capture (MIOpen search)
             cur.wait_stream(side[0])
             graph = torch.cuda.CUDAGraph()
             outs = []
             with torch.cuda.graph(graph, capture_error_mode='thread_local'):
                 cap = torch.cuda.current_stream(self.device)
-                for m, st in zip(twin['mods'], side):            # fork: one branch per lane
+                for m, st in zip(mods, side):                    # fork: one branch per lane
                     st.wait_stream(cap)
                     with torch.cuda.stream(st):
                         outs.append(m(sx))
                 for st in side:                                  # join
                     cap.wait_stream(st)
-            g = twin['graphs'][key] = (graph, sx, outs)
-        return g
+            run = graph.replay
+            self.stats['captures'] += 1
+        r = twin['runners'][key] = (run, sx, outs)
+        return r
 
     @torch.no_grad()
     def accumulate(self, members):
         S = len(members)
+        if S == 0:
+            return
         for m in members:
-            m.to(self.device)          # no-op for bank-resident members; moves foreign CPU models once
+            if getattr(m, '_ursa_row', None) is None:
+                m.to(self.device)      # foreign (e.g. CPU deep copies from the reference's samplers): moved once
             m.eval()
         # plan: per twin, the member indices it serves in groups of LANES; the rest run eagerly
         by_twin, eager = {}, []
@@ -171,15 +202,17 @@ class EnsembleAccumulator:
             if slab is None:
                 slab = self._slabs[(S, b)] = torch.empty(S, b, self.C, device=self.device)
             for twin, idxs in by_twin.values():
-                graph, sx, outs = self._twin_graph(twin, x)
-                if outs[0].shape != (b, self.C):
-                    raise ValueError(f'members return logits {tuple(outs[0].shape)}, expected {(b, self.C)}')
-                sx.copy_(x)
                 for g0 in range(0, len(idxs), self.LANES):
                     group = idxs[g0:g0 + self.LANES]
+                    run, sx, outs = self._twin_runner(twin, x, len(group))   # a partial group runs only its lanes
+                    if outs[0].shape != (b, self.C):
+                        raise ValueError(f'members return logits {tuple(outs[0].shape)}, expected {(b, self.C)}')
+                    if g0 == 0:
+                        sx.copy_(x)
                     for lane, s in enumerate(group):
-                        twin['rows'][lane].copy_(members[s]._ursa_row)
-                    graph.replay()                               # unused lanes recompute a stale member: ignored
+                        self._load_lane(twin, lane, members[s])
+                    run()
+                    self.stats['twin_forwards'] += len(group)
                     for lane, s in enumerate(group):
                         slab[s].copy_(outs[lane])
             for s in eager:
@@ -187,34 +220,42 @@ class EnsembleAccumulator:
                 if z.shape != (b, self.C):
                     raise ValueError(f'member {s} returned logits {tuple(z.shape)}, expected {(b, self.C)}')
                 slab[s].copy_(z)
+                self.stats['eager_forwards'] += 1
             self.K.bma_accumulate(slab, self.proba[start:start + b],
                                   None if self.ent is None else self.ent[start:start + b],
                                   one_minus_gamma=1 - GAMMA, gamma_over_c=GAMMA * 1 / self.C, smoothed=self.smoothed,
                                   risk_sum=None if self.risk is None else self.risk[start:start + b], cost=self.cost)
             start += b
 
+    def local(self):
+        """Host copies of this rank's accumulators (zeros right after construction / reset): no collective."""
+        cpu = lambda t: None if t is None else t.cpu()
+        return cpu(self.proba), cpu(self.ent), cpu(self.risk)
+
     def reduced(self, count, group=None):
-        """(proba_sum, ent_sum, risk_sum, total member count) summed over ranks: ONE all-reduce of
-        the concatenated fp32 accumulators over RCCL/xGMI (gloo on CPU), + the count."""
+        """(proba_sum, ent_sum, risk_sum, total member count) summed over ranks, as HOST tensors: ONE
+        all-reduce of the concatenated fp32 accumulators (+ the member count in the last slot) over
+        RCCL/xGMI (gloo on CPU), then ONE device-to-host copy. This is the path's only collective and the
+        only place the host waits for the device; it is entered from update_statistics alone (never from
+        a constructor or reset()), so every rank must call update_statistics the same number of times —
+        with an empty member list if it holds none."""
         parts = [self.proba.reshape(-1)]
         if self.ent is not None:
             parts.append(self.ent)
         if self.risk is not None:
             parts.append(self.risk.reshape(-1))
+        buf = torch.cat(parts + [torch.tensor([float(count)], device=self.device)])
         if dist.is_available() and dist.is_initialized():       # also at world size 1: the collective is then a no-op
-            buf = torch.cat(parts + [torch.tensor([float(count)], device=self.device)])
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-            count = int(round(buf[-1].item()))
-            buf = buf[:-1]
-        else:
-            buf = torch.cat(parts)
+        buf = buf.cpu()
+        count = int(round(float(buf[-1])))
         nc = self.N * self.C
-        proba = buf[:nc].view(self.N, self.C)
+        proba = buf[:nc].view(self.N, self.C).clone()
         off = nc
         ent = risk = None
         if self.ent is not None:
-            ent = buf[off:off + self.N]
+            ent = buf[off:off + self.N].clone()
             off += self.N
         if self.risk is not None:
-            risk = buf[off:off + nc].view(self.N, self.C)
+            risk = buf[off:off + nc].view(self.N, self.C).clone()
         return proba, ent, risk, count
