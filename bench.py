@@ -1,21 +1,30 @@
 """Headline benchmark: posterior-samples/sec (+ BMA-predictions/sec) for PreResNet-20 / CIFAR-10-
 shaped synthetic data, SGHMC, one chain per GPU (BASELINE.json configs[1]; configs[2] at N > 1).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c4|c5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one posterior sample: one epoch of ceil(50000/128) = 391 minibatch updates
-(forward + backward in stock PyTorch-ROCm, then ONE fused gfx950 update launch) followed by a
-device-to-device snapshot into the member bank (URSABench/inference/sghmc.py:65-101; protocol of
-URSABench/time_script.py:89-114: burn-in 0). W untimed samples, then exactly K timed samples
-bracketed by barrier + synchronize; rank 0 prints ONE JSON line. value = samples of ALL ranks /
-max-over-ranks time. After the timed region the K-member ensemble of every rank is evaluated on
-the 10,000-row test set (Prediction.update_statistics + one all-reduce): `bma_preds_per_s`.
+c2 (default, the driver's run). A "step" is one posterior sample: one epoch of ceil(50000/128) = 391
+minibatch updates (forward + backward in stock PyTorch-ROCm, then ONE fused gfx950 update launch)
+followed by a device-to-device snapshot into the member bank (URSABench/inference/sghmc.py:65-101;
+protocol of URSABench/time_script.py:89-114: burn-in 0). W untimed samples, then exactly K timed
+samples bracketed by barrier + synchronize; rank 0 prints ONE JSON line. value = samples of ALL ranks /
+max-over-ranks time. After the timed region the K-member ensemble of every rank is evaluated on the
+10,000-row test set (Prediction.update_statistics + one all-reduce): `bma_preds_per_s`.
 
-Extra objects: `roofline` (the update kernel, HIP events on its own stream, same launch as the
-workload's) and `cpu_baseline` (the torch-CPU port of the reference path, oracle/torch_cpu_path.py,
-timed on this box's host cores on a bounded sample; rank 0, N = 1 only).
+The run is a sequence of LEGS. Each leg's exception is caught and recorded under "errors" and the
+JSON line is printed from a `finally:` with whatever completed, so a late failure never erases the
+timed result; the exit code is non-zero if any leg failed. Legs (c2): parity (before timing: GPU
+path vs the torch-CPU port of the reference on identical inputs and noise, asserted <= 1e-5 relative
+on the predictive probabilities), sampling (timed), bma, roofline (HIP events on the launch stream),
+multi_chain_per_gpu / reference_style_gpu (informational, N = 1), cpu_baseline (port of the reference
+CPU path + the scalar-C kernels of oracle/, on this box's host cores, bounded sample, N = 1).
+
+c4 / c5 are BASELINE.json configs[3] / [4] at full size (WideResNet-28-10 SWAG 30-member BMA;
+PreResNet-164 HMC, 4 chains); see their legs below. --dry-run-cpu walks the c2 control flow at toy
+sizes on CPU tensors (gloo, tests' oracle kernel set): it exists so the N > 1 JSON assembly is exercised
+by the CPU test-suite and is NOT a measurement (the line says so).
 """
 import argparse
 import importlib.util
@@ -24,6 +33,7 @@ import os
 import sys
 import tempfile
 import time
+import traceback
 
 # A private MIOpen user find-db for this process: MIOpen caches its per-layer solver search under
 # $HOME and reuses it across processes, whatever switches the recording process ran with (a search
@@ -39,6 +49,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); measured float4 copy ceiling: 6290
 HBM_COPY_GBPS = 6290.0
+PARITY_RTOL = 1e-5              # north_star: fp32 predictive probabilities within 1e-5 relative of the CPU path
 
 # C2 hyper-parameters: URSABench/hyperparams/ResNet50CIFAR10/sghmc_hyperparams.json (no PreResNet-20
 # file exists in the reference), burn-in forced to 0 as time_script.py:89-90 does.
@@ -46,20 +57,77 @@ HYP = {'lr': 0.1, 'prior_std': 0.5, 'alpha': 0.5, 'burn_in_epochs': 0}
 N_TRAIN, N_TEST, BATCH, CLASSES = 50000, 10000, 128, 10
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3, help='timed posterior samples per chain (time_script S=3)')
-    ap.add_argument('--warmup', type=int, default=1, help='untimed posterior samples per chain')
+    ap.add_argument('--steps', type=int, default=None, help='timed steps (c2: posterior samples per chain, default 3 = time_script S)')
+    ap.add_argument('--warmup', type=int, default=None, help='untimed steps (default 1)')
+    ap.add_argument('--config', choices=['c2', 'c4', 'c5'], default='c2')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
     ap.add_argument('--chains-per-gpu', type=int, default=1, help='>1: ChainGroup (parallel graph branches); the headline config is 1')
     ap.add_argument('--multi-chain-probe', type=int, default=4, help='chains of the informational multi-chain run at N=1 (0: skip)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--force-dist', action='store_true', help='join an RCCL process group even when WORLD_SIZE is 1')
+    ap.add_argument('--no-parity', action='store_true')
+    ap.add_argument('--force-dist', action='store_true', help='join a process group even when WORLD_SIZE is 1')
     ap.add_argument('--cpu-steps', type=int, default=200, help='minibatch steps of the CPU port to time')
     ap.add_argument('--ref-style-steps', type=int, default=150, help='eager reference-style GPU steps to time (0: skip)')
     ap.add_argument('--large-n', type=int, default=1 << 26, help='elements of the roofline-sized K1 launch')
-    return ap.parse_args()
+    ap.add_argument('--c4-epochs', type=int, default=3, help='c4: SGD trajectory epochs over the 50,000 images (1 burn-in + rest collected)')
+    ap.add_argument('--c4-train', type=int, default=N_TRAIN)
+    ap.add_argument('--c5-batch', type=int, default=256, help='c5: full-batch size N of the HMC potential')
+    ap.add_argument('--c5-chains', type=int, default=4)
+    ap.add_argument('--c5-L', type=int, default=3)
+    ap.add_argument('--dry-run-cpu', action='store_true', help='toy-size CPU walk of the c2 control flow (tests only; not a measurement)')
+    ap.add_argument('--inject-failure', default='', help='(tests) raise inside the named leg')
+    a = ap.parse_args(argv)
+    if a.steps is None:
+        a.steps = {'c2': 3, 'c4': 29, 'c5': 20}[a.config]
+    if a.warmup is None:
+        a.warmup = 1
+    return a
+
+
+# ------------------------------------------------------------------------------------------------------
+class Legs:
+    """Runs named legs, keeps going after a failure, remembers the traceback tails."""
+
+    def __init__(self, inject=''):
+        self.errors, self.inject = {}, inject
+
+    def run(self, name, fn, *args, **kw):
+        try:
+            if self.inject == name:
+                raise RuntimeError(f'injected failure in leg {name!r}')
+            return fn(*args, **kw)
+        except BaseException as e:       # noqa: BLE001 — a leg must never take the JSON line down with it
+            if isinstance(e, KeyboardInterrupt):
+                raise
+            self.errors[name] = ''.join(traceback.format_exception(type(e), e, e.__traceback__))[-1500:]
+            sys.stderr.write(f'[bench] leg {name!r} failed:\n{self.errors[name]}\n')
+            return None
+
+
+def load_port():
+    spec = importlib.util.spec_from_file_location('torch_cpu_path', os.path.join(ROOT, 'oracle', 'torch_cpu_path.py'))
+    port = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(port)
+    return port
+
+
+def load_oracle_lib():
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import oracle_lib
+    return oracle_lib
+
+
+def cpu_model_name():
+    try:
+        for ln in open('/proc/cpuinfo'):
+            if ln.startswith('model name'):
+                return ln.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
 
 
 def event_time_ms(fn, iters, stream, graph_batch=0):
@@ -97,17 +165,82 @@ def event_time_ms(fn, iters, stream, graph_batch=0):
     return a.elapsed_time(b) / iters
 
 
-def pmc_traffic(elements):
-    """HBM bytes per launch of the update kernel from PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate
-    rocprofv3 --pmc passes, tools/pmc_collect.sh): PMC needs the profiler, so the figure is the committed
-    measurement in profiles/ for a launch of exactly this size, or None."""
-    path = os.path.join(ROOT, 'profiles', 'r01_k1_pmc.json')
-    if not os.path.exists(path):
-        return None
-    for v in json.load(open(path))['kernels'].values():
-        if v['elements'] == elements:
-            return v['hbm_bytes_per_launch_corrected']
+def pmc_traffic(kernel_key, elements):
+    """HBM bytes per launch from PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc
+    passes, tools/pmc_collect.sh): PMC needs the profiler, so the figure is the committed measurement
+    under profiles/ for a launch of exactly this kernel and size, or None."""
+    for name in ('r02_pmc.json', 'r01_k1_pmc.json'):
+        path = os.path.join(ROOT, 'profiles', name)
+        if not os.path.exists(path):
+            continue
+        for k, v in json.load(open(path))['kernels'].items():
+            if v.get('elements') == elements and (kernel_key in k or name.startswith('r01')):
+                return v['hbm_bytes_per_launch_corrected']
     return None
+
+
+# ---- c2 legs ------------------------------------------------------------------------------------------
+def parity_block(dev, steps_per_sample=1, samples=3, rows=64):
+    """§8(d): before timing, the GPU path against the reference CPU path (its torch-CPU port,
+    oracle/torch_cpu_path.py — pinned bitwise to the imported reference in tests/test_cpu_port.py) on
+    IDENTICAL inputs, initial weights and Langevin noise: PreResNet-20, `samples` SGHMC samples of
+    `steps_per_sample` minibatch steps on a `rows`-row slice, then the BMA predictive of the ensemble on
+    `rows` test rows. Asserts max relative error of the predictive probabilities <= 1e-5."""
+    import copy
+    from ursabench_amd import inference, models, tasks
+    from ursabench_amd.data import DeviceLoader
+    port = load_port()
+    torch.manual_seed(4242)
+    net_cpu = models.PreResNet(CLASSES, 20)
+    net_gpu = copy.deepcopy(net_cpu)
+    g = torch.Generator().manual_seed(4243)
+    n_tr = rows * steps_per_sample
+    xtr, ytr = torch.randn(n_tr, 3, 32, 32, generator=g), torch.randint(0, CLASSES, (n_tr,), generator=g)
+    xte, yte = torch.randn(rows, 3, 32, 32, generator=g), torch.randint(0, CLASSES, (rows,), generator=g)
+    hyp = dict(HYP, num_samples=samples)
+    # the noise the port will draw: torch.randn_like per tensor, in parameters() order, from the global generator
+    total = samples * steps_per_sample
+    torch.manual_seed(777)
+    eps_steps = [[torch.randn_like(p) for p in net_cpu.parameters()] for _ in range(total)]
+    # GPU: the product path with that noise injected through the kernel's eps input
+    train = DeviceLoader(xtr.to(dev), ytr.to(dev), rows)
+    test = DeviceLoader(xte.to(dev), yte.to(dev), rows)
+    s = inference.SGHMC(dict(hyp), net_gpu, train, device=dev, seed=1)
+    idx = s.arena.layout.gather_index(dev)
+
+    def eps(k):
+        e = torch.zeros(s.arena.n, device=dev)
+        e[idx] = torch.cat([t.reshape(-1) for t in eps_steps[k]]).to(dev)
+        return e
+    s.eps_provider = eps
+    lrs, ens = [], []
+    for _ in range(samples):
+        lrs.append(s.optimizer.param_groups[0]['lr'])         # CosineAnnealingLR moves it once per sample (sghmc.py:44,87)
+        ens.append(s.sample_iterative())
+    pred = tasks.Prediction({'in_distribution_test': test}, CLASSES, dev, 'ALL')
+    pred.update_statistics(ens, output_performance=False)
+    # CPU: the port, same generator state -> same noise
+    torch.manual_seed(777)
+    state, cpu_members = {}, []
+    batches = [(xtr[i:i + rows], ytr[i:i + rows]) for i in range(0, n_tr, rows)]
+    for lr in lrs:
+        port.sghmc_epoch(net_cpu, batches, state, lr=lr, momentum=1 - HYP['alpha'],
+                         weight_decay=1 / HYP['prior_std'] ** 2, num_training_samples=n_tr)
+        cpu_members.append(copy.deepcopy(net_cpu))
+    p_cpu, e_cpu, _, _ = port.prediction_accumulate(cpu_members, [(xte, yte)], CLASSES, rows)
+    p_gpu, e_gpu = pred.ensemble_proba, pred.expected_data_uncertainty
+    rel = ((p_gpu - p_cpu).abs() / p_cpu.abs()).max().item()
+    rel_e = ((e_gpu - e_cpu).abs() / e_cpu.abs()).max().item()
+    th_gpu = torch.cat([p.detach().reshape(-1) for p in ens[-1].parameters()]).cpu()
+    th_cpu = torch.cat([p.detach().reshape(-1) for p in cpu_members[-1].parameters()])
+    out = {'what': f'PreResNet-20 SGHMC, {samples} samples x {steps_per_sample} minibatch step(s) of {rows} rows, identical init / '
+                   f'inputs / injected noise; BMA predictive of the {samples}-member ensemble on {rows} test rows; GPU path vs '
+                   'torch-CPU port of the reference path',
+           'max_rel_err_proba': rel, 'max_rel_err_entropy': rel_e, 'rtol': PARITY_RTOL,
+           'max_abs_diff_params_last_member': (th_gpu - th_cpu).abs().max().item(), 'pass': bool(rel <= PARITY_RTOL)}
+    if not out['pass']:
+        raise AssertionError(f'parity: predictive probabilities differ by {rel:.3e} relative (> {PARITY_RTOL}): {out}')
+    return out
 
 
 def roofline_block(sampler, large_n):
@@ -123,9 +256,8 @@ def roofline_block(sampler, large_n):
                        graph_batch=256)
     bytes_per_launch = 20 * arena.n
     achieved = bytes_per_launch / (ms * 1e-3) / 1e9
-    traffic = pmc_traffic(arena.n)
     out = {'bound': 'hbm', 'kernel': 'k_sgmcmc_step_ctl', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS,
-           'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': traffic,
+           'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': pmc_traffic('step_ctl', arena.n),
            'bytes_per_launch': bytes_per_launch, 'us_per_launch': round(ms * 1e3, 3),
            'note': 'workload-sized launch (5.5 MB of state, L2/Infinity-Cache resident, one float4 per lane): '
                    'latency-bound; us_per_launch is a 256-launch hipGraph replay / 256 and includes the '
@@ -140,18 +272,34 @@ def roofline_block(sampler, large_n):
     large = {'kernel': 'k_sgmcmc_step<mom,philox>', 'elements': n, 'achieved': round(ach_l, 1), 'peak': HBM_PEAK_GBPS,
              'unit': 'GB/s', 'frac': round(ach_l / HBM_PEAK_GBPS, 4), 'frac_of_measured_copy_ceiling':
              round(ach_l / HBM_COPY_GBPS, 4), 'us_per_launch': round(ms_l * 1e3, 2), 'bytes_per_launch': 20 * n,
-             'traffic': pmc_traffic(n)}
+             'traffic': pmc_traffic('sgmcmc_step', n)}
     del th, g, m
     return out, large
 
 
+def bma_kernel_block(S, B, C):
+    """K5 at the shape this workload feeds it ([S, B, C] logit slab per batch): HIP events over a graph-batched
+    replay. Algorithmic bytes: 4*S*B*C read + read-modify-write of B*(C+1)*4."""
+    from ursabench_amd import _native
+    K = _native.default_kernels()
+    z = torch.randn(S, B, C, device='cuda')
+    p, e = torch.zeros(B, C, device='cuda'), torch.zeros(B, device='cuda')
+    fn = lambda: K.bma_accumulate(z, p, e, one_minus_gamma=1 - 1e-4, gamma_over_c=1e-4 / C, smoothed=False)
+    ms = event_time_ms(fn, 2048, torch.cuda.current_stream(), graph_batch=256)
+    nbytes = 4 * S * B * C + 2 * 4 * B * (C + 1)
+    ach = nbytes / (ms * 1e-3) / 1e9
+    return {'kernel': 'k_bma_accumulate', 'shape': [S, B, C], 'us_per_launch': round(ms * 1e3, 3), 'bytes_per_launch': nbytes,
+            'achieved': round(ach, 1), 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBPS, 4)}
+
+
 def cpu_baseline_block(steps):
     """Reference CPU path (port): PreResNet-20 forward/backward + per-tensor torch update loop on
-    this box's host cores, `steps` minibatch steps of the same workload; extrapolated to
-    posterior-samples/s = 1 / (391 x seconds-per-step)."""
-    spec = importlib.util.spec_from_file_location('torch_cpu_path', os.path.join(ROOT, 'oracle', 'torch_cpu_path.py'))
-    port = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(port)
+    this box's host cores, `steps` minibatch steps of the same workload, extrapolated to
+    posterior-samples/s = 1 / (391 x seconds-per-step); the CPU Prediction loop (prediction.py:52-64) on a
+    bounded number of test batches; and the scalar-C kernels of oracle/ (1 thread) on K1 at the workload
+    size and at the roofline size."""
+    import numpy as np
+    port = load_port()
     from ursabench_amd import models
     torch.manual_seed(0)
     # probed on the GPU box (256 logical CPUs, tools/cpu_threads_probe.py): 8/16/32/64/128 threads ->
@@ -172,20 +320,37 @@ def cpu_baseline_block(steps):
     torch.set_num_threads(1)                                              # the scalar figure, on a few steps
     n1, secs1 = port.sghmc_epoch(net, batches[3:3 + max(4, steps // 20)], state, **kw)
     torch.set_num_threads(threads)
-    cpu_model = 'unknown'
-    try:
-        for ln in open('/proc/cpuinfo'):
-            if ln.startswith('model name'):
-                cpu_model = ln.split(':', 1)[1].strip()
-                break
-    except OSError:
-        pass
-    return {'value': round(1.0 / (steps_per_sample * secs / n), 5), 'unit': 'posterior-samples/s',
-            'cores': threads, 'kind': 'port', 'cpu_model': cpu_model, 'logical_cpus': os.cpu_count(),
-            'value_1_thread': round(1.0 / (steps_per_sample * secs1 / n1), 5),
-            'sample': f'{n} minibatch steps (B={BATCH}) of PreResNet-20 SGHMC on torch-CPU '
-                      f'({secs:.1f} s, {1e3 * secs / n:.1f} ms/step), extrapolated to {steps_per_sample} steps/sample',
-            'ms_per_minibatch_step': round(1e3 * secs / n, 2)}
+    out = {'value': round(1.0 / (steps_per_sample * secs / n), 5), 'unit': 'posterior-samples/s',
+           'cores': threads, 'kind': 'port', 'cpu_model': cpu_model_name(), 'logical_cpus': os.cpu_count(),
+           'value_1_thread': round(1.0 / (steps_per_sample * secs1 / n1), 5),
+           'sample': f'{n} minibatch steps (B={BATCH}) of PreResNet-20 SGHMC on torch-CPU '
+                     f'({secs:.1f} s, {1e3 * secs / n:.1f} ms/step), extrapolated to {steps_per_sample} steps/sample',
+           'ms_per_minibatch_step': round(1e3 * secs / n, 2)}
+    # BMA: the reference's CPU accumulation loop, 3 members, a bounded number of 128-row batches
+    import copy
+    members = [copy.deepcopy(net) for _ in range(3)]
+    nb = 12
+    port.prediction_accumulate(members, batches[:2], CLASSES, 2 * BATCH)                       # warm up
+    _, _, rows, secs_b = port.prediction_accumulate(members, batches[:nb], CLASSES, nb * BATCH)
+    out['bma'] = {'value': round(rows / secs_b, 1), 'unit': 'BMA-preds/s', 'members': 3, 'cores': threads,
+                  'member_forwards_per_s': round(3 * rows / secs_b, 1),
+                  'sample': f'{rows} test rows x 3 PreResNet-20 members through the CPU loop of prediction.py:52-64 ({secs_b:.1f} s)'}
+    # the scalar-C restatement of K1 (oracle/ursa_oracle.c), one thread
+    O = load_oracle_lib()
+    ck = {}
+    for label, nel, reps in (('workload', 273408, 40), ('roofline_size', 1 << 26, 1)):
+        rng = np.random.default_rng(0)
+        th, gr, mo = (rng.standard_normal(nel, dtype=np.float32) for _ in range(3))
+        sc = O.step_scalars(HYP['lr'], 1 - HYP['alpha'], 1 / HYP['prior_std'] ** 2, N_TRAIN)
+        O.sgmcmc_step(th[:4096], gr[:4096], mo[:4096], flags=O.STEP_NOISE | O.STEP_WD, seed=1, step=0, **sc)
+        t0 = time.perf_counter()
+        for k in range(reps):
+            O.sgmcmc_step(th, gr, mo, flags=O.STEP_NOISE | O.STEP_WD, seed=1, step=k, **sc)
+        dt = (time.perf_counter() - t0) / reps
+        ck[label] = {'elements': nel, 'ms_per_launch': round(dt * 1e3, 3), 'GBps_algorithmic': round(20 * nel / dt / 1e9, 3)}
+        del th, gr, mo
+    out['c_kernels'] = {'kind': 'oracle/ursa_oracle.c oracle_sgmcmc_step_f32 (SGHMC + Philox), scalar C', 'cores': 1, 'k1': ck}
+    return out
 
 
 def multi_chain_block(k, make_chain, inference):
@@ -262,110 +427,291 @@ def reference_style_gpu_block(steps, dev):
             'sample': f'{steps} eager minibatch steps, extrapolated'}
 
 
-def main():
-    a = parse()
-    rank = int(os.environ.get('RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
-    local = int(os.environ.get('LOCAL_RANK', 0))
-    if world != a.gpus:
-        raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1')
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs a HIP device (no CPU fallback)')
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
-    if world > 1 or a.force_dist:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29533')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)      # RCCL over xGMI
+# ---- the job ------------------------------------------------------------------------------------------
+class Job:
+    """Rank / world / device, barrier + synchronize, max-over-ranks timing."""
 
+    def __init__(self, a):
+        self.rank = int(os.environ.get('RANK', 0))
+        self.world = int(os.environ.get('WORLD_SIZE', 1))
+        self.local = int(os.environ.get('LOCAL_RANK', 0))
+        if self.world != a.gpus:
+            raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={self.world}: launch with torch.distributed.run for N > 1')
+        self.cpu = a.dry_run_cpu
+        if self.cpu:
+            self.dev = torch.device('cpu')
+        else:
+            if not torch.cuda.is_available():
+                raise SystemExit('bench.py needs a HIP device (no CPU fallback)')
+            torch.cuda.set_device(self.local)
+            self.dev = torch.device('cuda', self.local)
+        if self.world > 1 or a.force_dist:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29533')
+            if self.cpu:
+                dist.init_process_group('gloo', rank=self.rank, world_size=self.world)
+            else:
+                dist.init_process_group('nccl', rank=self.rank, world_size=self.world, device_id=self.dev)   # RCCL over xGMI
+        self.use_dist = dist.is_initialized()
+
+    def barrier(self):
+        if self.use_dist:
+            dist.barrier()
+        if not self.cpu:
+            torch.cuda.synchronize()
+
+    def max_over_ranks(self, seconds):
+        if not self.use_dist:
+            return seconds
+        t = torch.tensor([seconds], device=self.dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.item()
+
+    def timed(self, fn):
+        """barrier + synchronize, fn(), barrier + synchronize; MAX over ranks of the wall time."""
+        self.barrier()
+        t0 = time.perf_counter()
+        out = fn()
+        self.barrier()
+        return out, self.max_over_ranks(time.perf_counter() - t0)
+
+    def close(self):
+        if self.use_dist:
+            try:
+                dist.barrier()
+                dist.destroy_process_group()
+            except Exception:      # noqa: BLE001
+                pass
+
+
+def base_line(a, job, metric, unit, workload):
+    return {'metric': metric, 'value': None, 'unit': unit, 'n_gpus': job.world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': None, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'data': 'synthetic' if not job.cpu else 'DRY RUN on CPU tensors with the tests\' oracle kernel set: control flow only, NOT a measurement',
+            'config': {'workload': workload}}
+
+
+def run_c2(a, job, legs, line):
     from ursabench_amd import inference, models, tasks, util
     from ursabench_amd.data import synthetic
-
-    train = synthetic(N_TRAIN, (3, 32, 32), CLASSES, seed=0, device=dev, batch_size=BATCH)
-    test = synthetic(N_TEST, (3, 32, 32), CLASSES, seed=1, device=dev, batch_size=BATCH)
-    hyp = dict(HYP, num_samples=a.steps + a.warmup)
+    dev, rank, world = job.dev, job.rank, job.world
+    n_train, n_test, batch, depth = (N_TRAIN, N_TEST, BATCH, 20) if not job.cpu else (256, 96, 64, 8)
+    kw = {}
+    if job.cpu:
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        from oracle_kernels import OracleKernels
+        kw = dict(kernels=OracleKernels())
     kpg = max(1, a.chains_per_gpu)
+    line['metric'] = (f'posterior-samples/sec (PreResNet-20 SGHMC, {kpg} chain{"s" if kpg > 1 else ""} per GPU); '
+                      'bma_preds_per_s beside it')
+    line['config'].update({'n_train': n_train, 'n_test': n_test, 'batch': batch, 'hyper': HYP, 'chains': world * kpg,
+                           'chains_per_gpu': kpg, 'hip_graph': not a.no_graph and not job.cpu,
+                           'sharding': 'one independent chain per rank; members stay on their rank; one RCCL '
+                                       'all-reduce of [N*C + N] fp32 for the predictive'})
+
+    if rank == 0 and not a.no_parity and not job.cpu:
+        line['parity'] = legs.run('parity', parity_block, dev)
+
+    train = synthetic(n_train, (3, 32, 32), CLASSES, seed=0, device=dev, batch_size=batch)
+    test = synthetic(n_test, (3, 32, 32), CLASSES, seed=1, device=dev, batch_size=batch)
+    hyp = dict(HYP, num_samples=a.steps + a.warmup)
 
     def make_chain(c):
         util.set_random_seed(c)                                # chain c uses seed c (experiment.py:170)
-        return inference.SGHMC(dict(hyp), models.PreResNet(CLASSES, 20).to(dev), train, device=dev,
-                               use_graph=not a.no_graph)
+        return inference.SGHMC(dict(hyp), models.PreResNet(CLASSES, depth).to(dev), train, device=dev,
+                               use_graph=(not a.no_graph and not job.cpu), seed=c, **kw)
 
     chains = [make_chain(rank * kpg + k) for k in range(kpg)]
     sampler = chains[0]
-    group = inference.ChainGroup(chains, use_graph=not a.no_graph) if kpg > 1 else None
+    group = inference.ChainGroup(chains, use_graph=(not a.no_graph and not job.cpu)) if kpg > 1 else None
+    steps_per_sample = len(train)
+    line['config'].update({'minibatch_steps_per_sample': steps_per_sample, 'params': sampler.arena.num_parameters})
 
     def one_sample():                                          # one posterior sample from every local chain
         return group.sample_iterative() if group is not None else [sampler.sample_iterative()]
 
-    use_dist = dist.is_initialized()
+    ensemble = []
 
-    def barrier():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(a.warmup):
-        one_sample()
-    barrier()
-    t0 = time.perf_counter()
-    ensemble = [m for _ in range(a.steps) for m in one_sample()]          # EXACTLY K timed steps (per chain)
-    barrier()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([dt], device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+    def sampling():
+        for _ in range(a.warmup):
+            one_sample()
+        ens, dt = job.timed(lambda: [m for _ in range(a.steps) for m in one_sample()])   # EXACTLY K timed steps (per chain)
+        ensemble.extend(ens)
+        line.update({'value': round(world * kpg * a.steps / dt, 4), 'unit': 'posterior-samples/s',
+                     'ms_per_step': round(1e3 * dt / a.steps, 2),
+                     'minibatch_steps_per_s': round(world * kpg * a.steps * steps_per_sample / dt, 1),
+                     'engine': dict(group.stats if group is not None else sampler.engine.stats)})
+    legs.run('sampling', sampling)
 
     # ---- BMA predictive over the test set: members sharded over ranks, one all-reduce -------------
-    pred = tasks.Prediction({'in_distribution_test': test}, CLASSES, dev, 'ALL')
-    pred.update_statistics(ensemble[:1], output_performance=False)        # warm up MIOpen eval-mode kernels
-    pred.reset()
-    barrier()
-    t1 = time.perf_counter()
-    pred.update_statistics(ensemble, output_performance=False)
-    barrier()
-    dt_bma = time.perf_counter() - t1
-    if use_dist:
-        t = torch.tensor([dt_bma], device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt_bma = t.item()
-    metrics = pred.get_performance_metrics()
-    members = pred.num_samples_collected
+    def bma():
+        pred = tasks.Prediction({'in_distribution_test': test}, CLASSES, dev, 'ALL', **kw)
+        pred.update_statistics(ensemble[:1], output_performance=False)        # warm up MIOpen eval-mode kernels / capture
+        pred.reset()
+        _, dt_bma = job.timed(lambda: pred.update_statistics(ensemble, output_performance=False))
+        metrics = pred.get_performance_metrics()
+        members = pred.num_samples_collected
+        line.update({'bma_preds_per_s': round(n_test / dt_bma, 1), 'bma_members': members,
+                     'bma_member_forwards_per_s': round(members * n_test / dt_bma, 1),
+                     'bma_nll': round(float(metrics['nll']), 5), 'bma_engine': dict(pred._acc.stats)})
+    if ensemble:
+        legs.run('bma', bma)
 
-    if rank == 0:
-        roof, roof_large = roofline_block(sampler, a.large_n)
-        steps_per_sample = len(train)
-        line = {
-            'metric': f'posterior-samples/sec (PreResNet-20 SGHMC, {kpg} chain{"s" if kpg > 1 else ""} per GPU); '
-                      'bma_preds_per_s beside it',
-            'value': round(world * kpg * a.steps / dt, 4), 'unit': 'posterior-samples/s', 'n_gpus': world, 'steps': a.steps,
-            'warmup': a.warmup, 'ms_per_step': round(1e3 * dt / a.steps, 2), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'PreResNet-20 / CIFAR-10-shaped synthetic, SGHMC {kpg} chain(s) per GPU '
-                                   '(BASELINE configs[1] at 1 chain, 1 GPU; configs[2] when n_gpus > 1)', 'n_train': N_TRAIN,
-                       'n_test': N_TEST, 'batch': BATCH, 'minibatch_steps_per_sample': steps_per_sample,
-                       'params': sampler.arena.num_parameters, 'hyper': HYP, 'chains': world * kpg, 'chains_per_gpu': kpg,
-                       'hip_graph': not a.no_graph, 'sharding': 'one independent chain per rank; members stay on '
-                       'their rank; one RCCL all-reduce of [N*C + N] fp32 for the predictive'},
-            'minibatch_steps_per_s': round(world * kpg * a.steps * steps_per_sample / dt, 1),
-            'bma_preds_per_s': round(N_TEST / dt_bma, 1), 'bma_members': members,
-            'bma_member_forwards_per_s': round(members * N_TEST / dt_bma, 1),
-            'bma_nll': round(float(metrics['nll']), 5),
-            'engine': group.stats if group is not None else sampler.engine.stats,
-            'roofline': roof, 'roofline_large': roof_large,
-        }
+    if rank == 0 and not job.cpu:
+        r = legs.run('roofline', roofline_block, sampler, a.large_n)
+        if r is not None:
+            line['roofline'], line['roofline_large'] = r
+        line['roofline_bma_kernel'] = legs.run('roofline_bma_kernel', bma_kernel_block, max(1, len(ensemble)), BATCH, CLASSES)
         if world == 1 and kpg == 1 and a.multi_chain_probe > 1:
-            line['multi_chain_per_gpu'] = multi_chain_block(a.multi_chain_probe, make_chain, inference)
+            line['multi_chain_per_gpu'] = legs.run('multi_chain_per_gpu', multi_chain_block, a.multi_chain_probe,
+                                                   make_chain, inference)
         if world == 1 and a.ref_style_steps > 0:
-            line['reference_style_gpu'] = reference_style_gpu_block(a.ref_style_steps, dev)
+            line['reference_style_gpu'] = legs.run('reference_style_gpu', reference_style_gpu_block, a.ref_style_steps, dev)
         if world == 1 and not a.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline_block(a.cpu_steps)
-        print(json.dumps(line), flush=True)
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+            line['cpu_baseline'] = legs.run('cpu_baseline', cpu_baseline_block, a.cpu_steps)
+
+
+def run_c4(a, job, legs, line):
+    """BASELINE configs[3]: WideResNet-28-10 / CIFAR-100-shaped, SWAG (as published: reference_quirks=False), 30-member
+    BMA. Rank 0 runs the SGD trajectory (`--c4-epochs` epochs over the full 50,000 images; the draw/eval cost
+    does not depend on the moments' values) and broadcasts the two moment vectors (2 x 146 MB, RCCL); then a
+    "step" is one member: K3 draw (one launch, 438 MB) + the reference's full bn_update pass (391 train-mode
+    batches, util.py:212-247) + device snapshot; members are sharded over ranks (weak scaling: `--steps`
+    members per rank), every rank evaluates its members on the 10,000-row test set, one all-reduce."""
+    from ursabench_amd import inference, models, tasks, util
+    from ursabench_amd.data import synthetic
+    dev, rank, world = job.dev, job.rank, job.world
+    C = 100
+    line['metric'] = 'SWAG members/sec (draw + bn_update + snapshot) and bma_preds_per_s, WideResNet-28-10 / CIFAR-100-shaped'
+    util.set_random_seed(0)
+    train = synthetic(a.c4_train, (3, 32, 32), C, seed=0, device=dev, batch_size=BATCH)
+    test = synthetic(N_TEST, (3, 32, 32), C, seed=1, device=dev, batch_size=BATCH)
+    # hyperparams/WideResNet28x10CIFAR100/swag_hyperparams.json's keys; epochs cut to --c4-epochs
+    hyp = {'swag_lr': 0.01, 'swag_wd': 3e-4, 'lr_init': 0.1, 'num_samples': a.steps + a.warmup, 'momentum': 0.9,
+           'burn_in_epochs': 1, 'num_iterates': max(1, a.c4_epochs - 1)}
+    net = models.WideResNet(C, 28, 10).to(dev)
+    s = inference.SWAG(hyp, net, train, device=dev, reference_quirks=False, seed=1000 + rank)
+    line['config'].update({'params': s.num_parameters, 'n_train': a.c4_train, 'n_test': N_TEST, 'batch': BATCH, 'hyper': hyp,
+                           'members_per_rank': a.steps + a.warmup, 'members': world * (a.steps + a.warmup),
+                           'sharding': 'rank 0 trains, moments broadcast; members sharded over ranks; one all-reduce of [N*C + N]'})
+
+    def trajectory():
+        t0 = time.perf_counter()
+        if rank == 0:
+            s.run_trajectory()
+        if job.use_dist:
+            dist.broadcast(s._mean, 0)
+            dist.broadcast(s._sq, 0)
+            s.adopt_moments()
+        job.barrier()
+        line['trajectory_seconds'] = round(time.perf_counter() - t0, 2)
+        line['trajectory_engine'] = dict(s.engine.stats)
+    legs.run('trajectory', trajectory)
+
+    ensemble = []
+
+    def members():
+        for _ in range(a.warmup):
+            ensemble.append(s.sample_iterative())
+        ens, dt = job.timed(lambda: [s.sample_iterative() for _ in range(a.steps)])
+        ensemble.extend(ens)
+        line.update({'value': round(world * a.steps / dt, 4), 'unit': 'SWAG members/s', 'ms_per_step': round(1e3 * dt / a.steps, 2)})
+    legs.run('members', members)
+
+    def bma():
+        pred = tasks.Prediction({'in_distribution_test': test}, C, dev, 'ALL')
+        pred.update_statistics(ensemble[:1], output_performance=False)
+        pred.reset()
+        _, dt = job.timed(lambda: pred.update_statistics(ensemble, output_performance=False))
+        m = pred.get_performance_metrics()
+        line.update({'bma_preds_per_s': round(N_TEST / dt, 1), 'bma_members': pred.num_samples_collected, 'bma_seconds': round(dt, 2),
+                     'bma_member_forwards_per_s': round(pred.num_samples_collected * N_TEST / dt, 1),
+                     'bma_nll': round(float(m['nll']), 5), 'bma_engine': dict(pred._acc.stats)})
+    if ensemble:
+        legs.run('bma', bma)
+
+    def roofline():
+        K, n = s.kernels, s.arena.n
+        out = torch.empty(n, device=dev)
+        ms = event_time_ms(lambda: K.swag_draw(out, s._mean, s._sq, var_clamp=1e-30, scale=1.0, seed=3, draw=1), 30,
+                           torch.cuda.current_stream())
+        ach = 12 * n / (ms * 1e-3) / 1e9
+        line['roofline'] = {'bound': 'hbm', 'kernel': 'k_swag_draw_v (K3, one member)', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBPS,
+                            'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBPS, 4), 'traffic': pmc_traffic('swag_draw', n),
+                            'bytes_per_launch': 12 * n, 'us_per_launch': round(ms * 1e3, 2)}
+        line['roofline_bma_kernel'] = bma_kernel_block(len(ensemble) or 30, BATCH, C)
+    if rank == 0:
+        legs.run('roofline', roofline)
+
+
+def run_c5(a, job, legs, line):
+    """BASELINE configs[4]: PreResNet-164 / CIFAR-100-shaped, HMC (hamiltorch-style leapfrog; PARITY UNPINNED, see
+    DESIGN.md §5), `--c5-chains` chains. At N = 1 the chains share the GPU (run one after another per proposal
+    round: each leapfrog step is a full-batch forward/backward that already fills the GPU); at N > 1 chain c
+    runs on rank c mod N. A "step" is one HMC proposal (L leapfrog steps + MH test) of every chain."""
+    from ursabench_amd import inference, models, util
+    from ursabench_amd.data import synthetic
+    dev, rank, world = job.dev, job.rank, job.world
+    C = 100
+    local_chains = [c for c in range(a.c5_chains) if c % world == rank]
+    line['metric'] = 'HMC proposals/sec and leapfrog steps/sec, PreResNet-164 / CIFAR-100-shaped, full-batch potential'
+    train = synthetic(a.c5_batch, (3, 32, 32), C, seed=0, device=dev, batch_size=BATCH)
+    hyp = {'step_size': 2e-4, 'num_samples': 1, 'L': a.c5_L, 'tau': 1.0, 'burn': 0, 'mass': 1.0}
+    chains = []
+    for c in local_chains:
+        util.set_random_seed(c)
+        chains.append(inference.HMC(dict(hyp), models.PreResNet(C, 164).to(dev), train, device=dev, seed=c))
+    line['config'].update({'params': None, 'full_batch': a.c5_batch, 'hyper': hyp, 'chains': a.c5_chains,
+                           'chains_on_rank0': len(local_chains), 'sharding': 'chain c on rank c mod N; no communication'})
+
+    def proposals():
+        for _ in range(a.warmup + 1):                          # MIOpen search, 2 eager evaluations, graph capture
+            for h in chains:
+                h.sample()
+        for h in chains:
+            h.accepted = 0
+        _, dt = job.timed(lambda: [h.sample() for _ in range(a.steps) for h in chains])
+        n_prop = a.steps * a.c5_chains
+        acc = sum(h.accepted for h in chains)
+        line['config']['params'] = chains[0].arena.num_parameters
+        line.update({'value': round(n_prop / dt, 4), 'unit': 'HMC proposals/s (all chains)', 'ms_per_step': round(1e3 * dt / a.steps, 2),
+                     'leapfrog_steps_per_s': round(n_prop * a.c5_L / dt, 3), 'accepted_rank0': acc,
+                     'acceptance_rate_rank0': round(acc / max(1, a.steps * len(chains)), 3)})
+    legs.run('proposals', proposals)
+
+    def roofline():
+        from ursabench_amd import _native
+        h = chains[0]
+        K, n = h.kernels, h.arena.n
+        ms = event_time_ms(lambda: K.leapfrog(h.arena.theta, h._p, h._glogp, kick_coef=0.0, step_size=0.0, inv_mass=1.0,
+                                              flags=_native.LEAP_KICK | _native.LEAP_DRIFT), 2048,
+                           torch.cuda.current_stream(), graph_batch=256)
+        ach = 20 * n / (ms * 1e-3) / 1e9
+        line['roofline'] = {'bound': 'hbm', 'kernel': 'k_leapfrog_v (K4 kick+drift)', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBPS,
+                            'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBPS, 4), 'traffic': None, 'bytes_per_launch': 20 * n,
+                            'us_per_launch': round(ms * 1e3, 3),
+                            'note': '1.7 M parameters = 6.9 MB per vector: cache-resident, latency-bound like K1 at C2'}
+    if rank == 0 and chains:
+        legs.run('roofline', roofline)
+
+
+def main(argv=None):
+    a = parse(argv)
+    job = Job(a)
+    legs = Legs(a.inject_failure)
+    workload = {'c2': 'PreResNet-20 / CIFAR-10-shaped synthetic, SGHMC (BASELINE configs[1] at 1 chain, 1 GPU; configs[2] when n_gpus > 1)',
+                'c4': 'WideResNet-28-10 / CIFAR-100-shaped synthetic, SWAG 30-sample BMA ensemble (BASELINE configs[3])',
+                'c5': 'PreResNet-164 / CIFAR-100-shaped synthetic, HMC 4 chains (BASELINE configs[4])'}[a.config]
+    line = base_line(a, job, '', '', workload)
+    try:
+        legs.run('job', {'c2': run_c2, 'c4': run_c4, 'c5': run_c5}[a.config], a, job, legs, line)
+    finally:
+        if job.rank == 0:
+            line['errors'] = legs.errors
+            print(json.dumps(line), flush=True)
+        job.close()
+    return 1 if legs.errors else 0
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main())

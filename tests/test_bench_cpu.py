@@ -1,0 +1,61 @@
+"""CPU: bench.py's control flow — the JSON line survives a failing leg, and the N > 1 assembly
+(value = world x K / max-over-ranks time, scaling weak, one all-reduce for the predictive) runs under
+gloo at world size 2. `--dry-run-cpu` is the toy-size walk of the c2 flow on CPU tensors with the
+tests' oracle kernel set; its line says it is not a measurement."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {'metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+        'vs_baseline', 'dtype', 'data', 'config', 'errors'}
+
+
+def run_bench(args, world=1):
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    if world == 1:
+        cmd = [sys.executable, os.path.join(ROOT, 'bench.py')] + args
+    else:
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={world}', '--master-addr',
+               '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py')] + args
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, (p.stdout[-2000:], p.stderr[-2000:])
+    return p.returncode, json.loads(lines[0])
+
+
+def test_dry_run_single_process():
+    rc, line = run_bench(['--dry-run-cpu', '--steps', '2', '--warmup', '1'])
+    assert rc == 0 and line['errors'] == {}
+    assert KEYS <= set(line) and 'NOT a measurement' in line['data']
+    assert line['n_gpus'] == 1 and line['steps'] == 2 and line['scaling'] == 'weak' and line['vs_baseline'] is None
+    assert line['value'] > 0 and line['ms_per_step'] > 0 and line['bma_members'] == 2
+    assert line['value'] == pytest.approx(2 / (line['ms_per_step'] * 2 / 1e3), rel=1e-3)
+    assert line['config']['workload'].startswith('PreResNet-20')
+
+
+def test_dry_run_world_size_2_gloo():
+    rc, line = run_bench(['--dry-run-cpu', '--gpus', '2', '--steps', '2', '--warmup', '0'], world=2)
+    assert rc == 0 and line['errors'] == {}
+    assert line['n_gpus'] == 2 and line['config']['chains'] == 2
+    assert line['bma_members'] == 4                       # 2 members per rank, summed by the all-reduce
+    # whole-job aggregate: world x K samples over the max-over-ranks time
+    assert line['value'] == pytest.approx(2 * 2 / (line['ms_per_step'] * 2 / 1e3), rel=1e-3)
+
+
+@pytest.mark.parametrize('leg', ['bma', 'sampling'])
+def test_a_failing_leg_keeps_the_line(leg):
+    rc, line = run_bench(['--dry-run-cpu', '--steps', '1', '--warmup', '0', '--inject-failure', leg])
+    assert rc != 0 and leg in line['errors'] and 'injected failure' in line['errors'][leg]
+    assert KEYS <= set(line)
+    if leg == 'bma':                                      # the timed sampling result survives a late failure
+        assert line['value'] > 0 and line['ms_per_step'] > 0 and 'bma_preds_per_s' not in line
+    else:
+        assert line['value'] is None

@@ -233,7 +233,7 @@ def test_bma_graph_replay_equals_eager_member_forwards():
     ens = s.sample()
     a = tasks.Prediction({'in_distribution_test': test}, 10, DEV, 'ALL')
     a.update_statistics(ens, output_performance=False)
-    assert len(a._acc._twins) == 1 and len(next(iter(a._acc._twins.values()))['graphs']) == 2
+    assert len(a._acc._twins) == 1 and len(next(iter(a._acc._twins.values()))['runners']) == 2
     foreign = []
     for m in ens:
         c = copy.deepcopy(m)

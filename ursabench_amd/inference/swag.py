@@ -204,19 +204,29 @@ class SWAG(SWA):
                                    seed=self.seed, draw=self._draws, eps=eps)
         self._draws += 1
 
+    def run_trajectory(self, val_loader=None, debug_val_loss=False, wandb_debug=False):
+        """swag.py:55-83 — the SGD trajectory of the first sample_iterative call: burn_in_epochs +
+        num_iterates epochs, moments collected after burn-in."""
+        for epoch in range(self.burn_in_epochs + self.num_iterates):
+            self._train_epoch(val_loader, debug_val_loss, wandb_debug)
+            if epoch >= self.burn_in_epochs:
+                self._collect_model()
+                if not self.reference_quirks:
+                    self.num_models_collected += 1
+        self.adopt_moments()
+
+    def adopt_moments(self):
+        """Mark the moments in self._mean / self._sq as final (after run_trajectory, or after another rank's
+        moments were received into them): later sample_iterative calls only draw."""
+        self.burnt_in = True
+        _, self.weight_variance = self._get_mean_and_variance()
+
     def sample_iterative(self, update_bn=True, val_loader=None, debug_val_loss=False, wandb_debug=False,
                          full_cov=False):
         if full_cov:
             raise NotImplementedError('full_cov needs the covariance subspace, outside the hot path')
         if self.burnt_in is False:
-            for epoch in range(self.burn_in_epochs + self.num_iterates):
-                self._train_epoch(val_loader, debug_val_loss, wandb_debug)
-                if epoch >= self.burn_in_epochs:
-                    self._collect_model()
-                    if not self.reference_quirks:
-                        self.num_models_collected += 1
-            self.burnt_in = True
-            _, self.weight_variance = self._get_mean_and_variance()
+            self.run_trajectory(val_loader, debug_val_loss, wandb_debug)
         self._draw_into_swag_model()
         if update_bn:
             bn_update(self.train_loader, self.swag_model, device=self.device)
