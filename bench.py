@@ -180,7 +180,7 @@ def pmc_traffic(kernel_key, elements):
 
 
 # ---- c2 legs ------------------------------------------------------------------------------------------
-def parity_block(dev, steps_per_sample=1, samples=3, rows=64):
+def parity_block(dev, steps_per_sample=1, samples=3, rows=64, test_rows=64, depth=20, n_noise=None):
     """§8(d): before timing, the GPU path against the reference CPU path (its torch-CPU port,
     oracle/torch_cpu_path.py — pinned bitwise to the imported reference in tests/test_cpu_port.py) on
     IDENTICAL inputs, initial weights and Langevin noise: PreResNet-20, `samples` SGHMC samples of
@@ -191,12 +191,12 @@ def parity_block(dev, steps_per_sample=1, samples=3, rows=64):
     from ursabench_amd.data import DeviceLoader
     port = load_port()
     torch.manual_seed(4242)
-    net_cpu = models.PreResNet(CLASSES, 20)
+    net_cpu = models.PreResNet(CLASSES, depth)
     net_gpu = copy.deepcopy(net_cpu)
     g = torch.Generator().manual_seed(4243)
     n_tr = rows * steps_per_sample
     xtr, ytr = torch.randn(n_tr, 3, 32, 32, generator=g), torch.randint(0, CLASSES, (n_tr,), generator=g)
-    xte, yte = torch.randn(rows, 3, 32, 32, generator=g), torch.randint(0, CLASSES, (rows,), generator=g)
+    xte, yte = torch.randn(test_rows, 3, 32, 32, generator=g), torch.randint(0, CLASSES, (test_rows,), generator=g)
     hyp = dict(HYP, num_samples=samples)
     # the noise the port will draw: torch.randn_like per tensor, in parameters() order, from the global generator
     total = samples * steps_per_sample
@@ -204,8 +204,10 @@ def parity_block(dev, steps_per_sample=1, samples=3, rows=64):
     eps_steps = [[torch.randn_like(p) for p in net_cpu.parameters()] for _ in range(total)]
     # GPU: the product path with that noise injected through the kernel's eps input
     train = DeviceLoader(xtr.to(dev), ytr.to(dev), rows)
-    test = DeviceLoader(xte.to(dev), yte.to(dev), rows)
+    test = DeviceLoader(xte.to(dev), yte.to(dev), test_rows)
     s = inference.SGHMC(dict(hyp), net_gpu, train, device=dev, seed=1)
+    if n_noise:                                           # the N the prior pull and the noise are divided by (optim_sghmc.py:48,64)
+        s.optimizer.param_groups[0]['num_training_samples'] = n_noise
     idx = s.arena.layout.gather_index(dev)
 
     def eps(k):
@@ -225,9 +227,9 @@ def parity_block(dev, steps_per_sample=1, samples=3, rows=64):
     batches = [(xtr[i:i + rows], ytr[i:i + rows]) for i in range(0, n_tr, rows)]
     for lr in lrs:
         port.sghmc_epoch(net_cpu, batches, state, lr=lr, momentum=1 - HYP['alpha'],
-                         weight_decay=1 / HYP['prior_std'] ** 2, num_training_samples=n_tr)
+                         weight_decay=1 / HYP['prior_std'] ** 2, num_training_samples=n_noise or n_tr)
         cpu_members.append(copy.deepcopy(net_cpu))
-    p_cpu, e_cpu, _, _ = port.prediction_accumulate(cpu_members, [(xte, yte)], CLASSES, rows)
+    p_cpu, e_cpu, _, _ = port.prediction_accumulate(cpu_members, [(xte, yte)], CLASSES, test_rows)
     p_gpu, e_gpu = pred.ensemble_proba, pred.expected_data_uncertainty
     rel = ((p_gpu - p_cpu).abs() / p_cpu.abs()).max().item()
     rel_e = ((e_gpu - e_cpu).abs() / e_cpu.abs()).max().item()

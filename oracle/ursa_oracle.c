@@ -243,7 +243,7 @@ int oracle_bma_accumulate_f32(const float* logits, float* proba_sum, float* ent_
                 const float p = expf((z[c] - mx) - lse);                       /* log_softmax().exp_() */
                 const float q = p * one_minus_gamma + gamma_over_c;            /* util.py:134 */
                 ps[c] = q;
-                ent += q * logf(q);                                            /* util.py:144 */
+                ent += q > 0.0f ? q * logf(q) : 0.0f;                          /* util.py:144; 0 ln 0 := 0 (gamma = 0 only) */
                 proba_sum[b * C + c] += (flags & BMA_SMOOTHED) ? q : p;
             }
             if (ent_sum) ent_sum[b] += -ent;

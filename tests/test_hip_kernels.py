@@ -234,6 +234,88 @@ def test_k5_vs_oracle_shapes(K, S, B, C):
     np.testing.assert_allclose(host(p.sum(1)), np.full(B, S, np.float32), rtol=2e-6)
 
 
+def _k5_check(K, z, smoothed, risk, rng, rtol=1e-5):
+    S, B, C = z.shape
+    cost = rng.random((C, C)).astype(np.float32)
+    gam = dict(one_minus_gamma=1 - 1e-4, gamma_over_c=1e-4 * 1 / C)
+    p0, e0, r0 = rng.random((B, C)).astype(np.float32), rng.random(B).astype(np.float32), rng.random((B, C)).astype(np.float32)
+    po, eo, ro = p0.copy(), e0.copy(), r0.copy()
+    O.bma_accumulate(z, po, eo, smoothed=smoothed, risk_sum=ro if risk else None, cost=cost if risk else None, **gam)
+    pd, ed, rd = dev(p0), dev(e0), dev(r0)
+    K.bma_accumulate(dev(z), pd, ed, smoothed=smoothed, risk_sum=rd if risk else None, cost=dev(cost) if risk else None, **gam)
+    np.testing.assert_allclose(host(pd), po, rtol=rtol, atol=1e-8)
+    np.testing.assert_allclose(host(ed), eo, rtol=rtol, atol=1e-6)
+    if risk:
+        np.testing.assert_allclose(host(rd), ro, rtol=rtol, atol=1e-6)
+    else:
+        assert np.array_equal(host(rd), r0)
+    return host(pd), host(ed), host(rd)
+
+
+@pytest.mark.parametrize('C', [1, 2, 3, 4, 5, 7, 8, 9, 10, 12, 16])
+@pytest.mark.parametrize('S,B', [(1, 16), (3, 128), (16, 48), (17, 20), (50, 1000), (64, 16), (130, 36), (5, 4), (33, 10000)])
+def test_k5_rowlane_few_classes(K, S, B, C):
+    """C <= 16 with 16-byte aligned member tiles (B*C % 4 == 0) runs k_bma_rowlane (one lane per row and member
+    slot, LDS-staged tiles): every member-slot split (S < slots, S = slots, several rounds, several chunks),
+    partial last tile, risk on/off — against the oracle; and bit-for-bit against nothing: the fold order is
+    slot order, so only the 1e-5 bar applies."""
+    if (B * C) % 4:
+        B = B + (4 - B % 4) % 4 if C % 2 else B + B % 2       # make B*C a multiple of 4 so the row-lane kernel is the one tested
+    assert (B * C) % 4 == 0
+    rng = np.random.default_rng(S * 131 + B * 7 + C)
+    z = (rng.standard_normal((S, B, C)) * 4).astype(np.float32)
+    z[0, 0, :] = 50.0 * rng.standard_normal(C)
+    _k5_check(K, z, False, False, rng)
+    _k5_check(K, z, True, True, rng)
+    p = torch.zeros(B, C, device='cuda')
+    K.bma_accumulate(dev(z), p, None, smoothed=False, one_minus_gamma=1 - 1e-4, gamma_over_c=1e-4 / C)
+    np.testing.assert_allclose(host(p.sum(1)), np.full(B, S, np.float32), rtol=2e-6)
+
+
+@pytest.mark.parametrize('S,B,C', [(3, 7, 20), (2, 129, 32), (4, 65, 64), (30, 257, 100), (2, 33, 128), (3, 17, 200), (2, 9, 256)])
+def test_k5_float4_rows(K, S, B, C):
+    """C % 4 == 0, 16 < C <= 256: the lane-group kernel with four consecutive classes per float4 load."""
+    rng = np.random.default_rng(S * 17 + B + C)
+    z = (rng.standard_normal((S, B, C)) * 4).astype(np.float32)
+    _k5_check(K, z, False, False, rng)
+    _k5_check(K, z, True, True, rng)
+
+
+@pytest.mark.parametrize('S,B,C', [(50, 1000, 10), (7, 64, 16), (30, 256, 100), (3, 64, 64)])
+def test_k5_fast_paths_agree_with_the_lane_group_kernel(K, S, B, C, monkeypatch):
+    """The debug switches select the generic lane-group kernel (scalar loads); both must satisfy the same bar and
+    agree with each other to rounding."""
+    rng = np.random.default_rng(5)
+    z = (rng.standard_normal((S, B, C)) * 3).astype(np.float32)
+    fast = _k5_check(K, z, True, True, np.random.default_rng(9))
+    monkeypatch.setenv('URSA_BMA_NO_ROWLANE', '1')
+    monkeypatch.setenv('URSA_BMA_NO_V4', '1')
+    slow = _k5_check(K, z, True, True, np.random.default_rng(9))
+    for a, b in zip(fast, slow):
+        np.testing.assert_allclose(a, b, rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize('C,B', [(10, 64), (100, 16), (7, 5)])
+def test_k5_masked_classes_and_zero_smoothing(K, C, B):
+    """a -inf logit (masked class) contributes probability 0 like the reference's log_softmax().exp()
+    — not NaN — and with gamma_over_c = 0 (allowed by the header) an underflowing probability contributes
+    0 ln 0 = 0 to the entropy."""
+    rng = np.random.default_rng(C)
+    z = (rng.standard_normal((3, B, C)) * 2).astype(np.float32)
+    z[:, :, 1] = -np.inf
+    z[1, 0, :] = -300.0
+    z[1, 0, 0] = 0.0                                        # 300-logit gap: p underflows to exactly 0
+    for omg, goc in ((1 - 1e-4, 1e-4 / C), (1.0, 0.0)):
+        po, eo = np.zeros((B, C), np.float32), np.zeros(B, np.float32)
+        O.bma_accumulate(z, po, eo, one_minus_gamma=omg, gamma_over_c=goc, smoothed=False)
+        pd, ed = torch.zeros(B, C, device='cuda'), torch.zeros(B, device='cuda')
+        K.bma_accumulate(dev(z), pd, ed, one_minus_gamma=omg, gamma_over_c=goc, smoothed=False)
+        assert np.isfinite(host(pd)).all() and np.isfinite(host(ed)).all() and np.isfinite(po).all() and np.isfinite(eo).all()
+        assert (host(pd)[:, 1] == 0).all()
+        np.testing.assert_allclose(host(pd), po, rtol=1e-5, atol=1e-8)
+        np.testing.assert_allclose(host(ed), eo, rtol=1e-5, atol=1e-6)
+
+
 def test_k5_empty_and_errors(K):
     p = torch.zeros(4, 10, device='cuda')
     K.bma_accumulate(torch.zeros(0, 4, 10, device='cuda'), p, None, one_minus_gamma=0.9999, gamma_over_c=1e-5, smoothed=False)

@@ -17,6 +17,7 @@
 // (the rounding sequence of each update is part of the contract, see the header).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/ursa_hip.h"
 #include "ursa_rng.h"
@@ -69,6 +70,14 @@ inline int bma_grid(int64_t rows, int rows_per_block)      // one block per row 
 {
     int64_t g = (rows + rows_per_block - 1) / rows_per_block;
     return (int)(g < 1 ? 1 : g > (1 << 20) ? (1 << 20) : g);
+}
+
+// Debug-only kernel-selection switches (tools/exp/k5_sweep.sh): an environment variable set to anything
+// but "0" / empty disables the named fast path. Never needed for correctness.
+inline bool getenv_flag(const char* name)
+{
+    const char* v = getenv(name);
+    return v && v[0] && !(v[0] == '0' && !v[1]);
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -366,14 +375,15 @@ __global__ __launch_bounds__(kBlock) void k_swag_draw_s(float* __restrict__ out,
 // (hi/lo split of log2 e): 1-2 ulp, 6 instructions instead of ocml expf's ~15.
 __device__ __forceinline__ float exp_nonpos(float x)
 {
+    // A masked class (logit -inf) must give exp = 0 like the reference's log_softmax().exp(); unclamped,
+    // t = -inf makes the compensation term inf - inf = NaN. exp(-150) is already 0 in fp32.
+    x = fmaxf(x, -150.0f);
     const float t = x * 1.44269502162933349609375f;
     float r = __builtin_fmaf(x, 1.44269502162933349609375f, -t);
     r = __builtin_fmaf(x, 1.925963033500011e-08f, r);
     const float e = __builtin_amdgcn_exp2f(t);
     return __builtin_fmaf(e, r * 0.693147182464599609375f, e);
 }
-// ln(q) for normal q > 0 on v_log_f32 (<= 2 ulp)
-__device__ __forceinline__ float ln_pos(float q) { return __builtin_amdgcn_logf(q) * 0.693147182464599609375f; }
 
 // Lane-group reductions on the VALU only (no LDS round trip, no s_waitcnt): xor butterflies inside
 // a quad (DPP quad_perm), then row_half_mirror / row_mirror inside a 16-lane row; across rows
@@ -416,7 +426,99 @@ __device__ __forceinline__ float group_max(float v) { return group_reduce<G>(v, 
 template <int G>
 __device__ __forceinline__ float group_sum(float v) { return group_reduce<G>(v, OpSum()); }
 
-template <int G, int EPL, bool RISK>
+// Class owned by register e of lane `lane`. Scalar mapping: lane + e*G (4-byte loads, any C / alignment).
+// V4 mapping: 4*(lane + (e/4)*G) + e%4 — four consecutive classes per float4 load (rows must be 16-byte
+// aligned: C % 4 == 0 and aligned base pointers); EPL is then a multiple of 4.
+template <int G, bool V4>
+__device__ __forceinline__ int bma_class(int lane, int e) { return V4 ? 4 * (lane + (e >> 2) * G) + (e & 3) : lane + e * G; }
+
+// U consecutive members of one row, for the lane group that owns the row: the U x EPL loads are issued before
+// any arithmetic; each member is folded into the wave's partial sums as soon as it is computed (member order).
+// K5 is a 1e-5-relative kernel (ATen's softmax is not bit-reproducible in scalar code anyway), so unlike K1-K4
+// its arithmetic fuses explicitly: e = exp(x - max) through v_exp_f32 with a compensated exponent (1-2 ulp),
+// p = e / sum (one IEEE reciprocal per row instead of the reference's second exp), q = fma(p, 1-g, g/C),
+// entropy accumulated as sum q log2 q on v_log_f32 (ln 2 applied once per row at the end).
+template <int G, int EPL, bool RISK, bool V4, int U>
+__device__ __forceinline__ void lg_members(const float* __restrict__ z0, int64_t member_stride, int lane, int C,
+                                           float omg, float goc, bool smoothed, bool want_ent,
+                                           const float* __restrict__ cost, float (&acc_p)[EPL],
+                                           float (&acc_r)[RISK ? EPL : 1], float& acc_e2)
+{
+    float xs[U][EPL];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const float* z = z0 + u * member_stride;
+        if (V4) {
+#pragma unroll
+            for (int v4 = 0; v4 < EPL / 4; ++v4) {
+                const int c0 = 4 * (lane + v4 * G);         // C % 4 == 0: a float4 is all inside or all outside
+                const float4 v = *reinterpret_cast<const float4*>(z + (c0 < C ? c0 : C - 4));
+                const bool in = c0 < C;                     // unconditional load (clamped index): a guarded load
+                xs[u][4 * v4 + 0] = in ? v.x : -INFINITY;   // becomes a branch and serialises the batch
+                xs[u][4 * v4 + 1] = in ? v.y : -INFINITY;
+                xs[u][4 * v4 + 2] = in ? v.z : -INFINITY;
+                xs[u][4 * v4 + 3] = in ? v.w : -INFINITY;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                const int c = lane + e * G;
+                const float v = z[c < C ? c : C - 1];
+                xs[u][e] = (c < C) ? v : -INFINITY;
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        float mx = xs[u][0];
+#pragma unroll
+        for (int e = 1; e < EPL; ++e) mx = fmaxf(mx, xs[u][e]);
+        mx = group_max<G>(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            xs[u][e] = exp_nonpos(xs[u][e] - mx);           // classes beyond C hold -inf: exp = 0
+            sum += xs[u][e];
+        }
+        const float inv = 1.0f / group_sum<G>(sum);
+        float ent2 = 0.f;
+        float qv[RISK ? EPL : 1];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int c = bma_class<G, V4>(lane, e);
+            const float p = xs[u][e] * inv;
+            const float q = (c < C) ? __builtin_fmaf(p, omg, goc) : 0.f;
+            // q log2 q with the limit 0 at q = 0 (classes beyond C; gamma = 0): the floor leaves normal q untouched
+            ent2 = __builtin_fmaf(q, __builtin_amdgcn_logf(fmaxf(q, 1.17549435e-38f)), ent2);
+            acc_p[e] += smoothed ? q : p;
+            if (RISK) qv[e] = q;
+        }
+        if (want_ent) acc_e2 += group_sum<G>(ent2);
+        if (RISK) {
+            // risk[b, j] += sum_c ps[c] * cost[c, j]; ps[c] broadcast from its owner lane
+            float r[RISK ? EPL : 1];
+#pragma unroll
+            for (int e = 0; e < (RISK ? EPL : 1); ++e) r[e] = 0.f;
+#pragma unroll
+            for (int es = 0; es < (RISK ? EPL : 1); ++es) {
+                for (int src = 0; src < G; ++src) {
+                    const int c = bma_class<G, V4>(src, es);
+                    if (c >= C) break;                      // uniform across the group
+                    const float pc = __shfl(qv[es], src, G);
+#pragma unroll
+                    for (int e = 0; e < (RISK ? EPL : 1); ++e) {
+                        const int j = bma_class<G, V4>(lane, e);
+                        if (j < C) r[e] = __builtin_fmaf(pc, cost[c * C + j], r[e]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < (RISK ? EPL : 1); ++e) acc_r[e] += r[e];
+        }
+    }
+}
+
+template <int G, int EPL, bool RISK, bool V4>
 __global__ __launch_bounds__(kBlock) void k_bma_accumulate(const float* __restrict__ logits,
                                                            float* __restrict__ proba_sum,
                                                            float* __restrict__ ent_sum,
@@ -442,90 +544,32 @@ __global__ __launch_bounds__(kBlock) void k_bma_accumulate(const float* __restri
     const int s_hi = s_lo + s_per < S ? s_lo + s_per : S;
     const int64_t row_stride = (int64_t)gridDim.x * kRows;
     const int64_t nrounds = (B + row_stride - 1) / row_stride;   // same trip count for every wave (barriers)
+    const int64_t BC = B * (int64_t)C;
 
     for (int64_t it = 0; it < nrounds; ++it) {
         const int64_t b = it * row_stride + (int64_t)blockIdx.x * kRows + grp;
         const bool row_ok = b < B;
         float acc_p[EPL], acc_r[RISK ? EPL : 1];
-        float acc_e = 0.f;
+        float acc_e2 = 0.f;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) acc_p[e] = 0.f;
 #pragma unroll
         for (int e = 0; e < (RISK ? EPL : 1); ++e) acc_r[e] = 0.f;
 
-        // Members are walked in order, U at a time: the U x EPL loads of a chunk are issued before any of
-        // its arithmetic. Arithmetic per element is ~13 VALU instructions: e = exp(x - max) through
-        // v_exp_f32 with a compensated exponent (1-2 ulp), p = e / sum (one IEEE reciprocal per row instead
-        // of the reference's second exp), ln q through v_log_f32. Each member is folded into the wave's
-        // partial sums as soon as it is computed (member order).
+        // full chunks of U members, then the remainder one at a time: no per-member liveness masks anywhere
         constexpr int U = EPL <= 2 ? 8 : EPL <= 4 ? 4 : EPL <= 8 ? 2 : 1;     // U * EPL <= 16 logits in flight per lane
-        const int64_t row_off = (row_ok ? b : 0) * (int64_t)C;
-        for (int s0 = s_lo; s0 < s_hi; s0 += U) {
-            float xs[U][EPL];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int sm = (s0 + u < s_hi) ? s0 + u : s_hi - 1;
-                const float* z = logits + (int64_t)sm * B * C + row_off;
-#pragma unroll
-                for (int e = 0; e < EPL; ++e) {
-                    const int c = lane + e * G;
-                    const float v = z[c < C ? c : C - 1];       // unconditional load (clamped index): a guarded
-                    xs[u][e] = (c < C) ? v : -INFINITY;         // load becomes a branch and serialises the batch
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const bool live = s0 + u < s_hi;                // uniform across the wave
-                float mx = -INFINITY;
-#pragma unroll
-                for (int e = 0; e < EPL; ++e) mx = fmaxf(mx, xs[u][e]);
-                mx = group_max<G>(mx);
-                float sum = 0.f;
-#pragma unroll
-                for (int e = 0; e < EPL; ++e) {
-                    const int c = lane + e * G;
-                    xs[u][e] = (c < C) ? exp_nonpos(xs[u][e] - mx) : 0.f;
-                    sum += xs[u][e];
-                }
-                const float inv = 1.0f / group_sum<G>(sum);
-                float ent = 0.f;
-                float qv[RISK ? EPL : 1];
-#pragma unroll
-                for (int e = 0; e < EPL; ++e) {
-                    const int c = lane + e * G;
-                    const float p = xs[u][e] * inv;
-                    const float q = (c < C) ? p * omg + goc : 0.f;
-                    ent += (c < C) ? q * ln_pos(q) : 0.f;
-                    acc_p[e] += live ? (smoothed ? q : p) : 0.f;
-                    if (RISK) qv[e] = q;
-                }
-                if (ent_sum) {
-                    const float en = group_sum<G>(ent);
-                    acc_e += live ? -en : 0.f;
-                }
-                if (RISK && live) {
-                    // risk[b, j] += sum_c ps[c] * cost[c, j]; ps[c] broadcast from its owner lane
-                    float r[RISK ? EPL : 1];
-#pragma unroll
-                    for (int e = 0; e < (RISK ? EPL : 1); ++e) r[e] = 0.f;
-#pragma unroll
-                    for (int es = 0; es < (RISK ? EPL : 1); ++es) {
-                        for (int src = 0; src < G; ++src) {
-                            const int c = src + es * G;
-                            if (c >= C) break;                      // uniform across the group
-                            const float pc = __shfl(qv[es], src, G);
-#pragma unroll
-                            for (int e = 0; e < (RISK ? EPL : 1); ++e) {
-                                const int j = lane + e * G;
-                                if (j < C) r[e] += pc * cost[c * C + j];
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int e = 0; e < (RISK ? EPL : 1); ++e) acc_r[e] += r[e];
-                }
-            }
-        }
+        const float* zrow = logits + (row_ok ? b : 0) * (int64_t)C;          // rows past B recompute row 0 (never stored)
+        int s0 = s_lo;
+#pragma unroll 1
+        for (; s0 + U <= s_hi; s0 += U)
+            lg_members<G, EPL, RISK, V4, U>(zrow + s0 * BC, BC, lane, C, omg, goc, smoothed, ent_sum != nullptr, cost,
+                                            acc_p, acc_r, acc_e2);
+        if (U > 1)
+#pragma unroll 1
+            for (; s0 < s_hi; ++s0)
+                lg_members<G, EPL, RISK, V4, 1>(zrow + s0 * BC, BC, lane, C, omg, goc, smoothed, ent_sum != nullptr,
+                                                cost, acc_p, acc_r, acc_e2);
+        const float acc_e = -0.693147182464599609375f * acc_e2;
 
         if (wave > 0) {
 #pragma unroll
@@ -539,7 +583,7 @@ __global__ __launch_bounds__(kBlock) void k_bma_accumulate(const float* __restri
         if (wave == 0 && row_ok) {
 #pragma unroll
             for (int e = 0; e < EPL; ++e) {
-                const int c = lane + e * G;
+                const int c = bma_class<G, V4>(lane, e);
                 if (c < C) {
                     float p = proba_sum[b * C + c] + acc_p[e];
 #pragma unroll
@@ -561,6 +605,187 @@ __global__ __launch_bounds__(kBlock) void k_bma_accumulate(const float* __restri
             }
         }
         __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// K5, few classes (C <= 16): ONE LANE OWNS ONE (row, member-slot) — all C classes in registers, zero
+// cross-lane reductions, no idle lanes. A block owns a tile of 16 consecutive rows; its W waves x 4
+// quarter-waves are 4W member slots, slot q walks a contiguous range of members in order. For one member
+// the tile's 16 x C logits are CONTIGUOUS in the [S, B, C] slab, so a wave fetches the four tiles of a
+// round (one per quarter-wave) with coalesced float4 loads — every round of a chunk issued before any
+// arithmetic — and passes them through a wave-private LDS stage to turn "float4 i of the tile" into "row r
+// of the tile" (the LDS-staged transpose north_star names; 10 floats per row make direct row loads 40-byte
+// strided). Partial sums of the 4W slots are folded in slot order through LDS into ONE read-modify-write
+// of the global accumulators per row: a fixed, reproducible order. 16-row tiles give ceil(B/16) blocks
+// (625 for the 10,000-row test set: every CU streams; with 64-row tiles only 157 of 256 CUs would).
+// Needs 16-byte aligned member tiles: aligned `logits` and B*C % 4 == 0; otherwise the lane-group kernel runs.
+constexpr int kRlRows = 16;      // rows per tile
+constexpr int kRlChunk = 4;      // rounds whose loads are in flight together
+
+// K5 tolerates 1e-5 relative (ATen's own softmax is not bit-reproducible in scalar code), so unlike
+// K1-K4 its arithmetic may fuse: explicit fmaf where a multiply feeds an add.
+// One (row, member): C logits from the LDS stage -> softmax -> smoothed entropy -> fold into the slot's sums.
+// EXACT: C == CP (no class masks). MASKED: the slot may have no member in this round (last round only).
+template <int CP, bool EXACT, bool RISK, bool MASKED>
+__device__ __forceinline__ void rl_member(const float* __restrict__ row, int C, bool live, float omg, float goc,
+                                          bool smoothed, const float* __restrict__ cost, float (&acc_p)[CP],
+                                          float (&acc_r)[RISK ? CP : 1], float& acc_e2)
+{
+    float x[CP];
+    if (EXACT && CP % 2 == 0) {                          // rows are 8-byte aligned in the stage: ds_read_b64
+#pragma unroll
+        for (int c = 0; c < CP; c += 2) {
+            const float2 v = *reinterpret_cast<const float2*>(row + c);
+            x[c] = v.x; x[c + 1] = v.y;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < CP; ++c) x[c] = (EXACT || c < C) ? row[(EXACT || c < C) ? c : 0] : -INFINITY;
+    }
+    float mx = x[0];
+#pragma unroll
+    for (int c = 1; c < CP; ++c) mx = fmaxf(mx, x[c]);
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < CP; ++c) {
+        x[c] = exp_nonpos(x[c] - mx);                    // masked classes: exp(-inf) = 0
+        sum += x[c];
+    }
+    const float inv = 1.0f / sum;
+    const float w = (MASKED && !live) ? 0.f : 1.f;       // an idle slot computes on zeros and adds nothing
+    float ent2 = 0.f;                                    // sum q log2 q (ln 2 applied once per slot at the end)
+    float qv[RISK ? CP : 1];
+#pragma unroll
+    for (int c = 0; c < CP; ++c) {
+        const float p = x[c] * inv;
+        float q = __builtin_fmaf(p, omg, goc);
+        if (!EXACT) q = c < C ? q : 0.f;
+        // q log2 q with the limit 0 at q = 0 (gamma = 0 only): the floor leaves normal q untouched
+        ent2 = __builtin_fmaf(q, __builtin_amdgcn_logf(fmaxf(q, 1.17549435e-38f)), ent2);
+        const float a = smoothed ? q : p;
+        acc_p[c] = MASKED ? __builtin_fmaf(w, a, acc_p[c]) : acc_p[c] + a;
+        if (RISK) qv[c] = q;
+    }
+    acc_e2 = MASKED ? __builtin_fmaf(w, ent2, acc_e2) : acc_e2 + ent2;
+    if (RISK) {
+#pragma unroll
+        for (int jc = 0; jc < (RISK ? CP : 1); ++jc) {
+            float rr = 0.f;
+#pragma unroll
+            for (int c = 0; c < (RISK ? CP : 1); ++c)
+                if (EXACT || (c < C && jc < C)) rr = __builtin_fmaf(qv[c], cost[c * C + jc], rr);   // uniform address: scalar loads
+            acc_r[jc] = MASKED ? __builtin_fmaf(w, rr, acc_r[jc]) : acc_r[jc] + rr;
+        }
+    }
+}
+
+template <int CP, bool EXACT, bool RISK>
+__global__ __launch_bounds__(512) void k_bma_rowlane(const float* __restrict__ logits, float* __restrict__ proba_sum,
+                                                      float* __restrict__ ent_sum, float* __restrict__ risk_sum,
+                                                      const float* __restrict__ cost, int S, int64_t B, int C,
+                                                      float omg, float goc, uint32_t flags)
+{
+    extern __shared__ float4 smem4[];
+    float* smem = reinterpret_cast<float*>(smem4);
+    constexpr int NL = (CP + 3) / 4;                     // float4 loads per lane per round (16*C float4 over 64 lanes)
+    const int W = blockDim.x >> 6;
+    const int wave = threadIdx.x >> 6, wl = threadIdx.x & 63;
+    const int r = wl & 15, k = wl >> 4;
+    const int nslots = 4 * W;
+    const int base = S / nslots, extra = S % nslots;     // every slot has `base` members, the first `extra` one more
+    const int tile4 = 4 * C;                             // float4 per (member, tile): 16 rows x C floats
+    const int64_t r0 = (int64_t)blockIdx.x * kRlRows;
+    const int64_t BC = B * (int64_t)C;
+    const bool smoothed = flags & URSA_BMA_SMOOTHED;
+    float* stage = smem + wave * (4 * kRlRows * C);      // wave-private: 4 tiles
+    const int out_per_slot = kRlRows * C * (RISK ? 2 : 1) + kRlRows;
+    float* part = smem + W * (4 * kRlRows * C);          // [nslots][out_per_slot]
+
+    // global address of output o of this tile ([16 x C] probabilities, [16] entropies, [16 x C] risks), or null
+    auto out_ptr = [&](int o) -> float* {
+        if (o < kRlRows * C) return r0 * C + o < BC ? proba_sum + r0 * C + o : nullptr;
+        if (o < kRlRows * C + kRlRows) return (ent_sum && r0 + (o - kRlRows * C) < B) ? ent_sum + r0 + (o - kRlRows * C) : nullptr;
+        const int64_t i = r0 * C + (o - kRlRows * C - kRlRows);
+        return i < BC ? risk_sum + i : nullptr;
+    };
+    // the first accumulator this thread will fold into is fetched now and consumed after the member loop
+    float* const dst0 = (int)threadIdx.x < out_per_slot ? out_ptr(threadIdx.x) : nullptr;
+    const float prev0 = dst0 ? *dst0 : 0.f;
+
+    // which (quarter, float4) each of this lane's loads fetches, and the member range of that quarter's slot
+    int ld_lo[NL], ld_cnt[NL];
+    int64_t ld_base[NL];
+#pragma unroll
+    for (int t = 0; t < NL; ++t) {
+        const int i = wl + 64 * t;
+        const int kk = i / tile4;                        // quarter-wave whose tile this float4 belongs to
+        const int q = wave * 4 + (kk < 4 ? kk : 3);
+        const int off = i - kk * tile4;
+        ld_lo[t] = q * base + (q < extra ? q : extra);
+        const bool in_tile = kk < 4 && (r0 * C + 4 * (int64_t)off < BC);          // B*C % 4 == 0: no straddling
+        ld_cnt[t] = in_tile ? base + (q < extra ? 1 : 0) : 0;
+        ld_base[t] = r0 * C + 4 * (int64_t)off;
+    }
+    const int slot = wave * 4 + k;
+    const bool tail_live = slot < extra;
+    const int rounds = base + (extra ? 1 : 0);           // uniform across the block
+
+    float acc_p[CP], acc_r[RISK ? CP : 1];
+    float acc_e2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < CP; ++c) acc_p[c] = 0.f;
+#pragma unroll
+    for (int c = 0; c < (RISK ? CP : 1); ++c) acc_r[c] = 0.f;
+    const float* row = stage + (k * kRlRows + r) * C;
+
+    for (int j0 = 0; j0 < rounds; j0 += kRlChunk) {
+        float4 buf[kRlChunk][NL];
+#pragma unroll
+        for (int u = 0; u < kRlChunk; ++u) {
+#pragma unroll
+            for (int t = 0; t < NL; ++t) {
+                const int j = j0 + u;
+                const bool ok = j < ld_cnt[t];
+                const float4 v = *reinterpret_cast<const float4*>(logits + (ok ? (ld_lo[t] + j) * BC + ld_base[t] : 0));
+                buf[u][t] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);   // unconditional load from a valid address
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kRlChunk; ++u) {
+            const int j = j0 + u;
+            if (j >= rounds) break;                      // uniform
+#pragma unroll
+            for (int t = 0; t < NL; ++t) {
+                const int i = wl + 64 * t;
+                if ((EXACT && NL * 64 <= 16 * CP) || i < 4 * tile4) reinterpret_cast<float4*>(stage)[i] = buf[u][t];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (j < base) rl_member<CP, EXACT, RISK, false>(row, C, true, omg, goc, smoothed, cost, acc_p, acc_r, acc_e2);
+            else rl_member<CP, EXACT, RISK, true>(row, C, tail_live, omg, goc, smoothed, cost, acc_p, acc_r, acc_e2);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();             // the next round's stage writes must not pass these reads
+        }
+    }
+
+    // partial sums -> LDS, then every thread folds whole outputs over the slots in slot order
+    float* mine = part + slot * out_per_slot;
+#pragma unroll
+    for (int c = 0; c < CP; ++c)
+        if (EXACT || c < C) {
+            mine[r * C + c] = acc_p[c];
+            if (RISK) mine[kRlRows * C + kRlRows + r * C + c] = acc_r[c];
+        }
+    mine[kRlRows * C + r] = -0.693147182464599609375f * acc_e2;
+    __syncthreads();
+    for (int o = threadIdx.x; o < out_per_slot; o += blockDim.x) {
+        float* const dst = o == (int)threadIdx.x ? dst0 : out_ptr(o);
+        if (!dst) continue;
+        float a = o == (int)threadIdx.x ? prev0 : *dst;
+        for (int q = 0; q < nslots; ++q) a += part[q * out_per_slot + o];
+        *dst = a;
     }
 }
 
@@ -851,22 +1076,60 @@ int ursa_bma_accumulate_f32(const float* logits, float* proba_sum, float* ent_su
     if (!aligned4(logits) || !aligned4(proba_sum) || !aligned4(ent_sum) || !aligned4(risk_sum) || !aligned4(cost))
         return URSA_EALIGN;
     hipStream_t st = (hipStream_t)stream;
-#define URSA_LAUNCH(G, EPL)                                                                                     \
+    // Few classes and 16-byte aligned member tiles: the row-per-lane kernel (see k_bma_rowlane).
+    const bool tiles_aligned = aligned16(logits) && ((B * (int64_t)C) % 4 == 0);
+    // (11 <= C <= 15 with a cost matrix spills registers in the masked 16-class body: lane-group kernel instead)
+    if (C <= 16 && tiles_aligned && !(risk_sum && C > 10 && C < 16) && !getenv_flag("URSA_BMA_NO_ROWLANE")) {
+        // waves per block: enough member slots (4 per wave) for S, at most 4 rounds per slot when possible
+        int W = (S + 15) / 16;
+        W = W < 1 ? 1 : W > 8 ? 8 : W;
+        if (const char* w = getenv("URSA_BMA_RL_WAVES")) {        // debug: tools/k5_bench.py sweeps
+            const int v = atoi(w);
+            if (v >= 1 && v <= 8) W = v;
+        }
+        const int cp = C <= 4 ? 4 : C <= 8 ? 8 : C == 10 ? 10 : 16;
+        const bool exact = C == cp;
+        const size_t lds = sizeof(float) * ((size_t)W * 4 * kRlRows * C
+                                            + (size_t)4 * W * (kRlRows * C * (risk_sum ? 2 : 1) + kRlRows));
+        const dim3 grid((unsigned)bma_grid(B, kRlRows)), block(64 * W);
+#define URSA_RL2(CPV, EX, RK)                                                                                   \
+        hipLaunchKernelGGL((k_bma_rowlane<CPV, EX, RK>), grid, block, lds, st, logits, proba_sum, ent_sum,      \
+                           risk_sum, cost, (int)S, B, (int)C, one_minus_gamma, gamma_over_c, flags)
+#define URSA_RL(CPV)                                                                                            \
+        do {                                                                                                    \
+            if (risk_sum) { if (exact) URSA_RL2(CPV, true, true); else URSA_RL2(CPV, false, true); }            \
+            else { if (exact) URSA_RL2(CPV, true, false); else URSA_RL2(CPV, false, false); }                   \
+        } while (0)
+        if (cp == 4) URSA_RL(4);
+        else if (cp == 8) URSA_RL(8);
+        else if (cp == 10) URSA_RL(10);
+        else URSA_RL(16);
+#undef URSA_RL2
+#undef URSA_RL
+        return launch_status();
+    }
+#define URSA_LAUNCH_V(G, EPL, V4)                                                                               \
     do {                                                                                                        \
         if (risk_sum)                                                                                           \
-            hipLaunchKernelGGL((k_bma_accumulate<G, EPL, true>), dim3(bma_grid(B, 64 / G)), dim3(kBlock), 0, st, \
+            hipLaunchKernelGGL((k_bma_accumulate<G, EPL, true, V4>), dim3(bma_grid(B, 64 / G)), dim3(kBlock), 0, st, \
                                logits, proba_sum, ent_sum, risk_sum, cost, (int)S, B, (int)C, one_minus_gamma,  \
                                gamma_over_c, flags);                                                            \
         else                                                                                                    \
-            hipLaunchKernelGGL((k_bma_accumulate<G, EPL, false>), dim3(bma_grid(B, 64 / G)), dim3(kBlock), 0, st, \
+            hipLaunchKernelGGL((k_bma_accumulate<G, EPL, false, V4>), dim3(bma_grid(B, 64 / G)), dim3(kBlock), 0, st, \
                                logits, proba_sum, ent_sum, risk_sum, cost, (int)S, B, (int)C, one_minus_gamma,  \
                                gamma_over_c, flags);                                                            \
     } while (0)
+#define URSA_LAUNCH(G, EPL) URSA_LAUNCH_V(G, EPL, false)
     // Rows are owned by 16-lane groups whenever C <= 256: the three row reductions are then pure DPP
     // (no cross-row step) and one DPP instruction serves the 4 rows of the wave at once; more classes per
-    // lane also means more independent exp/log work per lane. Measured at S=30, B=1e4, C=100:
-    // <64 lanes, 2 per lane> 103 us, <16 lanes, 8 per lane> see DESIGN.md.
-    if (C <= 4) URSA_LAUNCH(4, 1);
+    // lane also means more independent exp/log work per lane. With 16-byte aligned rows (C % 4 == 0) every
+    // lane fetches its classes as float4 (four consecutive classes per load) instead of 4-byte strided loads.
+    const bool rows_aligned = aligned16(logits) && (C % 4 == 0) && !getenv_flag("URSA_BMA_NO_V4");
+    if (rows_aligned && C > 16 && C <= 32) URSA_LAUNCH_V(8, 4, true);          // 8 float4 per row: 8 lanes, 8 rows per wave
+    else if (rows_aligned && C > 32 && C <= 64) URSA_LAUNCH_V(16, 4, true);
+    else if (rows_aligned && C > 64 && C <= 128) URSA_LAUNCH_V(16, 8, true);
+    else if (rows_aligned && C > 128 && C <= 256) URSA_LAUNCH_V(16, 16, true);
+    else if (C <= 4) URSA_LAUNCH(4, 1);
     else if (C <= 8) URSA_LAUNCH(8, 1);
     else if (C <= 16) URSA_LAUNCH(16, 1);
     else if (C <= 32) URSA_LAUNCH(16, 2);
@@ -875,6 +1138,7 @@ int ursa_bma_accumulate_f32(const float* logits, float* proba_sum, float* ent_su
     else if (C <= 256) URSA_LAUNCH(16, 16);
     else if (C <= 512) URSA_LAUNCH(64, 8);
     else URSA_LAUNCH(64, 16);
+#undef URSA_LAUNCH_V
 #undef URSA_LAUNCH
     return launch_status();
 }
