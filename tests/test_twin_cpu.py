@@ -155,3 +155,22 @@ def test_empty_member_list_is_a_noop_but_still_publishes():
     pred = tasks.Prediction({'in_distribution_test': test}, 10, torch.device('cpu'), 'ALL', kernels=OracleKernels())
     pred.update_statistics([], output_performance=False)
     assert pred.num_samples_collected == 0 and float(pred.ensemble_proba.abs().sum()) == 0
+
+
+def test_several_row_chunks_and_one_kernel_launch_per_chunk(monkeypatch):
+    """The logits of all members for a chunk of test rows land in one [S, rows, C] slab and ONE BMA launch folds
+    it; chunks are whole batches bounded by a byte budget (normally the whole test set is one chunk)."""
+    from ursabench_amd.tasks.task_base import EnsembleAccumulator
+    train, test = img_loader(32, 16), img_loader(37, 8, seed=5)
+    _, ens = bn_chain(6, 5, train)
+    whole = tasks.Prediction({'in_distribution_test': test}, 10, torch.device('cpu'), 'ALL', kernels=OracleKernels(), acc_kw=TWIN)
+    whole.update_statistics(ens, output_performance=False)
+    assert whole._acc.stats['bma_launches'] == 1
+    monkeypatch.setattr(EnsembleAccumulator, 'SLAB_BYTES', 4 * 5 * 10 * 17)        # room for 17 rows: 2 batches of 8
+    parts = tasks.Prediction({'in_distribution_test': test}, 10, torch.device('cpu'), 'ALL', kernels=OracleKernels(), acc_kw=TWIN)
+    parts.update_statistics(ens, output_performance=False)
+    assert parts._acc.stats['bma_launches'] == 3                                   # 16 + 16 + 5 rows
+    assert torch.equal(whole.ensemble_proba, parts.ensemble_proba)
+    assert torch.equal(whole.expected_data_uncertainty, parts.expected_data_uncertainty)
+    p, e = eager_reference(ens, test)
+    np.testing.assert_allclose(whole.ensemble_proba.numpy(), p, rtol=1e-6, atol=1e-9)

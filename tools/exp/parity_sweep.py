@@ -6,15 +6,12 @@ import torch
 import bench
 dev = torch.device('cuda', 0)
 res = []
-for kw in (dict(steps_per_sample=1, samples=3, rows=64), dict(steps_per_sample=1, samples=3, rows=128),
-           dict(steps_per_sample=1, samples=3, rows=128, n_noise=50000), dict(steps_per_sample=2, samples=3, rows=128, n_noise=50000),
-           dict(steps_per_sample=1, samples=3, rows=128, depth=8, n_noise=50000), dict(steps_per_sample=1, samples=1, rows=128, n_noise=50000),
-           dict(steps_per_sample=1, samples=2, rows=128, n_noise=50000), dict(steps_per_sample=1, samples=3, rows=64, n_noise=50000)):
+for kw in (dict(), dict(rows=64), dict(steps_per_sample=2), dict(depth=8), dict(samples=4)):
     for rep in range(2):
         try:
             out = bench.parity_block(dev, **kw)
         except AssertionError as e:
-            out = eval(str(e).split(': ', 2)[2])
-        r = dict(kw, rep=rep, proba=out['max_rel_err_proba'], ent=out['max_rel_err_entropy'], params=out['max_abs_diff_params_last_member'])
-        print(r, flush=True); res.append(r)
+            out = json.loads(str(e).split(': ', 2)[2])
+        r = dict(kw, rep=rep, sampler=out['sampler_first_sample'], bma=out['bma_same_members'], growth=out['trajectory_growth_reported_not_asserted'])
+        print(json.dumps(r), flush=True); res.append(r)
 json.dump(res, open('gpurun_out/parity_sweep.json', 'w'), indent=1)
