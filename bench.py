@@ -361,7 +361,7 @@ def cpu_baseline_block(steps):
     # BMA: the reference's CPU accumulation loop, 3 members, a bounded number of 128-row batches
     import copy
     members = [copy.deepcopy(net) for _ in range(3)]
-    nb = 12
+    nb = min(len(batches), (N_TEST + BATCH - 1) // BATCH)                                      # the whole 10,000-row test set
     port.prediction_accumulate(members, batches[:2], CLASSES, 2 * BATCH)                       # warm up
     _, _, rows, secs_b = port.prediction_accumulate(members, batches[:nb], CLASSES, nb * BATCH)
     out['bma'] = {'value': round(rows / secs_b, 1), 'unit': 'BMA-preds/s', 'members': 3, 'cores': threads,

@@ -81,8 +81,10 @@ int ursa_sgmcmc_step_f32(float* theta, float* grad, float* mom /* NULL iff mu ==
  * ursa_step_ctl_advance (1 thread) does step += 1, clears FIRST, and if `sched` != NULL
  * loads (lr, c_noise) = sched[(step - sched_base) % sched_len] — the per-iteration cyclical
  * schedule of csghmc.py:64-72 precomputed by the host in float64 and rounded once; the host
- * sets sched_base = step when it uploads an epoch's table. `step` is also the Philox call
- * index, so it only ever grows. */
+ * sets sched_base = step when it uploads an epoch's table. In SGD mode (URSA_STEP_SGD in
+ * ctl->flags; no noise there) the second column is the MOMENTUM instead: per-iteration
+ * (lr, momentum) of OneCycleLR, URSABench/inference/vi_dropout.py:59-61,107. `step` is also
+ * the Philox call index, so it only ever grows. */
 typedef struct ursa_step_ctl {
     float lr, mu, c_wd, c_noise, n_train;
     uint32_t flags;

@@ -45,7 +45,11 @@ class OracleKernels:
         c.flags &= ~O.STEP_FIRST
         if sched is not None:
             k = (c.step - c.sched_base) % sched.shape[0]
-            c.lr, c.c_noise = float(sched[k, 0]), float(sched[k, 1])
+            c.lr = float(sched[k, 0])
+            if c.flags & O.STEP_SGD:
+                c.mu = float(sched[k, 1])
+            else:
+                c.c_noise = float(sched[k, 1])
         ctl.copy_(torch.frombuffer(bytearray(bytes(c)), dtype=torch.uint8))
 
     def philox_normal(self, out, *, seed, step):

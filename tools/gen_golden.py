@@ -415,6 +415,55 @@ def gen_e2e_preresnet():
     print('G9 e2e_preresnet8 steps', out['eps'].shape)
 
 
+def gen_mcdropout():
+    """G10: the reference's MCdropout (vi_dropout.py) on its own MLP -> MLP_dropout swap: per-minibatch OneCycleLR
+    (lr, momentum) pairs, parameters after each sample_iterative, then update_hyp (CosineAnnealingLR per minibatch)
+    and one more sample; and 3 stochastic eval forwards (masks stay on). Everything is a function of torch's
+    global CPU generator: seed, then construct, then run."""
+    hyp = {'lr': 0.05, 'epochs': 1, 'dropout': 0.2, 'lengthscale': 0.01, 'num_samples': 2, 'momentum': 0.9,
+           'weight_decay': 0}
+    hyp2 = dict(hyp, lr=0.02, momentum=0.8, weight_decay=1e-3)
+    loader = tiny_loader()
+    torch.manual_seed(21)
+    s = inference.MCdropout(dict(hyp), models.mlp.MLP(16, 12, 4), loader)
+    theta0 = flat(s.model.parameters())
+    log = []
+    orig = s.optimizer.step
+
+    def tap(*a, **k):
+        g = s.optimizer.param_groups[0]
+        log.append((g['lr'], g['momentum']))
+        return orig(*a, **k)
+    s.optimizer.step = tap
+    samples = []
+    with quiet():
+        for _ in range(2):
+            m = s.sample_iterative()
+            samples.append(flat(m.parameters()))
+    xt = torch.randn(5, 12, generator=torch.Generator().manual_seed(4))
+    s.model.eval()
+    with torch.no_grad():
+        mc = np.stack([s.model(xt).numpy() for _ in range(3)])
+    # update_hyp: reset_model re-initialises from the global generator, new optimizer, cosine per minibatch
+    s.update_hyp(dict(hyp2))
+    theta1 = flat(s.model.parameters())
+    log2 = []
+    orig2 = s.optimizer.step
+
+    def tap2(*a, **k):
+        g = s.optimizer.param_groups[0]
+        log2.append((g['lr'], g['momentum']))
+        return orig2(*a, **k)
+    s.optimizer.step = tap2
+    with quiet():
+        m = s.sample_iterative()
+    np.savez(os.path.join(OUT, 'mcdropout.npz'), hyper=json.dumps(hyp), hyper2=json.dumps(hyp2), theta0=theta0,
+             lr_mom=np.array(log), samples=np.stack(samples), mc_logits=mc, x_test=xt.numpy(), theta1=theta1,
+             lr_mom2=np.array(log2), sample2=flat(m.parameters()), weight_decay=np.float64(s.weight_decay))
+    print('mcdropout: steps', len(log), len(log2), 'lr range', min(l for l, _ in log), max(l for l, _ in log),
+          'mom range', min(m_ for _, m_ in log), max(m_ for _, m_ in log), 'mc spread', float(np.abs(mc[0] - mc[1]).max()))
+
+
 def gen_model_keys():
     res = {}
     for name, ref, ours in (
@@ -448,8 +497,8 @@ def gen_model_keys():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['k1', 'sgd', 'sched', 'csghmc', 'tasks', 'swag', 'swag_e2e', 'e2e', 'e2e_preresnet', 'keys']
+    which = sys.argv[1:] or ['k1', 'sgd', 'sched', 'csghmc', 'tasks', 'swag', 'swag_e2e', 'e2e', 'e2e_preresnet', 'mcdropout', 'keys']
     fns = dict(k1=gen_k1, sgd=gen_sgd, swag_e2e=gen_swag_e2e, e2e_preresnet=gen_e2e_preresnet, sched=gen_schedules, csghmc=gen_csghmc, tasks=gen_tasks, swag=gen_swag, e2e=gen_e2e,
-               keys=gen_model_keys)
+               keys=gen_model_keys, mcdropout=gen_mcdropout)
     for w in which:
         fns[w]()

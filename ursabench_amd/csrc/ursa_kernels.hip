@@ -211,7 +211,8 @@ __global__ void k_step_ctl_advance(ursa_step_ctl* ctl, const float* sched, uint3
         if (sched != nullptr && sched_len != 0) {
             const uint64_t k = (step - ctl->sched_base) % sched_len;
             ctl->lr = sched[2 * k];
-            ctl->c_noise = sched[2 * k + 1];
+            if (ctl->flags & URSA_STEP_SGD) ctl->mu = sched[2 * k + 1];      // SGD mode has no noise: the column is the momentum
+            else ctl->c_noise = sched[2 * k + 1];
         }
     }
 }

@@ -7,5 +7,6 @@ from .csghmc import cSGHMC, cSGLD  # noqa: F401
 from .flat_sgd import FlatSGD  # noqa: F401
 from .swag import SWA, SWAG  # noqa: F401
 from .hmc import HMC  # noqa: F401
-from .sgd import SGD, MCdropout  # noqa: F401
+from .sgd import SGD  # noqa: F401
+from .vi_dropout import MCdropout  # noqa: F401
 from .chain_group import ChainGroup  # noqa: F401

@@ -144,7 +144,11 @@ class optimSGHMC(Optimizer):
                             step=self._step,
                             sched_base=self._step)
         if sched is not None:
-            c.lr, c.c_noise = float(sched[0, 0]), float(sched[0, 1])
+            c.lr = float(sched[0, 0])
+            if sc['flags'] & _native.STEP_SGD:
+                c.mu = float(sched[0, 1])         # SGD mode: the table's second column is the momentum
+            else:
+                c.c_noise = float(sched[0, 1])
         host = torch.frombuffer(bytearray(bytes(c)), dtype=torch.uint8)
         if self._ctl is None:
             self._ctl = torch.zeros(ctypes.sizeof(_native.StepCtl), dtype=torch.uint8, device=a.device)
@@ -159,7 +163,7 @@ class optimSGHMC(Optimizer):
             if self._sched.shape != sched.shape:
                 raise ValueError(f'schedule table changed shape {tuple(self._sched.shape)} -> {tuple(sched.shape)}')
             self._sched.copy_(sched)
-        self._ctl_mu = sc['mu']
+        self._ctl_mu = c.mu
 
     @torch.no_grad()
     def ctl_step(self, eps=None):

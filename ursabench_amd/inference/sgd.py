@@ -3,9 +3,7 @@ resolves. Not an MCMC method: SGD-momentum epochs with cosine annealing, then th
 returned (the same object for every requested sample). The trajectory runs on the ChainEngine with
 FlatSGD (K1 SGD mode). Quirks kept: update_hyp stores `epochs` but the loop keeps using the
 constructor's `burn_in_epochs`; eta_min is lr/100 in the constructor and lr/2 after update_hyp.
-
-MCdropout (vi_dropout.py) is outside the hot path (it needs the reference's `*_dropout` model
-variants and has no MCMC update): constructing it raises NotImplementedError."""
+"""
 import torch
 from torch.optim.lr_scheduler import CosineAnnealingLR
 
@@ -77,8 +75,3 @@ class SGD(_Inference):
             num_samples = self.num_samples
         return [self.sample_iterative(val_loader=val_loader, debug_val_loss=debug_val_loss, wandb_debug=wandb_debug)
                 for _ in range(num_samples)]
-
-
-class MCdropout(_Inference):
-    def __init__(self, *args, **kwargs):
-        raise NotImplementedError('MCdropout (URSABench/inference/vi_dropout.py) is outside the SG-MCMC/BMA hot path')

@@ -18,8 +18,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-__all__ = ['LeNet5', 'MLP', 'PreResNet', 'WideResNet', 'MLP200MNIST', 'LeNet5MNIST', 'PreResNet20',
-           'PreResNet164', 'WideResNet28x10']
+__all__ = ['LeNet5', 'MLP', 'MLP_dropout', 'PreResNet', 'PreResNet_dropout', 'WideResNet', 'MLP200MNIST',
+           'MLP200MNIST_dropout', 'LeNet5MNIST', 'PreResNet20', 'PreResNet164', 'WideResNet28x10']
 
 
 class LeNet5(nn.Module):
@@ -49,6 +49,25 @@ class MLP(nn.Module):
     def forward(self, x):
         h = F.relu(self.fc1(x.view(-1, self.input_dim)))
         return self.fc3(F.relu(self.fc2(h)))
+
+
+class MLP_dropout(nn.Module):
+    """URSABench/models/mlp.py:25-41 — dropout through F.dropout with its default training=True, i.e. the
+    masks stay ON in eval mode: that is what makes T forwards of ONE model an MC-dropout ensemble
+    (inference/vi_dropout.py returns the same live model `num_samples` times)."""
+
+    def __init__(self, hidden_size, input_dim, num_classes, dropout=0.2):
+        super().__init__()
+        self.input_dim, self.hidden_size, self.num_classes = input_dim, hidden_size, num_classes
+        self.fc1 = nn.Linear(input_dim, hidden_size)
+        self.fc2 = nn.Linear(hidden_size, hidden_size)
+        self.fc3 = nn.Linear(hidden_size, num_classes)
+        self.dropout = dropout
+
+    def forward(self, x):
+        x = self.fc1(x.view(-1, self.input_dim))
+        x = self.fc2(F.relu(F.dropout(x, p=self.dropout)))
+        return self.fc3(F.relu(F.dropout(x, p=self.dropout)))
 
 
 # ---- pre-activation ResNet --------------------------------------------------------------
@@ -96,6 +115,7 @@ class PreResNet(nn.Module):
 
     def __init__(self, num_classes=10, depth=110):
         super().__init__()
+        self.num_classes, self.depth = num_classes, depth     # read back by vi_dropout.change_to_dropout_model
         if depth >= 44:
             if (depth - 2) % 9:
                 raise AssertionError('depth should be 9n+2')
@@ -134,6 +154,21 @@ class PreResNet(nn.Module):
         x = self.layer3(self.layer2(self.layer1(self.conv1(x))))
         x = self.avgpool(self.relu(self.bn(x)))
         return self.fc(x.flatten(1))
+
+
+class PreResNet_dropout(PreResNet):
+    """Not in the reference (it ships MLP_, ResNet_ and WideResNet_dropout only): the benchmark's PreResNet with
+    always-on dropout before the classifier, placed like ResNet_dropout's (imagenet_resnet.py:141), so that
+    MCdropout can run on BASELINE configs[1]'s network."""
+
+    def __init__(self, num_classes=10, depth=110, dropout=0.2):
+        super().__init__(num_classes, depth)
+        self.dropout = dropout
+
+    def forward(self, x):
+        x = self.layer3(self.layer2(self.layer1(self.conv1(x))))
+        x = self.avgpool(self.relu(self.bn(x)))
+        return self.fc(F.dropout(x.flatten(1), p=self.dropout))
 
 
 # ---- wide ResNet -------------------------------------------------------------------------
@@ -193,6 +228,11 @@ class _Cfg:
 class MLP200MNIST(_Cfg):
     base = MLP
     kwargs = {'hidden_size': 200, 'input_dim': 784}
+
+
+class MLP200MNIST_dropout(_Cfg):
+    base = MLP_dropout
+    kwargs = {'hidden_size': 200, 'input_dim': 784, 'dropout': 0.2}
 
 
 class LeNet5MNIST(_Cfg):
