@@ -52,7 +52,7 @@ def _evaluate(members, group_ok):
                 risk=dec.risk.numpy(), decision=dm['Decision'].numpy(), ood_count=ood.num_samples_collected)
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, n_members=5):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
@@ -60,7 +60,7 @@ def _worker(rank, world, port, outdir):
     from ursabench_amd.distributed import init_from_env, shard
     r, w, dev = init_from_env('cpu')
     assert (r, w) == (rank, world) and dist.is_initialized() and dist.get_backend() == 'gloo'
-    mine = shard(_members(), rank, world)            # 5 members over 2 ranks: 3 + 2
+    mine = shard(_members(S=n_members), rank, world)   # round robin: 5 over 2 ranks = 3 + 2; 30 over 4 = 8, 8, 7, 7
     res = _evaluate(mine, True)
     np.savez(os.path.join(outdir, f'rank{rank}.npz'), proba=res['proba'], ent=res['ent'], risk=res['risk'],
              decision=res['decision'], count=res['count'], nll=res['metrics']['nll'],
@@ -86,6 +86,61 @@ def test_member_sharded_bma_equals_single_process(tmp_path):
         assert float(r['nll']) == pytest.approx(ref['metrics']['nll'], rel=1e-5)
         assert float(r['auroc']) == pytest.approx(ref['ood']['model_uncertainty_auroc'], abs=1e-9)
     assert np.array_equal(r0['proba'], r1['proba'])
+
+
+@pytest.mark.parametrize('n_members,counts', [(30, [8, 8, 7, 7]), (3, [1, 1, 1, 0])])
+def test_world_size_4_uneven_shards_and_an_empty_rank(tmp_path, n_members, counts):
+    """BASELINE configs[3]'s split (30 members over the ranks, uneven) at world size 4, and a rank that holds NO
+    member: it still calls update_statistics (with an empty list) and so takes part in the one all-reduce; no
+    task constructor or reset() communicates, so ranks may build their tasks in any order."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(4, port, str(tmp_path), n_members), nprocs=4, join=True)
+    ref = _evaluate(_members(S=n_members), False)
+    ranks = [np.load(tmp_path / f'rank{r}.npz') for r in range(4)]
+    assert [int(r['n_local']) for r in ranks] == counts
+    for r in ranks:
+        assert int(r['count']) == n_members and int(r['ood_count']) == n_members
+        np.testing.assert_allclose(r['proba'], ref['proba'], rtol=3e-6, atol=1e-7)
+        np.testing.assert_allclose(r['ent'], ref['ent'], rtol=3e-6, atol=1e-6)
+        np.testing.assert_allclose(r['risk'], ref['risk'], rtol=3e-6, atol=1e-6)
+        assert np.array_equal(r['decision'], ref['decision'])
+        assert float(r['nll']) == pytest.approx(ref['metrics']['nll'], rel=1e-5)
+        assert np.array_equal(r['proba'], ranks[0]['proba'])
+
+
+def test_task_construction_and_reset_do_not_communicate():
+    """collectives hidden in constructors deadlock a job in which one rank builds a task and another
+    does not. With a process group initialised (world size 1 here: the collective would still be issued) the
+    constructors and reset() must not call all_reduce."""
+    import torch.distributed as dist
+    from ursabench_amd import tasks
+    from ursabench_amd.tasks.decision_making import CIFAR10_cost
+    from oracle_kernels import OracleKernels
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1)
+    calls = []
+    orig = dist.all_reduce
+    dist.all_reduce = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        l_in, l_out = _loaders()
+        dev = torch.device('cpu')
+        pred = tasks.Prediction({'in_distribution_test': l_in}, 10, dev, 'ALL', kernels=OracleKernels())
+        ood = tasks.OODDetection({'in_distribution_test': l_in, 'out_distribution_test': l_out}, 10, dev, kernels=OracleKernels())
+        dec = tasks.Decision({'decision_data_test': l_in}, 10, dev, cost_mat=CIFAR10_cost(10), kernels=OracleKernels())
+        for t in (pred, ood, dec):
+            t.reset()
+        assert calls == []
+        pred.update_statistics(_members(S=2), output_performance=False)
+        assert len(calls) == 1                          # exactly one all-reduce per update (one accumulator)
+        ood.update_statistics(_members(S=2), output_performance=False)
+        assert len(calls) == 3                          # in- and out-of-distribution accumulators
+    finally:
+        dist.all_reduce = orig
+        dist.destroy_process_group()
 
 
 def test_shard_and_seed_helpers():

@@ -464,6 +464,34 @@ def gen_mcdropout():
           'mom range', min(m_ for _, m_ in log), max(m_ for _, m_ in log), 'mc spread', float(np.abs(mc[0] - mc[1]).max()))
 
 
+def gen_experiment_columns():
+    """G11: the on-disk row format of URSABench/experiment.py:249-266 — six fixed columns, the hyper-parameter
+    values in sorted-key order, then results_dic's values in sorted-key order. The key NAMES come from the
+    reference's own task objects run here (Prediction.required_metric_list with metric_list='ALL',
+    OODDetection.update_statistics(...).keys()), combined by the rules of experiment.py:203-216 and :249-250;
+    the OOD data-set names are the literals of experiment.py:115,137. Also time_script.py:114-125's JSON keys."""
+    g = torch.Generator().manual_seed(0)
+    x, y = torch.randn(8, 12, generator=g), torch.randint(0, 4, (8,), generator=g)
+    ds = torchvision.datasets.cifar.CIFAR10
+    l_in = DataLoader(ds(x, y), batch_size=4)
+    l_out = DataLoader(ds(x * 2, y), batch_size=4)
+    ms = [member(12, 4, 1, 1.0), member(12, 4, 2, 1.0)]
+    pred = tasks.Prediction({'in_distribution_test': l_in}, 4, torch.device('cpu'), 'ALL')
+    ood = tasks.OODDetection({'in_distribution_test': l_in, 'out_distribution_test': l_out}, 4, torch.device('cpu'))
+    with quiet():
+        ood_keys = list(ood.update_statistics(ms, output_performance=True).keys())
+    out = {'fixed_columns': ['dataset', 'model', 'seed', 'inference_method', 'task', 'batch_size'], 'datasets': {}}
+    for name, oods in (('MNIST', ['FashionMNIST', 'KMNIST']), ('CIFAR10', ['STL10', 'SVHN']), ('CIFAR100', ['STL10', 'SVHN'])):
+        keys = [k + '_' + d + sfx for d in oods for k in ood_keys for sfx in ('_mean', '_std')]
+        keys += [k + sfx for k in pred.required_metric_list for sfx in ('_mean', '_std')]
+        keys += ['cost_mean', 'cost_std']
+        out['datasets'][name] = sorted(keys)
+    out['time_script_keys_rule'] = ['<method>_mean', '<method>_std']
+    out['time_script_methods'] = ['HMC', 'SGLD', 'SGHMC', 'cSGLD', 'cSGHMC', 'SWAG', 'PCA', 'MCdropout', 'SGD', 'PCASubspaceSampler']
+    json.dump(out, open(os.path.join(OUT, 'experiment_columns.json'), 'w'), indent=1)
+    print('experiment_columns', {k: len(v) for k, v in out['datasets'].items()}, ood_keys)
+
+
 def gen_model_keys():
     res = {}
     for name, ref, ours in (
@@ -497,8 +525,8 @@ def gen_model_keys():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['k1', 'sgd', 'sched', 'csghmc', 'tasks', 'swag', 'swag_e2e', 'e2e', 'e2e_preresnet', 'mcdropout', 'keys']
+    which = sys.argv[1:] or ['k1', 'sgd', 'sched', 'csghmc', 'tasks', 'swag', 'swag_e2e', 'e2e', 'e2e_preresnet', 'mcdropout', 'columns', 'keys']
     fns = dict(k1=gen_k1, sgd=gen_sgd, swag_e2e=gen_swag_e2e, e2e_preresnet=gen_e2e_preresnet, sched=gen_schedules, csghmc=gen_csghmc, tasks=gen_tasks, swag=gen_swag, e2e=gen_e2e,
-               keys=gen_model_keys, mcdropout=gen_mcdropout)
+               keys=gen_model_keys, mcdropout=gen_mcdropout, columns=gen_experiment_columns)
     for w in which:
         fns[w]()

@@ -19,7 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 __all__ = ['LeNet5', 'MLP', 'MLP_dropout', 'PreResNet', 'PreResNet_dropout', 'WideResNet', 'MLP200MNIST',
-           'MLP200MNIST_dropout', 'LeNet5MNIST', 'PreResNet20', 'PreResNet164', 'WideResNet28x10']
+           'MLP200MNIST_dropout', 'LeNet5MNIST', 'PreResNet8', 'PreResNet20', 'PreResNet164', 'WideResNet28x10']
 
 
 class LeNet5(nn.Module):
@@ -237,6 +237,11 @@ class MLP200MNIST_dropout(_Cfg):
 
 class LeNet5MNIST(_Cfg):
     base = LeNet5
+
+
+class PreResNet8(_Cfg):
+    base = PreResNet
+    kwargs = {'depth': 8}
 
 
 class PreResNet20(_Cfg):

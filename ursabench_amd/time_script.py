@@ -25,6 +25,9 @@ DEFAULTS = {
     'SWAG': {'swag_lr': 0.01, 'swag_wd': 3e-4, 'lr_init': 0.1, 'num_samples': 3, 'momentum': 0.9,
              'burn_in_epochs': 1, 'num_iterates': 1},
     'HMC': {'step_size': 2e-4, 'num_samples': 3, 'L': 3, 'tau': 1.0, 'burn': -1, 'mass': 1.0},
+    'MCdropout': {'lr': 0.01, 'epochs': 0, 'dropout': 0.2, 'lengthscale': 0.01, 'num_samples': 3, 'momentum': 0.9,
+                  'weight_decay': 0},
+    'SGD': {'lr': 0.1, 'epochs': 0, 'momentum': 0.9, 'weight_decay': 5e-4},
 }
 
 
@@ -41,6 +44,8 @@ def prepare(method, hyp, S):
         hyp['burn_in_epochs'] = 0
         hyp['num_cycles'] = 1
         hyp['num_samples_per_cycle'] = S
+    if method in ('MCdropout', 'SGD'):
+        hyp['epochs'] = 0
     hyp['num_samples'] = S
     return hyp
 
