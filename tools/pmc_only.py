@@ -1,0 +1,50 @@
+"""Launch each hot kernel a few times in isolation, for rocprofv3 --pmc passes (tools/r02_profiles.sh), and
+write the launch manifest (kernel-name pattern, algorithmic bytes per launch) next to the counters.
+    python3 tools/pmc_only.py <manifest.json>"""
+import json, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ursabench_amd import _native
+K = _native.default_kernels()
+manifest = []
+
+
+def note(pattern, label, alg_bytes, **kw):
+    manifest.append(dict(pattern=pattern, label=label, algorithmic_bytes_per_launch=alg_bytes, **kw))
+
+
+# K1 at the PreResNet-20 arena size through the control-block entry point (the workload's launch)
+n = 273408
+th, g, m = (torch.randn(n, device='cuda') for _ in range(3))
+c = _native.StepCtl(lr=0.1, mu=0.5, c_wd=8e-5, c_noise=0.3, n_train=50000.0, flags=0x1 | 0x8, seed=1, step=0)
+ctl = torch.frombuffer(bytearray(bytes(c)), dtype=torch.uint8).cuda()
+for _ in range(20):
+    K.sgmcmc_step_ctl(th, g, m, ctl)
+    K.step_ctl_advance(ctl)
+note('k_sgmcmc_step_ctl', 'K1 workload size (control block)', 20 * n, elements=n)
+# K1 at 2^26
+n = 1 << 26
+th, g, m = (torch.randn(n, device='cuda') for _ in range(3))
+for k in range(10):
+    K.sgmcmc_step(th, g, m, lr=0.1, mu=0.5, c_wd=8e-5, c_noise=0.3, n_train=50000.0, flags=0x1 | 0x8, seed=1, step=k)
+note('k_sgmcmc_step<', 'K1 2^26 elements (SGHMC + Philox)', 20 * n, elements=n)
+# K2 / K3 at the WideResNet-28-10 arena size
+n = 36546980 + (-36546980) % 4
+out = torch.empty(n, device='cuda')
+for k in range(10):
+    K.swag_draw(out, th[:n], m[:n], var_clamp=1e-30, scale=1.0, seed=3, draw=k)
+note('k_swag_draw', 'K3 WideResNet-28-10 member draw (Philox)', 12 * n, elements=n)
+for k in range(10):
+    K.swag_collect(th[:n], m[:n], g[:n], decay=0.75, denom=4.0)
+note('k_swag_collect', 'K2 WideResNet-28-10 moment update', 20 * n, elements=n)
+del th, g, m, out
+# K5 at the shapes the tasks feed it
+for (S, B, C) in ((50, 10000, 10), (20, 10000, 10), (30, 10000, 100)):
+    z = torch.randn(S, B, C, device='cuda') * 3
+    p, e = torch.zeros(B, C, device='cuda'), torch.zeros(B, device='cuda')
+    for _ in range(10):
+        K.bma_accumulate(z, p, e, one_minus_gamma=0.9999, gamma_over_c=1e-4 / C, smoothed=False)
+    grid = (B + 15) // 16 if C <= 16 else (B + 3) // 4
+    note('k_bma_', f'K5 S={S} B={B} C={C}', 4 * S * B * C + 8 * B * (C + 1), shape=[S, B, C], blocks=grid)
+torch.cuda.synchronize()
+json.dump(manifest, open(sys.argv[1], 'w'), indent=1)

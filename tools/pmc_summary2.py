@@ -1,0 +1,44 @@
+"""Combine separate rocprofv3 --pmc passes into one JSON: per kernel (name + grid), the mean of each counter
+over its dispatches, HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB; gfx950 counts a 128-B streaming-read request
+as 64 B: MI355X_MICROARCH.md §HBM), against the algorithmic bytes of tools/pmc_only.py's manifest.
+    python3 tools/pmc_summary2.py <manifest.json> <out.json> <pass_dir> [<pass_dir> ...]"""
+import collections, csv, glob, json, re, sys
+
+manifest = json.load(open(sys.argv[1]))
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for d in sys.argv[3:]:
+    for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
+        for r in csv.DictReader(open(f)):
+            name = r['Kernel_Name']
+            if 'anonymous namespace' not in name or '::k_' not in name:
+                continue
+            short = re.search(r'k_\w+(<[^>]*>)?', name).group(0)
+            acc[short + '|grid=' + r.get('Grid_Size', '?') + '|wg=' + r.get('Workgroup_Size', '?')][r['Counter_Name']].append(float(r['Counter_Value']))
+out = {'method': 'rocprofv3 --pmc <counters> (one pass per counter group, no trace domains), mean over the dispatches of each '
+                 '(kernel, grid); FETCH_SIZE / WRITE_SIZE are KiB per dispatch; hbm bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 '
+                 '(gfx950: FETCH_SIZE tallies a 128-B streaming-read request as 64 B)', 'kernels': {}}
+for key, ctrs in sorted(acc.items()):
+    row = {c: sum(v) / len(v) for c, v in ctrs.items()}
+    row['launches'] = max(len(v) for v in ctrs.values())
+    grid = int(key.split('grid=')[1].split('|')[0])
+    wg = int(key.split('wg=')[1])
+    cands = [m for m in manifest if m['pattern'] in key]
+    m = None
+    for cand in cands:                       # pick the manifest entry whose launch geometry matches
+        if 'elements' in cand and abs(grid * 4 - cand['elements']) <= 4 * 512:
+            m = cand
+        if 'blocks' in cand and grid == cand['blocks'] * wg:
+            m = cand
+    if m is not None:
+        row.update({k: v for k, v in m.items() if k != 'pattern'})
+    if 'FETCH_SIZE' in row and 'WRITE_SIZE' in row:
+        row['hbm_bytes_per_launch_corrected'] = int((2 * row['FETCH_SIZE'] + row['WRITE_SIZE']) * 1024)
+        if m is not None:
+            row['traffic_over_algorithmic'] = round(row['hbm_bytes_per_launch_corrected'] / m['algorithmic_bytes_per_launch'], 5)
+    if 'SQ_WAVE_CYCLES' in row and row['SQ_WAVE_CYCLES']:
+        for c in ('SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_VALU', 'SQ_ACTIVE_INST_LDS', 'SQ_INST_CYCLES_VMEM'):
+            if c in row:
+                row[c + '_over_WAVE_CYCLES'] = round(row[c] / row['SQ_WAVE_CYCLES'], 4)
+    out['kernels'][key] = row
+json.dump(out, open(sys.argv[2], 'w'), indent=1)
+print(json.dumps(out, indent=1))
