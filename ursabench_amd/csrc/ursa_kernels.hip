@@ -28,7 +28,22 @@ constexpr int kBlock = 256;          // reductions / row kernels: 4 waves, one p
 constexpr int kMaxGrid = 256 * 8;    // grid-stride kernels (reductions): 256 CUs x 8 blocks/CU
 constexpr int kSBlock = 512;         // streaming kernels: one float4 per thread
 constexpr int64_t kMaxElems = 1ll << 40;    // keeps ceil(n/2048) blocks inside a 31-bit grid
-constexpr int64_t kNtBytes = 512ll << 20;   // state larger than this streams past the Infinity Cache
+// State larger than the 256 MiB Infinity Cache streams past it with non-temporal loads/stores. Measured
+// (tools/exp/nt_threshold.py, profiles/r02_nt_threshold.json): at the WideResNet-28-10 arena (36.5 M elements,
+// 438-731 MB per launch) NT is +9..15 % (K1 5.49 -> 6.13, K2 5.46 -> 6.27, K3 5.06 -> 5.51 TB/s); at 2^24
+// elements (201-335 MB, mostly cache-resident) it costs 12 %; round 1's 512 MiB threshold missed the first case.
+constexpr int64_t kNtBytesDefault = 256ll << 20;
+
+// Debug override of the non-temporal threshold in MiB (tools/exp/nt_threshold.py); read once.
+inline int64_t nt_bytes()
+{
+    static const int64_t v = [] {
+        const char* e = getenv("URSA_NT_MIB");
+        return e && e[0] ? (int64_t)atoll(e) << 20 : kNtBytesDefault;
+    }();
+    return v;
+}
+#define kNtBytes nt_bytes()
 
 inline int sgrid(int64_t items)      // one item per thread
 {
