@@ -141,7 +141,8 @@ def event_time_ms(fn, iters, stream, graph_batch=0):
             fn()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, capture_error_mode='thread_local'):     # RCCL's watchdog thread may be alive
+        from ursabench_amd._capture import capture
+        with capture(g):                 # thread-local capture (RCCL's watchdog thread may be alive), GC held off
             for _ in range(graph_batch):
                 fn()
         g.replay()

@@ -272,7 +272,8 @@ def test_k5_rowlane_few_classes(K, S, B, C):
     np.testing.assert_allclose(host(p.sum(1)), np.full(B, S, np.float32), rtol=2e-6)
 
 
-@pytest.mark.parametrize('S,B,C', [(3, 7, 20), (2, 129, 32), (4, 65, 64), (30, 257, 100), (2, 33, 128), (3, 17, 200), (2, 9, 256)])
+@pytest.mark.parametrize('S,B,C', [(3, 7, 20), (2, 129, 32), (4, 65, 64), (30, 257, 100), (5, 31, 104), (9, 16, 112), (1, 1, 100),
+                                   (2, 33, 128), (3, 17, 200), (2, 9, 256)])
 def test_k5_float4_rows(K, S, B, C):
     """C % 4 == 0, 16 < C <= 256: the lane-group kernel with four consecutive classes per float4 load."""
     rng = np.random.default_rng(S * 17 + B + C)

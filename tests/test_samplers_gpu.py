@@ -351,3 +351,25 @@ def test_chain_group_parallel_branches_match_single_chains():
         np.testing.assert_allclose(flat_params(a).cpu().numpy(), flat_params(b).cpu().numpy(), rtol=2e-3, atol=3e-4)
     assert not torch.equal(flat_params(together[0]), flat_params(together[1]))
     assert all(s.optimizer._step == 18 for s in group.samplers)
+
+
+def test_many_samplers_and_tasks_in_one_process():
+    """What a hyper-optimisation loop does: a new sampler and new tasks per trial, the old ones dropped whenever
+    Python gets to it. With side streams taken from PyTorch's round-robin pool per capture this segfaulted in
+    hipGraphLaunch (hip::Graph::UpdateStreams, ROCm 7.2) on the third trial — the pool wraps after 32 streams and a
+    new multi-branch capture forks onto streams a live graph was captured on; the package now forks every capture
+    onto ONE fixed set of side streams (ursabench_amd/_capture.py; tools/exp/graph_stress.py)."""
+    from ursabench_amd import util
+    train = synthetic(512, (3, 32, 32), 10, seed=0, device=DEV, batch_size=128)
+    test = synthetic(300, (3, 32, 32), 10, seed=1, device=DEV, batch_size=128)
+    hyp = {'lr': 0.05, 'prior_std': 0.5, 'num_samples': 3, 'alpha': 0.5, 'burn_in_epochs': 0}
+    sums = []
+    for trial in range(8):
+        util.set_random_seed(trial)
+        s = inference.SGHMC(dict(hyp), models.PreResNet(10, 8).to(DEV), train, device=DEV)
+        ens = s.sample()
+        for _ in range(2):
+            p = tasks.Prediction({'in_distribution_test': test}, 10, DEV, 'ALL')
+            p.update_statistics(ens, output_performance=False)
+        sums.append(float(p.ensemble_proba.sum()))
+    assert all(abs(v - 3 * 300) < 1e-2 for v in sums)

@@ -14,7 +14,7 @@ res = []
 VARIANTS = [('fast', {}), ('lane_group_scalar', {'URSA_BMA_NO_ROWLANE': '1', 'URSA_BMA_NO_V4': '1'})]
 VARIANTS += [(f'rowlane_waves{w}', {'URSA_BMA_RL_WAVES': str(w)}) for w in (1, 2, 4, 8)]
 for variant, env in VARIANTS:
-    for k in ('URSA_BMA_NO_ROWLANE', 'URSA_BMA_NO_V4', 'URSA_BMA_RL_WAVES'):
+    for k in ('URSA_BMA_NO_ROWLANE', 'URSA_BMA_NO_V4', 'URSA_BMA_RL_WAVES', 'URSA_BMA_NO_G4'):
         os.environ.pop(k, None)
     os.environ.update(env)
     for (S, B, C) in shapes:

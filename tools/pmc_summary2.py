@@ -27,7 +27,7 @@ for key, ctrs in sorted(acc.items()):
     for cand in cands:                       # pick the manifest entry whose launch geometry matches
         if 'elements' in cand and abs(grid * 4 - cand['elements']) <= 4 * 512:
             m = cand
-        if 'blocks' in cand and grid == cand['blocks'] * wg:
+        if 'blocks' in cand and grid == cand['blocks'] * wg and cand.get('wg', wg) == wg:
             m = cand
     if m is not None:
         row.update({k: v for k, v in m.items() if k != 'pattern'})

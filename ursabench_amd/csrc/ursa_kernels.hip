@@ -11,7 +11,7 @@
 // update at 6.36 TB/s (6.61 with non-temporal accesses) against 4.76 TB/s for the textbook
 // "2048 blocks + grid-stride" shape: many short blocks keep every HBM channel busy and let
 // the dispatcher balance the 8 XCDs. Non-temporal loads/stores are used only when the state
-// exceeds ~2x the 256 MiB Infinity Cache (they cost 3-15 % on cache-resident state).
+// exceeds the 256 MiB Infinity Cache (they cost 3-15 % on cache-resident state; nt_bytes()).
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt
 // (the rounding sequence of each update is part of the contract, see the header).

@@ -13,6 +13,7 @@ what it would compute alone on the same minibatch sequence.
 """
 import torch
 
+from .._capture import capture, side_streams
 from .sghmc import _ChainSampler
 
 
@@ -48,9 +49,9 @@ class ChainGroup:
         self._static = (torch.empty_like(x), torch.empty_like(y))
         self._static[0].copy_(x)
         self._static[1].copy_(y)
-        side = [torch.cuda.Stream(self.device) for _ in self.samplers]
+        side = side_streams(self.device, len(self.samplers))
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, capture_error_mode='thread_local'):
+        with capture(g):
             cap = torch.cuda.current_stream(self.device)
             for s, st in zip(self.samplers, side):          # fork: one branch per chain
                 st.wait_stream(cap)
@@ -90,7 +91,7 @@ class ChainGroup:
                     self._graph.replay()
                     self.stats['graph_replays'] += 1
                 else:
-                    side = torch.cuda.Stream(self.device)
+                    side = side_streams(self.device, 1)[0]
                     side.wait_stream(torch.cuda.current_stream(self.device))
                     with torch.cuda.stream(side):
                         self._round_eager(x, y)

@@ -11,6 +11,8 @@ gap (graph replay). Per-step scalars (lr, noise scale, noise on/off, Philox coun
 """
 import torch
 
+from .._capture import capture, side_streams
+
 
 class ChainEngine:
     WARMUP_STEPS = 3
@@ -77,7 +79,7 @@ class ChainEngine:
         g = torch.cuda.CUDAGraph()
         # thread_local: RCCL's watchdog thread (one process per GPU jobs) may touch the HIP runtime while
         # this thread captures; only this thread's calls belong to the capture
-        with torch.cuda.graph(g, capture_error_mode='thread_local'):
+        with capture(g):
             self._train_step(*self._static)
         self._graph = g
         self.stats['captures'] += 1
@@ -107,7 +109,7 @@ class ChainEngine:
                     self.stats['graph_replays'] += 1
                 else:
                     # warm-up steps are real steps, run on a side stream as capture will be
-                    s = torch.cuda.Stream(self.device)
+                    s = side_streams(self.device, 1)[0]
                     s.wait_stream(torch.cuda.current_stream(self.device))
                     with torch.cuda.stream(s):
                         self._train_step(x, y)

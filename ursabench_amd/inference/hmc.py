@@ -18,6 +18,7 @@ import math
 import torch
 
 from .. import _native
+from .._capture import capture, side_streams
 from ..arena import FlatArena, MemberBank
 from ..util import reset_model
 from .inference_base import _Inference
@@ -95,13 +96,13 @@ class HMC(_Inference):
             self._u = torch.zeros((), device=self.arena.device)
         if self.use_graph and self._graph is None and self._evals >= 2:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode='thread_local'):
+            with capture(g):
                 self._eval_potential()
             self._graph = g
         if self._graph is not None:
             self._graph.replay()
         elif self.use_graph:
-            side = torch.cuda.Stream(self.arena.device)
+            side = side_streams(self.arena.device, 1)[0]
             side.wait_stream(torch.cuda.current_stream(self.arena.device))
             with torch.cuda.stream(side):
                 self._eval_potential()

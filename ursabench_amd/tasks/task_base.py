@@ -4,6 +4,7 @@ import torch
 import torch.distributed as dist
 
 from .. import _native
+from .._capture import capture, side_streams
 
 GAMMA = 1e-4   # util.central_smoothing default (util.py:126)
 
@@ -156,7 +157,7 @@ class EnsembleAccumulator:
                     o.copy_(m(_sx))
         else:
             cur = torch.cuda.current_stream(self.device)
-            side = [torch.cuda.Stream(self.device) for _ in mods]
+            side = side_streams(self.device, len(mods))
             side[0].wait_stream(cur)
             with torch.cuda.stream(side[0]):
                 for m in mods:
@@ -164,7 +165,7 @@ class EnsembleAccumulator:
             cur.wait_stream(side[0])
             graph = torch.cuda.CUDAGraph()
             outs = []
-            with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+            with capture(graph):
                 cap = torch.cuda.current_stream(self.device)
                 for m, st in zip(mods, side):                    # fork: one branch per lane
                     st.wait_stream(cap)
