@@ -825,7 +825,8 @@ __device__ __forceinline__ float block_sum(float v)
     return t;   // valid in thread 0
 }
 
-// Streaming form (no energy wanted): one float4 per thread like K1.
+// Streaming form (no energy wanted): one float4 per thread like K1 (non-temporal past the Infinity Cache).
+template <bool NT>
 __global__ __launch_bounds__(kSBlock) void k_leapfrog_v(float* __restrict__ theta, float* __restrict__ mom,
                                                         const float* __restrict__ grad, int64_t n, float kick,
                                                         float drift, uint32_t flags)
@@ -834,16 +835,16 @@ __global__ __launch_bounds__(kSBlock) void k_leapfrog_v(float* __restrict__ thet
     const int64_t n4 = n >> 2;
     const int64_t i = (int64_t)blockIdx.x * kSBlock + threadIdx.x;
     if (i < n4) {
-        float4 p = reinterpret_cast<float4*>(mom)[i];
+        float4 p = ld4<NT>(reinterpret_cast<const float4*>(mom) + i);
         if (do_kick) {
-            const float4 g = reinterpret_cast<const float4*>(grad)[i];
+            const float4 g = ld4<NT>(reinterpret_cast<const float4*>(grad) + i);
             p.x = p.x + kick * g.x; p.y = p.y + kick * g.y; p.z = p.z + kick * g.z; p.w = p.w + kick * g.w;
-            reinterpret_cast<float4*>(mom)[i] = p;
+            st4<NT>(reinterpret_cast<float4*>(mom) + i, p);
         }
         if (do_drift) {
-            float4 t = reinterpret_cast<float4*>(theta)[i];
+            float4 t = ld4<NT>(reinterpret_cast<const float4*>(theta) + i);
             t.x = t.x + drift * p.x; t.y = t.y + drift * p.y; t.z = t.z + drift * p.z; t.w = t.w + drift * p.w;
-            reinterpret_cast<float4*>(theta)[i] = t;
+            st4<NT>(reinterpret_cast<float4*>(theta) + i, t);
         }
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
@@ -1177,9 +1178,12 @@ int ursa_leapfrog_f32(float* theta, float* mom, const float* grad, int64_t n, fl
     hipStream_t st = (hipStream_t)stream;
     float* wsp = kinetic_out ? ws : nullptr;
     const float drift = step_size * inv_mass;
-    if (vec && !kinetic_out)
-        hipLaunchKernelGGL(k_leapfrog_v, dim3(sgrid(n >> 2)), dim3(kSBlock), 0, st, theta, mom, grad, n, kick_coef,
-                           drift, flags);
+    if (vec && !kinetic_out && n * 12ll > kNtBytes)
+        hipLaunchKernelGGL(k_leapfrog_v<true>, dim3(sgrid(n >> 2)), dim3(kSBlock), 0, st, theta, mom, grad, n,
+                           kick_coef, drift, flags);
+    else if (vec && !kinetic_out)
+        hipLaunchKernelGGL(k_leapfrog_v<false>, dim3(sgrid(n >> 2)), dim3(kSBlock), 0, st, theta, mom, grad, n,
+                           kick_coef, drift, flags);
     else if (vec)
         hipLaunchKernelGGL(k_leapfrog<true>, dim3(grid), dim3(kBlock), 0, st, theta, mom, grad, n, kick_coef, drift,
                            flags, wsp);
