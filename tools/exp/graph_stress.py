@@ -2,7 +2,7 @@
 hipGraphs accumulate and old ones are destroyed?  python tools/exp/graph_stress.py            (runs every mode in a child)
                                               python tools/exp/graph_stress.py <mode> [iters]"""
 import gc, os, subprocess, sys, tempfile
-MODES = ['full', 'full_fresh_streams', 'full_keep_samplers', 'tasks', 'engine']
+MODES = ["full", "full_fresh_streams", "tasks", "engine"]
 if len(sys.argv) == 1:
     for m in MODES:
         env = dict(os.environ, URSA_SIDE_STREAMS='fresh') if m == 'full_fresh_streams' else dict(os.environ)
