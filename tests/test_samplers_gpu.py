@@ -227,7 +227,7 @@ def test_bma_graph_replay_equals_eager_member_forwards():
     import copy
     torch.manual_seed(0)
     train = synthetic(512, (3, 32, 32), 10, seed=0, device=DEV, batch_size=128)
-    test = synthetic(1000, (3, 32, 32), 10, seed=1, device=DEV, batch_size=128)     # ragged last batch: 104
+    test = synthetic(1500, (3, 32, 32), 10, seed=1, device=DEV, batch_size=128)     # evaluation batches: 1024 + 476 rows
     s = inference.SGHMC({'lr': 0.05, 'prior_std': 0.5, 'num_samples': 3, 'alpha': 0.5, 'burn_in_epochs': 0},
                         models.PreResNet(10, 8).to(DEV), train, device=DEV)
     ens = s.sample()

@@ -13,6 +13,14 @@ from ursabench_amd.tasks.decision_making import CIFAR10_cost
 from oracle_kernels import OracleKernels
 
 TWIN = dict(use_twin=True, use_graph=False)
+
+
+@pytest.fixture(autouse=True)
+def one_forward_per_loader_batch(monkeypatch):
+    """These tests count forwards per loader batch and compare bit for bit with per-batch member calls: switch the
+    merging of loader batches into larger evaluation batches off (covered by its own test below)."""
+    from ursabench_amd.tasks.task_base import EnsembleAccumulator
+    monkeypatch.setattr(EnsembleAccumulator, 'EVAL_ROWS', 0)
 HYP = {'lr': 0.05, 'prior_std': 1.0, 'num_samples': 2, 'alpha': 0.5, 'burn_in_epochs': 0}
 
 
@@ -174,3 +182,23 @@ def test_several_row_chunks_and_one_kernel_launch_per_chunk(monkeypatch):
     assert torch.equal(whole.expected_data_uncertainty, parts.expected_data_uncertainty)
     p, e = eager_reference(ens, test)
     np.testing.assert_allclose(whole.ensemble_proba.numpy(), p, rtol=1e-6, atol=1e-9)
+
+
+def test_loader_batches_are_merged_into_evaluation_batches(monkeypatch):
+    """EVAL_ROWS: consecutive loader batches are concatenated (never split) up to that many rows per member forward;
+    an eval-mode forward is row-independent, so the predictive is the same to rounding."""
+    from ursabench_amd.tasks.task_base import EnsembleAccumulator
+    train, test = img_loader(32, 16), img_loader(37, 8, seed=7)              # loader batches: 8, 8, 8, 8, 5
+    _, ens = bn_chain(8, 3, train)
+    monkeypatch.setattr(EnsembleAccumulator, 'EVAL_ROWS', 20)               # -> 16, 16, 5
+    pred = tasks.Prediction({'in_distribution_test': test}, 10, torch.device('cpu'), 'ALL', kernels=OracleKernels(), acc_kw=TWIN)
+    sizes = [[len(x) for _, x in batches] for _, _, batches in pred._acc._chunks(3)]
+    assert sizes == [[16, 16, 5]]
+    pred.update_statistics(ens, output_performance=False)
+    assert pred._acc.stats['twin_forwards'] == 3 * 3 and pred._acc.stats['bma_launches'] == 1
+    p, e = eager_reference(ens, test)
+    np.testing.assert_allclose(pred.ensemble_proba.numpy(), p, rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(pred.expected_data_uncertainty.numpy(), e, rtol=1e-5, atol=1e-6)
+    monkeypatch.setattr(EnsembleAccumulator, 'EVAL_ROWS', 1024)             # everything in one forward
+    one = tasks.Prediction({'in_distribution_test': test}, 10, torch.device('cpu'), 'ALL', kernels=OracleKernels(), acc_kw=TWIN)
+    assert [[len(x) for _, x in b] for _, _, b in one._acc._chunks(3)] == [[37]]
