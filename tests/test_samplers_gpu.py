@@ -353,13 +353,15 @@ def test_chain_group_parallel_branches_match_single_chains():
     assert all(s.optimizer._step == 18 for s in group.samplers)
 
 
-def test_many_samplers_and_tasks_in_one_process():
+def test_many_samplers_and_tasks_in_one_process(monkeypatch):
     """What a hyper-optimisation loop does: a new sampler and new tasks per trial, the old ones dropped whenever
     Python gets to it. With side streams taken from PyTorch's round-robin pool per capture this segfaulted in
     hipGraphLaunch (hip::Graph::UpdateStreams, ROCm 7.2) on the third trial — the pool wraps after 32 streams and a
     new multi-branch capture forks onto streams a live graph was captured on; the package now forks every capture
     onto ONE fixed set of side streams (ursabench_amd/_capture.py; tools/exp/graph_stress.py)."""
     from ursabench_amd import util
+    from ursabench_amd.tasks.task_base import EnsembleAccumulator
+    monkeypatch.setattr(EnsembleAccumulator, 'EVAL_ROWS', 0)      # a captured graph per loader-batch shape: the pattern that crashed
     train = synthetic(512, (3, 32, 32), 10, seed=0, device=DEV, batch_size=128)
     test = synthetic(300, (3, 32, 32), 10, seed=1, device=DEV, batch_size=128)
     hyp = {'lr': 0.05, 'prior_std': 0.5, 'num_samples': 3, 'alpha': 0.5, 'burn_in_epochs': 0}

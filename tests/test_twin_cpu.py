@@ -202,3 +202,8 @@ def test_loader_batches_are_merged_into_evaluation_batches(monkeypatch):
     monkeypatch.setattr(EnsembleAccumulator, 'EVAL_ROWS', 1024)             # everything in one forward
     one = tasks.Prediction({'in_distribution_test': test}, 10, torch.device('cpu'), 'ALL', kernels=OracleKernels(), acc_kw=TWIN)
     assert [[len(x) for _, x in b] for _, _, b in one._acc._chunks(3)] == [[37]]
+    # networks above MERGE_MAX_PARAMS keep one forward per loader batch (a 128-row WideResNet-28-10 forward already fills the GPU)
+    monkeypatch.setattr(EnsembleAccumulator, 'MERGE_MAX_PARAMS', 10)
+    big = tasks.Prediction({'in_distribution_test': test}, 10, torch.device('cpu'), 'ALL', kernels=OracleKernels(), acc_kw=TWIN)
+    big.update_statistics(ens, output_performance=False)
+    assert big._acc.stats['twin_forwards'] == 3 * 5

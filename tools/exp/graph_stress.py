@@ -21,6 +21,7 @@ dev = torch.device('cuda', 0)
 train = synthetic(512, (3, 32, 32), 10, seed=0, device=dev, batch_size=128)
 test = synthetic(300, (3, 32, 32), 10, seed=1, device=dev, batch_size=128)
 hyp = {'lr': 0.05, 'prior_std': 0.5, 'num_samples': 3, 'alpha': 0.5, 'burn_in_epochs': 0}
+task_base.EnsembleAccumulator.EVAL_ROWS = 0      # one forward (and one captured graph) per loader-batch shape, as when the crash was found
 if mode == 'tasks_lanes1':
     task_base.EnsembleAccumulator.LANES = 1
 if mode == 'tasks_nobn':

@@ -181,16 +181,21 @@ class EnsembleAccumulator:
     SLAB_BYTES = 1 << 30       # logits of one chunk of test rows, all members: [S, rows, C] fp32
     INPUT_BYTES = 2 << 30      # device copies of the chunk's input batches (host-resident loaders)
 
-    EVAL_ROWS = 1024           # rows per member forward: consecutive loader batches are merged up to this many
+    EVAL_ROWS = 1024           # rows per member forward: consecutive loader batches are merged up to this many ...
+    MERGE_MAX_PARAMS = 4_000_000   # ... for networks up to this many parameters
 
-    def _chunks(self, S):
+    def _chunks(self, S, eval_rows=None):
         """The loader's batches grouped into chunks of consecutive rows: (first row, rows, [(offset, x on device), ...]).
         A chunk is as many batches as fit the slab / input budgets — the whole 10,000-row test set for every
         configuration in BASELINE.json — so the loader is walked ONCE per call, like the reference's loop
         (prediction.py:52), and a host-resident batch crosses PCIe once. Inside a chunk, consecutive loader
         batches are concatenated into evaluation batches of up to EVAL_ROWS rows: an eval-mode forward is
         row-independent, and a 128-row PreResNet-20 forward is ~100 kernels of a few microseconds each — 8x the
-        rows per launch is 8x fewer launches for the same arithmetic (`tools/exp/bma_probe.py`)."""
+        rows per launch is 8x fewer launches for the same arithmetic. Measured (profiles/r02_bench_line.json,
+        r02_c4_bench_line.json): PreResNet-20 280k -> 379k member-forwards/s; WideResNet-28-10 (36.5 M parameters,
+        a 128-row forward already fills the GPU) 10.4k -> 9.1k — so `accumulate` merges only for networks of at
+        most MERGE_MAX_PARAMS parameters (eval_rows=0: one forward per loader batch)."""
+        eval_rows = self.EVAL_ROWS if eval_rows is None else eval_rows
         start, rows, nbytes, batches = 0, 0, 0, []
         per_row = 4 * S * self.C
         pend, pend_rows = [], 0
@@ -210,16 +215,22 @@ class EnsembleAccumulator:
                 flush()
                 yield start, rows, batches
                 start, rows, nbytes, batches = start + rows, 0, 0, []
-            if pend and pend_rows + b > max(self.EVAL_ROWS, 1):
+            if pend and pend_rows + b > max(eval_rows, 1):
                 flush()
             pend.append(x)
             pend_rows += b
             nbytes += xb
-            if pend_rows >= self.EVAL_ROWS:
+            if pend_rows >= eval_rows:
                 flush()
         flush()
         if batches:
             yield start, rows, batches
+
+    def _param_count(self, member):
+        bank = getattr(member, '_ursa_bank', None)
+        if bank is not None:
+            return bank.arena.num_parameters
+        return sum(p.numel() for p in member.parameters())
 
     @torch.no_grad()
     def accumulate(self, members):
@@ -242,7 +253,9 @@ class EnsembleAccumulator:
                 eager.append(s)
             else:
                 by_twin.setdefault(id(twin), (twin, []))[1].append(s)
-        for start, rows, batches in self._chunks(S):
+        biggest = max(self._param_count(m) for m in members)
+        eval_rows = self.EVAL_ROWS if biggest <= self.MERGE_MAX_PARAMS else 0
+        for start, rows, batches in self._chunks(S, eval_rows):
             slab = self._slabs.get((S, rows))
             if slab is None:
                 if len(self._slabs) >= 4:
