@@ -45,7 +45,7 @@ for (S, B, C) in ((50, 10000, 10), (20, 10000, 10), (30, 10000, 100)):
     for _ in range(10):
         K.bma_accumulate(z, p, e, one_minus_gamma=0.9999, gamma_over_c=1e-4 / C, smoothed=False)
     grid = (B + 15) // 16 if C <= 16 else (B + 3) // 4
-    wg = 64 * min(8, max(1, (S + 15) // 16)) if C <= 16 else 256
+    wg = 64 * (4 if S >= 12 else 2 if S >= 5 else 1) if C <= 16 else 256
     note('k_bma_', f'K5 S={S} B={B} C={C}', 4 * S * B * C + 8 * B * (C + 1), shape=[S, B, C], blocks=grid, wg=wg)
 torch.cuda.synchronize()
 json.dump(manifest, open(sys.argv[1], 'w'), indent=1)

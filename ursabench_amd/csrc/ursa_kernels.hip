@@ -1097,9 +1097,9 @@ int ursa_bma_accumulate_f32(const float* logits, float* proba_sum, float* ent_su
     const bool tiles_aligned = aligned16(logits) && ((B * (int64_t)C) % 4 == 0);
     // (11 <= C <= 15 with a cost matrix spills registers in the masked 16-class body: lane-group kernel instead)
     if (C <= 16 && tiles_aligned && !(risk_sum && C > 10 && C < 16) && !getenv_flag("URSA_BMA_NO_ROWLANE")) {
-        // waves per block: enough member slots (4 per wave) for S, at most 4 rounds per slot when possible
-        int W = (S + 15) / 16;
-        W = W < 1 ? 1 : W > 8 ? 8 : W;
+        // 4 waves (16 member slots) from 12 members up: measured best at S = 20 (5.7 vs 6.2 us with 2 waves) and at
+        // S = 50 (8.0 vs 9.0 us with 8 waves); small ensembles keep small blocks (tools/k5_bench.py rowlane_wavesN)
+        int W = S >= 12 ? 4 : S >= 5 ? 2 : 1;
         if (const char* w = getenv("URSA_BMA_RL_WAVES")) {        // debug: tools/k5_bench.py sweeps
             const int v = atoi(w);
             if (v >= 1 && v <= 8) W = v;
