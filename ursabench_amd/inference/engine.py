@@ -12,6 +12,7 @@ gap (graph replay). Per-step scalars (lr, noise scale, noise on/off, Philox coun
 import torch
 
 from .._capture import capture, side_streams
+from ..util import deferred_bn_counters
 
 
 class ChainEngine:
@@ -44,7 +45,8 @@ class ChainEngine:
         self.invalidate()
 
     def _train_step(self, x, y, eps=None):
-        logits = self.model(x)
+        with deferred_bn_counters(self.model):       # 19 one-element counter kernels -> one multi-tensor add
+            logits = self.model(x)
         loss = self.crit(logits, y)
         # Gradients: with p.grad = None autograd hands over its freshly computed tensors (no kernel);
         # ONE multi-tensor copy then packs them into the flat arena. Leaving the arena views in
@@ -67,7 +69,7 @@ class ChainEngine:
             torch._foreach_copy_(self._grad_views, grads)
         for p in self._params:
             p.grad = None
-        self.loss_acc += loss.detach() * x.shape[0]
+        self.loss_acc.add_(loss.detach(), alpha=x.shape[0])
         self.opt.ctl_step(eps=eps)
         if keep is not None:
             self.opt.arena.unstash(keep)

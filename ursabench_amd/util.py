@@ -87,6 +87,32 @@ def compute_predictive_entropy(proba):
     return -(proba * torch.log(proba)).sum(dim=-1)
 
 
+class deferred_bn_counters:
+    """Train-mode BatchNorm bumps `num_batches_tracked` with its own tiny kernel per layer per forward (19 launches
+    of ~4 us in a PreResNet-20 step: 3 % of it, `CUDAFunctorOnSelf_add<long>` in profiles/r02_bench_kernel_stats.csv).
+    Inside this context the layers see no counter (nn.BatchNorm skips the increment when the buffer is None); on exit
+    the counters are put back and bumped by `forwards` with ONE multi-tensor add: same integers, one launch.
+    Layers with momentum=None (cumulative average: the counter feeds the update) are left alone."""
+
+    def __init__(self, model, forwards=1):
+        self.mods = [m for m in model.modules() if isinstance(m, _BatchNorm) and m.momentum is not None
+                     and m.track_running_stats and m._buffers.get('num_batches_tracked') is not None]
+        self.forwards = forwards
+
+    def __enter__(self):
+        self.counters = [m._buffers['num_batches_tracked'] for m in self.mods]
+        for m in self.mods:
+            m._buffers['num_batches_tracked'] = None
+        return self
+
+    def __exit__(self, *exc):
+        for m, c in zip(self.mods, self.counters):
+            m._buffers['num_batches_tracked'] = c
+        if self.counters and exc[0] is None and self.forwards:
+            torch._foreach_add_(self.counters, self.forwards)
+        return False
+
+
 def check_bn(model):
     """util.py:185-193."""
     return any(isinstance(m, _BatchNorm) for m in model.modules())
@@ -111,7 +137,8 @@ def bn_update(loader, model, subset=None, device=None, **kwargs):
         momenta[m] = m.momentum
     n = 0
     num_batches = len(loader)
-    with torch.no_grad():
+    counters = deferred_bn_counters(model, forwards=0)      # bumped once at the end by the number of forwards done
+    with torch.no_grad(), counters:
         it = iter(loader)
         if subset is not None:
             num_batches = int(num_batches * subset)
@@ -125,6 +152,7 @@ def bn_update(loader, model, subset=None, device=None, **kwargs):
                 m.momentum = mom
             model(x, **kwargs)
             n += b
+            counters.forwards += 1
     for m in bns:
         m.momentum = momenta[m]
     model.train(was_training)
