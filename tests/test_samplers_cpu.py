@@ -275,3 +275,43 @@ def test_tensors_without_gradient_are_skipped_like_the_reference():
     opt.step(add_langevin_noise=True)
     assert torch.equal(params[1], after1[1]) and not torch.equal(params[0], after1[0])
     assert float(opt.arena.grad_views[1].abs().sum()) == 0  # the previous step's gradient is gone, not re-applied
+
+
+def _cyclic_replay(golden_dir, name, device, kernels=None, atol=0.0):
+    g = np.load(os.path.join(golden_dir, 'e2e_cyclic.npz'))
+    hyp = json.loads(str(g[f'{name}/hyper']))
+    net = tiny_net()
+    with torch.no_grad():
+        off = 0
+        for p in net.parameters():
+            p.copy_(torch.tensor(g[f'{name}/theta0'][off:off + p.numel()]).view_as(p))
+            off += p.numel()
+    kw = {} if kernels is None else dict(kernels=kernels, use_graph=False)
+    s = getattr(inference, name)(dict(hyp), net, tiny_loader(), device=device, **kw)
+
+    def eps(k):
+        e = torch.zeros(s.arena.n, device=device)
+        e[s.arena.layout.gather_index(device)] = torch.tensor(g[f'{name}/eps'][k], device=device)
+        return e
+    s.eps_provider = eps
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):          # the reference prints 'Epoch: ... lr: ...' every epoch; so do we
+        ens = s.sample()
+    assert len(ens) == len(g[f'{name}/samples']) == 4 and s.optimizer._step == len(g[f'{name}/lr']) == 16
+    return s, ens, g
+
+
+@pytest.mark.parametrize('name', ['cSGHMC', 'cSGLD'])
+def test_cyclic_samplers_end_to_end_vs_reference(golden_dir, name):
+    """G12: the reference's own cSGHMC / cSGLD runs (tiny MLP, 2 cycles of 4 epochs) replayed with its captured
+    noise: every emitted sample bit-identical on CPU — the per-iteration cyclical lr through the schedule table,
+    the noise / collect masks, the momentum first-step rule and the float `num_batch` quirk all in one trajectory."""
+    K = OracleKernels()
+    s, ens, g = _cyclic_replay(golden_dir, name, torch.device('cpu'), K)
+    for m, ref in zip(ens, g[f'{name}/samples']):
+        got = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).numpy()
+        assert np.array_equal(got, ref)
+    used = np.array([lr for lr, _, _, _ in K.step_log], np.float64)
+    np.testing.assert_allclose(used, g[f'{name}/lr'], rtol=1e-7)
+    noise_on = np.array([bool(fl & 1) for _, _, fl, _ in K.step_log])
+    assert np.array_equal(noise_on, g[f'{name}/noise'])

@@ -415,6 +415,31 @@ def gen_e2e_preresnet():
     print('G9 e2e_preresnet8 steps', out['eps'].shape)
 
 
+def gen_e2e_cyclic():
+    """G12: the reference's cSGHMC and cSGLD end to end on a tiny MLP: per-iteration cyclical lr, noise only in the
+    tail of each cycle, samples only from the last epochs of a cycle — parameters of every emitted sample with the
+    noise the reference drew."""
+    out = {}
+    loader = tiny_loader()
+    for name, cls, alpha in (('cSGHMC', inference.cSGHMC, 0.5), ('cSGLD', inference.cSGLD, 1.0)):
+        hyp = {'lr_0': 0.05, 'prior_std': 1.0, 'num_samples_per_cycle': 2, 'cycle_length': 4, 'burn_in_epochs': 1,
+               'num_cycles': 2, 'alpha': alpha}
+        util.set_random_seed(3)
+        net = tiny_net()
+        out[f'{name}/theta0'] = flat(net.parameters())
+        s = cls(dict(hyp), net, loader)
+        tap = NoiseTap(s.optimizer)
+        with quiet():
+            ens = s.sample()
+        out[f'{name}/eps'] = np.stack([r['eps'] for r in tap.records])
+        out[f'{name}/lr'] = np.array([r['lr'] for r in tap.records])
+        out[f'{name}/noise'] = np.array([r['noise'] for r in tap.records])
+        out[f'{name}/samples'] = np.stack([flat(m.parameters()) for m in ens])
+        out[f'{name}/hyper'] = json.dumps(hyp)
+        print('G12', name, 'steps', len(tap.records), 'samples', len(ens), 'noisy steps', int(out[f'{name}/noise'].sum()))
+    np.savez_compressed(os.path.join(OUT, 'e2e_cyclic.npz'), **out)
+
+
 def gen_mcdropout():
     """G10: the reference's MCdropout (vi_dropout.py) on its own MLP -> MLP_dropout swap: per-minibatch OneCycleLR
     (lr, momentum) pairs, parameters after each sample_iterative, then update_hyp (CosineAnnealingLR per minibatch)
@@ -525,8 +550,8 @@ def gen_model_keys():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['k1', 'sgd', 'sched', 'csghmc', 'tasks', 'swag', 'swag_e2e', 'e2e', 'e2e_preresnet', 'mcdropout', 'columns', 'keys']
+    which = sys.argv[1:] or ['k1', 'sgd', 'sched', 'csghmc', 'tasks', 'swag', 'swag_e2e', 'e2e', 'e2e_preresnet', 'mcdropout', 'columns', 'cyclic', 'keys']
     fns = dict(k1=gen_k1, sgd=gen_sgd, swag_e2e=gen_swag_e2e, e2e_preresnet=gen_e2e_preresnet, sched=gen_schedules, csghmc=gen_csghmc, tasks=gen_tasks, swag=gen_swag, e2e=gen_e2e,
-               keys=gen_model_keys, mcdropout=gen_mcdropout, columns=gen_experiment_columns)
+               keys=gen_model_keys, mcdropout=gen_mcdropout, columns=gen_experiment_columns, cyclic=gen_e2e_cyclic)
     for w in which:
         fns[w]()
