@@ -65,3 +65,27 @@ def test_member_bank_checkpoint_roundtrip(tmp_path):
     assert torch.equal(fresh(x), ens[1](x))
     with pytest.raises(ValueError):
         checkpoint.save_ensemble([net], p)
+
+
+def test_sgd_sampler_equals_the_reference_run(golden_dir):
+    """G13: the reference's SGD baseline (inference/sgd.py) — constructor run, update_hyp (re-init in place, new
+    optimizer and cosine floor, same epoch count: the quirk), second run — bit-identical parameters on CPU."""
+    import json
+    import os
+    from ursabench_amd import util
+    g = np.load(os.path.join(golden_dir, 'sgd_sampler.npz'))
+    hyp, hyp2 = json.loads(str(g['hyper'])), json.loads(str(g['hyper2']))
+    flat = lambda m: torch.cat([p.detach().reshape(-1) for p in m.parameters()]).numpy()
+    util.set_random_seed(5)
+    net = tiny_net()
+    assert np.array_equal(flat(net), g['theta0'])
+    s = inference.SGD(dict(hyp), net, tiny_loader(), kernels=OracleKernels(), use_graph=False)
+    m = s.sample(num_samples=2)
+    assert np.array_equal(flat(m[0]), g['sample'])
+    assert s.optimizer.param_groups[0]['lr'] == pytest.approx(float(g['lr_after']), rel=1e-12)
+    util.set_random_seed(6)
+    s.update_hyp(dict(hyp2))
+    assert np.array_equal(flat(s.model), g['theta1'])
+    m = s.sample()
+    assert np.array_equal(flat(m[0]), g['sample2'])
+    assert s.optimizer.param_groups[0]['lr'] == pytest.approx(float(g['lr_after2']), rel=1e-12)

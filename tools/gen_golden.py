@@ -440,6 +440,30 @@ def gen_e2e_cyclic():
     np.savez_compressed(os.path.join(OUT, 'e2e_cyclic.npz'), **out)
 
 
+def gen_sgd_sampler():
+    """G13: the reference's SGD baseline sampler (inference/sgd.py) on a tiny MLP: constructor run (cosine to lr/100),
+    then update_hyp (re-init, cosine to lr/2, loop still uses the constructor's epoch count) and a second run."""
+    hyp = {'lr': 0.1, 'epochs': 2, 'momentum': 0.9, 'weight_decay': 1e-3}
+    hyp2 = {'lr': 0.05, 'epochs': 5, 'momentum': 0.8, 'weight_decay': 0.0}
+    util.set_random_seed(5)
+    net = tiny_net()
+    out = {'theta0': flat(net.parameters()), 'hyper': json.dumps(hyp), 'hyper2': json.dumps(hyp2)}
+    s = inference.SGD(dict(hyp), net, tiny_loader())
+    with quiet():
+        m = s.sample(num_samples=2)
+    out['sample'] = flat(m[0].parameters())
+    out['lr_after'] = np.float64(s.optimizer.param_groups[0]['lr'])
+    util.set_random_seed(6)
+    s.update_hyp(dict(hyp2))
+    out['theta1'] = flat(s.model.parameters())
+    with quiet():
+        m = s.sample()
+    out['sample2'] = flat(m[0].parameters())
+    out['lr_after2'] = np.float64(s.optimizer.param_groups[0]['lr'])
+    np.savez(os.path.join(OUT, 'sgd_sampler.npz'), **out)
+    print('G13 sgd_sampler lr after', float(out['lr_after']), float(out['lr_after2']))
+
+
 def gen_mcdropout():
     """G10: the reference's MCdropout (vi_dropout.py) on its own MLP -> MLP_dropout swap: per-minibatch OneCycleLR
     (lr, momentum) pairs, parameters after each sample_iterative, then update_hyp (CosineAnnealingLR per minibatch)
@@ -550,8 +574,8 @@ def gen_model_keys():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['k1', 'sgd', 'sched', 'csghmc', 'tasks', 'swag', 'swag_e2e', 'e2e', 'e2e_preresnet', 'mcdropout', 'columns', 'cyclic', 'keys']
+    which = sys.argv[1:] or ['k1', 'sgd', 'sched', 'csghmc', 'tasks', 'swag', 'swag_e2e', 'e2e', 'e2e_preresnet', 'mcdropout', 'columns', 'cyclic', 'sgd_sampler', 'keys']
     fns = dict(k1=gen_k1, sgd=gen_sgd, swag_e2e=gen_swag_e2e, e2e_preresnet=gen_e2e_preresnet, sched=gen_schedules, csghmc=gen_csghmc, tasks=gen_tasks, swag=gen_swag, e2e=gen_e2e,
-               keys=gen_model_keys, mcdropout=gen_mcdropout, columns=gen_experiment_columns, cyclic=gen_e2e_cyclic)
+               keys=gen_model_keys, mcdropout=gen_mcdropout, columns=gen_experiment_columns, cyclic=gen_e2e_cyclic, sgd_sampler=gen_sgd_sampler)
     for w in which:
         fns[w]()
