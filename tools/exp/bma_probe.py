@@ -15,8 +15,10 @@ s = inference.SGHMC({'lr': 0.1, 'prior_std': 0.5, 'num_samples': 20, 'alpha': 0.
                     models.PreResNet(10, 20).to(dev), train, device=dev)
 ens = s.sample()
 res = []
-for lanes in [int(v) for v in sys.argv[1:]] or [4]:
+ROWS = [int(v[5:]) for v in sys.argv[1:] if v.startswith('rows=')] or [EnsembleAccumulator.EVAL_ROWS]
+for lanes, rows in [(int(v), r) for v in ([a for a in sys.argv[1:] if not a.startswith('rows=')] or ['4']) for r in ROWS]:
     EnsembleAccumulator.LANES = lanes
+    EnsembleAccumulator.EVAL_ROWS = rows
     for S in (3, 4, 8, 20):
         pred = tasks.Prediction({'in_distribution_test': test}, 10, dev, 'ALL')
         pred.update_statistics(ens[:S], output_performance=False)
@@ -24,9 +26,10 @@ for lanes in [int(v) for v in sys.argv[1:]] or [4]:
         torch.cuda.synchronize(); t0 = time.perf_counter()
         pred.update_statistics(ens[:S], output_performance=False)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
-        r = dict(lanes=lanes, members=S, seconds=round(dt, 4), preds_per_s=round(10000 / dt), member_forwards_per_s=round(S * 10000 / dt))
+        r = dict(lanes=lanes, eval_rows=rows, members=S, seconds=round(dt, 4), preds_per_s=round(10000 / dt), member_forwards_per_s=round(S * 10000 / dt))
         print(r, flush=True); res.append(r)
 EnsembleAccumulator.LANES = 4
+EnsembleAccumulator.EVAL_ROWS = 1024
 from torch.profiler import profile, ProfilerActivity
 pred = tasks.Prediction({'in_distribution_test': test}, 10, dev, 'ALL')
 pred.update_statistics(ens[:8], output_performance=False); pred.reset()

@@ -66,8 +66,8 @@ class EnsembleAccumulator:
 
     Reference loop (prediction.py:52-64): for every (batch, member): move ALL weights host->device,
     forward, softmax twice, two D2H copies, CPU `+=`, move the weights back. Here: members stay in
-    HBM, the S logit blocks of a batch land in one [S, B, C] slab and ONE launch of
-    `ursa_bma_accumulate_f32` folds them into device accumulators; the host sees the result once,
+    HBM, the logits of all S members for the whole test set land in one [S, N, C] slab and ONE launch
+    of `ursa_bma_accumulate_f32` folds them into device accumulators; the host sees the result once,
     after an optional all-reduce across ranks (one process per GPU, members sharded over ranks).
     """
 
