@@ -637,10 +637,8 @@ def run_c4(a, job, legs, line):
         t0 = time.perf_counter()
         if rank == 0:
             s.run_trajectory()
-        if job.use_dist:
-            dist.broadcast(s._mean, 0)
-            dist.broadcast(s._sq, 0)
-            s.adopt_moments()
+        from ursabench_amd.distributed import share_swag_moments
+        share_swag_moments(s, src=0)
         job.barrier()
         line['trajectory_seconds'] = round(time.perf_counter() - t0, 2)
         line['trajectory_engine'] = dict(s.engine.stats)

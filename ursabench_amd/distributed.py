@@ -39,3 +39,18 @@ def shard(items, rank, world):
 def chain_seed(base_seed, rank):
     """Chain c uses seed base + c, mirroring URSABench/experiment.py:169-170 (set_random_seed(s) per trial)."""
     return int(base_seed) + int(rank)
+
+
+def share_swag_moments(sampler, src=0, group=None):
+    """BASELINE configs[3] on N GPUs: rank `src` ran the SWAG trajectory (`sampler.run_trajectory()`); every other
+    rank receives the two moment vectors (2 x 4 B x n_pad: 2 x 146 MB for WideResNet-28-10) and the collected
+    count with RCCL broadcasts over xGMI and marks them final, so each rank can draw its own share of members.
+    A no-op without a process group."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    dist.broadcast(sampler._mean, src, group=group)
+    dist.broadcast(sampler._sq, src, group=group)
+    count = sampler.num_models_collected.to(sampler._mean.device)
+    dist.broadcast(count, src, group=group)
+    sampler.num_models_collected = count.cpu()
+    sampler.adopt_moments()
