@@ -42,3 +42,30 @@ def test_time_script_json(tmp_path):
     h = time_script.prepare('cSGHMC', time_script.DEFAULTS['cSGHMC'], 3)
     assert h['burn_in_epochs'] == 0 and h['num_cycles'] == 1 and h['num_samples_per_cycle'] == 3
     assert time_script.prepare('MCdropout', dict(time_script.DEFAULTS['MCdropout'], epochs=7), 3)['epochs'] == 0   # time_script.py:96-97
+
+
+def test_experiment_accepts_the_reference_flags(tmp_path, monkeypatch):
+    """--use_val / --validation / --split_classes / --use_dm_imbalance of URSABench/experiment.py:27-31: the
+    validation path appends the hyper-optimisation row to ./results.csv and runs the trials without OOD sets; the
+    imbalance path retrains per seed on the thinned training set (classes 3 and 7 of MNIST cut by 99 %)."""
+    from ursabench_amd import datasets
+    monkeypatch.chdir(tmp_path)
+    hyp = {'lr': 0.05, 'prior_std': 1.0, 'num_samples': 2, 'alpha': 1.0, 'burn_in_epochs': 0}
+    base = ['--dataset', 'MNIST', '--model', 'MLP200MNIST', '--inference_method', 'SGLD', '--hyperparams', json.dumps(hyp),
+            '--save_path', str(tmp_path) + '/out_', '--num_trials', '2', '--batch_size', '32', '--train_size', '200',
+            '--test_size', '48', '--data_path', 'ignored', '--num_workers', '4']
+    args = experiment.build_parser().parse_args(base + ['--use_val', '--validation', '0.25', '--split_classes', '0'])
+    res = experiment.run(args, device=torch.device('cpu'), kernels=OracleKernels())
+    assert not any('auroc_FashionMNIST' in k for k in res) and 'nll_mean' in res and 'cost_mean' in res
+    hrow = next(csv.reader(open(tmp_path / 'results.csv')))
+    assert hrow[:6] == ['MNIST', 'MLP200MNIST', '1', 'SGLD', 'Prediction', '32'] and len(hrow) == 6 + len(hyp) + 11
+    args = experiment.build_parser().parse_args(base + ['--use_dm_imbalance'])
+    res = experiment.run(args, device=torch.device('cpu'), kernels=OracleKernels())
+    assert 'cost_mean' in res and torch.isfinite(res['cost_mean'])
+    l, _ = datasets.loaders('MNIST', batch_size=32, device='cpu', train_size=2000, test_size=10, imbalance=True)
+    y = l['train'].dataset.y
+    full, _ = datasets.loaders('MNIST', batch_size=32, device='cpu', train_size=2000, test_size=10)
+    yf = full['train'].dataset.y
+    for c in range(10):
+        n, nf = int((y == c).sum()), int((yf == c).sum())
+        assert n == (int(nf - 0.99 * nf) if c in (3, 7) else nf)

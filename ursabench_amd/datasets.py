@@ -21,6 +21,19 @@ def _named_dataset_cls(name):
     return type(name, (TensorSet,), {})
 
 
+# classes thinned for the imbalanced decision-making task and the fraction removed (datasets.py:173-195)
+IMBALANCE = {'MNIST': ([3, 7], 0.99), 'CIFAR10': ([0, 1, 8, 9], 0.9), 'CIFAR100': ([58, 69, 85], 0.9)}
+
+
+def increase_data_imbalance(label, x, y, remove_frac=0.9):
+    """util.py:356-377 (deterministic form): keep the first int(N - remove_frac*N) rows of class `label`."""
+    ind = torch.where(y == label)[0]
+    keep_n = int(len(ind) - remove_frac * len(ind))
+    drop = torch.zeros(len(y), dtype=torch.bool)
+    drop[ind[keep_n:]] = True
+    return x[~drop], y[~drop]
+
+
 def loaders(dataset, path=None, batch_size=128, num_workers=0, transform_train=None, transform_test=None,
             use_validation=False, val_size=0.2, split_classes=None, shuffle_train=True, imbalance=False,
             device='cuda', train_size=None, test_size=None, seed=0, **kwargs):
@@ -37,6 +50,11 @@ def loaders(dataset, path=None, batch_size=128, num_workers=0, transform_train=N
         if ood:
             x = x * 2.0 + 0.5
         y = torch.randint(0, classes, (n,), generator=g)
+        if split == 'train' and imbalance and dataset in IMBALANCE:
+            labels, frac = IMBALANCE[dataset]
+            for l in labels:
+                x, y = increase_data_imbalance(l, x, y, frac)
+            n = len(y)
         if split == 'train' and use_validation:
             n_val = int(n * val_size)
             out['train'] = DeviceLoader(x[:-n_val].to(device), y[:-n_val].to(device), batch_size, shuffle_train, s, cls)

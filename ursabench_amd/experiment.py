@@ -36,6 +36,11 @@ def build_parser():
     p.add_argument('--device_num', type=int, default=0)
     p.add_argument('--num_trials', type=int, default=5)
     p.add_argument('--pretrained_model_path', type=str, default=None)
+    p.add_argument('--split_classes', type=int, default=None)
+    p.add_argument('--validation', type=float, default=0.2, help='proportion of training used as validation')
+    p.add_argument('--use_val', dest='use_val', action='store_true', help='use a validation split instead of the test set')
+    p.add_argument('--use_dm_imbalance', dest='use_dm_imbalance', action='store_true',
+                   help='decision making on a model retrained on class-imbalanced data (experiment.py:218-247)')
     p.add_argument('--train_size', type=int, default=None, help='synthetic train-set size (default: the dataset\'s)')
     p.add_argument('--test_size', type=int, default=None)
     return p
@@ -54,19 +59,38 @@ def run(args, device=None, kernels=None):
         hyperparams = json.load(open(args.hyperparams_path))
     model_cfg = getattr(models, args.model)
     ds = dict(batch_size=args.batch_size, device=device, train_size=args.train_size, test_size=args.test_size)
-    loaders, num_classes = datasets.loaders(args.dataset, **ds)
+    loaders, num_classes = datasets.loaders(args.dataset, use_validation=getattr(args, 'use_val', False),
+                                            val_size=getattr(args, 'validation', 0.2),
+                                            split_classes=getattr(args, 'split_classes', None), **ds)
     train_loader, test_loader = loaders['train'], loaders['test']
     model = model_cfg.base(*model_cfg.args, num_classes=num_classes, **model_cfg.kwargs).to(device)
     if args.pretrained_model_path is not None:
         model.load_state_dict(torch.load(args.pretrained_model_path))
     inference_method = getattr(inference, args.inference_method)
     task_method = getattr(tasks, args.task)
-    if args.dataset not in OOD_SETS:
-        raise NotImplementedError
+    use_val, dm_imbalance = getattr(args, 'use_val', False), getattr(args, 'use_dm_imbalance', False)
+    os.makedirs(os.path.dirname(args.save_path) or '.', exist_ok=True)
+    if args.task == 'Prediction' and use_val:
+        # the hyper-optimisation row of experiment.py:84-109: Prediction metrics on the validation split, appended to
+        # `results.csv` in the WORKING directory (the reference's literal path). The reference reads an ensemble it
+        # never sampled there (NameError); here it is sampled first.
+        util.set_random_seed(args.seed)
+        sampler = inference_method(hyperparameters=hyperparams, model=model, train_loader=train_loader, device=device, **kw)
+        pred = task_method(dataloader={'in_distribution_test': test_loader}, num_classes=num_classes, device=device,
+                           metric_list='ALL', **kw)
+        pred.update_statistics(models=sampler.sample(), output_performance=False, smoothing=True)
+        perf = pred.get_performance_metrics()
+        with open('results.csv', 'a+') as f:
+            csv.writer(f, dialect='excel').writerow([args.dataset, args.model, args.seed, args.inference_method, args.task,
+                                                     args.batch_size, *[hyperparams[k] for k in sorted(hyperparams)],
+                                                     *[perf[k] for k in sorted(perf)]])
     ood_loaders = []
-    for name in OOD_SETS[args.dataset]:
-        l, _ = datasets.loaders(name, **ds)
-        ood_loaders.append({'data': name, 'in_distribution_test': test_loader, 'out_distribution_test': l['test']})
+    if not use_val:                                               # experiment.py:113-160
+        if args.dataset not in OOD_SETS:
+            raise NotImplementedError
+        for name in OOD_SETS[args.dataset]:
+            l, _ = datasets.loaders(name, **ds)
+            ood_loaders.append({'data': name, 'in_distribution_test': test_loader, 'out_distribution_test': l['test']})
 
     S = args.num_trials
     results, temp, costs = {}, {}, []
@@ -79,9 +103,10 @@ def run(args, device=None, kernels=None):
                            metric_list='ALL', **kw)
         pred.update_statistics(models=ensemble, output_performance=False, smoothing=True)
         perf = pred.get_performance_metrics()
-        dec = tasks.Decision(dataloader={'decision_data_test': test_loader}, num_classes=num_classes, device=device, **kw)
-        dec.update_statistics(models=ensemble, output_performance=False, smoothing=True)
-        costs.append(dec.get_performance_metrics()['True_Cost'])
+        if not dm_imbalance:
+            dec = tasks.Decision(dataloader={'decision_data_test': test_loader}, num_classes=num_classes, device=device, **kw)
+            dec.update_statistics(models=ensemble, output_performance=False, smoothing=True)
+            costs.append(dec.get_performance_metrics()['True_Cost'])
         for ood in ood_loaders:
             o = tasks.OODDetection(data_loader=ood, num_classes=num_classes, device=device, **kw)
             for key, val in o.update_statistics(ensemble, output_performance=True).items():
@@ -91,10 +116,18 @@ def run(args, device=None, kernels=None):
     for key, vals in temp.items():
         t = torch.tensor(vals).float()
         results[key + '_mean'], results[key + '_std'] = torch.mean(t), torch.std(t)
+    if dm_imbalance:
+        # experiment.py:218-247: per seed, retrain on the class-imbalanced training set and decide on its test set
+        for s in range(S):
+            util.set_random_seed(s)
+            l, _ = datasets.loaders(args.dataset, imbalance=True, **ds)
+            sampler = inference_method(hyperparameters=hyperparams, model=model, train_loader=l['train'], device=device, **kw)
+            dec = tasks.Decision(dataloader={'decision_data_test': l['test']}, num_classes=num_classes, device=device, **kw)
+            dec.update_statistics(models=sampler.sample(), output_performance=False, smoothing=True)
+            costs.append(dec.get_performance_metrics()['True_Cost'])
     results['cost_mean'] = torch.mean(torch.tensor(costs))
     results['cost_std'] = torch.std(torch.tensor(costs))
 
-    os.makedirs(os.path.dirname(args.save_path) or '.', exist_ok=True)
     row = [args.dataset, args.model, args.seed, args.inference_method, args.task, args.batch_size,
            *[hyperparams[k] for k in sorted(hyperparams)], *[results[k] for k in sorted(results)]]
     with open(args.save_path + 'results.csv', 'a+') as f:
