@@ -92,6 +92,10 @@ def main(argv=None):
     p.add_argument('--dataset', type=str, default='CIFAR10')
     p.add_argument('--model', type=str, required=True)
     p.add_argument('--seed', type=int, default=1)
+    p.add_argument('--data_path', type=str, default=None, help='ignored: data is synthetic (time_script.py:16)')
+    p.add_argument('--num_workers', type=int, default=0, help='ignored (time_script.py:18)')
+    p.add_argument('--validation', type=float, default=0.2, help='ignored (time_script.py:28)')
+    p.add_argument('--use_val', action='store_true', help='ignored (time_script.py:30)')
     p.add_argument('--hyperparams_path', type=str, default=None)
     p.add_argument('--batch_size', type=int, default=128)
     p.add_argument('--save_path', type=str, required=True)
