@@ -387,19 +387,13 @@ __global__ __launch_bounds__(kBlock) void k_swag_draw_s(float* __restrict__ out,
 // are xor-butterflies over the G lanes (ds_swizzle/dpp, no LDS round trip). The S members
 // are walked in order with the accumulators in registers: one read-modify-write of
 // proba_sum / ent_sum / risk_sum per row per launch.
-// exp(x) for x <= 0: 2^(x*log2e) on v_exp_f32 with the product's rounding error folded back in
-// (hi/lo split of log2 e): 1-2 ulp, 6 instructions instead of ocml expf's ~15.
-__device__ __forceinline__ float exp_nonpos(float x)
-{
-    // A masked class (logit -inf) must give exp = 0 like the reference's log_softmax().exp(); unclamped,
-    // t = -inf makes the compensation term inf - inf = NaN. exp(-150) is already 0 in fp32.
-    x = fmaxf(x, -150.0f);
-    const float t = x * 1.44269502162933349609375f;
-    float r = __builtin_fmaf(x, 1.44269502162933349609375f, -t);
-    r = __builtin_fmaf(x, 1.925963033500011e-08f, r);
-    const float e = __builtin_amdgcn_exp2f(t);
-    return __builtin_fmaf(e, r * 0.693147182464599609375f, e);
-}
+// Softmax arithmetic of K5 (both kernels): e^(x - max) = 2^(x log2e - max log2e) as ONE fma + v_exp_f32 per class.
+// The fma's rounding (half an ulp of |x - max| log2e <= ~2^-19 for gaps < 44) gives <= 7e-7 relative error in e —
+// the size of the error the reference's own log_softmax().exp() carries from rounding x - logsumexp(x) — against the
+// 1e-5 bar; the rounding of max*log2e is common to a row and cancels in e / sum. (This round first used a hi/lo
+// split of log2e that folded the product's error back in, 1-2 ulp, 6 instructions: at C = 100 the kernel is
+// VALU-bound and that cost 2 us of 30; measured worst case of the plain form over 8 members: 1.6e-6 on p, 2.5e-6
+// on the entropy.) 2^-inf = 0 exactly: a masked class (-inf logit) needs no special case.
 
 // Lane-group reductions on the VALU only (no LDS round trip, no s_waitcnt): xor butterflies inside
 // a quad (DPP quad_perm), then row_half_mirror / row_mirror inside a 16-lane row; across rows
@@ -460,6 +454,8 @@ __device__ __forceinline__ void lg_members(const float* __restrict__ z0, int64_t
                                            const float* __restrict__ cost, float (&acc_p)[EPL],
                                            float (&acc_r)[RISK ? EPL : 1], float& acc_e2)
 {
+    // Loads carry NO class masks: a lane whose classes lie beyond C reads (clamped address) logits that really exist,
+    // which cannot change the row maximum; the mask enters once, as the -inf bias of the exponent fma below.
     float xs[U][EPL];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -469,31 +465,33 @@ __device__ __forceinline__ void lg_members(const float* __restrict__ z0, int64_t
             for (int v4 = 0; v4 < EPL / 4; ++v4) {
                 const int c0 = 4 * (lane + v4 * G);         // C % 4 == 0: a float4 is all inside or all outside
                 const float4 v = *reinterpret_cast<const float4*>(z + (c0 < C ? c0 : C - 4));
-                const bool in = c0 < C;                     // unconditional load (clamped index): a guarded load
-                xs[u][4 * v4 + 0] = in ? v.x : -INFINITY;   // becomes a branch and serialises the batch
-                xs[u][4 * v4 + 1] = in ? v.y : -INFINITY;
-                xs[u][4 * v4 + 2] = in ? v.z : -INFINITY;
-                xs[u][4 * v4 + 3] = in ? v.w : -INFINITY;
+                xs[u][4 * v4 + 0] = v.x; xs[u][4 * v4 + 1] = v.y; xs[u][4 * v4 + 2] = v.z; xs[u][4 * v4 + 3] = v.w;
             }
         } else {
 #pragma unroll
             for (int e = 0; e < EPL; ++e) {
                 const int c = lane + e * G;
-                const float v = z[c < C ? c : C - 1];
-                xs[u][e] = (c < C) ? v : -INFINITY;
+                xs[u][e] = z[c < C ? c : C - 1];
             }
         }
     }
+    constexpr float kLog2e = 1.44269502162933349609375f;
+    // every class slot beyond C adds exactly q = gamma/C to the entropy sum: taken out analytically, per row and member
+    const float ent_fake = (float)(G * EPL - C) * (goc * __builtin_amdgcn_logf(goc));
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         float mx = xs[u][0];
 #pragma unroll
         for (int e = 1; e < EPL; ++e) mx = fmaxf(mx, xs[u][e]);
         mx = group_max<G>(mx);
+        // e^(x - max) = 2^(x log2e - max log2e): ONE fma per class; its bias is -inf for class slots beyond C (e = 0
+        // there). The rounding of max*log2e is common to the row and cancels in e / sum; a -inf logit gives 0.
+        const float nb = -(mx * kLog2e);
         float sum = 0.f;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
-            xs[u][e] = exp_nonpos(xs[u][e] - mx);           // classes beyond C hold -inf: exp = 0
+            const bool in = bma_class<G, V4>(lane, e) < C;  // per float4 in the V4 mapping
+            xs[u][e] = __builtin_amdgcn_exp2f(__builtin_fmaf(xs[u][e], kLog2e, in ? nb : -INFINITY));
             sum += xs[u][e];
         }
         const float inv = 1.0f / group_sum<G>(sum);
@@ -501,15 +499,13 @@ __device__ __forceinline__ void lg_members(const float* __restrict__ z0, int64_t
         float qv[RISK ? EPL : 1];
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
-            const int c = bma_class<G, V4>(lane, e);
             const float p = xs[u][e] * inv;
-            const float q = (c < C) ? __builtin_fmaf(p, omg, goc) : 0.f;
-            // q log2 q with the limit 0 at q = 0 (classes beyond C; gamma = 0): the floor leaves normal q untouched
-            ent2 = __builtin_fmaf(q, __builtin_amdgcn_logf(fmaxf(q, 1.17549435e-38f)), ent2);
-            acc_p[e] += smoothed ? q : p;
-            if (RISK) qv[e] = q;
+            const float q = __builtin_fmaf(p, omg, goc);    // goc > 0 (the launcher floors it): q > 0, log finite
+            ent2 = __builtin_fmaf(q, __builtin_amdgcn_logf(q), ent2);
+            acc_p[e] += smoothed ? q : p;                    // slots beyond C accumulate junk that is never stored
+            if (RISK) qv[e] = q;                             // ... and never read: sources are classes < C only
         }
-        if (want_ent) acc_e2 += group_sum<G>(ent2);
+        if (want_ent) acc_e2 += group_sum<G>(ent2) - ent_fake;
         if (RISK) {
             // risk[b, j] += sum_c ps[c] * cost[c, j]; ps[c] broadcast from its owner lane
             float r[RISK ? EPL : 1];
@@ -662,10 +658,12 @@ __device__ __forceinline__ void rl_member(const float* __restrict__ row, int C, 
     float mx = x[0];
 #pragma unroll
     for (int c = 1; c < CP; ++c) mx = fmaxf(mx, x[c]);
+    constexpr float kLog2e = 1.44269502162933349609375f;
+    const float nb = -(mx * kLog2e);                     // see lg_members: one fma per class, common rounding cancels
     float sum = 0.f;
 #pragma unroll
     for (int c = 0; c < CP; ++c) {
-        x[c] = exp_nonpos(x[c] - mx);                    // masked classes: exp(-inf) = 0
+        x[c] = __builtin_amdgcn_exp2f(__builtin_fmaf(x[c], kLog2e, nb));      // masked classes hold -inf: exp = 0
         sum += x[c];
     }
     const float inv = 1.0f / sum;
@@ -675,10 +673,10 @@ __device__ __forceinline__ void rl_member(const float* __restrict__ row, int C, 
 #pragma unroll
     for (int c = 0; c < CP; ++c) {
         const float p = x[c] * inv;
-        float q = __builtin_fmaf(p, omg, goc);
+        float q = __builtin_fmaf(p, omg, goc);           // goc > 0 (the launcher floors it): q > 0, log finite
+        const float ql = q * __builtin_amdgcn_logf(q);
+        ent2 += (EXACT || c < C) ? ql : 0.f;
         if (!EXACT) q = c < C ? q : 0.f;
-        // q log2 q with the limit 0 at q = 0 (gamma = 0 only): the floor leaves normal q untouched
-        ent2 = __builtin_fmaf(q, __builtin_amdgcn_logf(fmaxf(q, 1.17549435e-38f)), ent2);
         const float a = smoothed ? q : p;
         acc_p[c] = MASKED ? __builtin_fmaf(w, a, acc_p[c]) : acc_p[c] + a;
         if (RISK) qv[c] = q;
@@ -1093,6 +1091,9 @@ int ursa_bma_accumulate_f32(const float* logits, float* proba_sum, float* ent_su
     if (!aligned4(logits) || !aligned4(proba_sum) || !aligned4(ent_sum) || !aligned4(risk_sum) || !aligned4(cost))
         return URSA_EALIGN;
     hipStream_t st = (hipStream_t)stream;
+    // gamma = 0 (allowed): an underflowing probability must add 0 ln 0 = 0 to the entropy. With the smallest normal
+    // number in place of 0 every q is positive, log2 q is finite and q log2 q < 1e-35: no per-class guard in the kernels.
+    if (!(gamma_over_c > 0.0f)) gamma_over_c = 1.17549435e-38f;
     // Few classes and 16-byte aligned member tiles: the row-per-lane kernel (see k_bma_rowlane).
     const bool tiles_aligned = aligned16(logits) && ((B * (int64_t)C) % 4 == 0);
     // (11 <= C <= 15 with a cost matrix spills registers in the masked 16-class body: lane-group kernel instead)
