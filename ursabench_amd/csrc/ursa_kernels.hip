@@ -450,7 +450,7 @@ __device__ __forceinline__ int bma_class(int lane, int e) { return V4 ? 4 * (lan
 // entropy accumulated as sum q log2 q on v_log_f32 (ln 2 applied once per row at the end).
 template <int G, int EPL, bool RISK, bool V4, int U>
 __device__ __forceinline__ void lg_members(const float* __restrict__ z0, int64_t member_stride, int lane, int C,
-                                           float omg, float goc, bool smoothed, bool want_ent,
+                                           float omg, float goc, bool want_ent,
                                            const float* __restrict__ cost, float (&acc_p)[EPL],
                                            float (&acc_r)[RISK ? EPL : 1], float& acc_e2)
 {
@@ -487,11 +487,13 @@ __device__ __forceinline__ void lg_members(const float* __restrict__ z0, int64_t
         // e^(x - max) = 2^(x log2e - max log2e): ONE fma per class; its bias is -inf for class slots beyond C (e = 0
         // there). The rounding of max*log2e is common to the row and cancels in e / sum; a -inf logit gives 0.
         const float nb = -(mx * kLog2e);
+        float nbv[V4 ? EPL / 4 : EPL];                      // one bias per float4 (V4) or per class
+#pragma unroll
+        for (int k = 0; k < (V4 ? EPL / 4 : EPL); ++k) nbv[k] = bma_class<G, V4>(lane, V4 ? 4 * k : k) < C ? nb : -INFINITY;
         float sum = 0.f;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
-            const bool in = bma_class<G, V4>(lane, e) < C;  // per float4 in the V4 mapping
-            xs[u][e] = __builtin_amdgcn_exp2f(__builtin_fmaf(xs[u][e], kLog2e, in ? nb : -INFINITY));
+            xs[u][e] = __builtin_amdgcn_exp2f(__builtin_fmaf(xs[u][e], kLog2e, nbv[V4 ? e / 4 : e]));
             sum += xs[u][e];
         }
         const float inv = 1.0f / group_sum<G>(sum);
@@ -502,8 +504,8 @@ __device__ __forceinline__ void lg_members(const float* __restrict__ z0, int64_t
             const float p = xs[u][e] * inv;
             const float q = __builtin_fmaf(p, omg, goc);    // goc > 0 (the launcher floors it): q > 0, log finite
             ent2 = __builtin_fmaf(q, __builtin_amdgcn_logf(q), ent2);
-            acc_p[e] += smoothed ? q : p;                    // slots beyond C accumulate junk that is never stored
-            if (RISK) qv[e] = q;                             // ... and never read: sources are classes < C only
+            acc_p[e] += p;                                   // raw p always; smoothing of the SUM is applied once per row
+            if (RISK) qv[e] = q;                             // (slots beyond C: junk, never stored / never read)
         }
         if (want_ent) acc_e2 += group_sum<G>(ent2) - ent_fake;
         if (RISK) {
@@ -574,14 +576,19 @@ __global__ __launch_bounds__(kBlock) void k_bma_accumulate(const float* __restri
         int s0 = s_lo;
 #pragma unroll 1
         for (; s0 + U <= s_hi; s0 += U)
-            lg_members<G, EPL, RISK, V4, U>(zrow + s0 * BC, BC, lane, C, omg, goc, smoothed, ent_sum != nullptr, cost,
+            lg_members<G, EPL, RISK, V4, U>(zrow + s0 * BC, BC, lane, C, omg, goc, ent_sum != nullptr, cost,
                                             acc_p, acc_r, acc_e2);
         if (U > 1)
 #pragma unroll 1
             for (; s0 < s_hi; ++s0)
-                lg_members<G, EPL, RISK, V4, 1>(zrow + s0 * BC, BC, lane, C, omg, goc, smoothed, ent_sum != nullptr,
+                lg_members<G, EPL, RISK, V4, 1>(zrow + s0 * BC, BC, lane, C, omg, goc, ent_sum != nullptr,
                                                 cost, acc_p, acc_r, acc_e2);
         const float acc_e = -0.693147182464599609375f * acc_e2;
+        if (smoothed) {                                      // sum_s ((1-g) p_s + g/C) = (1-g) sum_s p_s + n g/C
+            const float ng = (float)(s_hi - s_lo) * goc;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) acc_p[e] = __builtin_fmaf(acc_p[e], omg, ng);
+        }
 
         if (wave > 0) {
 #pragma unroll
@@ -641,7 +648,7 @@ constexpr int kRlChunk = 4;      // rounds whose loads are in flight together
 // EXACT: C == CP (no class masks). MASKED: the slot may have no member in this round (last round only).
 template <int CP, bool EXACT, bool RISK, bool MASKED>
 __device__ __forceinline__ void rl_member(const float* __restrict__ row, int C, bool live, float omg, float goc,
-                                          bool smoothed, const float* __restrict__ cost, float (&acc_p)[CP],
+                                          const float* __restrict__ cost, float (&acc_p)[CP],
                                           float (&acc_r)[RISK ? CP : 1], float& acc_e2)
 {
     float x[CP];
@@ -677,8 +684,7 @@ __device__ __forceinline__ void rl_member(const float* __restrict__ row, int C, 
         const float ql = q * __builtin_amdgcn_logf(q);
         ent2 += (EXACT || c < C) ? ql : 0.f;
         if (!EXACT) q = c < C ? q : 0.f;
-        const float a = smoothed ? q : p;
-        acc_p[c] = MASKED ? __builtin_fmaf(w, a, acc_p[c]) : acc_p[c] + a;
+        acc_p[c] = MASKED ? __builtin_fmaf(w, p, acc_p[c]) : acc_p[c] + p;    // raw p; the SUM is smoothed once per slot
         if (RISK) qv[c] = q;
     }
     acc_e2 = MASKED ? __builtin_fmaf(w, ent2, acc_e2) : acc_e2 + ent2;
@@ -777,13 +783,18 @@ __global__ __launch_bounds__(512) void k_bma_rowlane(const float* __restrict__ l
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (j < base) rl_member<CP, EXACT, RISK, false>(row, C, true, omg, goc, smoothed, cost, acc_p, acc_r, acc_e2);
-            else rl_member<CP, EXACT, RISK, true>(row, C, tail_live, omg, goc, smoothed, cost, acc_p, acc_r, acc_e2);
+            if (j < base) rl_member<CP, EXACT, RISK, false>(row, C, true, omg, goc, cost, acc_p, acc_r, acc_e2);
+            else rl_member<CP, EXACT, RISK, true>(row, C, tail_live, omg, goc, cost, acc_p, acc_r, acc_e2);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();             // the next round's stage writes must not pass these reads
         }
     }
 
+    if (smoothed) {                                      // sum_s ((1-g) p_s + g/C) = (1-g) sum_s p_s + n g/C
+        const float ng = (float)(base + (tail_live ? 1 : 0)) * goc;
+#pragma unroll
+        for (int c = 0; c < CP; ++c) acc_p[c] = __builtin_fmaf(acc_p[c], omg, ng);
+    }
     // partial sums -> LDS, then every thread folds whole outputs over the slots in slot order
     float* mine = part + slot * out_per_slot;
 #pragma unroll
