@@ -137,9 +137,11 @@ int ursa_swag_draw_f32(float* theta_out, const float* mean, const float* sq,
  * one_minus_gamma = float(1-gamma), gamma_over_c = float(gamma*1/C) from the host.
  * ent_sum may be NULL (Decision). 1 <= C <= URSA_BMA_MAX_CLASSES.
  * Results are within 1e-5 relative of that sequence, not bit-exact: members are summed in a fixed
- * but blocked order (partial sums per member slot, folded in slot order), e = exp(z - max) uses
- * v_exp_f32 with a compensated exponent, p = e / sum. A logit of -inf (masked class) gives p = 0;
- * with gamma_over_c = 0 a probability that underflows to 0 adds 0 (not NaN) to ent_sum.
+ * but blocked order (partial sums per member slot, folded in slot order), e = 2^(z log2e - max log2e)
+ * on v_exp_f32 (<= 7e-7 relative per exponential), p = e / sum, entropy through v_log_f32; measured
+ * worst case 2e-6 on proba_sum and 3.5e-6 on ent_sum (tools/exp/k5_accuracy.py). A logit of -inf
+ * (masked class) gives p = 0; with gamma_over_c = 0 a probability that underflows to 0 adds 0 (not
+ * NaN) to ent_sum. SMOOTHED sums are formed as (1-gamma) * sum_s p + S * gamma/C.
  * Fast paths need alignment, the generic kernel does not: C <= 16 with logits 16-byte aligned and
  * B*C % 4 == 0 (row-per-lane kernel, LDS-staged tiles); C % 4 == 0 with logits 16-byte aligned
  * (float4 class loads). Give the call the logits of as many rows as there are (e.g. the whole test
