@@ -39,7 +39,7 @@ for k in range(10):
 note('k_swag_collect', 'K2 WideResNet-28-10 moment update', 20 * n, elements=n)
 del th, g, m, out
 # K5 at the shapes the tasks feed it
-for (S, B, C) in ((50, 10000, 10), (20, 10000, 10), (30, 10000, 100)):
+for (S, B, C) in ((50, 10000, 10), (20, 9984, 10), (30, 10000, 100)):      # 9,984 rows: a grid of its own in the counter CSVs
     z = torch.randn(S, B, C, device='cuda') * 3
     p, e = torch.zeros(B, C, device='cuda'), torch.zeros(B, device='cuda')
     for _ in range(10):
