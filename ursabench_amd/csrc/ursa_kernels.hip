@@ -5,13 +5,12 @@
 // (zero bytes), wave64 shuffles for row reductions. MFMA is deliberately unused: nothing
 // here is GEMM-shaped.
 //
-// Launch shape of the streaming kernels (measured, tools/exp/k1_variants.hip, random data,
-// interleaved A/B in one process): ONE float4 per thread, 512-thread blocks, grid =
-// ceil(n4/512), no grid-stride loop. At 2^26 elements (805 MB of state) that runs the fused
-// update at 6.36 TB/s (6.61 with non-temporal accesses) against 4.76 TB/s for the textbook
-// "2048 blocks + grid-stride" shape: many short blocks keep every HBM channel busy and let
-// the dispatcher balance the 8 XCDs. Non-temporal loads/stores are used only when the state
-// exceeds the 256 MiB Infinity Cache (they cost 3-15 % on cache-resident state; nt_bytes()).
+// Launch shape of the streaming kernels (A/B in one process, tools/exp/k1_variants.hip, round 1): ONE float4 per
+// thread, 512-thread blocks, grid = ceil(n4/512), no grid-stride loop — a third faster at 2^26 elements than the
+// textbook "2048 blocks + grid-stride" shape: many short blocks keep every HBM channel busy and let the dispatcher
+// balance the 8 XCDs. What the shipped kernels reach is in profiles/r02_kbench.json (K1 at 2^26 elements: 210-231 us
+// = 5.8-6.4 TB/s across boxes). Non-temporal loads/stores are used only when the state exceeds the 256 MiB Infinity
+// Cache (they cost 3-15 % on cache-resident state; nt_bytes()).
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt
 // (the rounding sequence of each update is part of the contract, see the header).
