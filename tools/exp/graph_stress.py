@@ -2,7 +2,7 @@
 hipGraphs accumulate and old ones are destroyed?  python tools/exp/graph_stress.py            (runs every mode in a child)
                                               python tools/exp/graph_stress.py <mode> [iters]"""
 import gc, os, subprocess, sys, tempfile
-MODES = ["full", "full_fresh_streams", "tasks", "engine"]
+MODES = ["full", "full_fresh_streams", "tasks", "engine", "update_hyp_loop", "group_update_hyp_loop"]
 if len(sys.argv) == 1:
     for m in MODES:
         env = dict(os.environ, URSA_SIDE_STREAMS='fresh') if m == 'full_fresh_streams' else dict(os.environ)
@@ -44,6 +44,31 @@ if mode.startswith('tasks'):
             del m._ursa_bank
 if mode == 'full_gcdisabled':
     gc.disable()
+if mode.endswith('update_hyp_loop'):
+    # the reference's hyper-optimisation flow (hyper_optimization.py:51-73): ONE sampler and ONE task object,
+    # update_hyp -> reset -> sample -> update_statistics per trial; every trial re-captures the step graph
+    import random
+    util.set_random_seed(0)
+    if mode.startswith('group'):
+        chains = [inference.SGHMC(dict(hyp), models.PreResNet(10, 8).to(dev), train, device=dev, seed=c) for c in range(3)]
+        group = inference.ChainGroup(chains)
+    else:
+        s = inference.SGHMC(dict(hyp), models.PreResNet(10, 8).to(dev), train, device=dev)
+    p = tasks.Prediction({'in_distribution_test': test}, 10, dev, ['nll'])
+    for it in range(iters):
+        h = dict(hyp, lr=random.uniform(0.01, 0.1), alpha=random.uniform(0.1, 0.9))
+        if mode.startswith('group'):
+            for c in chains:
+                c.update_hyp(dict(h))
+            ens = [m for ch in group.sample() for m in ch]
+        else:
+            s.update_hyp(dict(h))
+            ens = s.sample()
+        p.reset()
+        v = p.update_statistics(ens, output_performance=True)
+        torch.cuda.synchronize()
+        print('it', it, 'ok nll %.4f' % v, 'alloc MB', torch.cuda.memory_allocated() >> 20, flush=True)
+    sys.exit(0)
 for it in range(iters):
     if mode == 'full_del_first' and it:
         torch.cuda.synchronize()
