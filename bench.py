@@ -77,7 +77,7 @@ def parse(argv=None):
     ap.add_argument('--c5-batch', type=int, default=256, help='c5: full-batch size N of the HMC potential')
     ap.add_argument('--c5-chains', type=int, default=4)
     ap.add_argument('--c5-L', type=int, default=3)
-    ap.add_argument('--dry-run-cpu', action='store_true', help='toy-size CPU walk of the c2 control flow (tests only; not a measurement)')
+    ap.add_argument('--dry-run-cpu', action='store_true', help='toy-size CPU walk of the c2 / c4 control flow (tests only; not a measurement)')
     ap.add_argument('--inject-failure', default='', help='(tests) raise inside the named leg')
     a = ap.parse_args(argv)
     if a.steps is None:
@@ -621,15 +621,21 @@ def run_c4(a, job, legs, line):
     dev, rank, world = job.dev, job.rank, job.world
     C = 100
     line['metric'] = 'SWAG members/sec (draw + bn_update + snapshot) and bma_preds_per_s, WideResNet-28-10 / CIFAR-100-shaped'
+    n_train, n_test, batch, depth, widen, kw = a.c4_train, N_TEST, BATCH, 28, 10, {}
+    if job.cpu:                                                  # --dry-run-cpu: control flow only (tests)
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        from oracle_kernels import OracleKernels
+        n_train, n_test, batch, depth, widen, kw = 64, 48, 32, 10, 1, dict(kernels=OracleKernels(), use_graph=False)
     util.set_random_seed(0)
-    train = synthetic(a.c4_train, (3, 32, 32), C, seed=0, device=dev, batch_size=BATCH)
-    test = synthetic(N_TEST, (3, 32, 32), C, seed=1, device=dev, batch_size=BATCH)
+    train = synthetic(n_train, (3, 32, 32), C, seed=0, device=dev, batch_size=batch)
+    test = synthetic(n_test, (3, 32, 32), C, seed=1, device=dev, batch_size=batch)
     # hyperparams/WideResNet28x10CIFAR100/swag_hyperparams.json's keys; epochs cut to --c4-epochs
     hyp = {'swag_lr': 0.01, 'swag_wd': 3e-4, 'lr_init': 0.1, 'num_samples': a.steps + a.warmup, 'momentum': 0.9,
            'burn_in_epochs': 1, 'num_iterates': max(1, a.c4_epochs - 1)}
-    net = models.WideResNet(C, 28, 10).to(dev)
-    s = inference.SWAG(hyp, net, train, device=dev, reference_quirks=False, seed=1000 + rank)
-    line['config'].update({'params': s.num_parameters, 'n_train': a.c4_train, 'n_test': N_TEST, 'batch': BATCH, 'hyper': hyp,
+    net = models.WideResNet(C, depth, widen).to(dev)
+    s = inference.SWAG(hyp, net, train, device=dev, reference_quirks=False, seed=1000 + rank, **kw)
+    N_TEST_ = n_test
+    line['config'].update({'params': s.num_parameters, 'n_train': n_train, 'n_test': n_test, 'batch': batch, 'hyper': hyp,
                            'members_per_rank': a.steps + a.warmup, 'members': world * (a.steps + a.warmup),
                            'sharding': 'rank 0 trains, moments broadcast; members sharded over ranks; one all-reduce of [N*C + N]'})
 
@@ -655,13 +661,13 @@ def run_c4(a, job, legs, line):
     legs.run('members', members)
 
     def bma():
-        pred = tasks.Prediction({'in_distribution_test': test}, C, dev, 'ALL')
+        pred = tasks.Prediction({'in_distribution_test': test}, C, dev, 'ALL', **({'kernels': kw['kernels']} if kw else {}))
         pred.update_statistics(ensemble[:1], output_performance=False)
         pred.reset()
         _, dt = job.timed(lambda: pred.update_statistics(ensemble, output_performance=False))
         m = pred.get_performance_metrics()
-        line.update({'bma_preds_per_s': round(N_TEST / dt, 1), 'bma_members': pred.num_samples_collected, 'bma_seconds': round(dt, 2),
-                     'bma_member_forwards_per_s': round(pred.num_samples_collected * N_TEST / dt, 1),
+        line.update({'bma_preds_per_s': round(N_TEST_ / dt, 1), 'bma_members': pred.num_samples_collected, 'bma_seconds': round(dt, 2),
+                     'bma_member_forwards_per_s': round(pred.num_samples_collected * N_TEST_ / dt, 1),
                      'bma_nll': round(float(m['nll']), 5), 'bma_engine': dict(pred._acc.stats)})
     if ensemble:
         legs.run('bma', bma)
@@ -677,7 +683,7 @@ def run_c4(a, job, legs, line):
                             'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBPS, 4), 'traffic': pmc_traffic('swag_draw', n),
                             'bytes_per_launch': 12 * n, 'us_per_launch': round(ms * 1e3, 2)}
         line['roofline_bma_kernel'] = bma_kernel_block(len(ensemble) or 30, N_TEST, C)
-    if rank == 0:
+    if rank == 0 and not job.cpu:
         legs.run('roofline', roofline)
 
 

@@ -59,3 +59,13 @@ def test_a_failing_leg_keeps_the_line(leg):
         assert line['value'] > 0 and line['ms_per_step'] > 0 and 'bma_preds_per_s' not in line
     else:
         assert line['value'] is None
+
+
+def test_dry_run_c4_world_size_2_gloo():
+    """BASELINE configs[3]'s N > 1 flow: rank 0 runs the SWAG trajectory, the moments are broadcast, every rank draws
+    its own members and evaluates them, one all-reduce; toy WideResNet on CPU tensors."""
+    rc, line = run_bench(['--dry-run-cpu', '--config', 'c4', '--gpus', '2', '--steps', '2', '--warmup', '1', '--c4-epochs', '2'], world=2)
+    assert rc == 0 and line['errors'] == {}, line['errors']
+    assert line['n_gpus'] == 2 and line['config']['members'] == 6 and line['bma_members'] == 6
+    assert line['unit'] == 'SWAG members/s' and line['value'] > 0 and 'NOT a measurement' in line['data']
+    assert line['value'] == pytest.approx(2 * 2 / (line['ms_per_step'] * 2 / 1e3), rel=1e-3)
