@@ -614,7 +614,8 @@ def run_c4(a, job, legs, line):
     BMA. Rank 0 runs the SGD trajectory (`--c4-epochs` epochs over the full 50,000 images; the draw/eval cost
     does not depend on the moments' values) and broadcasts the two moment vectors (2 x 146 MB, RCCL); then a
     "step" is one member: K3 draw (one launch, 438 MB) + the reference's full bn_update pass (391 train-mode
-    batches, util.py:212-247) + device snapshot; members are sharded over ranks (weak scaling: `--steps`
+    batches, util.py:212-247) + device snapshot — `SWAG.sample()` forms 4 members per pass over the training set (their
+    refresh forwards run concurrently on 4 streams; each member is bit-identical to one formed alone); members are sharded over ranks (weak scaling: `--steps`
     members per rank), every rank evaluates its members on the 10,000-row test set, one all-reduce."""
     from ursabench_amd import inference, models, tasks, util
     from ursabench_amd.data import synthetic
@@ -653,9 +654,9 @@ def run_c4(a, job, legs, line):
     ensemble = []
 
     def members():
-        for _ in range(a.warmup):
-            ensemble.append(s.sample_iterative())
-        ens, dt = job.timed(lambda: [s.sample_iterative() for _ in range(a.steps)])
+        if a.warmup:
+            ensemble.extend(s.sample(num_samples=a.warmup))
+        ens, dt = job.timed(lambda: s.sample(num_samples=a.steps))      # SWAG.sample: LANES members per pass over the training set
         ensemble.extend(ens)
         line.update({'value': round(world * a.steps / dt, 4), 'unit': 'SWAG members/s', 'ms_per_step': round(1e3 * dt / a.steps, 2)})
     legs.run('members', members)

@@ -92,3 +92,27 @@ def test_swag_corrected_mode_is_a_real_diagonal_gaussian():
         s.sample_iterative(full_cov=True)
     s.update_hyp(dict(hyp))
     assert s.num_models_collected.item() == 0 and not s._mean.any() and s.burnt_in is False
+
+
+def test_grouped_sampling_equals_one_member_at_a_time():
+    """SWAG.sample() forms LANES members per pass over the training set (draws into scratch models, one shared
+    BatchNorm refresh pass); every member — parameters, BN statistics, step counters — and the final state of
+    swag_model are what sample_iterative() produces one at a time."""
+    hyp = {'swag_lr': 0.01, 'swag_wd': 1e-4, 'lr_init': 0.05, 'num_samples': 6, 'momentum': 0.9,
+           'burn_in_epochs': 1, 'num_iterates': 2}
+
+    def run(lanes):
+        torch.manual_seed(0)
+        s = inference.SWAG(dict(hyp), bn_net(), bn_loader(), kernels=OracleKernels(), use_graph=False,
+                           reference_quirks=False, seed=11)
+        s.LANES = lanes
+        return s, s.sample()
+    s1, one = run(1)
+    s4, grp = run(4)                                      # groups of 4 + 2
+    assert len(one) == len(grp) == 6
+    for a, b in zip(one, grp):
+        for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+            assert ka == kb and torch.equal(va, vb), ka
+    for (ka, va), (kb, vb) in zip(s1.swag_model.state_dict().items(), s4.swag_model.state_dict().items()):
+        assert torch.equal(va, vb), ka
+    assert s1._draws == s4._draws == 6

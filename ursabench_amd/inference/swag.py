@@ -24,7 +24,8 @@ from copy import deepcopy
 import torch
 
 from ..arena import FlatArena, MemberBank
-from ..util import adjust_learning_rate, bn_update, get_loss_criterion, reset_model
+from .._capture import side_streams
+from ..util import adjust_learning_rate, bn_update, bn_update_many, get_loss_criterion, reset_model
 from .engine import ChainEngine
 from .flat_sgd import FlatSGD
 from .inference_base import _Inference
@@ -232,8 +233,67 @@ class SWAG(SWA):
             bn_update(self.train_loader, self.swag_model, device=self.device)
         return self.bank.snapshot(self.swag_model)
 
+    LANES = 4      # members whose BatchNorm refresh passes run concurrently in sample()
+
+    def _lanes(self, n):
+        """Scratch copies of swag_model (own flat arenas) for concurrent draw + bn_update of several members."""
+        lanes = getattr(self, '_lane_models', None)
+        if lanes is None:
+            lanes = self._lane_models = [(self.swag_model, self.swag_arena)]
+        while len(lanes) < n:
+            m = deepcopy(self.swag_model)
+            lanes.append((m, FlatArena(m.parameters(), module=m)))
+        return lanes[:n]
+
+    def _sample_group(self, k):
+        """k members at once: k draws (K3) into k scratch models, ONE pass over the training set refreshing the
+        BatchNorm statistics of all k on k streams, k device snapshots. Each member is, bit for bit, what
+        sample_iterative() returns for the same draw index."""
+        lanes = self._lanes(k)
+        lanes = lanes[1:] + lanes[:1]        # the group's LAST member is formed in swag_model itself, where the reference leaves it
+        for model, arena in lanes:
+            if self.reference_quirks:
+                arena.theta.copy_(self._mean)                     # swag.py:98 — the draw is discarded
+            else:
+                eps = None if self.eps_provider is None else self.eps_provider(self._draws)
+                self.kernels.swag_draw(arena.theta, self._mean, self._sq, var_clamp=self.var_clamp, scale=1.0,
+                                       seed=self.seed, draw=self._draws, eps=eps)
+            self._draws += 1
+        on_hip = torch.device(self.device).type == 'cuda'
+        main = self.swag_arena
+        before = [b.clone() for _, b in main.ibufs]               # BatchNorm step counters of THE swag_model
+        bn_update_many(self.train_loader, [m for m, _ in lanes], device=self.device,
+                       streams=side_streams(self.device, k) if on_hip and k > 1 else None)
+        # The reference refreshes one and the same swag_model for every sample, so its num_batches_tracked keeps
+        # counting across samples (reset_bn leaves it alone, util.py:195-199): member j of this group carries
+        # counter_before + (j + 1) * forwards, and the swag_model ends at counter_before + k * forwards.
+        done = [b - b0 for (_, b), b0 in zip(main.ibufs, before)]  # forwards of one refresh pass, per counter
+        out = []
+        for j, (model, arena) in enumerate(lanes):
+            row, irow = self.bank.new_row()
+            with torch.no_grad():
+                self.bank.theta_of(row).copy_(arena.theta)
+                if arena.fbuf is not None and arena.fbuf.numel():
+                    row[arena.layout.padded:].copy_(arena.fbuf)
+                for dst, b0, d in zip(irow, before, done):
+                    dst.copy_(b0 + (j + 1) * d)
+            out.append(self.bank.materialise(row, irow, self.swag_model))
+        with torch.no_grad():
+            for (_, b), b0, d in zip(main.ibufs, before, done):
+                b.copy_(b0 + k * d)
+        return out
+
     def sample(self, num_samples=None, val_loader=None, debug_val_loss=False, wandb_debug=False, full_cov=False):
         if num_samples is None:
             num_samples = self.num_samples
-        return [self.sample_iterative(update_bn=True, val_loader=val_loader, debug_val_loss=debug_val_loss,
-                                      wandb_debug=wandb_debug, full_cov=full_cov) for _ in range(num_samples)]
+        if full_cov:
+            raise NotImplementedError('full_cov needs the covariance subspace, outside the hot path')
+        if self.LANES <= 1 or num_samples <= 1:
+            return [self.sample_iterative(update_bn=True, val_loader=val_loader, debug_val_loss=debug_val_loss,
+                                          wandb_debug=wandb_debug, full_cov=full_cov) for _ in range(num_samples)]
+        if self.burnt_in is False:
+            self.run_trajectory(val_loader, debug_val_loss, wandb_debug)
+        out = []
+        while len(out) < num_samples:
+            out.extend(self._sample_group(min(self.LANES, num_samples - len(out))))
+        return out

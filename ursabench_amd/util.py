@@ -123,36 +123,62 @@ def bn_update(loader, model, subset=None, device=None, **kwargs):
     the cumulative-average momentum b/(n+b). The reference hard-codes input.cuda() (:236); here
     the batch goes to the model's own device. Statistics are reset IN PLACE (the reference
     re-assigns the buffers, :198-199) so member-bank views stay valid."""
-    bns = [m for m in model.modules() if isinstance(m, _BatchNorm)]
-    if not bns:
+    bn_update_many(loader, [model], subset=subset, device=device, **kwargs)
+
+
+def bn_update_many(loader, models, subset=None, device=None, streams=None, **kwargs):
+    """bn_update for several independent models in ONE pass over the loader: every batch is pushed through each
+    model, each on its own stream when `streams` is given (the forwards of different SWAG members share nothing, and
+    a 128-row WideResNet-28-10 forward leaves a quarter of the GPU idle). Per model the operations, their order and
+    their arguments are exactly bn_update's, so the statistics are the same bits."""
+    groups = [[m for m in model.modules() if isinstance(m, _BatchNorm)] for model in models]
+    if not any(groups):
         return
     if device is None:
-        device = next(model.parameters()).device
-    was_training = model.training
-    model.train()
+        device = next(models[0].parameters()).device
+    was_training = [model.training for model in models]
     momenta = {}
-    for m in bns:
-        m.running_mean.zero_()
-        m.running_var.fill_(1)
-        momenta[m] = m.momentum
+    for model, bns in zip(models, groups):
+        model.train()
+        for m in bns:
+            m.running_mean.zero_()
+            m.running_var.fill_(1)
+            momenta[m] = m.momentum
     n = 0
     num_batches = len(loader)
-    counters = deferred_bn_counters(model, forwards=0)      # bumped once at the end by the number of forwards done
-    with torch.no_grad(), counters:
-        it = iter(loader)
-        if subset is not None:
-            num_batches = int(num_batches * subset)
-        for bi, (x, _) in enumerate(it):
-            if subset is not None and bi >= num_batches:
-                break
-            x = x.to(device, non_blocking=True)
-            b = x.size(0)
-            mom = b / (n + b)
-            for m in bns:
-                m.momentum = mom
-            model(x, **kwargs)
-            n += b
-            counters.forwards += 1
-    for m in bns:
-        m.momentum = momenta[m]
-    model.train(was_training)
+    counters = [deferred_bn_counters(model, forwards=0) for model in models]   # bumped once, by the forwards done
+    cur = torch.cuda.current_stream(device) if streams else None
+    with torch.no_grad():
+        for c in counters:
+            c.__enter__()
+        try:
+            if subset is not None:
+                num_batches = int(num_batches * subset)
+            for bi, (x, _) in enumerate(iter(loader)):
+                if subset is not None and bi >= num_batches:
+                    break
+                x = x.to(device, non_blocking=True)
+                b = x.size(0)
+                mom = b / (n + b)
+                for k, (model, bns) in enumerate(zip(models, groups)):
+                    for m in bns:
+                        m.momentum = mom
+                    if streams:
+                        streams[k].wait_stream(cur)
+                        with torch.cuda.stream(streams[k]):
+                            model(x, **kwargs)
+                    else:
+                        model(x, **kwargs)
+                n += b
+                for c in counters:
+                    c.forwards += 1
+            if streams:
+                for st in streams[:len(models)]:
+                    cur.wait_stream(st)
+        finally:
+            for c in counters:
+                c.__exit__(None, None, None)
+    for model, bns, tr in zip(models, groups, was_training):
+        for m in bns:
+            m.momentum = momenta[m]
+        model.train(tr)
