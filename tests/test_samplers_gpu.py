@@ -386,3 +386,28 @@ def test_cyclic_samplers_end_to_end_vs_reference_on_gpu(golden_dir, name):
     s, ens, g = _cyclic_replay(golden_dir, name, DEV)
     for m, ref in zip(ens, g[f'{name}/samples']):
         np.testing.assert_allclose(flat_params(m).cpu().numpy(), ref, rtol=1e-4, atol=1e-5)
+
+
+def test_swag_grouped_sampling_on_gpu():
+    """SWAG.sample() refreshes the BatchNorm statistics of LANES members in one pass over the training set, their
+    forwards running on LANES side streams: members equal the ones formed one at a time."""
+    from ursabench_amd import util
+    hyp = {'swag_lr': 0.01, 'swag_wd': 1e-4, 'lr_init': 0.05, 'num_samples': 5, 'momentum': 0.9, 'burn_in_epochs': 1,
+           'num_iterates': 2}
+    train = synthetic(512, (3, 32, 32), 10, seed=0, device=DEV, batch_size=128)
+
+    def run(lanes):
+        util.set_random_seed(3)
+        s = inference.SWAG(dict(hyp), models.PreResNet(10, 8).to(DEV), train, device=DEV, reference_quirks=False, seed=5)
+        s.LANES = lanes
+        return s.sample()
+    one, grp = run(1), run(4)
+    assert len(one) == len(grp) == 5
+    for a, b in zip(one, grp):
+        # the two runs repeat the SGD trajectory (MIOpen's atomics make it reproducible only to rounding)
+        np.testing.assert_allclose(flat_params(a).cpu().numpy(), flat_params(b).cpu().numpy(), rtol=2e-3, atol=3e-4)
+        for (ka, va), (kb, vb) in zip(a.named_buffers(), b.named_buffers()):
+            assert ka == kb
+            np.testing.assert_allclose(va.float().cpu().numpy(), vb.float().cpu().numpy(), rtol=2e-3, atol=3e-4)
+    assert int(dict(grp[4].named_buffers())['bn.num_batches_tracked']) == int(dict(one[4].named_buffers())['bn.num_batches_tracked'])
+    assert not torch.equal(flat_params(grp[0]), flat_params(grp[1]))
