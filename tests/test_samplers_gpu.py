@@ -402,7 +402,7 @@ def test_swag_grouped_sampling_on_gpu():
     s.LANES = 1
     one = s.sample()
     s._draws = 0                                           # same Philox draw indices again
-    s.LANES = 4
+    s.LANES, s.GROUP_MIN_PARAMS = 4, 0
     grp = s.sample()                                       # a group of 4 and a group of 1
     assert len(one) == len(grp) == 5
     for a, b in zip(one, grp):

@@ -105,7 +105,7 @@ def test_grouped_sampling_equals_one_member_at_a_time():
         torch.manual_seed(0)
         s = inference.SWAG(dict(hyp), bn_net(), bn_loader(), kernels=OracleKernels(), use_graph=False,
                            reference_quirks=False, seed=11)
-        s.LANES = lanes
+        s.LANES, s.GROUP_MIN_PARAMS = lanes, 0
         return s, s.sample()
     s1, one = run(1)
     s4, grp = run(4)                                      # groups of 4 + 2
