@@ -168,15 +168,18 @@ def event_time_ms(fn, iters, stream, graph_batch=0):
 
 def pmc_traffic(kernel_key, elements):
     """HBM bytes per launch from PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc
-    passes, tools/pmc_collect.sh): PMC needs the profiler, so the figure is the committed measurement
-    under profiles/ for a launch of exactly this kernel and size, or None."""
+    passes, tools/pmc_run.sh): PMC needs the profiler, so the figure is the committed measurement
+    under profiles/ for a launch of this kernel at this size (within 0.1 %: arena padding; scaled by the
+    element ratio), or None."""
     for name in ('r02_pmc.json', 'r01_k1_pmc.json'):
         path = os.path.join(ROOT, 'profiles', name)
         if not os.path.exists(path):
             continue
         for k, v in json.load(open(path))['kernels'].items():
-            if v.get('elements') == elements and (kernel_key in k or name.startswith('r01')):
-                return v['hbm_bytes_per_launch_corrected']
+            n = v.get('elements')
+            if n and abs(n - elements) <= 1e-3 * elements and (kernel_key in k or name.startswith('r01')) \
+                    and 'hbm_bytes_per_launch_corrected' in v:
+                return int(round(v['hbm_bytes_per_launch_corrected'] * elements / n))
     return None
 
 
