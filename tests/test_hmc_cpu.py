@@ -77,3 +77,36 @@ def test_hmc_samples_a_gaussian_posterior():
     w = torch.stack([m.w.detach() for m in out])
     assert s.accepted >= 50
     assert abs(float(w.var()) - 0.25) < 0.03 and abs(float(w.mean())) < 0.02
+
+
+def test_wrapper_semantics_vs_reference(golden_dir):
+    """G14: the reference's HMC wrapper run around a stand-in hamiltorch (tools/gen_golden.py gen_hmc_wrapper): which
+    trajectory positions become members for each (num_samples, L, burn) — including burn = -1 (the last L positions
+    only) and burn = 0 (the initial position IS returned) —, how many, that they are independent modules, and the
+    arguments the wrapper derives (one tau per tensor, inv_mass = 1/mass, tau_out = 1, burn = -1 passed down,
+    the whole training set as one batch). hamiltorch's arithmetic itself stays unpinned."""
+    import json
+    import os
+    g = json.load(open(os.path.join(golden_dir, 'hmc_wrapper.json')))
+    call = g['call']
+    assert call['burn'] == -1 and call['tau_out'] == 1.0 and call['model_loss'] == 'multi_class_linear_output'
+    for case in g['cases']:
+        torch.manual_seed(1)
+        hyp = {'step_size': 1e-4, 'num_samples': case['num_samples'], 'L': case['L'], 'tau': 2.5, 'burn': case['burn'],
+               'mass': 4.0}
+        h = inference.HMC(dict(hyp), tiny_net(), tiny_loader(), kernels=OracleKernels(), use_graph=False, seed=3)
+        assert h._wanted_indices() == case['selected'], case
+        assert len(h.x) == call['x_rows'] and 1.0 / h.mass == call['inv_mass_unique'][0]
+        assert all(t == h.tau for t in call['tau_list'])
+        ens = h.sample()
+        assert len(ens) == case['n_members'] and h.accepted == case['num_samples']      # tiny step: every proposal accepted
+        assert case['independent'] and len({id(m) for m in ens}) == len(ens) and all(m is not h.model for m in ens)
+        ptrs = {m._ursa_row.data_ptr() for m in ens}
+        assert len(ptrs) == len(ens)
+        if 0 in case['selected']:                     # burn = 0: the first member is the initial position itself
+            assert torch.equal(torch.cat([p.detach().reshape(-1) for p in ens[0].parameters()]), theta0_of(hyp))
+
+
+def theta0_of(hyp):
+    torch.manual_seed(1)
+    return torch.cat([p.detach().reshape(-1) for p in tiny_net().parameters()])

@@ -464,6 +464,50 @@ def gen_sgd_sampler():
     print('G13 sgd_sampler lr after', float(out['lr_after']), float(out['lr_after2']))
 
 
+def gen_hmc_wrapper():
+    """G14: the reference's HMC WRAPPER (inference/hmc.py:62-85 + util.convert_sample_to_net) around a stand-in
+    hamiltorch: `sample_model` is replaced by a function that records its keyword arguments and returns a marked
+    trajectory (position k is params_init + k), so the fixture pins what the wrapper — not hamiltorch — decides:
+    the arguments it derives from the hyper-parameters, which trajectory positions become ensemble members for
+    each (num_samples, L, burn), and that members are independent copies. hamiltorch's arithmetic stays unpinned."""
+    import hamiltorch
+    calls = []
+
+    def flatten(model):
+        return torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+
+    def unflatten(model, flat):
+        out, off = [], 0
+        for p in model.parameters():
+            out.append(flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        return out
+
+    def sample_model(model, x, y, params_init=None, model_loss=None, num_samples=None, burn=None, inv_mass=None,
+                     step_size=None, num_steps_per_sample=None, tau_out=None, tau_list=None, debug=None):
+        calls.append(dict(model_loss=model_loss, num_samples=num_samples, burn=burn, step_size=step_size,
+                          num_steps_per_sample=num_steps_per_sample, tau_out=tau_out, tau_list=tau_list.tolist(),
+                          inv_mass_unique=sorted(set(inv_mass.tolist())), x_rows=len(x), n_params=len(params_init)))
+        return [params_init + float(k) for k in range(num_steps_per_sample * num_samples + 1)]
+    hamiltorch.util.flatten, hamiltorch.util.unflatten, hamiltorch.sample_model = flatten, unflatten, sample_model
+    out = {'cases': []}
+    for num_samples, L, burn in ((4, 1, -1), (4, 1, 0), (4, 3, 0), (5, 2, 1), (6, 3, 2), (3, 4, -1), (2, 5, 0), (7, 1, 3)):
+        util.set_random_seed(1)
+        net = tiny_net()
+        theta0 = flat(net.parameters())
+        s = inference.HMC({'step_size': 0.01, 'num_samples': num_samples, 'L': L, 'tau': 2.5, 'burn': burn, 'mass': 4.0},
+                          net, tiny_loader())
+        with quiet():
+            ens = s.sample()
+        idx = [int(round(float(flat(m.parameters())[0] - theta0[0]))) for m in ens]
+        independent = all(a is not b for a in ens for b in ens if a is not b) and all(m is not net for m in ens)
+        out['cases'].append(dict(num_samples=num_samples, L=L, burn=burn, selected=idx, n_members=len(ens),
+                                 independent=bool(independent)))
+    out['call'] = calls[0]
+    json.dump(out, open(os.path.join(OUT, 'hmc_wrapper.json'), 'w'), indent=1)
+    print('G14 hmc_wrapper', [(c['num_samples'], c['L'], c['burn'], c['selected']) for c in out['cases']][:4], out['call'])
+
+
 def gen_mcdropout():
     """G10: the reference's MCdropout (vi_dropout.py) on its own MLP -> MLP_dropout swap: per-minibatch OneCycleLR
     (lr, momentum) pairs, parameters after each sample_iterative, then update_hyp (CosineAnnealingLR per minibatch)
@@ -574,8 +618,8 @@ def gen_model_keys():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['k1', 'sgd', 'sched', 'csghmc', 'tasks', 'swag', 'swag_e2e', 'e2e', 'e2e_preresnet', 'mcdropout', 'columns', 'cyclic', 'sgd_sampler', 'keys']
+    which = sys.argv[1:] or ['k1', 'sgd', 'sched', 'csghmc', 'tasks', 'swag', 'swag_e2e', 'e2e', 'e2e_preresnet', 'mcdropout', 'columns', 'cyclic', 'sgd_sampler', 'hmc_wrapper', 'keys']
     fns = dict(k1=gen_k1, sgd=gen_sgd, swag_e2e=gen_swag_e2e, e2e_preresnet=gen_e2e_preresnet, sched=gen_schedules, csghmc=gen_csghmc, tasks=gen_tasks, swag=gen_swag, e2e=gen_e2e,
-               keys=gen_model_keys, mcdropout=gen_mcdropout, columns=gen_experiment_columns, cyclic=gen_e2e_cyclic, sgd_sampler=gen_sgd_sampler)
+               keys=gen_model_keys, mcdropout=gen_mcdropout, columns=gen_experiment_columns, cyclic=gen_e2e_cyclic, sgd_sampler=gen_sgd_sampler, hmc_wrapper=gen_hmc_wrapper)
     for w in which:
         fns[w]()

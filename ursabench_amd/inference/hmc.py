@@ -118,13 +118,18 @@ class HMC(_Inference):
                               kinetic_out=self._acc, ws=self._ws)
         return self._acc[0].clone()
 
+    def _wanted_indices(self):
+        """Trajectory positions (0 = the initial one, then L per proposal) that hmc.py:77-82 turns into ensemble
+        members: `samples[burn*L::L]` of the L*num_samples+1 positions hamiltorch returns (pinned against the
+        reference's wrapper by tests/golden/hmc_wrapper.json)."""
+        return list(range(self.L * self.num_samples + 1)[self.burn * self.L::self.L])
+
     def sample(self, debug=False):
         if not isinstance(self.model, torch.nn.Module):
             raise NotImplementedError
         self._bind()
         a, K, L, eps, inv_mass = self.arena, self.kernels, self.L, self.step_size, 1.0 / self.mass
-        total = L * self.num_samples + 1
-        wanted = set(range(total)[self.burn * L::L])                    # what hmc.py:80 will select
+        wanted = set(self._wanted_indices())                            # what hmc.py:80 will select
         kept = {}
 
         def keep(idx):
