@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define URSA_ABI_VERSION 1
+#define URSA_ABI_VERSION 2
 
 typedef void* ursa_stream_t; /* hipStream_t */
 
@@ -68,7 +68,7 @@ typedef void* ursa_stream_t; /* hipStream_t */
  *     theta = fmaf(-lr, b, theta)
  */
 #define URSA_STEP_SGD       0x10u
-#define URSA_STEP_ALLFLAGS  0x1Fu
+#define URSA_STEP_ALLFLAGS  0x1Fu   /* flags of the scalar-argument launch */
 
 int ursa_sgmcmc_step_f32(float* theta, float* grad, float* mom /* NULL iff mu == 0 */,
                          const float* eps /* NULL => Philox */, float* snapshot /* or NULL */,
@@ -78,24 +78,45 @@ int ursa_sgmcmc_step_f32(float* theta, float* grad, float* mom /* NULL iff mu ==
 
 /* Same update with the per-step scalars read from a DEVICE control block, so the launch
  * can sit inside a captured hipGraph and be replayed while lr / step / flags change.
- * ursa_step_ctl_advance (1 thread) does step += 1, clears FIRST, and if `sched` != NULL
- * loads (lr, c_noise) = sched[(step - sched_base) % sched_len] — the per-iteration cyclical
+ *
+ * Advancing a block = step += 1, clear FIRST, and if `sched` != NULL load
+ * (lr, c_noise) = sched[(step - sched_base) % sched_len] — the per-iteration cyclical
  * schedule of csghmc.py:64-72 precomputed by the host in float64 and rounded once; the host
  * sets sched_base = step when it uploads an epoch's table. In SGD mode (URSA_STEP_SGD in
  * ctl->flags; no noise there) the second column is the MOMENTUM instead: per-iteration
  * (lr, momentum) of OneCycleLR, URSABench/inference/vi_dropout.py:59-61,107. `step` is also
- * the Philox call index, so it only ever grows. */
+ * the Philox call index, so it only ever grows.
+ * With URSA_STEP_ADVANCE in ctl->flags the update launch advances its own block: every
+ * workgroup takes a ticket when it retires and the last one of the chain does the advance
+ * (all others have read the block by then) and re-arms the ticket — no second launch.
+ * ursa_step_ctl_advance is the same advance as a 1-thread launch, for hosts that step
+ * a block without an update. `ticket` is device scratch: upload it as 0. */
+#define URSA_STEP_ADVANCE   0x20u
 typedef struct ursa_step_ctl {
     float lr, mu, c_wd, c_noise, n_train;
     uint32_t flags;
     uint64_t seed, step, sched_base;
-} ursa_step_ctl;
+    const float* sched;       /* DEVICE pointer, [sched_len][2], or NULL */
+    uint32_t sched_len;
+    uint32_t ticket;
+} ursa_step_ctl;              /* 64 bytes */
 
 int ursa_sgmcmc_step_ctl_f32(float* theta, float* grad, float* mom, const float* eps,
-                             float* snapshot, int64_t n, const ursa_step_ctl* ctl,
+                             float* snapshot, int64_t n, ursa_step_ctl* ctl,
                              ursa_stream_t stream);
-int ursa_step_ctl_advance(ursa_step_ctl* ctl, const float* sched /* [sched_len][2] or NULL */,
-                          uint32_t sched_len, ursa_stream_t stream);
+int ursa_step_ctl_advance(ursa_step_ctl* ctl, ursa_stream_t stream);
+
+/* K chains in ONE launch (SURVEY.md 8b `n_chains`, 8f-1): the K independent chains that share a GPU
+ * keep their vectors in [K, chain_stride] slabs — chain k's theta / grad / mom (/ eps / snapshot)
+ * start at element k * chain_stride of the base pointers — and their control blocks in ctl[K].
+ * Chain k is updated exactly as ursa_sgmcmc_step_ctl_f32(theta + k*chain_stride, ..., n_per_chain,
+ * ctl + k) would (own lr / flags / Philox key and call index; element i of chain k draws Philox
+ * lane (i, ctl[k].step) of key ctl[k].seed), bit for bit. grid = (ceil(n_per_chain/2048), K).
+ * chain_stride must be a multiple of 4 and >= n_per_chain; pointers 16-byte aligned. */
+int ursa_sgmcmc_step_multi_f32(float* theta, float* grad, float* mom, const float* eps,
+                               float* snapshot, int64_t n_per_chain, int32_t n_chains,
+                               int64_t chain_stride, ursa_step_ctl* ctl /* [n_chains] */,
+                               ursa_stream_t stream);
 
 /* Standard-normal fill with the same Philox/Box-Muller stream as K1 (element i of call
  * (seed, step) is exactly the eps K1 would use). Used by tests and by SWAG/HMC hosts. */

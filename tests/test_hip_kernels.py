@@ -113,41 +113,111 @@ def test_k1_trajectory_bitwise_philox(K):
     assert np.array_equal(host(dth), th) and np.array_equal(host(dmo), mo)
 
 
-def _ctl_tensor(**kw):
-    import ctypes
+def _ctl_tensor(*blocks):
+    """Device array of control blocks from keyword dicts."""
     from ursabench_amd._native import StepCtl
-    c = StepCtl(**kw)
-    return torch.frombuffer(bytearray(bytes(c)), dtype=torch.uint8).cuda()
+    raw = b''.join(bytes(StepCtl(**kw)) for kw in blocks)
+    return torch.frombuffer(bytearray(raw), dtype=torch.uint8).cuda()
 
 
-def test_k1_ctl_variant_and_advance(K):
-    """Device-control-block launch (graph-replayable) == the scalar-argument launch; advance walks the
-    (lr, c_noise) schedule table and clears FIRST."""
-    import ctypes
-    from ursabench_amd._native import StepCtl
-    n = 4096 + 4
+def _ctl_back(ctl, k=0):
+    from ursabench_amd._native import CTL_BYTES, StepCtl
+    return StepCtl.from_buffer_copy(bytes(ctl.cpu().numpy())[k * CTL_BYTES:(k + 1) * CTL_BYTES])
+
+
+@pytest.mark.parametrize('self_advance', [True, False])
+def test_k1_ctl_variant_and_advance(K, self_advance):
+    """Device-control-block launch (graph-replayable) == the scalar-argument launch == the oracle, bit for bit; the
+    advance (folded into the update launch: last retiring workgroup, or the explicit 1-thread launch) walks the
+    (lr, c_noise) schedule table whose address rides in the block, clears FIRST and re-arms the ticket."""
+    from ursabench_amd._native import STEP_ADVANCE
+    n = 3 * 2048 + 4 + 2                                   # several workgroups at every block size + a scalar tail
     rng = np.random.default_rng(11)
     th0, mo0 = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
     lrs = [0.1, 0.07, 0.03]
     sched = np.array([[lr, np.sqrt(2 * (1 - 0.5) * lr)] for lr in lrs], np.float32)
-    a = [dev(th0), dev(mo0)]
-    b = [dev(th0), dev(mo0)]
+    buf = [torch.zeros(n + 2, device='cuda') for _ in range(6)]        # n is not a multiple of 4: keep bases aligned
+    a = [buf[0][:n], buf[1][:n]]
+    b = [buf[2][:n], buf[3][:n]]
+    for t, v in ((a[0], th0), (a[1], mo0), (b[0], th0), (b[1], mo0)):
+        t.copy_(dev(v))
+    oth, omo = th0.copy(), mo0.copy()
     sc0 = O.step_scalars(lrs[0], 0.5, 4.0, 1000)
-    ctl = _ctl_tensor(lr=sc0['lr'], mu=0.5, c_wd=sc0['c_wd'], c_noise=float(sched[0, 1]), n_train=1000.0,
-                      flags=O.STEP_NOISE | O.STEP_WD | O.STEP_FIRST | O.STEP_ZERO_GRAD, seed=99, step=0)
     dsched = dev(sched)
+    base = O.STEP_NOISE | O.STEP_WD | O.STEP_ZERO_GRAD
+    ctl = _ctl_tensor(dict(lr=sc0['lr'], mu=0.5, c_wd=sc0['c_wd'], c_noise=float(sched[0, 1]), n_train=1000.0,
+                           flags=base | O.STEP_FIRST | (STEP_ADVANCE if self_advance else 0), seed=99, step=0,
+                           sched=dsched.data_ptr(), sched_len=3))
     for k in range(5):
         gr = rng.standard_normal(n).astype(np.float32)
-        ga, gb = dev(gr), dev(gr)
-        flags = O.STEP_NOISE | O.STEP_WD | O.STEP_ZERO_GRAD | (O.STEP_FIRST if k == 0 else 0)
+        ga, gb = buf[4][:n], buf[5][:n]
+        ga.copy_(dev(gr)); gb.copy_(dev(gr))
+        flags = base | (O.STEP_FIRST if k == 0 else 0)
         lr, cn = sched[k % 3]
-        K.sgmcmc_step(a[0], ga, a[1], lr=float(lr), mu=0.5, c_wd=sc0['c_wd'], c_noise=float(cn), n_train=1000.0,
-                      flags=flags, seed=99, step=k)
+        kw = dict(lr=float(lr), mu=0.5, c_wd=sc0['c_wd'], c_noise=float(cn), n_train=1000.0, flags=flags, seed=99, step=k)
+        K.sgmcmc_step(a[0], ga, a[1], **kw)
+        O.sgmcmc_step(oth, gr.copy(), omo, **kw)
         K.sgmcmc_step_ctl(b[0], gb, b[1], ctl)
-        K.step_ctl_advance(ctl, dsched)
+        if not self_advance:
+            K.step_ctl_advance(ctl)
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and not gb.any(), k
-    back = StepCtl.from_buffer_copy(bytes(ctl.cpu().numpy()))
-    assert back.step == 5 and not (back.flags & O.STEP_FIRST) and back.lr == sched[5 % 3, 0]
+        assert np.array_equal(host(b[0]), oth) and np.array_equal(host(b[1]), omo), k
+    back = _ctl_back(ctl)
+    assert back.step == 5 and not (back.flags & O.STEP_FIRST) and back.lr == sched[5 % 3, 0] and back.ticket == 0
+    assert back.c_noise == sched[5 % 3, 1] and back.sched == dsched.data_ptr()
+
+
+@pytest.mark.parametrize('n,stride', [(273408, 273408), (61706, 61760), (5, 8), (1 << 23, 1 << 23)])
+@pytest.mark.parametrize('inject', [False, True])
+def test_k1_multi_chain_launch_bitwise(K, n, stride, inject):
+    """ONE launch over a [K, stride] slab (SURVEY.md 8b n_chains): chain k == the oracle's single-chain update with
+    ctl[k]'s own scalars, Philox key and call index, for SGHMC / SGLD / noise-off / scheduled chains side by side; every
+    chain's block advances itself. (1 << 23) x 3 chains x 12 B is past the 256 MiB non-temporal threshold."""
+    from ursabench_amd._native import STEP_ADVANCE
+    if inject and n >= (1 << 23):
+        pytest.skip('injected noise is covered at the smaller sizes')
+    Kc, steps = 4 if n < (1 << 23) else 3, 3
+    rng = np.random.default_rng(n % 1000 + 7)
+    th = rng.standard_normal((Kc, stride)).astype(np.float32)
+    mo = rng.standard_normal((Kc, stride)).astype(np.float32)
+    sched = np.array([[0.05, 0.21], [0.04, 0.2], [0.03, 0.17]], np.float32)
+    dsched = dev(sched)
+    chains = [dict(lr=0.1, mu=0.5, c_wd=8e-5, c_noise=0.3162, n_train=50000.0, flags=O.STEP_NOISE | O.STEP_WD | O.STEP_FIRST, seed=11),
+              dict(lr=0.02, mu=0.0, c_wd=4e-5, c_noise=0.2, n_train=1000.0, flags=O.STEP_NOISE | O.STEP_WD, seed=12),
+              dict(lr=0.05, mu=0.9, c_wd=0.0, c_noise=0.1, n_train=10.0, flags=0, seed=13),
+              dict(lr=float(sched[0, 0]), mu=0.3, c_wd=1e-4, c_noise=float(sched[0, 1]), n_train=64.0,
+                   flags=O.STEP_NOISE | O.STEP_WD, seed=14, sched=dsched.data_ptr(), sched_len=3)][:Kc]
+    ctl = _ctl_tensor(*[dict(c, flags=c['flags'] | STEP_ADVANCE, step=100 * k, sched_base=100 * k) for k, c in enumerate(chains)])
+    dth, dmo = dev(th), dev(mo)
+    dgr = torch.empty_like(dth)
+    deps = torch.empty_like(dth) if inject else None
+    for it in range(steps):
+        gr = rng.standard_normal((Kc, stride)).astype(np.float32)
+        ep = rng.standard_normal((Kc, stride)).astype(np.float32) if inject else None
+        dgr.copy_(dev(gr))
+        if inject:
+            deps.copy_(dev(ep))
+        K.sgmcmc_step_multi(dth, dgr, dmo, ctl, n_per_chain=n, eps=deps)
+        for k, c in enumerate(chains):
+            kw = {f: c[f] for f in ('lr', 'mu', 'c_wd', 'c_noise', 'n_train', 'seed')}
+            flags = c['flags'] & ~(O.STEP_FIRST if it else 0)
+            if 'sched' in c:
+                kw['lr'], kw['c_noise'] = float(sched[it % 3, 0]), float(sched[it % 3, 1])
+            O.sgmcmc_step(th[k, :n], gr[k, :n].copy(), mo[k, :n] if c['mu'] else None, flags=flags, step=100 * k + it,
+                          eps=None if not inject else ep[k, :n], **kw)
+    got_th, got_mo = host(dth), host(dmo)
+    for k, c in enumerate(chains):
+        assert np.array_equal(got_th[k, :n], th[k, :n]), k
+        if c['mu']:
+            assert np.array_equal(got_mo[k, :n], mo[k, :n]), k
+        assert np.array_equal(got_th[k, n:], th[k, n:]) and np.array_equal(got_mo[k, n:], mo[k, n:])     # row pads untouched
+        b = _ctl_back(ctl, k)
+        assert b.step == 100 * k + steps and b.ticket == 0 and not (b.flags & O.STEP_FIRST)
+    # argument checks happen on the host, before any launch
+    with pytest.raises(ValueError):
+        K.sgmcmc_step_multi(dth, dgr[:, :-4].contiguous(), dmo, ctl)
+    with pytest.raises(ValueError):
+        K.sgmcmc_step_multi(dth, dgr, dmo, ctl[:-8])
 
 
 @pytest.mark.parametrize('mode', ['degenerate', 'counting'])

@@ -277,7 +277,7 @@ def test_tensors_without_gradient_are_skipped_like_the_reference():
     assert float(opt.arena.grad_views[1].abs().sum()) == 0  # the previous step's gradient is gone, not re-applied
 
 
-def _cyclic_replay(golden_dir, name, device, kernels=None, atol=0.0):
+def _cyclic_replay(golden_dir, name, device, kernels=None, atol=0.0, use_graph=None, warmup_steps=None):
     g = np.load(os.path.join(golden_dir, 'e2e_cyclic.npz'))
     hyp = json.loads(str(g[f'{name}/hyper']))
     net = tiny_net()
@@ -286,8 +286,10 @@ def _cyclic_replay(golden_dir, name, device, kernels=None, atol=0.0):
         for p in net.parameters():
             p.copy_(torch.tensor(g[f'{name}/theta0'][off:off + p.numel()]).view_as(p))
             off += p.numel()
-    kw = {} if kernels is None else dict(kernels=kernels, use_graph=False)
+    kw = dict(use_graph=use_graph) if kernels is None else dict(kernels=kernels, use_graph=False)
     s = getattr(inference, name)(dict(hyp), net, tiny_loader(), device=device, **kw)
+    if warmup_steps is not None:
+        s.engine.WARMUP_STEPS = warmup_steps
 
     def eps(k):
         e = torch.zeros(s.arena.n, device=device)

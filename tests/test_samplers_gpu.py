@@ -21,10 +21,20 @@ def flat_params(m):
     return torch.cat([p.detach().reshape(-1) for p in m.parameters()])
 
 
+def _replay_mode(s, use_graph):
+    """use_graph=True: ONE eager warm-up step (MIOpen's solver search cannot run inside a capture), then every
+    full-size batch is a hipGraph replay that reads the injected noise from the engine's persistent buffer — the
+    execution path bench.py times."""
+    if use_graph:
+        s.engine.WARMUP_STEPS = 1
+
+
+@pytest.mark.parametrize('use_graph', [False, True])
 @pytest.mark.parametrize('name', ['SGLD', 'SGHMC'])
-def test_end_to_end_lenet5_vs_reference_on_gpu(golden_dir, name):
+def test_end_to_end_lenet5_vs_reference_on_gpu(golden_dir, name, use_graph):
     """The reference's CPU run (LeNet-5, 6 minibatch steps, 2 samples) replayed on the GPU with the
-    captured noise. Forward/backward are MIOpen/rocBLAS instead of oneDNN, so parameters agree to
+    captured noise — with eager launches and through hipGraph replay (the timed path). Forward/backward are
+    MIOpen/rocBLAS instead of oneDNN, so parameters agree to
     rounding amplified over 6 steps (1e-4 relative, 2e-5 absolute here); the predictive probabilities — north_star's
     criterion — agree within 1e-5 relative."""
     g = np.load(os.path.join(golden_dir, 'e2e_lenet5.npz'))
@@ -37,7 +47,8 @@ def test_end_to_end_lenet5_vs_reference_on_gpu(golden_dir, name):
         for p in net.parameters():
             p.copy_(torch.tensor(g[f'{name}/theta0'][off:off + p.numel()]).view_as(p))
             off += p.numel()
-    s = getattr(inference, name)(dict(hyp), net, train, device=DEV)
+    s = getattr(inference, name)(dict(hyp), net, train, device=DEV, use_graph=use_graph)
+    _replay_mode(s, use_graph)
 
     def eps(k):
         e = torch.zeros(s.arena.n, device=DEV)
@@ -45,6 +56,7 @@ def test_end_to_end_lenet5_vs_reference_on_gpu(golden_dir, name):
         return e
     s.eps_provider = eps
     ens = s.sample()
+    assert (s.engine.stats['graph_replays'] >= 4) if use_graph else (s.engine.stats['graph_replays'] == 0), s.engine.stats
     for m, ref in zip(ens, g[f'{name}/samples']):
         np.testing.assert_allclose(flat_params(m).cpu().numpy(), ref, rtol=1e-4, atol=2e-5)
     pred = tasks.Prediction({'in_distribution_test': test}, 10, DEV, 'ALL')
@@ -113,6 +125,133 @@ def test_update_matches_oracle_inside_the_training_loop():
                        a.mom[:next(net.parameters()).numel()])
 
 
+class _SpyLoader:
+    """Wraps a loader and calls `on_next()` before every batch is handed out and once after the last one: between
+    two calls exactly one minibatch step of the engine (eager or one hipGraph replay) has been enqueued."""
+
+    def __init__(self, loader, on_next):
+        self.loader, self.on_next = loader, on_next
+        self.dataset, self.batch_size = loader.dataset, loader.batch_size
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        for b in self.loader:
+            self.on_next()
+            yield b
+        self.on_next()
+
+
+def _check_steps_against_oracle(recs, seed, lr, mu, wd, n_train, first_step=0):
+    """recs[k] = (theta, mom, grad) on the host BEFORE step k (grad = what step k-1 consumed: the engine packs fresh
+    gradients every step and does not re-zero them). Step k, recomputed by the oracle from the GPU's own gradients,
+    must reproduce the GPU's theta and momentum bit for bit. Returns the number of steps checked."""
+    sc = O.step_scalars(lr, mu, wd, n_train)
+    for k in range(len(recs) - 1):
+        th, mo = recs[k][0].copy(), recs[k][1].copy()
+        flags = O.STEP_NOISE | O.STEP_WD | (O.STEP_FIRST if first_step + k == 0 else 0)
+        O.sgmcmc_step(th, recs[k + 1][2].copy(), mo if mu else None, flags=flags, seed=seed, step=first_step + k, **sc)
+        assert np.array_equal(th, recs[k + 1][0]), f'theta differs from the oracle at step {first_step + k}'
+        if mu:
+            assert np.array_equal(mo, recs[k + 1][1]), f'momentum differs from the oracle at step {first_step + k}'
+    return len(recs) - 1
+
+
+@pytest.mark.parametrize('size', ['small', 'c2_full_sample'])
+def test_replayed_steps_equal_oracle_given_the_gpus_gradients(size):
+    """The path bench.py times — hipGraph replays of {forward, backward, pack, k_sgmcmc_step_ctl with Philox noise and
+    the folded control-block advance} — checked against the oracle step by step: before every step theta / momentum
+    are copied out, after it the gradients the step consumed; the oracle's update from those inputs (same Philox key
+    and call index) must equal the GPU's bit for bit. `c2_full_sample` is BASELINE configs[1] at full size: all 391
+    minibatch steps of one PreResNet-20 posterior sample (387 of them replays) — the implementation adds nothing to the
+    MIOpen-vs-oneDNN gradient differences (URSABench/inference/sghmc.py:72-87 + optim_sghmc.py:43-67)."""
+    from ursabench_amd import util
+    n_rows, depth = (50000, 20) if size == 'c2_full_sample' else (1152 + 40, 8)
+    util.set_random_seed(3)
+    recs = []
+    holder = {}
+
+    def on_next():
+        a = holder['s'].arena
+        recs.append(tuple(t.cpu().numpy().copy() for t in (a.theta, a.mom if a.mom is not None else a.theta, a.grad)))
+    train = _SpyLoader(synthetic(n_rows, (3, 32, 32), 10, seed=0, device=DEV, batch_size=128), on_next)
+    hyp = {'lr': 0.1, 'prior_std': 0.5, 'num_samples': 3, 'alpha': 0.5, 'burn_in_epochs': 0}
+    s = holder['s'] = inference.SGHMC(dict(hyp), models.PreResNet(10, depth).to(DEV), train, device=DEV, seed=77)
+    s.arena.ensure_mom()
+    s.sample_iterative()
+    steps = _check_steps_against_oracle(recs, 77, 0.1, 0.5, 1 / 0.5 ** 2, n_rows)
+    st = s.engine.stats
+    assert steps == len(train) and st['graph_replays'] + st['eager_steps'] == steps
+    assert st['graph_replays'] == (n_rows // 128) - 3 and st['captures'] == 1, st     # all full-size batches after 3 warm-up steps
+    # second sample: CosineAnnealingLR moved lr (0.1 -> 0.075), the Philox call index continues, FIRST is gone
+    recs.clear()
+    lr2 = s.optimizer.param_groups[0]['lr']
+    assert 0 < lr2 < 0.1
+    s.sample_iterative()
+    _check_steps_against_oracle(recs, 77, lr2, 0.5, 1 / 0.5 ** 2, n_rows, first_step=steps)
+    assert s.engine.stats['captures'] == 1
+
+
+def test_chain_group_replayed_steps_equal_oracle_for_every_chain():
+    """Same check for every branch of a ChainGroup of 3: ONE ursa_sgmcmc_step_multi_f32 launch per lock-step round
+    over the [3, n] slabs (asserted: update launches == rounds), each chain bit-identical to the oracle run on that
+    chain's own gradients, Philox key and call index."""
+    from ursabench_amd import util
+    recs = [[], [], []]
+    holder = {}
+
+    def on_next():
+        for k, s in enumerate(holder['g'].samplers):
+            a = s.arena
+            recs[k].append(tuple(t.cpu().numpy().copy() for t in (a.theta, a.mom, a.grad)))
+    train = _SpyLoader(synthetic(1152 + 40, (3, 32, 32), 10, seed=0, device=DEV, batch_size=128), on_next)
+    hyp = {'lr': 0.05, 'prior_std': 0.5, 'num_samples': 1, 'alpha': 0.5, 'burn_in_epochs': 0}
+
+    def make(k):
+        util.set_random_seed(k)
+        return inference.SGHMC(dict(hyp), models.PreResNet(10, 8).to(DEV), train, device=DEV, seed=40 + k)
+    group = holder['g'] = inference.ChainGroup([make(k) for k in range(3)])
+    assert all(s.arena.theta.data_ptr() == group.theta[k].data_ptr() for k, s in enumerate(group.samplers))
+    group.sample_iterative()
+    for k in range(3):
+        assert _check_steps_against_oracle(recs[k], 40 + k, 0.05, 0.5, 1 / 0.5 ** 2, 1152 + 40) == 10
+    st = group.stats
+    assert st['graph_replays'] == 6 and st['eager_rounds'] == 4 and st['captures'] == 1, st      # 3 warm-up + the ragged tail
+    assert st['update_launches'] == 10                                                           # one per round, not K
+    assert not np.array_equal(recs[0][-1][0], recs[1][-1][0])
+
+
+def test_chain_group_replays_reference_run_with_injected_noise(golden_dir):
+    """G9 through the group path: two chains of a group, both fed the reference's captured noise from the same
+    initial weights, each reproduce the reference's PreResNet-8 SGHMC run (predictive within 1e-5) through graph
+    replays whose multi-chain update reads the [K, n] injected-noise slab."""
+    from test_samplers_cpu import _load_preresnet8, _preresnet8_inputs
+    g = np.load(os.path.join(golden_dir, 'e2e_preresnet8.npz'))
+    hyp = json.loads(str(g['hyper']))
+    train, test = _preresnet8_inputs(g)
+    chains = [inference.SGHMC(dict(hyp), _load_preresnet8(g), train, device=DEV, seed=k) for k in range(2)]
+    group = inference.ChainGroup(chains)
+    group.WARMUP_STEPS = 1
+
+    def provider(s):
+        def eps(k):
+            e = torch.zeros(s.arena.n, device=DEV)
+            e[s.arena.layout.gather_index(DEV)] = torch.tensor(g['eps'][k], device=DEV)
+            return e
+        return eps
+    for s in chains:
+        s.eps_provider = provider(s)
+    per_chain = group.sample()
+    assert group.stats['graph_replays'] >= 2
+    for ens in per_chain:
+        for m, ref in zip(ens, g['samples']):
+            np.testing.assert_allclose(flat_params(m).cpu().numpy(), ref, rtol=1e-4, atol=2e-5)
+        pred = tasks.Prediction({'in_distribution_test': test}, 10, DEV, 'ALL')
+        pred.update_statistics(ens, output_performance=False)
+        np.testing.assert_allclose(pred.ensemble_proba.numpy(), g['proba_sum'], rtol=1e-5, atol=1e-7)
+
+
 def test_csghmc_on_gpu_walks_the_device_schedule():
     hyp = {'lr_0': 0.05, 'prior_std': 1.0, 'num_samples_per_cycle': 1, 'cycle_length': 3, 'burn_in_epochs': 1,
            'num_cycles': 1, 'alpha': 0.3}
@@ -120,7 +259,7 @@ def test_csghmc_on_gpu_walks_the_device_schedule():
     assert len(ens) == 1 and s.epochs_run == 3 and s.engine.stats['graph_replays'] > 0
     from ursabench_amd._native import StepCtl
     c = StepCtl.from_buffer_copy(bytes(s.optimizer._ctl.cpu().numpy()))
-    assert c.step == 27
+    assert c.step == 27 and c.ticket == 0
     want = s._adjust_learning_rate(s.optimizer, s.epochs_run - 1, len(s.train_loader) - 1)   # last iteration run
     assert s.lr == pytest.approx(want) and s.optimizer.param_groups[0]['lr'] == pytest.approx(want)
     assert np.isfinite(flat_params(ens[0]).cpu().numpy()).all()
@@ -308,7 +447,8 @@ def test_rccl_process_group_with_graph_capture_world_size_1():
     assert total == pytest.approx(2 * 300, rel=1e-5)         # every member's probabilities sum to 1 per row
 
 
-def test_end_to_end_preresnet8_vs_reference_on_gpu(golden_dir):
+@pytest.mark.parametrize('use_graph', [False, True])
+def test_end_to_end_preresnet8_vs_reference_on_gpu(golden_dir, use_graph):
     """BASELINE configs[1]'s network family (PreResNet, BatchNorm) and sampler (SGHMC): the reference's CPU run
     replayed on the GPU with its captured noise. north_star's criterion — fp32 predictive probabilities
     within 1e-5 relative of the reference CPU path — on 64 test rows after 4 noisy SGHMC steps (measured:
@@ -317,7 +457,8 @@ def test_end_to_end_preresnet8_vs_reference_on_gpu(golden_dir):
     g = np.load(os.path.join(golden_dir, 'e2e_preresnet8.npz'))
     hyp = json.loads(str(g['hyper']))
     train, test = _preresnet8_inputs(g)
-    s = inference.SGHMC(dict(hyp), _load_preresnet8(g), train, device=DEV)
+    s = inference.SGHMC(dict(hyp), _load_preresnet8(g), train, device=DEV, use_graph=use_graph)
+    _replay_mode(s, use_graph)
 
     def eps(k):
         e = torch.zeros(s.arena.n, device=DEV)
@@ -325,6 +466,7 @@ def test_end_to_end_preresnet8_vs_reference_on_gpu(golden_dir):
         return e
     s.eps_provider = eps
     ens = s.sample()
+    assert (s.engine.stats['graph_replays'] >= 2) if use_graph else (s.engine.stats['graph_replays'] == 0), s.engine.stats
     for m, ref in zip(ens, g['samples']):
         np.testing.assert_allclose(flat_params(m).cpu().numpy(), ref, rtol=1e-4, atol=2e-5)
     pred = tasks.Prediction({'in_distribution_test': test}, 10, DEV, 'ALL')
@@ -377,13 +519,15 @@ def test_many_samplers_and_tasks_in_one_process(monkeypatch):
     assert all(abs(v - 3 * 300) < 1e-2 for v in sums)
 
 
+@pytest.mark.parametrize('use_graph', [False, True])
 @pytest.mark.parametrize('name', ['cSGHMC', 'cSGLD'])
-def test_cyclic_samplers_end_to_end_vs_reference_on_gpu(golden_dir, name):
+def test_cyclic_samplers_end_to_end_vs_reference_on_gpu(golden_dir, name, use_graph):
     """G12 on the HIP path: the reference's cSGHMC / cSGLD trajectories (tiny MLP, 16 steps, 4 samples) with its
     captured noise; the per-iteration lr walks the device schedule table. rocBLAS vs oneDNN gradients differ in the
     last bits, amplified over 16 steps: parameters agree to 1e-4 relative / 1e-5 absolute."""
     from test_samplers_cpu import _cyclic_replay
-    s, ens, g = _cyclic_replay(golden_dir, name, DEV)
+    s, ens, g = _cyclic_replay(golden_dir, name, DEV, use_graph=use_graph, warmup_steps=1 if use_graph else None)
+    assert (s.engine.stats['graph_replays'] >= 8) if use_graph else (s.engine.stats['graph_replays'] == 0), s.engine.stats
     for m, ref in zip(ens, g[f'{name}/samples']):
         np.testing.assert_allclose(flat_params(m).cpu().numpy(), ref, rtol=1e-4, atol=1e-5)
 

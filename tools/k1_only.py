@@ -9,11 +9,10 @@ which = sys.argv[1] if len(sys.argv) > 1 else 'both'
 if which in ('small', 'both'):
     n = 273408
     th, g, m = (torch.randn(n, device='cuda') for _ in range(3))
-    c = _native.StepCtl(lr=0.1, mu=0.5, c_wd=8e-5, c_noise=0.3, n_train=50000.0, flags=0x1 | 0x8, seed=1, step=0)
+    c = _native.StepCtl(lr=0.1, mu=0.5, c_wd=8e-5, c_noise=0.3, n_train=50000.0, flags=0x1 | 0x8 | 0x20, seed=1, step=0)     # NOISE | WD | ADVANCE
     ctl = torch.frombuffer(bytearray(bytes(c)), dtype=torch.uint8).cuda()
     for _ in range(20):
-        K.sgmcmc_step_ctl(th, g, m, ctl)
-        K.step_ctl_advance(ctl)
+        K.sgmcmc_step_ctl(th, g, m, ctl)           # advances its own control block
 if which in ('large', 'both'):
     n = 1 << 26
     th, g, m = (torch.randn(n, device='cuda') for _ in range(3))

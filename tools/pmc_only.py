@@ -16,11 +16,10 @@ def note(pattern, label, alg_bytes, **kw):
 # K1 at the PreResNet-20 arena size through the control-block entry point (the workload's launch)
 n = 273408
 th, g, m = (torch.randn(n, device='cuda') for _ in range(3))
-c = _native.StepCtl(lr=0.1, mu=0.5, c_wd=8e-5, c_noise=0.3, n_train=50000.0, flags=0x1 | 0x8, seed=1, step=0)
+c = _native.StepCtl(lr=0.1, mu=0.5, c_wd=8e-5, c_noise=0.3, n_train=50000.0, flags=0x1 | 0x8 | 0x20, seed=1, step=0)     # NOISE | WD | ADVANCE
 ctl = torch.frombuffer(bytearray(bytes(c)), dtype=torch.uint8).cuda()
 for _ in range(20):
-    K.sgmcmc_step_ctl(th, g, m, ctl)
-    K.step_ctl_advance(ctl)
+    K.sgmcmc_step_ctl(th, g, m, ctl)               # advances its own control block
 note('k_sgmcmc_step_ctl', 'K1 workload size (control block)', 20 * n, elements=n)
 # K1 at 2^26
 n = 1 << 26

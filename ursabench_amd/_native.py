@@ -17,10 +17,10 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libursa_hip.so')
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # flags (mirror include/ursa_hip.h)
-STEP_NOISE, STEP_FIRST, STEP_ZERO_GRAD, STEP_WD, STEP_SGD = 0x1, 0x2, 0x4, 0x8, 0x10
+STEP_NOISE, STEP_FIRST, STEP_ZERO_GRAD, STEP_WD, STEP_SGD, STEP_ADVANCE = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
 BMA_SMOOTHED = 0x1
 LEAP_KICK, LEAP_DRIFT = 0x1, 0x2
 REDUCE_WS_FLOATS = 2048
@@ -35,7 +35,8 @@ SIGNATURES = {
     'ursa_strerror': (ctypes.c_char_p, [ctypes.c_int]),
     'ursa_sgmcmc_step_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _u64, _u64, _u32, _vp]),
     'ursa_sgmcmc_step_ctl_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
-    'ursa_step_ctl_advance': (ctypes.c_int, [_vp, _vp, _u32, _vp]),
+    'ursa_step_ctl_advance': (ctypes.c_int, [_vp, _vp]),
+    'ursa_sgmcmc_step_multi_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp]),
     'ursa_philox_normal_f32': (ctypes.c_int, [_vp, _i64, _u64, _u64, _vp]),
     'ursa_swag_collect_f32': (ctypes.c_int, [_vp, _vp, _vp, _i64, _f, _f, _vp]),
     'ursa_swag_draw_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _f, _f, _u64, _u64, _vp]),
@@ -46,9 +47,21 @@ SIGNATURES = {
 
 
 class StepCtl(ctypes.Structure):
-    """struct ursa_step_ctl (48 bytes)."""
+    """struct ursa_step_ctl (64 bytes). `sched` is a DEVICE address; `ticket` is device scratch (upload 0)."""
     _fields_ = [('lr', _f), ('mu', _f), ('c_wd', _f), ('c_noise', _f), ('n_train', _f), ('flags', _u32),
-                ('seed', _u64), ('step', _u64), ('sched_base', _u64)]
+                ('seed', _u64), ('step', _u64), ('sched_base', _u64), ('sched', _u64), ('sched_len', _u32),
+                ('ticket', _u32)]
+
+
+CTL_BYTES = ctypes.sizeof(StepCtl)
+assert CTL_BYTES == 64
+
+
+def _ctl_ptr(ctl, n_chains=1):
+    if not (isinstance(ctl, torch.Tensor) and ctl.is_cuda and ctl.dtype == torch.uint8
+            and ctl.numel() == n_chains * CTL_BYTES and ctl.is_contiguous() and ctl.data_ptr() % 8 == 0):
+        raise ValueError(f'ctl must be a contiguous 8-byte aligned uint8 HIP tensor of {n_chains} x sizeof(ursa_step_ctl) bytes')
+    return ctl.data_ptr()
 
 
 class NativeLibraryMissing(RuntimeError):
@@ -135,22 +148,41 @@ class HipKernels:
         _check(self.lib, rc, 'ursa_sgmcmc_step_f32')
 
     def sgmcmc_step_ctl(self, theta, grad, mom, ctl, *, eps=None, snapshot=None):
+        """Scalars from the device control block; with STEP_ADVANCE in its flags the launch advances it too."""
         n, dev = theta.numel(), theta.device
         args = (_ptr(theta, 'theta'), _ptr(grad, 'grad', n, dev), _ptr(mom, 'mom', n, dev),
                 _ptr(eps, 'eps', n, dev, optional=True), _ptr(snapshot, 'snapshot', n, dev, optional=True))
-        if not (isinstance(ctl, torch.Tensor) and ctl.is_cuda and ctl.dtype == torch.uint8
-                and ctl.numel() == ctypes.sizeof(StepCtl) and ctl.is_contiguous()):
-            raise ValueError('ctl must be a contiguous uint8 HIP tensor of sizeof(ursa_step_ctl) bytes')
+        cp = _ctl_ptr(ctl)
         with torch.cuda.device(dev):
-            rc = self.lib.ursa_sgmcmc_step_ctl_f32(*args, n, ctl.data_ptr(), _stream(dev))
+            rc = self.lib.ursa_sgmcmc_step_ctl_f32(*args, n, cp, _stream(dev))
         _check(self.lib, rc, 'ursa_sgmcmc_step_ctl_f32')
 
-    def step_ctl_advance(self, ctl, sched=None):
-        dev = ctl.device
-        sp = _ptr(sched, 'sched', optional=True)
-        sl = 0 if sched is None else sched.numel() // 2
+    def sgmcmc_step_multi(self, theta, grad, mom, ctl, *, n_per_chain=None, eps=None, snapshot=None):
+        """K chains in one launch: theta / grad / mom (/ eps / snapshot) are [K, chain_stride] slabs, ctl holds K
+        control blocks. Host-side shape check before the launch: every slab has the same shape and the grid the
+        library derives from (n_per_chain, K) stays inside it."""
+        if theta.dim() != 2:
+            raise ValueError(f'theta must be a [K, chain_stride] slab, got {tuple(theta.shape)}')
+        K, stride = theta.shape
+        n = stride if n_per_chain is None else int(n_per_chain)
+        if not 0 <= n <= stride:
+            raise ValueError(f'n_per_chain {n} outside the slab row of {stride} elements')
+        dev, tot = theta.device, K * stride
+        for name, t in (('grad', grad), ('mom', mom), ('eps', eps), ('snapshot', snapshot)):
+            if t is not None and tuple(t.shape) != (K, stride):
+                raise ValueError(f'{name} must have the slab shape {(K, stride)}, got {tuple(t.shape)}')
+        args = (_ptr(theta, 'theta'), _ptr(grad, 'grad', tot, dev), _ptr(mom, 'mom', tot, dev),
+                _ptr(eps, 'eps', tot, dev, optional=True), _ptr(snapshot, 'snapshot', tot, dev, optional=True))
+        cp = _ctl_ptr(ctl, K)
         with torch.cuda.device(dev):
-            rc = self.lib.ursa_step_ctl_advance(ctl.data_ptr(), sp, sl, _stream(dev))
+            rc = self.lib.ursa_sgmcmc_step_multi_f32(*args, n, K, stride, cp, _stream(dev))
+        _check(self.lib, rc, 'ursa_sgmcmc_step_multi_f32')
+
+    def step_ctl_advance(self, ctl):
+        dev = ctl.device
+        cp = _ctl_ptr(ctl)
+        with torch.cuda.device(dev):
+            rc = self.lib.ursa_step_ctl_advance(cp, _stream(dev))
         _check(self.lib, rc, 'ursa_step_ctl_advance')
 
     def philox_normal(self, out, *, seed, step):

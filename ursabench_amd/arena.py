@@ -120,6 +120,32 @@ class FlatArena:
             self.mom = torch.zeros_like(self.theta)
         return self.mom
 
+    def rehome(self, theta, grad, mom):
+        """Move the chain's vectors into caller-provided storage (rows of a [K, n] slab that several chains of one
+        GPU share, so ONE update launch covers them all): contents are copied, parameters / gradients become views
+        of the new rows. Anything that cached views of the old buffers (captured graphs, momentum_buffer state
+        entries) must be rebuilt by the caller."""
+        n = self.layout.padded
+        for name, t in (('theta', theta), ('grad', grad), ('mom', mom)):
+            if not (t.dim() == 1 and t.numel() == n and t.is_contiguous() and t.dtype == torch.float32
+                    and t.device == self.theta.device):
+                raise ValueError(f'rehome: {name} must be a contiguous float32 [{n}] tensor on {self.theta.device}')
+        with torch.no_grad():
+            theta.copy_(self.theta)
+            grad.copy_(self.grad)
+            if self.mom is not None:
+                mom.copy_(self.mom)
+            else:
+                mom.zero_()
+            bound = [p.grad is not None and p.grad.data_ptr() == gv.data_ptr() for p, gv in zip(self.params, self.grad_views)]
+            self.theta, self.grad, self.mom = theta, grad, mom
+            for p, v in zip(self.params, self.layout.views(theta)):
+                p.data = v
+            self.grad_views = self.layout.views(grad)
+            for p, gv, b in zip(self.params, self.grad_views, bound):
+                if b:
+                    p.grad = gv
+
     def flatten(self, which='theta'):
         """Unpadded flat copy in model.parameters() order == URSABench/util.py:163-169 flatten()."""
         src = getattr(self, which)

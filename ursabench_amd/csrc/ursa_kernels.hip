@@ -147,7 +147,7 @@ __device__ __forceinline__ void step_body(float* __restrict__ theta, float* __re
     const float4* __restrict__ e4 = reinterpret_cast<const float4*>(eps);
     float4* __restrict__ s4 = reinterpret_cast<float4*>(snapshot);
 
-    const int64_t i = (int64_t)blockIdx.x * kSBlock + threadIdx.x;      // one float4 per thread
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one float4 per thread
     if (i < n4) {
         float4 t = ld4<NT>(th4 + i);
         const float4 g = ld4<NT>(g4 + i);
@@ -193,14 +193,39 @@ __global__ __launch_bounds__(kSBlock) void k_sgmcmc_step(float* theta, float* gr
     step_body<MOM, NOISE, NT>(theta, grad, mom, eps, snapshot, n, s);
 }
 
-// Scalars from a device control block (graph-replayable launch). One kernel covers every
-// (mu, noise) combination with wave-uniform branches: the replayed graph must keep working
-// when the host flips NOISE between replays.
+// Advance a control block: the Philox call index, the first-step flag, the per-iteration schedule row.
+__device__ __forceinline__ void ctl_advance(ursa_step_ctl* ctl)
+{
+    const uint64_t step = ctl->step + 1;
+    ctl->step = step;
+    const uint32_t flags = ctl->flags & ~URSA_STEP_FIRST;
+    ctl->flags = flags;
+    const float* sched = ctl->sched;
+    const uint32_t sched_len = ctl->sched_len;
+    if (sched != nullptr && sched_len != 0) {
+        const uint64_t k = (step - ctl->sched_base) % sched_len;
+        ctl->lr = sched[2 * k];
+        if (flags & URSA_STEP_SGD) ctl->mu = sched[2 * k + 1];      // SGD mode has no noise: the column is the momentum
+        else ctl->c_noise = sched[2 * k + 1];
+    }
+}
+
+// Scalars from a device control block (graph-replayable launch), K chains per launch: blockIdx.y is the
+// chain, its vectors start at blockIdx.y * chain_stride, its scalars are ctl[blockIdx.y]. One kernel covers
+// every (mu, noise) combination with wave-uniform branches: the replayed graph must keep working when the
+// host flips NOISE between replays. With URSA_STEP_ADVANCE the chain's last retiring workgroup advances the
+// block (every other workgroup of the chain has read it by then: the ticket is taken after a block-wide
+// barrier that follows every wave's reads) — the 1-thread advance launch of round 2 is gone.
 template <bool NT>
 __global__ __launch_bounds__(kSBlock) void k_sgmcmc_step_ctl(float* theta, float* grad, float* mom,
                                                              const float* eps, float* snapshot, int64_t n,
-                                                             const ursa_step_ctl* __restrict__ ctl)
+                                                             int64_t chain_stride, ursa_step_ctl* ctl_base)
 {
+    ursa_step_ctl* ctl = ctl_base + blockIdx.y;
+    const int64_t off = (int64_t)blockIdx.y * chain_stride;
+    theta += off; grad += off; mom += off;
+    if (eps) eps += off;
+    if (snapshot) snapshot += off;
     StepScalars s;
     s.lr = ctl->lr; s.mu = ctl->mu; s.c_wd = ctl->c_wd; s.c_noise = ctl->c_noise;
     s.n_train = ctl->n_train; s.flags = ctl->flags; s.seed = ctl->seed; s.step = ctl->step;
@@ -214,21 +239,23 @@ __global__ __launch_bounds__(kSBlock) void k_sgmcmc_step_ctl(float* theta, float
         else if (eps) step_body<false, kNoisePtr, NT>(theta, grad, mom, eps, snapshot, n, s);
         else step_body<false, kNoisePhilox, NT>(theta, grad, mom, eps, snapshot, n, s);
     }
-}
-
-__global__ void k_step_ctl_advance(ursa_step_ctl* ctl, const float* sched, uint32_t sched_len)
-{
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const uint64_t step = ctl->step + 1;
-        ctl->step = step;
-        ctl->flags &= ~URSA_STEP_FIRST;
-        if (sched != nullptr && sched_len != 0) {
-            const uint64_t k = (step - ctl->sched_base) % sched_len;
-            ctl->lr = sched[2 * k];
-            if (ctl->flags & URSA_STEP_SGD) ctl->mu = sched[2 * k + 1];      // SGD mode has no noise: the column is the momentum
-            else ctl->c_noise = sched[2 * k + 1];
+    if (s.flags & URSA_STEP_ADVANCE) {                   // uniform over the launch's chain
+        __syncthreads();                                 // every wave of this workgroup is past its reads of *ctl
+        if (threadIdx.x == 0) {
+            __threadfence();
+            const uint32_t t = atomicAdd(&ctl->ticket, 1u);
+            if (t == gridDim.x - 1) {                    // last workgroup of this chain
+                __threadfence();
+                ctl_advance(ctl);
+                ctl->ticket = 0;
+            }
         }
     }
+}
+
+__global__ void k_step_ctl_advance(ursa_step_ctl* ctl)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl_advance(ctl);
 }
 
 // Unaligned fallback: same arithmetic, 4 B per lane. Element i still takes lane (i & 3) of
@@ -1011,29 +1038,57 @@ int ursa_sgmcmc_step_f32(float* theta, float* grad, float* mom, const float* eps
                       : launch_step<false>(ns, vec, nt, st, theta, grad, mom, eps, snapshot, n, s);
 }
 
-int ursa_sgmcmc_step_ctl_f32(float* theta, float* grad, float* mom, const float* eps, float* snapshot,
-                             int64_t n, const ursa_step_ctl* ctl, ursa_stream_t stream)
+// Threads per workgroup of a control-block launch of n4 float4 per chain. Roofline-sized launches: 512 (one float4
+// per thread, kSBlock). A workload-sized chain (PreResNet-20: 68,352 float4 = 134 blocks of 512) would leave half
+// of the 256 CUs without a workgroup: smaller blocks spread the same lanes over every CU (debug override
+// URSA_CTL_BLOCK, tools/kbench.py).
+inline int ctl_block(int64_t n4, int n_chains)
 {
-    if (n < 0 || n > kMaxElems) return URSA_ESIZE;
-    if (n == 0) return URSA_OK;
+    static const int forced = [] {
+        const char* e = getenv("URSA_CTL_BLOCK");
+        const int v = e && e[0] ? atoi(e) : 0;
+        return (v == 64 || v == 128 || v == 256 || v == 512) ? v : 0;
+    }();
+    if (forced) return forced;
+    const int64_t lanes = n4 * n_chains;
+    return lanes >= 2048ll * kSBlock ? kSBlock : lanes >= 1024ll * 256 ? 256 : 128;
+}
+
+int ursa_sgmcmc_step_multi_f32(float* theta, float* grad, float* mom, const float* eps, float* snapshot,
+                               int64_t n_per_chain, int32_t n_chains, int64_t chain_stride, ursa_step_ctl* ctl,
+                               ursa_stream_t stream)
+{
+    const int64_t n = n_per_chain;
+    if (n < 0 || n > kMaxElems || n_chains < 0 || n_chains > 65535) return URSA_ESIZE;
+    if (n == 0 || n_chains == 0) return URSA_OK;
+    if (n_chains > 1 && (chain_stride < n || (chain_stride & 3))) return URSA_ESIZE;
     if (!theta || !grad || !mom || !ctl) return URSA_ENULL;   // mom always required: mu lives on the device
     if (!(aligned16(theta) && aligned16(grad) && aligned16(mom) && aligned16(eps) && aligned16(snapshot)))
         return URSA_EALIGN;                                    // the replayable form is float4-only
-    const int grid = sgrid(n >> 2);
-    if (n * 12ll > kNtBytes)
-        hipLaunchKernelGGL(k_sgmcmc_step_ctl<true>, dim3(grid), dim3(kSBlock), 0, (hipStream_t)stream, theta, grad,
-                           mom, eps, snapshot, n, ctl);
+    if (reinterpret_cast<uintptr_t>(ctl) & 7u) return URSA_EALIGN;
+    const int block = ctl_block(n >> 2, n_chains);
+    int64_t gx = ((n >> 2) + block - 1) / block;
+    if (gx < 1) gx = 1;
+    const dim3 grid((unsigned)gx, (unsigned)n_chains);
+    if (n * 12ll * n_chains > kNtBytes)
+        hipLaunchKernelGGL(k_sgmcmc_step_ctl<true>, grid, dim3(block), 0, (hipStream_t)stream, theta, grad, mom, eps,
+                           snapshot, n, chain_stride, ctl);
     else
-        hipLaunchKernelGGL(k_sgmcmc_step_ctl<false>, dim3(grid), dim3(kSBlock), 0, (hipStream_t)stream, theta, grad,
-                           mom, eps, snapshot, n, ctl);
+        hipLaunchKernelGGL(k_sgmcmc_step_ctl<false>, grid, dim3(block), 0, (hipStream_t)stream, theta, grad, mom, eps,
+                           snapshot, n, chain_stride, ctl);
     return launch_status();
 }
 
-int ursa_step_ctl_advance(ursa_step_ctl* ctl, const float* sched, uint32_t sched_len, ursa_stream_t stream)
+int ursa_sgmcmc_step_ctl_f32(float* theta, float* grad, float* mom, const float* eps, float* snapshot,
+                             int64_t n, ursa_step_ctl* ctl, ursa_stream_t stream)
+{
+    return ursa_sgmcmc_step_multi_f32(theta, grad, mom, eps, snapshot, n, 1, 0, ctl, stream);
+}
+
+int ursa_step_ctl_advance(ursa_step_ctl* ctl, ursa_stream_t stream)
 {
     if (!ctl) return URSA_ENULL;
-    if (sched && sched_len == 0) return URSA_ESIZE;
-    hipLaunchKernelGGL(k_step_ctl_advance, dim3(1), dim3(64), 0, (hipStream_t)stream, ctl, sched, sched_len);
+    hipLaunchKernelGGL(k_step_ctl_advance, dim3(1), dim3(64), 0, (hipStream_t)stream, ctl);
     return launch_status();
 }
 

@@ -7,12 +7,18 @@ the capture) and the runtime overlaps the branches. Measured on MI355X, PreResNe
 (tools/exp/multichain_onegraph.py): 422 -> 648 -> 859 -> 870 aggregate minibatch steps/s for K = 1, 2, 4,
 8. (K separate graphs launched on K streams do NOT overlap: 410-445 steps/s for every K.)
 
-Each chain keeps its own sampler object (model, arena, control block, Philox seed, member bank) and its
-own state machine; the group only drives their epoch generators together. Every chain computes exactly
-what it would compute alone on the same minibatch sequence.
+Each chain keeps its own sampler object (model, control block, Philox seed, member bank) and its own state
+machine; the group only drives their epoch generators together. Every chain computes exactly what it would
+compute alone on the same minibatch sequence.
+
+The chains' vectors live in ONE slab per kind — theta[K, n], grad[K, n], mom[K, n] — and their control blocks
+in one array ctl[K] (SURVEY.md 8b `n_chains`, 8f-1): the K forward/backward branches join, then ONE launch of
+`ursa_sgmcmc_step_multi_f32` (blockIdx.y = chain) updates all K chains and advances their K control blocks.
+Round 2 issued K x (update + 1-thread advance) launches per lock-step round.
 """
 import torch
 
+from .. import _native
 from .._capture import capture, side_streams
 from .sghmc import _ChainSampler
 
@@ -30,20 +36,43 @@ class ChainGroup:
         if len(set(seeds)) != len(seeds):
             raise ValueError(f'chains of a group share a Philox key {seeds}: they would draw bit-identical noise on the '
                              'same minibatches. Construct them with distinct seed= (or util.set_random_seed between them)')
+        if len({s.arena.n for s in samplers}) != 1:
+            raise ValueError('the chains of a group must have equally sized arenas (one [K, n] slab, one launch)')
         self.samplers = samplers
         self.loader = samplers[0].train_loader
         self.device = torch.device(samplers[0].device)
         self.use_graph = (self.device.type == 'cuda') if use_graph is None else use_graph
+        self.kernels = samplers[0].optimizer.kernels
         self._graph, self._static, self._warm, self._captured_with = None, None, 0, None
-        self.stats = dict(graph_replays=0, eager_rounds=0, captures=0)
+        self._graph_eps = False
+        self.stats = dict(graph_replays=0, eager_rounds=0, captures=0, update_launches=0)
+        # one slab per vector kind, one control-block array: chain k lives in row k
+        K, n, dev = len(samplers), samplers[0].arena.n, samplers[0].arena.device
+        self.theta, self.grad, self.mom = (torch.zeros(K, n, device=dev) for _ in range(3))
+        self.ctl = torch.zeros(K * _native.CTL_BYTES, dtype=torch.uint8, device=dev)
+        self.eps = None                                   # [K, n] injected noise (parity runs), allocated on demand
+        for k, s in enumerate(samplers):
+            s.arena.rehome(self.theta[k], self.grad[k], self.mom[k])
+            s.optimizer.rehomed()
+            s.optimizer.set_ctl_storage(self.ctl[k * _native.CTL_BYTES:(k + 1) * _native.CTL_BYTES])
+            s.engine.invalidate()                         # a graph of the chain alone holds the old addresses
 
     def __len__(self):
         return len(self.samplers)
 
     # ---- one lock-step minibatch round ------------------------------------------------------
+    def _update(self, keeps):
+        """ONE launch for the K chains (+ their control-block advances), then the rare put-backs."""
+        self.kernels.sgmcmc_step_multi(self.theta, self.grad, self.mom, self.ctl,
+                                       eps=self.eps if self._graph_eps else None)
+        self.stats['update_launches'] += 1
+        for s, keep in zip(self.samplers, keeps):
+            s.engine.finish(keep)
+
     def _round_eager(self, x, y):
-        for s in self.samplers:
-            s.engine._train_step(x, y)
+        keeps = [s.engine.forward_backward(x, y) for s in self.samplers]
+        with torch.no_grad():
+            self._update(keeps)
 
     def _capture(self, x, y):
         self._static = (torch.empty_like(x), torch.empty_like(y))
@@ -51,37 +80,58 @@ class ChainGroup:
         self._static[1].copy_(y)
         side = side_streams(self.device, len(self.samplers))
         g = torch.cuda.CUDAGraph()
+        launches = self.stats['update_launches']
         with capture(g):
             cap = torch.cuda.current_stream(self.device)
-            for s, st in zip(self.samplers, side):          # fork: one branch per chain
+            keeps = []
+            for s, st in zip(self.samplers, side):          # fork: one forward/backward branch per chain
                 st.wait_stream(cap)
                 with torch.cuda.stream(st):
-                    s.engine._train_step(*self._static)
+                    keeps.append(s.engine.forward_backward(*self._static))
             for st in side:                                  # join
                 cap.wait_stream(st)
+            with torch.no_grad():
+                self._update(keeps)                          # one update launch for all chains
+        self.stats['update_launches'] = launches             # a capture records, it does not execute
         self._graph = g
         self._captured_with = self._device_state()
         self.stats['captures'] += 1
 
     def _device_state(self):
         """What a captured round bakes in per chain: the optimizer object and the addresses of its control
-        block, schedule table and momentum buffer."""
+        block, schedule table and vectors."""
         ptr = lambda t: None if t is None else t.data_ptr()
-        return [(id(s.optimizer), ptr(s.optimizer._ctl), ptr(s.optimizer._sched), ptr(s.arena.mom)) for s in self.samplers]
+        return [(id(s.optimizer), ptr(s.optimizer._ctl), ptr(s.optimizer._sched), ptr(s.arena.mom), ptr(s.arena.theta))
+                for s in self.samplers]
 
     def _run_epoch(self, plans):
         for s, (noise, sched) in zip(self.samplers, plans):
             s.model.train()
             s.engine.loss_acc.zero_()
             s.optimizer.ctl_begin(noise, sched)
-        if self._graph is not None and self._device_state() != self._captured_with:
-            # update_hyp on a member rebuilt its optimizer: the captured round would step the old one
-            self._graph, self._static, self._warm, self._captured_with = None, None, 0, None
+        for k, s in enumerate(self.samplers):
+            if s.optimizer._ctl.data_ptr() != self.ctl.data_ptr() + k * _native.CTL_BYTES:
+                raise RuntimeError(f'chain {k}: its optimizer was replaced without adopting the group\'s control block '
+                                   '(use the sampler\'s update_hyp)')
+        providers = [s._eps_for_epoch() for s in self.samplers]
+        inject = any(p is not None for p in providers)
+        if inject and not all(p is not None for p in providers):
+            raise ValueError('either every chain of a group injects noise (eps_provider) or none does')
+        if inject and self.eps is None:
+            self.eps = torch.zeros_like(self.theta)
+        if self._graph is not None and (self._device_state() != self._captured_with or self._graph_eps != inject):
+            # update_hyp on a member rebuilt its optimizer (the captured round would step the old one), or the
+            # captured update launch reads / does not read the injected-noise slab
+            self._graph, self._captured_with = None, None
+        self._graph_eps = inject
         full = getattr(self.loader, 'batch_size', None)
         seen = steps = 0
         for x, y in self.loader:
             x = x.to(self.device, non_blocking=True)
             y = y.to(self.device, non_blocking=True)
+            if inject:
+                for k, p in enumerate(providers):
+                    self.eps[k].copy_(p(steps))
             if self.use_graph and x.shape[0] == full:
                 if self._graph is None and self._warm >= self.WARMUP_STEPS:
                     self._capture(x, y)
@@ -90,6 +140,7 @@ class ChainGroup:
                     self._static[1].copy_(y)
                     self._graph.replay()
                     self.stats['graph_replays'] += 1
+                    self.stats['update_launches'] += 1
                 else:
                     side = side_streams(self.device, 1)[0]
                     side.wait_stream(torch.cuda.current_stream(self.device))

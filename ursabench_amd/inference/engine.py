@@ -7,7 +7,12 @@ removed relative to the reference: 8 launches per parameter tensor per step (488
 PreResNet-20), `optimizer.zero_grad()` (fused into the update), the per-step host sync
 `loss.item()` (sghmc.py:82; the loss is accumulated on the device) and every host-side launch
 gap (graph replay). Per-step scalars (lr, noise scale, noise on/off, Philox counter) live in a
-48-byte device control block so the captured graph stays valid while they change.
+64-byte device control block so the captured graph stays valid while they change; the update
+launch advances the block itself.
+
+Injected noise (parity runs: `eps_per_step`) goes through ONE persistent device buffer that the
+captured update launch reads: the host refills it before every replay, so the replayed graph — the
+path that is timed — is the path the reference comparisons execute.
 """
 import torch
 
@@ -28,10 +33,11 @@ class ChainEngine:
         self.use_graph = use_graph
         self.loss_acc = torch.zeros((), device=self.device)     # sum_i loss_i * batch_i, on device
         self._params = list(optimizer.arena.params)
-        self._grad_views = list(optimizer.arena.grad_views)
         optimizer.ctl_zero_grad = False                         # the packed copy overwrites every gradient
         self._graph = None
+        self._graph_eps = False          # whether the captured update launch reads the injected-noise buffer
         self._static = None
+        self._eps_static = None
         self._eager_full_steps = 0
         self.stats = dict(graph_replays=0, eager_steps=0, captures=0)
 
@@ -44,7 +50,9 @@ class ChainEngine:
         optimizer.ctl_zero_grad = False
         self.invalidate()
 
-    def _train_step(self, x, y, eps=None):
+    def forward_backward(self, x, y):
+        """Forward + loss + backward, gradients packed into the arena. Returns what `finish` needs to put back
+        the tensors that received no gradient (None almost always)."""
         with deferred_bn_counters(self.model):       # 19 one-element counter kernels -> one multi-tensor add
             logits = self.model(x)
         loss = self.crit(logits, y)
@@ -56,23 +64,31 @@ class ChainEngine:
             p.grad = None
         loss.backward()
         grads = [p.grad for p in self._params]
+        grad_views = self.opt.arena.grad_views
         keep = None
         if any(g is None for g in grads):
             # a parameter that received no gradient (frozen / unused layer) is skipped by the reference
             # altogether (optim_sghmc.py:44-45): no prior pull, no noise. The flat launch covers it, so its
             # theta / momentum slices are copied aside and put back (device-to-device, part of the capture).
-            pairs = [(v, g) for v, g in zip(self._grad_views, grads) if g is not None]
+            pairs = [(v, g) for v, g in zip(grad_views, grads) if g is not None]
             torch._foreach_copy_([v for v, _ in pairs], [g for _, g in pairs])
             if getattr(self.opt, 'skip_grad_none', True):
                 keep = self.opt.arena.stash([i for i, g in enumerate(grads) if g is None])
         else:
-            torch._foreach_copy_(self._grad_views, grads)
+            torch._foreach_copy_(grad_views, grads)
         for p in self._params:
             p.grad = None
         self.loss_acc.add_(loss.detach(), alpha=x.shape[0])
-        self.opt.ctl_step(eps=eps)
+        return keep
+
+    def finish(self, keep):
         if keep is not None:
             self.opt.arena.unstash(keep)
+
+    def _train_step(self, x, y, eps=None):
+        keep = self.forward_backward(x, y)
+        self.opt.ctl_step(eps=eps)
+        self.finish(keep)
 
     def _capture(self, x, y):
         self._static = (torch.empty_like(x), torch.empty_like(y))
@@ -82,7 +98,7 @@ class ChainEngine:
         # thread_local: RCCL's watchdog thread (one process per GPU jobs) may touch the HIP runtime while
         # this thread captures; only this thread's calls belong to the capture
         with capture(g):
-            self._train_step(*self._static)
+            self._train_step(*self._static, eps=self._eps_static if self._graph_eps else None)
         self._graph = g
         self.stats['captures'] += 1
 
@@ -94,12 +110,20 @@ class ChainEngine:
         self.opt.ctl_begin(add_langevin_noise, sched)
         full = getattr(loader, 'batch_size', None)
         seen = steps = 0
-        graph_ok = self.use_graph and eps_per_step is None
+        inject = eps_per_step is not None
+        if inject and self._eps_static is None:
+            self._eps_static = torch.zeros_like(self.opt.arena.theta)
+        if self._graph is not None and self._graph_eps != inject:
+            self._graph = None                       # the captured launch reads / does not read the noise buffer
+        self._graph_eps = inject
+        eps_buf = self._eps_static if inject else None
         for bi, (x, y) in enumerate(loader):
             x = x.to(self.device, non_blocking=True)
             y = y.to(self.device, non_blocking=True)
             b = x.shape[0]
-            if graph_ok and b == full:
+            if inject:
+                self._eps_static.copy_(eps_per_step(steps))
+            if self.use_graph and b == full:
                 if self._graph is None and self._eager_full_steps >= self.WARMUP_STEPS:
                     self._capture(x, y)            # records the step; the replay below executes it
                 if self._graph is not None:
@@ -114,12 +138,12 @@ class ChainEngine:
                     s = side_streams(self.device, 1)[0]
                     s.wait_stream(torch.cuda.current_stream(self.device))
                     with torch.cuda.stream(s):
-                        self._train_step(x, y)
+                        self._train_step(x, y, eps_buf)
                     torch.cuda.current_stream(self.device).wait_stream(s)
                     self._eager_full_steps += 1
                     self.stats['eager_steps'] += 1
             else:
-                self._train_step(x, y, None if eps_per_step is None else eps_per_step(steps))
+                self._train_step(x, y, eps_buf)
                 self.stats['eager_steps'] += 1
             seen += b
             steps += 1

@@ -132,6 +132,21 @@ class optimSGHMC(Optimizer):
         return loss
 
     # ---- device-control-block stepping (used by the samplers; hipGraph-replayable) -----------
+    def set_ctl_storage(self, view):
+        """Keep this optimizer's control block in caller-provided device storage (one 64-byte slot of the block
+        array a ChainGroup hands to the multi-chain launch). The current contents move along."""
+        if view.numel() != _native.CTL_BYTES or view.dtype != torch.uint8:
+            raise ValueError('control-block storage must be sizeof(ursa_step_ctl) uint8 elements')
+        if self._ctl is not None:
+            view.copy_(self._ctl)
+        self._ctl = view
+
+    def rehomed(self):
+        """The arena moved (FlatArena.rehome): re-point the lazily created momentum_buffer state entries."""
+        for gi in range(len(self.param_groups)):
+            if self._has_mom[gi]:
+                self._register_momentum_views(gi)
+
     def ctl_begin(self, add_langevin_noise, sched=None):
         """Upload this epoch's scalars. sched: optional float32 [steps, 2] of (lr, c_noise) per step."""
         if len(self.param_groups) != 1:
@@ -139,10 +154,22 @@ class optimSGHMC(Optimizer):
         a, group = self.arena, self.param_groups[0]
         sc = self._scalars(group, add_langevin_noise, 0)
         a.ensure_mom()
+        if sched is None:
+            if self._sched is not None:
+                raise ValueError('this optimizer was stepped with a schedule table before; keep passing one')
+        else:
+            # persistent buffer: the control block (and so a captured graph) holds its address and length
+            if self._sched is None:
+                self._sched = torch.zeros(sched.shape[0], 2, device=a.device)
+            if self._sched.shape != sched.shape:
+                raise ValueError(f'schedule table changed shape {tuple(self._sched.shape)} -> {tuple(sched.shape)}')
+            self._sched.copy_(sched)
+        # the update launch advances the block itself (last retiring workgroup): no second launch per step
         c = _native.StepCtl(lr=sc['lr'], mu=sc['mu'], c_wd=sc['c_wd'], c_noise=sc['c_noise'], n_train=sc['n_train'],
-                            flags=sc['flags'] | (_native.STEP_ZERO_GRAD if self.ctl_zero_grad else 0), seed=self.seed,
-                            step=self._step,
-                            sched_base=self._step)
+                            flags=sc['flags'] | _native.STEP_ADVANCE | (_native.STEP_ZERO_GRAD if self.ctl_zero_grad else 0),
+                            seed=self.seed, step=self._step, sched_base=self._step,
+                            sched=0 if self._sched is None else self._sched.data_ptr(),
+                            sched_len=0 if self._sched is None else self._sched.shape[0], ticket=0)
         if sched is not None:
             c.lr = float(sched[0, 0])
             if sc['flags'] & _native.STEP_SGD:
@@ -151,25 +178,15 @@ class optimSGHMC(Optimizer):
                 c.c_noise = float(sched[0, 1])
         host = torch.frombuffer(bytearray(bytes(c)), dtype=torch.uint8)
         if self._ctl is None:
-            self._ctl = torch.zeros(ctypes.sizeof(_native.StepCtl), dtype=torch.uint8, device=a.device)
+            self._ctl = torch.zeros(_native.CTL_BYTES, dtype=torch.uint8, device=a.device)
         self._ctl.copy_(host)
-        if sched is None:
-            if self._sched is not None:
-                raise ValueError('this optimizer was stepped with a schedule table before; keep passing one')
-        else:
-            # persistent buffer: a captured graph bakes its address and length
-            if self._sched is None:
-                self._sched = torch.zeros(sched.shape[0], 2, device=a.device)
-            if self._sched.shape != sched.shape:
-                raise ValueError(f'schedule table changed shape {tuple(self._sched.shape)} -> {tuple(sched.shape)}')
-            self._sched.copy_(sched)
         self._ctl_mu = c.mu
 
     @torch.no_grad()
     def ctl_step(self, eps=None):
+        """ONE launch: the update, and (STEP_ADVANCE) the advance of the control block."""
         a = self.arena
         self.kernels.sgmcmc_step_ctl(a.theta, a.grad, a.mom, self._ctl, eps=eps)
-        self.kernels.step_ctl_advance(self._ctl, self._sched)
 
     def ctl_end(self, n_steps):
         self._step += n_steps
