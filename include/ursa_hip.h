@@ -87,10 +87,11 @@ int ursa_sgmcmc_step_f32(float* theta, float* grad, float* mom /* NULL iff mu ==
  * (lr, momentum) of OneCycleLR, URSABench/inference/vi_dropout.py:59-61,107. `step` is also
  * the Philox call index, so it only ever grows.
  * With URSA_STEP_ADVANCE in ctl->flags the update launch advances its own block: every
- * workgroup takes a ticket when it retires and the last one of the chain does the advance
- * (all others have read the block by then) and re-arms the ticket — no second launch.
- * ursa_step_ctl_advance is the same advance as a 1-thread launch, for hosts that step
- * a block without an update. `ticket` is device scratch: upload it as 0. */
+ * workgroup takes a ticket once all of its waves hold a copy of the block, and the one that
+ * draws the chain's last ticket does the advance (all others have read the block by then)
+ * and re-arms the ticket — no second launch. ursa_step_ctl_advance is the same advance as a
+ * launch of its own (one thread per block of ctl[n_ctl]), for roofline-sized chains and for
+ * hosts that step a block without an update. `ticket` is device scratch: upload it as 0. */
 #define URSA_STEP_ADVANCE   0x20u
 typedef struct ursa_step_ctl {
     float lr, mu, c_wd, c_noise, n_train;
@@ -104,7 +105,10 @@ typedef struct ursa_step_ctl {
 int ursa_sgmcmc_step_ctl_f32(float* theta, float* grad, float* mom, const float* eps,
                              float* snapshot, int64_t n, ursa_step_ctl* ctl,
                              ursa_stream_t stream);
-int ursa_step_ctl_advance(ursa_step_ctl* ctl, ursa_stream_t stream);
+int ursa_step_ctl_advance(ursa_step_ctl* ctl /* [n_ctl] */, int32_t n_ctl, ursa_stream_t stream);
+/* Self-advancing launches are for workload-sized chains (every workgroup takes a ticket, ~11 ns each on one
+ * address): hosts use them up to this many elements per chain and the explicit advance launch beyond. */
+#define URSA_SELF_ADVANCE_MAX_ELEMS (1 << 20)
 
 /* K chains in ONE launch (SURVEY.md 8b `n_chains`, 8f-1): the K independent chains that share a GPU
  * keep their vectors in [K, chain_stride] slabs — chain k's theta / grad / mom (/ eps / snapshot)

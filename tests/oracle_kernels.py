@@ -50,6 +50,10 @@ class OracleKernels:
                                  snapshot=None if snapshot is None else snapshot[k, :n])
 
     def step_ctl_advance(self, ctl):
+        if ctl.numel() > CTL_BYTES:
+            for k in range(ctl.numel() // CTL_BYTES):
+                self.step_ctl_advance(ctl[k * CTL_BYTES:(k + 1) * CTL_BYTES])
+            return
         c = StepCtl.from_buffer_copy(bytes(ctl.numpy()))
         c.step += 1
         c.flags &= ~O.STEP_FIRST

@@ -25,16 +25,23 @@ def one(block):
     out = []
     for chains in (1, 2, 4, 8, 16):
         th, g, m = (torch.randn(chains, n, device='cuda') for _ in range(3))
-        blocks = b''.join(bytes(_native.StepCtl(lr=0.1, mu=0.5, c_wd=8e-5, c_noise=0.3, n_train=50000.0, flags=0x1 | 0x8 | 0x20,
-                                                seed=1 + k, step=0)) for k in range(chains))
-        ctl = torch.frombuffer(bytearray(blocks), dtype=torch.uint8).cuda()
-        med, best = timeit(lambda: K.sgmcmc_step_multi(th, g, m, ctl), 30, batch=64)
-        back = _native.StepCtl.from_buffer_copy(bytes(ctl.cpu().numpy())[:_native.CTL_BYTES])
-        byt = 20 * n * chains
-        out.append(dict(block=block or 'auto', chains=chains, elements=n * chains, median_us=round(med * 1e6, 3), best_us=round(best * 1e6, 3),
-                        GBps_median=round(byt / med / 1e9, 1), frac_of_8TBps=round(byt / med / 8e12, 4), ctl_step_after=back.step,
-                        ticket_after=back.ticket))
-        print(json.dumps(out[-1]), flush=True)
+        for mode in ('self_advance', 'no_advance', 'explicit_advance_launch'):
+            fl = 0x1 | 0x8 | (0x20 if mode == 'self_advance' else 0)
+            blocks = b''.join(bytes(_native.StepCtl(lr=0.1, mu=0.5, c_wd=8e-5, c_noise=0.3, n_train=50000.0, flags=fl,
+                                                    seed=1 + k, step=0)) for k in range(chains))
+            ctl = torch.frombuffer(bytearray(blocks), dtype=torch.uint8).cuda()
+
+            def fn():
+                K.sgmcmc_step_multi(th, g, m, ctl)
+                if mode == 'explicit_advance_launch':
+                    K.step_ctl_advance(ctl)
+            med, best = timeit(fn, 30, batch=64)
+            back = _native.StepCtl.from_buffer_copy(bytes(ctl.cpu().numpy())[:_native.CTL_BYTES])
+            byt = 20 * n * chains
+            out.append(dict(block=block or 'auto', chains=chains, mode=mode, elements=n * chains, median_us=round(med * 1e6, 3),
+                            best_us=round(best * 1e6, 3), GBps_median=round(byt / med / 1e9, 1),
+                            frac_of_8TBps=round(byt / med / 8e12, 4), ctl_step_after=back.step, ticket_after=back.ticket))
+            print(json.dumps(out[-1]), flush=True)
     return out
 
 
@@ -46,7 +53,7 @@ def main():
         one(a.block)
         return
     res = []
-    for b in (0, 64, 128, 256, 512):
+    for b in (0, 256, 1024):
         p = subprocess.run([sys.executable, os.path.abspath(__file__), '--block', str(b)], capture_output=True, text=True)
         sys.stderr.write(p.stderr[-2000:])
         for ln in p.stdout.splitlines():

@@ -24,6 +24,7 @@ STEP_NOISE, STEP_FIRST, STEP_ZERO_GRAD, STEP_WD, STEP_SGD, STEP_ADVANCE = 0x1, 0
 BMA_SMOOTHED = 0x1
 LEAP_KICK, LEAP_DRIFT = 0x1, 0x2
 REDUCE_WS_FLOATS = 2048
+SELF_ADVANCE_MAX_ELEMS = 1 << 20
 BMA_MAX_CLASSES = 1024
 
 _vp, _i64, _i32, _u64, _u32, _f = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_uint64,
@@ -35,7 +36,7 @@ SIGNATURES = {
     'ursa_strerror': (ctypes.c_char_p, [ctypes.c_int]),
     'ursa_sgmcmc_step_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _u64, _u64, _u32, _vp]),
     'ursa_sgmcmc_step_ctl_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
-    'ursa_step_ctl_advance': (ctypes.c_int, [_vp, _vp]),
+    'ursa_step_ctl_advance': (ctypes.c_int, [_vp, _i32, _vp]),
     'ursa_sgmcmc_step_multi_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp]),
     'ursa_philox_normal_f32': (ctypes.c_int, [_vp, _i64, _u64, _u64, _vp]),
     'ursa_swag_collect_f32': (ctypes.c_int, [_vp, _vp, _vp, _i64, _f, _f, _vp]),
@@ -179,10 +180,12 @@ class HipKernels:
         _check(self.lib, rc, 'ursa_sgmcmc_step_multi_f32')
 
     def step_ctl_advance(self, ctl):
+        """Advance every control block of `ctl` (one launch, one thread per block)."""
         dev = ctl.device
-        cp = _ctl_ptr(ctl)
+        n_ctl = ctl.numel() // CTL_BYTES
+        cp = _ctl_ptr(ctl, n_ctl)
         with torch.cuda.device(dev):
-            rc = self.lib.ursa_step_ctl_advance(cp, _stream(dev))
+            rc = self.lib.ursa_step_ctl_advance(cp, n_ctl, _stream(dev))
         _check(self.lib, rc, 'ursa_step_ctl_advance')
 
     def philox_normal(self, out, *, seed, step):

@@ -134,10 +134,15 @@ __device__ __forceinline__ void step_elem(float& th, float g, float& v, float e,
     v = d;                                                                // :67
 }
 
-template <bool MOM, int NOISE, bool NT>
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+
+// `after_loads` runs once per thread right after the thread's vector loads (before the Philox arithmetic, the update
+// and the stores): the control-block launch takes its ticket there.
+template <bool MOM, int NOISE, bool NT, class Hook = NoHook>
 __device__ __forceinline__ void step_body(float* __restrict__ theta, float* __restrict__ grad,
                                           float* __restrict__ mom, const float* __restrict__ eps,
-                                          float* __restrict__ snapshot, int64_t n, const StepScalars& s)
+                                          float* __restrict__ snapshot, int64_t n, const StepScalars& s,
+                                          Hook after_loads = Hook())
 {
     const int64_t n4 = n >> 2;
     const bool zero_grad = s.flags & URSA_STEP_ZERO_GRAD;
@@ -154,6 +159,7 @@ __device__ __forceinline__ void step_body(float* __restrict__ theta, float* __re
         float4 v = MOM ? ld4<NT>(m4 + i) : make_float4(0.f, 0.f, 0.f, 0.f);
         float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
         if (NOISE == kNoisePtr) e = ld4<NT>(e4 + i);
+        after_loads();
         if (NOISE == kNoisePhilox) e = ursa::normal4(s.seed, s.step, (uint64_t)i);
         step_elem<MOM>(t.x, g.x, v.x, e.x, s, NOISE != kNoiseOff);
         step_elem<MOM>(t.y, g.y, v.y, e.y, s, NOISE != kNoiseOff);
@@ -163,6 +169,8 @@ __device__ __forceinline__ void step_body(float* __restrict__ theta, float* __re
         if (MOM) st4<NT>(m4 + i, v);
         if (zero_grad) st4<NT>(g4 + i, make_float4(0.f, 0.f, 0.f, 0.f));
         if (snapshot) st4<NT>(s4 + i, t);
+    } else {
+        after_loads();
     }
     // scalar tail (n % 4 elements): handled by the first lanes of block 0
     const int64_t tail0 = n4 << 2;
@@ -213,13 +221,25 @@ __device__ __forceinline__ void ctl_advance(ursa_step_ctl* ctl)
 // Scalars from a device control block (graph-replayable launch), K chains per launch: blockIdx.y is the
 // chain, its vectors start at blockIdx.y * chain_stride, its scalars are ctl[blockIdx.y]. One kernel covers
 // every (mu, noise) combination with wave-uniform branches: the replayed graph must keep working when the
-// host flips NOISE between replays. With URSA_STEP_ADVANCE the chain's last retiring workgroup advances the
-// block (every other workgroup of the chain has read it by then: the ticket is taken after a block-wide
-// barrier that follows every wave's reads) — the 1-thread advance launch of round 2 is gone.
+// host flips NOISE between replays.
+//
+// URSA_STEP_ADVANCE: the launch advances the chain's block itself (round 2: a second, 1-thread launch per step).
+// What has to be ordered is "every workgroup has READ *ctl" before "somebody WRITES *ctl". Each workgroup copies the
+// block into registers, passes a workgroup barrier (all of its waves hold their copy), and its thread 0 takes a ticket
+// (relaxed agent-scope fetch-add: tickets on one address are totally ordered) right after its vector loads, with the
+// next schedule row prefetched. The workgroup that drew the last ticket knows every workgroup of the chain holds its
+// copy: at its end it writes the next step's scalars and re-arms the ticket. Nobody waits on anybody else: no fence, no
+// spinning. Measured at the PreResNet-20 arena (134 workgroups of 512, tools/k1_ctl_bench.py, us per launch inside a
+// graph replay): no advance 2.8; ticket + advance at the END of the workgroup behind __threadfence() 6.5 (a release
+// fence is an L2 write-back per workgroup); same without fences 5.4; ticket right after the loads (this) 4.05 — the
+// launch grows by ~11 ns per workgroup (same-address atomics serialise); a dedicated ticket wave per workgroup that
+// fires at kernel start 5.4 and 3x worse for 16 chains (all tickets at once: 25-47 ns each). A streaming launch of
+// 100+ us does not want 11 ns x 18,000 workgroups: hosts self-advance up to URSA_SELF_ADVANCE_MAX_ELEMS per chain and
+// use the explicit advance launch beyond.
 template <bool NT>
-__global__ __launch_bounds__(kSBlock) void k_sgmcmc_step_ctl(float* theta, float* grad, float* mom,
-                                                             const float* eps, float* snapshot, int64_t n,
-                                                             int64_t chain_stride, ursa_step_ctl* ctl_base)
+__global__ __launch_bounds__(1024) void k_sgmcmc_step_ctl(float* theta, float* grad, float* mom,
+                                                          const float* eps, float* snapshot, int64_t n,
+                                                          int64_t chain_stride, ursa_step_ctl* ctl_base)
 {
     ursa_step_ctl* ctl = ctl_base + blockIdx.y;
     const int64_t off = (int64_t)blockIdx.y * chain_stride;
@@ -229,33 +249,60 @@ __global__ __launch_bounds__(kSBlock) void k_sgmcmc_step_ctl(float* theta, float
     StepScalars s;
     s.lr = ctl->lr; s.mu = ctl->mu; s.c_wd = ctl->c_wd; s.c_noise = ctl->c_noise;
     s.n_train = ctl->n_train; s.flags = ctl->flags; s.seed = ctl->seed; s.step = ctl->step;
-    const bool noise = s.flags & URSA_STEP_NOISE;
-    if (s.mu != 0.0f) {
-        if (!noise) step_body<true, kNoiseOff, NT>(theta, grad, mom, eps, snapshot, n, s);
-        else if (eps) step_body<true, kNoisePtr, NT>(theta, grad, mom, eps, snapshot, n, s);
-        else step_body<true, kNoisePhilox, NT>(theta, grad, mom, eps, snapshot, n, s);
-    } else {
-        if (!noise) step_body<false, kNoiseOff, NT>(theta, grad, mom, eps, snapshot, n, s);
-        else if (eps) step_body<false, kNoisePtr, NT>(theta, grad, mom, eps, snapshot, n, s);
-        else step_body<false, kNoisePhilox, NT>(theta, grad, mom, eps, snapshot, n, s);
-    }
-    if (s.flags & URSA_STEP_ADVANCE) {                   // uniform over the launch's chain
-        __syncthreads();                                 // every wave of this workgroup is past its reads of *ctl
+    const bool advance = s.flags & URSA_STEP_ADVANCE;    // uniform over the chain's workgroups
+    uint32_t ticket = 0;
+    float next_lr = 0.f, next_col = 0.f;
+    bool walk = false;
+    if (advance) {
+        __syncthreads();                                 // every wave of this workgroup holds its copy of *ctl
         if (threadIdx.x == 0) {
-            __threadfence();
-            const uint32_t t = atomicAdd(&ctl->ticket, 1u);
-            if (t == gridDim.x - 1) {                    // last workgroup of this chain
-                __threadfence();
-                ctl_advance(ctl);
-                ctl->ticket = 0;
+            const float* sched = ctl->sched;             // (sched, sched_len, sched_base are never written by the device)
+            const uint32_t sched_len = ctl->sched_len;
+            if (sched != nullptr && sched_len != 0) {
+                const uint64_t k = (s.step + 1 - ctl->sched_base) % sched_len;
+                next_lr = sched[2 * k];
+                next_col = sched[2 * k + 1];
+                walk = true;
             }
         }
     }
+    // The address goes through a VGPR the compiler must treat as lane-varying (with a provably uniform address its
+    // atomic optimizer rewrites the add into a wave-aggregated one whose v_readfirstlane waits for the result at once)
+    // and stays a GLOBAL pointer (a flat atomic forces vmcnt(0)/lgkmcnt(0) waits).
+    auto take_ticket = [&]() {
+        if (advance && threadIdx.x == 0) {
+            typedef __attribute__((address_space(1))) uint32_t gu32;
+            gu32* tp = (gu32*)&ctl->ticket;
+            asm volatile("" : "+v"(tp));
+            ticket = __hip_atomic_fetch_add(tp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    const bool noise = s.flags & URSA_STEP_NOISE;
+    if (s.mu != 0.0f) {
+        if (!noise) step_body<true, kNoiseOff, NT>(theta, grad, mom, eps, snapshot, n, s, take_ticket);
+        else if (eps) step_body<true, kNoisePtr, NT>(theta, grad, mom, eps, snapshot, n, s, take_ticket);
+        else step_body<true, kNoisePhilox, NT>(theta, grad, mom, eps, snapshot, n, s, take_ticket);
+    } else {
+        if (!noise) step_body<false, kNoiseOff, NT>(theta, grad, mom, eps, snapshot, n, s, take_ticket);
+        else if (eps) step_body<false, kNoisePtr, NT>(theta, grad, mom, eps, snapshot, n, s, take_ticket);
+        else step_body<false, kNoisePhilox, NT>(theta, grad, mom, eps, snapshot, n, s, take_ticket);
+    }
+    if (advance && threadIdx.x == 0 && ticket == gridDim.x - 1) {      // same arithmetic as ctl_advance()
+        ctl->step = s.step + 1;
+        ctl->flags = s.flags & ~URSA_STEP_FIRST;
+        if (walk) {
+            ctl->lr = next_lr;
+            if (s.flags & URSA_STEP_SGD) ctl->mu = next_col;
+            else ctl->c_noise = next_col;
+        }
+        __hip_atomic_store(&ctl->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
-__global__ void k_step_ctl_advance(ursa_step_ctl* ctl)
+__global__ void k_step_ctl_advance(ursa_step_ctl* ctl, int n_ctl)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0) ctl_advance(ctl);
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n_ctl) ctl_advance(ctl + k);
 }
 
 // Unaligned fallback: same arithmetic, 4 B per lane. Element i still takes lane (i & 3) of
@@ -1047,11 +1094,11 @@ inline int ctl_block(int64_t n4, int n_chains)
     static const int forced = [] {
         const char* e = getenv("URSA_CTL_BLOCK");
         const int v = e && e[0] ? atoi(e) : 0;
-        return (v == 64 || v == 128 || v == 256 || v == 512) ? v : 0;
+        return (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) ? v : 0;
     }();
     if (forced) return forced;
-    const int64_t lanes = n4 * n_chains;
-    return lanes >= 2048ll * kSBlock ? kSBlock : lanes >= 1024ll * 256 ? 256 : 128;
+    (void)n4; (void)n_chains;
+    return kSBlock;
 }
 
 int ursa_sgmcmc_step_multi_f32(float* theta, float* grad, float* mom, const float* eps, float* snapshot,
@@ -1085,10 +1132,12 @@ int ursa_sgmcmc_step_ctl_f32(float* theta, float* grad, float* mom, const float*
     return ursa_sgmcmc_step_multi_f32(theta, grad, mom, eps, snapshot, n, 1, 0, ctl, stream);
 }
 
-int ursa_step_ctl_advance(ursa_step_ctl* ctl, ursa_stream_t stream)
+int ursa_step_ctl_advance(ursa_step_ctl* ctl, int32_t n_ctl, ursa_stream_t stream)
 {
     if (!ctl) return URSA_ENULL;
-    hipLaunchKernelGGL(k_step_ctl_advance, dim3(1), dim3(64), 0, (hipStream_t)stream, ctl);
+    if (n_ctl < 0) return URSA_ESIZE;
+    if (n_ctl == 0) return URSA_OK;
+    hipLaunchKernelGGL(k_step_ctl_advance, dim3((n_ctl + 63) / 64), dim3(64), 0, (hipStream_t)stream, ctl, (int)n_ctl);
     return launch_status();
 }
 
