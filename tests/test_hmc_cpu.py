@@ -110,3 +110,48 @@ def test_wrapper_semantics_vs_reference(golden_dir):
 def theta0_of(hyp):
     torch.manual_seed(1)
     return torch.cat([p.detach().reshape(-1) for p in tiny_net().parameters()])
+
+
+def test_host_philox_matches_oracle_and_known_answers():
+    """The Metropolis uniform's generator: the host Philox4x32-10 of inference/hmc.py == the oracle's (itself pinned
+    by Random123's known-answer vectors, tests/test_oracle_golden.py) on those vectors and on random counters."""
+    import oracle_lib as O
+    from ursabench_amd.inference.hmc import mh_uniform, philox4x32_10
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        assert philox4x32_10(ctr, key) == want == tuple(O.philox4x32_10(ctr, key))
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        ctr, key = tuple(int(v) for v in rng.integers(0, 2 ** 32, 4)), tuple(int(v) for v in rng.integers(0, 2 ** 32, 2))
+        assert list(philox4x32_10(ctr, key)) == O.philox4x32_10(ctr, key)
+    us = [mh_uniform(7, k) for k in range(2000)]
+    assert all(0.0 < u < 1.0 for u in us) and abs(np.mean(us) - 0.5) < 0.03 and len(set(us)) == 2000
+    assert mh_uniform(7, 3) == mh_uniform(7, 3) != mh_uniform(8, 3)
+
+
+def test_accept_sequence_is_the_chains_own():
+    """the MH uniform came from the process-global torch.rand, so a chain's accept sequence
+    depended on how many chains shared the process. Now it is Philox under the chain's key: a chain run alone and the
+    same chain run interleaved with another (and with foreign torch.rand calls) accept the same proposals."""
+    hyp = {'step_size': 0.5, 'num_samples': 12, 'L': 2, 'tau': 4.0, 'burn': 0, 'mass': 1.0}       # coarse step: some rejects
+
+    def chain(seed):
+        torch.manual_seed(5)
+        return inference.HMC(dict(hyp, num_samples=1), Const(torch.randn(512)), const_loader(), kernels=OracleKernels(), seed=seed)
+    alone = chain(21)
+    seq_alone = []
+    for _ in range(12):
+        before = alone.accepted
+        alone.sample()
+        seq_alone.append(alone.accepted - before)
+    a, b = chain(21), chain(22)
+    seq_mixed = []
+    for _ in range(12):
+        before = a.accepted
+        a.sample()
+        torch.rand(3)
+        b.sample()
+        seq_mixed.append(a.accepted - before)
+    assert seq_alone == seq_mixed and 0 < sum(seq_alone) < 12

@@ -72,3 +72,22 @@ def test_preresnet_dropout_variant_and_dispatch():
     with pytest.raises(AttributeError):
         inference.vi_dropout.change_to_dropout_model(models.LeNet5(10), 0.2)                  # no LeNet5_dropout, as in the reference
     assert getattr(inference, 'MCdropout') is inference.vi_dropout.MCdropout
+
+
+def test_host_drawn_dropout_masks_are_atens(golden_dir, monkeypatch):
+    """The GPU replay of G10 (tests/test_samplers_gpu.py) feeds the device run the reference's dropout masks by drawing
+    them on the host the way ATen's CPU dropout does. Here, on CPU, that replacement must leave the bit-exact replay of
+    the reference's run intact."""
+    import torch.nn.functional as F
+
+    def cpu_stream_dropout(x, p=0.5, training=True, inplace=False):
+        if not training or p == 0:
+            return x
+        return x * torch.empty(x.shape, dtype=x.dtype).bernoulli_(1 - p).div_(1 - p).to(x.device)
+    monkeypatch.setattr(F, 'dropout', cpu_stream_dropout)
+    g = np.load(os.path.join(golden_dir, 'mcdropout.npz'))
+    torch.manual_seed(21)
+    s = inference.MCdropout(dict(json.loads(str(g['hyper']))), models.MLP(16, 12, 4), tiny_loader(), kernels=OracleKernels(),
+                            use_graph=False)
+    for k in range(2):
+        assert np.array_equal(flat(s.sample_iterative()), g['samples'][k]), k

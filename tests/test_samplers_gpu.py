@@ -560,3 +560,177 @@ def test_swag_grouped_sampling_on_gpu():
     assert [cnt(m) - cnt(one[0]) for m in one] == [k * steps for k in range(5)]       # the reference's cumulative counter
     assert [cnt(m) - cnt(grp[0]) for m in grp] == [k * steps for k in range(5)]
     assert not torch.equal(flat_params(grp[0]), flat_params(grp[1]))
+
+
+# ---- GPU replays of the reference's own runs that round 2 only replayed on CPU (G8, G10, G13) ---------------------
+@pytest.mark.parametrize('tag', ['mlp', 'bn'])
+@pytest.mark.parametrize('cls_name', ['SWAG', 'SWA'])
+def test_swag_swa_reference_run_on_gpu(golden_dir, tag, cls_name):
+    """G8 on the HIP path: the reference's SWA / SWAG runs (URSABench/inference/swag.py:51-129, swa.py) — FlatSGD
+    trajectory through hipGraph replays, K2 moments, the (bug-compatible) draw, and `bn_update`
+    (URSABench/util.py:212-247): BatchNorm running statistics of every member and the members' predictive through
+    Prediction within 1e-5 relative of the reference's. rocBLAS / MIOpen gradients differ from oneDNN's in the last
+    bits: parameters and moments agree to 1e-4 relative / 1e-6 absolute over the 8-step trajectory."""
+    from test_swag_cpu import bn_loader, bn_net
+    from test_samplers_cpu import tiny_loader, tiny_net
+    g = np.load(os.path.join(golden_dir, 'swag_e2e.npz'))
+    hyp = json.loads(str(g['hyper']))
+    torch.manual_seed(0)
+    net = (tiny_net if tag == 'mlp' else bn_net)()
+    assert np.array_equal(flat_params(net).numpy(), g[f'{tag}/{cls_name}/theta0'])
+    mk = tiny_loader if tag == 'mlp' else bn_loader
+    s = getattr(inference, cls_name)(dict(hyp), net, mk(), device=DEV)
+    s.engine.WARMUP_STEPS = 1
+    ens = s.sample(num_samples=2)
+    assert s.engine.stats['graph_replays'] >= 4, s.engine.stats
+    assert s.epochs_run == int(g[f'{tag}/{cls_name}/epochs_run'])
+    assert np.array_equal(s.num_models_collected.cpu().numpy(), g[f'{tag}/{cls_name}/n_collected'])
+    tol = dict(rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(flat_params(s.model).cpu().numpy(), g[f'{tag}/{cls_name}/live_theta'], **tol)
+    np.testing.assert_allclose(s.weight_mean.cpu().numpy(), g[f'{tag}/{cls_name}/weight_mean'], **tol)
+    np.testing.assert_allclose(s.sq_mean.cpu().numpy(), g[f'{tag}/{cls_name}/sq_mean'], **tol)
+    assert (ens[0] is ens[1]) == bool(g[f'{tag}/{cls_name}/same_object'])
+    for m, ref, refb in zip(ens, g[f'{tag}/{cls_name}/samples'], g[f'{tag}/{cls_name}/sample_buffers']):
+        np.testing.assert_allclose(flat_params(m).cpu().numpy(), ref, **tol)
+        if refb.size:                                    # BatchNorm statistics after bn_update (row a8)
+            got = torch.cat([b.detach().float().reshape(-1) for b in m.buffers()]).cpu().numpy()
+            np.testing.assert_allclose(got, refb, rtol=1e-5, atol=1e-6)
+    pred = tasks.Prediction({'in_distribution_test': mk(seed=1)}, 4, DEV, 'ALL')
+    pred.update_statistics(ens, output_performance=False)
+    np.testing.assert_allclose(pred.ensemble_proba.numpy(), g[f'{tag}/{cls_name}/proba_sum'], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(pred.expected_data_uncertainty.numpy(), g[f'{tag}/{cls_name}/ent_sum'], rtol=1e-5, atol=1e-6)
+
+
+def test_sgd_sampler_reference_run_on_gpu(golden_dir):
+    """G13 on the HIP path: the reference's SGD baseline sampler (URSABench/inference/sgd.py:69-113), constructor run
+    and the run after update_hyp, FlatSGD (K1 SGD mode) under hipGraph replay."""
+    from test_samplers_cpu import tiny_loader, tiny_net
+    from ursabench_amd import util
+    g = np.load(os.path.join(golden_dir, 'sgd_sampler.npz'))
+    hyp, hyp2 = json.loads(str(g['hyper'])), json.loads(str(g['hyper2']))
+    util.set_random_seed(5)
+    net = tiny_net()
+    assert np.array_equal(flat_params(net).numpy(), g['theta0'])
+    s = inference.SGD(dict(hyp), net, tiny_loader(), device=DEV)
+    s.engine.WARMUP_STEPS = 1
+    m = s.sample(num_samples=2)
+    assert s.engine.stats['graph_replays'] >= 4
+    np.testing.assert_allclose(flat_params(m[0]).cpu().numpy(), g['sample'], rtol=1e-4, atol=1e-6)
+    assert s.optimizer.param_groups[0]['lr'] == pytest.approx(float(g['lr_after']), rel=1e-12)
+    util.set_random_seed(6)
+    s.update_hyp(dict(hyp2))
+    s.engine.WARMUP_STEPS = 1
+    np.testing.assert_allclose(flat_params(s.model).cpu().numpy(), g['theta1'], rtol=0, atol=0)     # re-init: same generator stream
+    m = s.sample()
+    np.testing.assert_allclose(flat_params(m[0]).cpu().numpy(), g['sample2'], rtol=1e-4, atol=1e-6)
+    assert s.optimizer.param_groups[0]['lr'] == pytest.approx(float(g['lr_after2']), rel=1e-12)
+
+
+def cpu_stream_dropout(x, p=0.5, training=True, inplace=False):
+    """F.dropout with the mask drawn on the HOST from torch's global CPU generator, exactly as ATen's CPU dropout
+    draws it (empty_like(input).bernoulli_(1 - p).div_(1 - p); aten/src/ATen/native/Dropout.cpp): lets a device run
+    consume the very masks the reference's CPU run consumed. TEST ONLY (checked bit-exact on CPU in test_mcdropout_cpu)."""
+    if not training or p == 0:
+        return x
+    noise = torch.empty(x.shape, dtype=x.dtype).bernoulli_(1 - p).div_(1 - p)
+    return x * noise.to(x.device)
+
+
+def test_mcdropout_reference_run_on_gpu(golden_dir, monkeypatch):
+    """G10 on the HIP path: the reference's MCdropout run (URSABench/inference/vi_dropout.py:87-131) — model swap,
+    per-minibatch OneCycleLR (lr, momentum) walked from the device schedule table by the self-advancing K1 launch
+    (SGD mode), always-on dropout. The dropout masks are the reference's (host-drawn, see cpu_stream_dropout), so the
+    steps run eagerly (a captured graph cannot take a host-drawn mask)."""
+    from test_samplers_cpu import tiny_loader
+    import torch.nn.functional as F
+    monkeypatch.setattr(F, 'dropout', cpu_stream_dropout)
+    g = np.load(os.path.join(golden_dir, 'mcdropout.npz'))
+    hyp, hyp2 = json.loads(str(g['hyper'])), json.loads(str(g['hyper2']))
+    torch.manual_seed(21)
+    s = inference.MCdropout(dict(hyp), models.MLP(16, 12, 4), tiny_loader(), device=DEV, use_graph=False)
+    np.testing.assert_array_equal(flat_params(s.model).cpu().numpy(), g['theta0'])
+    for k in range(2):
+        m = s.sample_iterative()
+        np.testing.assert_allclose(flat_params(m).cpu().numpy(), g['samples'][k], rtol=1e-4, atol=1e-6)
+    from ursabench_amd._native import StepCtl
+    c = StepCtl.from_buffer_copy(bytes(s.optimizer._ctl.cpu().numpy()))
+    assert c.step == len(g['lr_mom']) and c.ticket == 0
+    s.model.eval()
+    with torch.no_grad():
+        mc = np.stack([s.model(torch.tensor(g['x_test']).to(DEV)).cpu().numpy() for _ in range(3)])
+    np.testing.assert_allclose(mc, g['mc_logits'], rtol=1e-4, atol=1e-5)
+    s.update_hyp(dict(hyp2))
+    np.testing.assert_array_equal(flat_params(s.model).cpu().numpy(), g['theta1'])
+    np.testing.assert_allclose(flat_params(s.sample_iterative()).cpu().numpy(), g['sample2'], rtol=1e-4, atol=1e-6)
+
+
+def test_hmc_fused_proposal_equals_oracle_substeps():
+    """One full HMC proposal (L = 3) at PreResNet-164's parameter count, P = 1,726,388, as the host issues it —
+    kinetic energy, fused half-kick + drift, two fused kick + drift launches, full kick, half-kick correction with the
+    kinetic-energy reduction: L + 3 K4 launches — against the oracle running hamiltorch's sub-step sequence (half kick;
+    L x (drift, gradient, kick); half-kick correction; call site URSABench/inference/hmc.py:71-75) on the gradients the
+    GPU produced: theta and momentum bit for bit, both energies within 2e-6 relative."""
+    from ursabench_amd import _native
+
+    class Wide(torch.nn.Module):                         # 3072 x 561 + 561 + 2435 = 1,726,388 parameters, cheap to evaluate
+        def __init__(self):
+            super().__init__()
+            self.lin = torch.nn.Linear(3072, 561)
+            self.extra = torch.nn.Parameter(torch.randn(2435) * 0.01)
+
+        def forward(self, x):
+            return self.lin(x.flatten(1))[:, :100] + self.extra[:100]
+    torch.manual_seed(0)
+    train = synthetic(256, (3, 32, 32), 100, seed=0, device=DEV, batch_size=128)
+    L, eps, tau, mass = 3, 2e-4, 1.0, 2.0
+    s = inference.HMC({'step_size': eps, 'num_samples': 1, 'L': L, 'tau': tau, 'burn': 0, 'mass': mass},
+                      Wide().to(DEV), train, device=DEV, seed=13, use_graph=False)
+    s._bind()
+    assert s.arena.num_parameters == 1726388
+    th0 = s.arena.theta.cpu().numpy().copy()
+    grads, launches = [], []
+    orig_eval, orig_leap = s._neg_logp_and_grad, s.kernels.leapfrog
+
+    def tap_eval():
+        u = orig_eval()
+        grads.append(s._glogp.cpu().numpy().copy())
+        return u
+
+    def tap_leap(*a, **k):
+        launches.append(k['flags'])
+        return orig_leap(*a, **k)
+    s._neg_logp_and_grad = tap_eval
+    import builtins
+    log = []
+    monkey_print = builtins.print
+    s.kernels.leapfrog = tap_leap
+    try:
+        builtins.print = lambda d, *a, **k: log.append(d)
+        s.sample(debug=True)
+    finally:
+        builtins.print = monkey_print
+        s.kernels.leapfrog = orig_leap
+    KD = _native.LEAP_KICK | _native.LEAP_DRIFT
+    assert launches == [0, KD, KD, KD, _native.LEAP_KICK, _native.LEAP_KICK] and len(launches) == L + 3
+    assert len(grads) == L + 1 and s.accepted == 1
+    # the oracle's sub-step sequence on the same gradients
+    n = s.arena.n
+    mask = s._mask.cpu().numpy()
+    p = (O.philox_normal(n, 13, 0) * mask) * np.float32(np.sqrt(mass))
+    th = th0.copy()
+    inv_mass = 1.0 / mass
+    ke0 = O.leapfrog(None, p, None, kick_coef=0.0, step_size=0.0, inv_mass=inv_mass, flags=0, want_kinetic=True)
+    O.leapfrog(None, p, grads[0], kick_coef=0.5 * eps, step_size=eps, inv_mass=inv_mass, flags=O.LEAP_KICK)
+    for l in range(L):
+        O.leapfrog(th, p, None, kick_coef=0.0, step_size=eps, inv_mass=inv_mass, flags=O.LEAP_DRIFT)
+        O.leapfrog(None, p, grads[l + 1], kick_coef=eps, step_size=eps, inv_mass=inv_mass, flags=O.LEAP_KICK)
+    ke1 = O.leapfrog(None, p, grads[L], kick_coef=-0.5 * eps, step_size=eps, inv_mass=inv_mass, flags=O.LEAP_KICK,
+                     want_kinetic=True)
+    assert np.array_equal(s.arena.theta.cpu().numpy(), th)            # accepted: the chain sits at the proposal
+    assert np.array_equal(s._p.cpu().numpy(), p)
+    # energies: the fused kinetic-energy reduction of the closing launch, and K of the fresh momentum, against the
+    # oracle's float64 sums
+    assert float(s._acc[0]) == pytest.approx(ke1, rel=2e-6)
+    assert np.isfinite(log[0]['H0']) and np.isfinite(log[0]['H1']) and abs(log[0]['H0'] - log[0]['H1']) < 1.0
+    s._p.copy_(torch.from_numpy((O.philox_normal(n, 13, 0) * mask) * np.float32(np.sqrt(mass))).to(DEV))
+    assert float(s._kinetic()) == pytest.approx(ke0, rel=2e-6)

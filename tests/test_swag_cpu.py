@@ -51,6 +51,13 @@ def test_swag_swa_bug_compatible_vs_reference(golden_dir, tag, cls_name):
         if refb.size:                                    # BatchNorm statistics after bn_update (util.py:212-247)
             got = torch.cat([b.detach().float().reshape(-1) for b in m.buffers()]).numpy()
             np.testing.assert_allclose(got, refb, rtol=1e-6, atol=1e-7)
+    # the members' predictive (what bn_update's statistics feed) vs the reference's own Prediction task
+    from ursabench_amd import tasks
+    pred = tasks.Prediction({'in_distribution_test': (tiny_loader if tag == 'mlp' else bn_loader)(seed=1)}, 4,
+                            torch.device('cpu'), 'ALL', kernels=OracleKernels())
+    pred.update_statistics(ens, output_performance=False)
+    np.testing.assert_allclose(pred.ensemble_proba.numpy(), g[f'{tag}/{cls_name}/proba_sum'], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(pred.expected_data_uncertainty.numpy(), g[f'{tag}/{cls_name}/ent_sum'], rtol=1e-5, atol=1e-6)
 
 
 def test_swag_schedule_matches_reference(golden_dir):

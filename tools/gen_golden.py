@@ -338,6 +338,13 @@ def gen_swag_e2e():
                     else np.zeros(0, np.float32) for m in ens]
             out[f'{tag}/{cls_name}/sample_buffers'] = np.stack(bufs)
             out[f'{tag}/{cls_name}/same_object'] = np.array(ens[0] is ens[1])
+            # the members' predictive through the reference's own Prediction task (prediction.py:52-64) on a held-out
+            # loader: what bn_update's statistics (util.py:212-247) feed into
+            test = mk_loader(seed=1)
+            pred = tasks.Prediction({'in_distribution_test': test}, 4, torch.device('cpu'), 'ALL')
+            pred.update_statistics(ens, output_performance=False)
+            out[f'{tag}/{cls_name}/proba_sum'] = pred.ensemble_proba.numpy().copy()
+            out[f'{tag}/{cls_name}/ent_sum'] = pred.expected_data_uncertainty.numpy().copy()
     np.savez_compressed(os.path.join(OUT, 'swag_e2e.npz'), **out)
     print('G8 swag_e2e', {k: v.shape for k, v in out.items() if k.endswith('samples')})
 

@@ -9,6 +9,15 @@ half-kick correction, Metropolis accept on H = -log p + 1/2 p^T M^-1 p. Forward/
 PyTorch-ROCm over the whole training set held on the device (hmc.py:44-50); the leapfrog
 sub-steps and both energy reductions are the K4 kernels on the flat arena.
 
+Launches per proposal (the leapfrog of hamiltorch, call site hmc.py:71-75): one K4 launch for the
+kinetic energy of the fresh momentum, one fused half-kick + first drift, one fused kick + drift
+between consecutive gradient evaluations (L - 1 of them, 20 B/param each instead of 24 for two
+launches), and after the last evaluation the full kick and the half-kick correction — kept as two
+roundings like hamiltorch's two statements — the second with the kinetic-energy reduction fused:
+L + 3 launches (round 2: 2L + 4). The Metropolis uniform is Philox4x32-10 under the chain's own
+key at (proposal index, lane 2^64 - 1), so a chain's accept sequence does not depend on what else
+draws random numbers in the process.
+
 The returned trajectory follows hamiltorch's layout: the initial position, then the L positions of
 every proposal (a rejected proposal repeats the previous L), thinned exactly like hmc.py:80 —
 `samples[burn*L::L]`. Only the positions that thinning selects are kept in HBM.
@@ -22,6 +31,26 @@ from .._capture import capture, side_streams
 from ..arena import FlatArena, MemberBank
 from ..util import reset_model
 from .inference_base import _Inference
+
+
+def philox4x32_10(ctr, key):
+    """Philox4x32-10 on the host (same function as csrc/ursa_rng.h; pinned against the oracle and Random123's
+    known-answer vectors in tests/test_hmc_cpu.py). ctr: 4 x u32, key: 2 x u32 -> 4 x u32."""
+    c0, c1, c2, c3 = ctr
+    k0, k1 = key
+    for _ in range(10):
+        p0, p1 = 0xD2511F53 * c0, 0xCD9E8D57 * c2
+        c0, c1, c2, c3 = ((p1 >> 32) ^ c1 ^ k0) & 0xFFFFFFFF, p1 & 0xFFFFFFFF, ((p0 >> 32) ^ c3 ^ k1) & 0xFFFFFFFF, p0 & 0xFFFFFFFF
+        k0, k1 = (k0 + 0x9E3779B9) & 0xFFFFFFFF, (k1 + 0xBB67AE85) & 0xFFFFFFFF
+    return c0, c1, c2, c3
+
+
+def mh_uniform(seed, proposal):
+    """u in (0, 1) for the accept test of proposal `proposal` of the chain keyed `seed`: Philox lane 2^64 - 1 (no
+    arena reaches it: the kernels stop at 2^40 elements) of call `proposal`, first word, as (x + 0.5) / 2^32."""
+    x = philox4x32_10((0xFFFFFFFF, 0xFFFFFFFF, proposal & 0xFFFFFFFF, (proposal >> 32) & 0xFFFFFFFF),
+                      (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF))[0]
+    return (x + 0.5) / 4294967296.0
 
 
 class HMC(_Inference):
@@ -139,33 +168,37 @@ class HMC(_Inference):
         self.model.train()      # hamiltorch runs the functional model in its current (training) mode
         keep(0)
         prev_positions = None
+        KD = _native.LEAP_KICK | _native.LEAP_DRIFT
         for n in range(self.num_samples):
             theta0 = a.theta.clone()
             fb0 = None if a.fbuf is None else a.fbuf.clone()
-            K.philox_normal(self._p, seed=self.seed, step=self._proposals)
+            proposal = self._proposals
+            K.philox_normal(self._p, seed=self.seed, step=proposal)
             self._p.mul_(self._mask).mul_(math.sqrt(self.mass))
             self._proposals += 1
             U0 = self._neg_logp_and_grad()
             H0 = U0 + self._kinetic()
-            K.leapfrog(None, self._p, self._glogp, kick_coef=0.5 * eps, step_size=eps, inv_mass=inv_mass,
-                       flags=_native.LEAP_KICK)
+            # opening half kick + first drift: one launch
+            K.leapfrog(a.theta, self._p, self._glogp, kick_coef=0.5 * eps, step_size=eps, inv_mass=inv_mass, flags=KD)
             positions = []
             for l in range(L):
-                K.leapfrog(a.theta, self._p, None, kick_coef=0.0, step_size=eps, inv_mass=inv_mass,
-                           flags=_native.LEAP_DRIFT)
-                U1 = self._neg_logp_and_grad()
-                K.leapfrog(None, self._p, self._glogp, kick_coef=eps, step_size=eps, inv_mass=inv_mass,
-                           flags=_native.LEAP_KICK)
+                U1 = self._neg_logp_and_grad()                          # at the position the last drift reached
                 idx = n * L + l + 1
                 if idx in wanted:
                     positions.append((idx, self.bank.snapshot(self.model)))
+                if l < L - 1:                                           # kick of step l + drift of step l+1: one launch
+                    K.leapfrog(a.theta, self._p, self._glogp, kick_coef=eps, step_size=eps, inv_mass=inv_mass, flags=KD)
+            # closing: full kick, then the half-kick correction (two roundings, like hamiltorch's two statements) with
+            # the kinetic-energy reduction fused into the second launch
+            K.leapfrog(None, self._p, self._glogp, kick_coef=eps, step_size=eps, inv_mass=inv_mass, flags=_native.LEAP_KICK)
+            self._acc.zero_()
             K.leapfrog(None, self._p, self._glogp, kick_coef=-0.5 * eps, step_size=eps, inv_mass=inv_mass,
-                       flags=_native.LEAP_KICK)
-            H1 = U1 + self._kinetic()
+                       flags=_native.LEAP_KICK, kinetic_out=self._acc, ws=self._ws)
+            H1 = U1 + self._acc[0]
             rho = min(0.0, float(H0 - H1))                  # the one host sync per proposal (MH test)
             if debug:
                 print({'proposal': n, 'H0': float(H0), 'H1': float(H1), 'rho': rho})
-            if math.isfinite(rho) and rho >= math.log(torch.rand(1).item()):
+            if math.isfinite(rho) and rho >= math.log(mh_uniform(self.seed, proposal)):
                 self.accepted += 1
                 for idx, m in positions:
                     kept[idx] = m
