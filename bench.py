@@ -74,14 +74,15 @@ def parse(argv=None):
     ap.add_argument('--large-n', type=int, default=1 << 26, help='elements of the roofline-sized K1 launch')
     ap.add_argument('--c4-epochs', type=int, default=3, help='c4: SGD trajectory epochs over the 50,000 images (1 burn-in + rest collected)')
     ap.add_argument('--c4-train', type=int, default=N_TRAIN)
+    ap.add_argument('--c4-weak', action='store_true', help='c4: every rank forms --steps members (weak scaling) instead of sharding them')
     ap.add_argument('--c5-batch', type=int, default=256, help='c5: full-batch size N of the HMC potential')
     ap.add_argument('--c5-chains', type=int, default=4)
     ap.add_argument('--c5-L', type=int, default=3)
-    ap.add_argument('--dry-run-cpu', action='store_true', help='toy-size CPU walk of the c2 / c4 control flow (tests only; not a measurement)')
+    ap.add_argument('--dry-run-cpu', action='store_true', help='toy-size CPU walk of the c2 / c4 / c5 control flow (tests only; not a measurement)')
     ap.add_argument('--inject-failure', default='', help='(tests) raise inside the named leg')
     a = ap.parse_args(argv)
     if a.steps is None:
-        a.steps = {'c2': 3, 'c4': 29, 'c5': 20}[a.config]
+        a.steps = {'c2': 3, 'c4': 30, 'c5': 20}[a.config]
     if a.warmup is None:
         a.warmup = 1
     return a
@@ -92,13 +93,23 @@ class Legs:
     """Runs named legs, keeps going after a failure, remembers the traceback tails."""
 
     def __init__(self, inject=''):
-        self.errors, self.inject = {}, inject
+        self.errors = {}
+        # "leg", "leg@rank" or "leg@rank:after" (tests). ":after" raises once the leg's work — collectives included — is
+        # done: a rank that leaves a leg BEFORE its collectives strands the other ranks in them (until the process group's
+        # timeout), which no bookkeeping on this side can repair.
+        leg, _, r = inject.partition('@')
+        r, _, when = r.partition(':')
+        self.inject = leg if (not r or int(r) == int(os.environ.get('RANK', 0))) else ''
+        self.inject_after = when == 'after'
 
     def run(self, name, fn, *args, **kw):
         try:
+            if self.inject == name and not self.inject_after:
+                raise RuntimeError(f'injected failure in leg {name!r}')
+            out = fn(*args, **kw)
             if self.inject == name:
                 raise RuntimeError(f'injected failure in leg {name!r}')
-            return fn(*args, **kw)
+            return out
         except BaseException as e:       # noqa: BLE001 — a leg must never take the JSON line down with it
             if isinstance(e, KeyboardInterrupt):
                 raise
@@ -168,10 +179,10 @@ def event_time_ms(fn, iters, stream, graph_batch=0):
 
 def pmc_traffic(kernel_key, elements):
     """HBM bytes per launch from PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc
-    passes, tools/pmc_run.sh): PMC needs the profiler, so the figure is the committed measurement
-    under profiles/ for a launch of this kernel at this size (within 0.1 %: arena padding; scaled by the
-    element ratio), or None."""
-    for name in ('r02_pmc.json', 'r01_k1_pmc.json'):
+    passes, tools/pmc_run.sh). PMC needs the profiler, so this is NOT measured in this run: it is the committed
+    measurement under profiles/ for a launch of this kernel at this size (within 0.1 %: arena padding; scaled by
+    the element ratio). Returns (bytes or None, source string) — the source travels in the line as `traffic_source`."""
+    for name in ('r03_pmc.json', 'r02_pmc.json', 'r01_k1_pmc.json'):
         path = os.path.join(ROOT, 'profiles', name)
         if not os.path.exists(path):
             continue
@@ -179,8 +190,9 @@ def pmc_traffic(kernel_key, elements):
             n = v.get('elements')
             if n and abs(n - elements) <= 1e-3 * elements and (kernel_key in k or name.startswith('r01')) \
                     and 'hbm_bytes_per_launch_corrected' in v:
-                return int(round(v['hbm_bytes_per_launch_corrected'] * elements / n))
-    return None
+                return (int(round(v['hbm_bytes_per_launch_corrected'] * elements / n)),
+                        f'profiles/{name} (rocprofv3 --pmc passes of an earlier run of this kernel at this size; not collected in this run)')
+    return None, 'none (no committed PMC pass for this kernel and size)'
 
 
 # ---- c2 legs ------------------------------------------------------------------------------------------
@@ -218,15 +230,35 @@ def parity_block(dev, steps_per_sample=1, samples=3, rows=128, test_rows=64, dep
     # GPU: the product path with that noise injected through the kernel's eps input
     train = DeviceLoader(xtr.to(dev), ytr.to(dev), rows)
     test = DeviceLoader(xte.to(dev), yte.to(dev), test_rows)
-    s = inference.SGHMC(dict(hyp), net_gpu, train, device=dev, seed=1)
+    s = inference.SGHMC(dict(hyp), net_gpu, train, device=dev, seed=1, use_graph=True)
     s.optimizer.param_groups[0]['num_training_samples'] = n_noise     # the N of optim_sghmc.py:48,64: the workload's 50,000
     idx = s.arena.layout.gather_index(dev)
 
     def eps(k):
         e = torch.zeros(s.arena.n, device=dev)
-        e[idx] = torch.cat([t.reshape(-1) for t in eps_steps[k]]).to(dev)
+        e[idx] = torch.cat([t.reshape(-1) for t in eps_steps[k % total]]).to(dev)
         return e
     s.eps_provider = eps
+    # Compare the path that is TIMED: hipGraph replays reading the injected noise from the engine's persistent
+    # buffer. Capture needs one eager warm-up step (MIOpen's solver search cannot run inside a capture): take it
+    # and the capture on this very chain, then put the chain back to its initial state, so that EVERY compared
+    # minibatch step below — the first sample included — is a graph replay.
+    a = s.arena
+    saved = (a.theta.clone(), None if a.fbuf is None else a.fbuf.clone(), [b.clone() for _, b in a.ibufs])
+    s.engine.WARMUP_STEPS = 1
+    for _ in range(2):                                                # eager warm-up step, then capture + first replay
+        s.engine.run_epoch(train, True, eps_per_step=eps)
+    assert s.engine.stats['captures'] == 1 and s.engine.stats['graph_replays'] >= 1, s.engine.stats
+    with torch.no_grad():
+        a.theta.copy_(saved[0])
+        if saved[1] is not None:
+            a.fbuf.copy_(saved[1])
+        for (_, b), v in zip(a.ibufs, saved[2]):
+            b.copy_(v)
+        a.mom.zero_()
+    s.optimizer._step, s.optimizer._has_mom = 0, [False]              # first-step rule and Philox call index as at construction
+    s.optimizer.state.clear()
+    s.engine.stats.update(graph_replays=0, eager_steps=0)
     lrs, ens = [], []
     for _ in range(samples):
         lrs.append(s.optimizer.param_groups[0]['lr'])         # CosineAnnealingLR moves it once per sample (sghmc.py:44,87)
@@ -270,12 +302,71 @@ def parity_block(dev, steps_per_sample=1, samples=3, rows=128, test_rows=64, dep
     pc, ec = cpu_predictive(host_members)
     bma = {'members': samples, 'max_rel_err_proba': rel(pg, pc), 'max_rel_err_entropy': rel(eg, ec)}
     ok = sampler['max_rel_err_proba'] <= PARITY_RTOL and bma['max_rel_err_proba'] <= PARITY_RTOL
+    if s.engine.stats['eager_steps'] != 0 or s.engine.stats['graph_replays'] != total:
+        raise AssertionError(f'parity: the compared steps were not all hipGraph replays: {s.engine.stats}')
     out = {'what': f'PreResNet-{depth} SGHMC at the workload hyper-parameters, identical init / inputs / injected noise, {rows}-row '
-                   f'minibatches, predictive on {test_rows} test rows; GPU path vs torch-CPU port of the reference path',
+                   f'minibatches, predictive on {test_rows} test rows; GPU path (every compared minibatch step a hipGraph replay '
+                   'reading the injected noise) vs torch-CPU port of the reference path',
+           'engine': dict(s.engine.stats),
            'rtol': PARITY_RTOL, 'sampler_first_sample': sampler, 'bma_same_members': bma,
            'trajectory_growth_reported_not_asserted': growth, 'pass': bool(ok)}
     if not ok:
         raise AssertionError(f'parity: predictive probabilities beyond {PARITY_RTOL} relative: {json.dumps(out)}')
+    return out
+
+
+class SpyLoader:
+    """Calls on_next() before every batch is handed out and once after the last: between two calls exactly one
+    minibatch step (eager or one hipGraph replay) has been enqueued."""
+
+    def __init__(self, loader, on_next):
+        self.loader, self.on_next = loader, on_next
+        self.dataset, self.batch_size = loader.dataset, loader.batch_size
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        for b in self.loader:
+            self.on_next()
+            yield b
+        self.on_next()
+
+
+def given_equal_gradients_block(dev, train, depth=20):
+    """Where the 1e-5 goes over a whole posterior sample. The first sample above agrees with the CPU path to ~5e-6 and
+    later ones drift apart because MIOpen's and oneDNN's gradients differ in the last bits and SG-MCMC at lr = 0.1
+    amplifies that ~10x per step. This leg removes the gradients from the comparison: ONE full posterior sample of the
+    workload (391 minibatch steps of PreResNet-20 on the 50,000-image set, Philox noise, hipGraph replay — the timed
+    configuration), theta / momentum copied out before every step and the gradients each step consumed after it; the
+    oracle (oracle/ursa_oracle.c: the reference's optim_sghmc.py:43-67 arithmetic + the same Philox stream) recomputes
+    every step from the GPU's own gradients and must reproduce theta and momentum BIT FOR BIT, 391 of 391 steps."""
+    import numpy as np
+    from ursabench_amd import inference, models, util
+    O = load_oracle_lib()
+    util.set_random_seed(11)
+    recs, holder = [], {}
+
+    def on_next():
+        a = holder['s'].arena
+        recs.append(tuple(t.cpu().numpy().copy() for t in (a.theta, a.mom, a.grad)))
+    spy = SpyLoader(train, on_next)
+    s = holder['s'] = inference.SGHMC(dict(HYP, num_samples=3), models.PreResNet(CLASSES, depth).to(dev), spy, device=dev, seed=11)
+    s.arena.ensure_mom()
+    s.sample_iterative()
+    sc = O.step_scalars(HYP['lr'], 1 - HYP['alpha'], 1 / HYP['prior_std'] ** 2, len(train.dataset))
+    ok = 0
+    for k in range(len(recs) - 1):
+        th, mo = recs[k][0].copy(), recs[k][1].copy()
+        flags = O.STEP_NOISE | O.STEP_WD | (O.STEP_FIRST if k == 0 else 0)
+        O.sgmcmc_step(th, recs[k + 1][2].copy(), mo, flags=flags, seed=11, step=k, **sc)
+        ok += int(np.array_equal(th, recs[k + 1][0]) and np.array_equal(mo, recs[k + 1][1]))
+    steps = len(recs) - 1
+    out = {'what': 'one full PreResNet-20 SGHMC posterior sample of the workload, Philox noise, hipGraph replay; every step '
+                   'recomputed by the oracle from the GPU\'s own per-step gradients', 'minibatch_steps': steps,
+           'steps_bit_identical_theta_and_momentum': ok, 'engine': dict(s.engine.stats), 'pass': ok == steps}
+    if ok != steps:
+        raise AssertionError(f'given equal gradients the update is not bit-identical to the oracle: {json.dumps(out)}')
     return out
 
 
@@ -293,11 +384,12 @@ def roofline_block(sampler, large_n):
     bytes_per_launch = 20 * arena.n
     achieved = bytes_per_launch / (ms * 1e-3) / 1e9
     out = {'bound': 'hbm', 'kernel': 'k_sgmcmc_step_ctl', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS,
-           'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': pmc_traffic('step_ctl', arena.n),
-           'bytes_per_launch': bytes_per_launch, 'us_per_launch': round(ms * 1e3, 3),
-           'note': 'workload-sized launch (5.5 MB of state, L2/Infinity-Cache resident, one float4 per lane): '
-                   'latency-bound; us_per_launch is a 256-launch hipGraph replay / 256 and includes the '
-                   '~1.5 us kernel boundary; see roofline_large for the HBM-sized launch of the same arithmetic'}
+           'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': pmc_traffic('step_ctl', arena.n)[0],
+           'traffic_source': pmc_traffic('step_ctl', arena.n)[1], 'bytes_per_launch': bytes_per_launch, 'us_per_launch': round(ms * 1e3, 3),
+           'note': 'workload-sized launch (5.5 MB of state, L2/Infinity-Cache resident, one float4 per lane, 134 workgroups), '
+                   'self-advancing its control block (no separate advance launch): latency-bound; us_per_launch is a '
+                   '256-launch hipGraph replay / 256 and includes the ~1.5 us kernel boundary; see roofline_large for the '
+                   'HBM-sized launch of the same arithmetic and roofline_kernels.k1_multi for K chains in one launch'}
     # the same arithmetic at a working set beyond the 256 MiB Infinity Cache
     n = large_n
     th, g, m = (torch.randn(n, device='cuda') for _ in range(3))
@@ -313,9 +405,74 @@ def roofline_block(sampler, large_n):
              'unit': 'GB/s', 'frac': round(ach_l / HBM_PEAK_GBPS, 4), 'frac_of_measured_copy_ceiling':
              round(ach_l / HBM_COPY_GBPS, 4), 'us_per_launch': round(ms_l * 1e3, 2),
              'us_per_launch_batches': [round(b * 1e3, 2) for b in batches], 'bytes_per_launch': 20 * n,
-             'traffic': pmc_traffic('sgmcmc_step<', n)}
+             'traffic': pmc_traffic('sgmcmc_step<', n)[0], 'traffic_source': pmc_traffic('sgmcmc_step<', n)[1]}
     del th, g, m
     return out, large
+
+
+def roofline_kernels_block(dev, large_n):
+    """Every hand-written kernel's roofline in the driver's own run, HIP events on the launch stream,
+    median of 5 batches: K2 / K3 at the WideResNet-28-10 arena (36,546,980 parameters); K4 in exactly the launch forms
+    inference/hmc.py issues (kinetic-only, fused kick+drift, kick, kick + kinetic-energy reduction) at PreResNet-164's
+    1,726,388 parameters (cache-resident: latency-bound, graph-batched timing) and at 2^26 elements (HBM-bound); K5 at
+    C4's (30, 10^4, 100); K1 for 4 and 8 PreResNet-20 chains in ONE multi-chain launch. bytes = algorithmic bytes per
+    launch; frac = bytes / time / 8 TB/s."""
+    from ursabench_amd import _native
+    K = _native.default_kernels()
+    stream = torch.cuda.current_stream()
+    out = {}
+
+    def entry(name, nbytes, fn, cache_resident=False, **extra):
+        if cache_resident:
+            batches = sorted(event_time_ms(fn, 1024, stream, graph_batch=128) for _ in range(5))
+        else:
+            batches = sorted(event_time_ms(fn, 10, stream) for _ in range(5))
+        ms = batches[2]
+        out[name] = dict(us=round(ms * 1e3, 3), bytes=int(nbytes), GBps=round(nbytes / (ms * 1e-3) / 1e9, 1),
+                         frac=round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), us_batches=[round(b * 1e3, 3) for b in batches], **extra)
+        if cache_resident:
+            out[name]['note'] = 'working set inside the 256 MiB Infinity Cache: latency-bound launch, not an HBM figure'
+
+    # K2 / K3 at the WideResNet-28-10 arena
+    n = 36546980 + (-36546980) % 64
+    mean, sq, w, outb = (torch.randn(n, device=dev) for _ in range(4))
+    sq.abs_().add_(mean * mean)
+    entry('k2_swag_collect_36.5M', 20 * n, lambda: K.swag_collect(mean, sq, w, decay=0.75, denom=4.0), elements=n)
+    entry('k3_swag_draw_36.5M', 12 * n, lambda: K.swag_draw(outb, mean, sq, var_clamp=1e-30, scale=1.0, seed=3, draw=1), elements=n)
+    del mean, sq, w, outb
+    # K4 as the HMC host issues it
+    ws, acc = torch.zeros(_native.REDUCE_WS_FLOATS, device=dev), torch.zeros(1, device=dev)
+    KD = _native.LEAP_KICK | _native.LEAP_DRIFT
+    for label, n, resident in (('1.73M', 1726388 + (-1726388) % 64, True), ('2^26', large_n, False)):
+        th, p, g = (torch.randn(n, device=dev) for _ in range(3))
+        forms = {'kick_drift': (20, lambda: K.leapfrog(th, p, g, kick_coef=1e-4, step_size=2e-4, inv_mass=1.0, flags=KD)),
+                 'kick': (12, lambda: K.leapfrog(None, p, g, kick_coef=1e-4, step_size=2e-4, inv_mass=1.0, flags=_native.LEAP_KICK)),
+                 'kick_kinetic': (12, lambda: K.leapfrog(None, p, g, kick_coef=-1e-4, step_size=2e-4, inv_mass=1.0,
+                                                         flags=_native.LEAP_KICK, kinetic_out=acc, ws=ws)),
+                 'kinetic_only': (4, lambda: K.leapfrog(None, p, None, kick_coef=0.0, step_size=0.0, inv_mass=1.0, flags=0,
+                                                        kinetic_out=acc, ws=ws))}
+        for form, (bpe, fn) in forms.items():
+            entry(f'k4_{form}_{label}', bpe * n, fn, cache_resident=resident, elements=n)
+        del th, p, g
+    # K5 at C4's shape
+    S, B, C = 30, N_TEST, 100
+    z = torch.randn(S, B, C, device=dev)
+    pr, en = torch.zeros(B, C, device=dev), torch.zeros(B, device=dev)
+    entry('k5_bma_30x10000x100', 4 * S * B * C + 2 * 4 * B * (C + 1),
+          lambda: K.bma_accumulate(z, pr, en, one_minus_gamma=1 - 1e-4, gamma_over_c=1e-4 / C, smoothed=False), shape=[S, B, C])
+    del z, pr, en
+    # K1: K PreResNet-20 chains in one self-advancing multi-chain launch
+    n = 273408
+    for chains in (4, 8):
+        th, g, m = (torch.randn(chains, n, device=dev) for _ in range(3))
+        blocks = b''.join(bytes(_native.StepCtl(lr=HYP['lr'], mu=1 - HYP['alpha'], c_wd=(1 / HYP['prior_std'] ** 2) / N_TRAIN, c_noise=0.3,
+                                                n_train=float(N_TRAIN), flags=_native.STEP_NOISE | _native.STEP_WD | _native.STEP_ADVANCE,
+                                                seed=1 + k, step=0)) for k in range(chains))
+        ctl = torch.frombuffer(bytearray(blocks), dtype=torch.uint8).to(dev)
+        entry(f'k1_multi_{chains}x273408', 20 * n * chains, lambda: K.sgmcmc_step_multi(th, g, m, ctl), cache_resident=True,
+              elements=n * chains, chains=chains)
+        del th, g, m
+    return out
 
 
 def bma_kernel_block(S, B, C):
@@ -516,6 +673,20 @@ class Job:
         self.barrier()
         return out, self.max_over_ranks(time.perf_counter() - t0)
 
+    def gather_errors(self, errors):
+        """Every rank's failed legs on rank 0, keyed 'rank<r>:<leg>' (a leg that fails on rank 3 only must show in the
+        one JSON line). Falls back to this rank's own errors if the collective itself cannot run any more."""
+        if not self.use_dist:
+            return dict(errors)
+        try:
+            every = [None] * self.world
+            dist.all_gather_object(every, dict(errors))
+            return {(k if r == 0 else f'rank{r}:{k}'): v for r, e in enumerate(every) for k, v in (e or {}).items()}
+        except Exception as exc:       # noqa: BLE001
+            out = dict(errors)
+            out['gather_errors'] = repr(exc)
+            return out
+
     def close(self):
         if self.use_dist:
             try:
@@ -550,11 +721,12 @@ def run_c2(a, job, legs, line):
                            'sharding': 'one independent chain per rank; members stay on their rank; one RCCL '
                                        'all-reduce of [N*C + N] fp32 for the predictive'})
 
-    if rank == 0 and not a.no_parity and not job.cpu:
-        line['parity'] = legs.run('parity', parity_block, dev)
-
     train = synthetic(n_train, (3, 32, 32), CLASSES, seed=0, device=dev, batch_size=batch)
     test = synthetic(n_test, (3, 32, 32), CLASSES, seed=1, device=dev, batch_size=batch)
+    if rank == 0 and not a.no_parity and not job.cpu:
+        line['parity'] = legs.run('parity', parity_block, dev)
+        if line['parity'] is not None:
+            line['parity']['given_equal_gradients'] = legs.run('given_equal_gradients', given_equal_gradients_block, dev, train)
     hyp = dict(HYP, num_samples=a.steps + a.warmup)
 
     def make_chain(c):
@@ -587,8 +759,9 @@ def run_c2(a, job, legs, line):
     # ---- BMA predictive over the test set: members sharded over ranks, one all-reduce -------------
     def bma():
         pred = tasks.Prediction({'in_distribution_test': test}, CLASSES, dev, 'ALL', **kw)
-        pred.update_statistics(ensemble[:1], output_performance=False)        # warm up MIOpen eval-mode kernels / capture
+        pred._acc.accumulate(ensemble[:1])                        # warm up MIOpen eval-mode kernels / capture (local: no collective)
         pred.reset()
+        pred._acc.reset(entropy_too=True)                         # (reset() keeps the entropy sums: prediction.py:33-35)
         _, dt_bma = job.timed(lambda: pred.update_statistics(ensemble, output_performance=False))
         metrics = pred.get_performance_metrics()
         members = pred.num_samples_collected
@@ -603,6 +776,8 @@ def run_c2(a, job, legs, line):
         if r is not None:
             line['roofline'], line['roofline_large'] = r
         line['roofline_bma_kernel'] = legs.run('roofline_bma_kernel', bma_kernel_block, max(1, len(ensemble)), N_TEST, CLASSES)
+        if world == 1:
+            line['roofline_kernels'] = legs.run('roofline_kernels', roofline_kernels_block, dev, a.large_n)
         if world == 1 and kpg == 1 and a.multi_chain_probe > 1:
             line['multi_chain_per_gpu'] = legs.run('multi_chain_per_gpu', multi_chain_block, a.multi_chain_probe,
                                                    make_chain, inference)
@@ -618,8 +793,11 @@ def run_c4(a, job, legs, line):
     does not depend on the moments' values) and broadcasts the two moment vectors (2 x 146 MB, RCCL); then a
     "step" is one member: K3 draw (one launch, 438 MB) + the reference's full bn_update pass (391 train-mode
     batches, util.py:212-247) + device snapshot — `SWAG.sample()` forms 4 members per pass over the training set (their
-    refresh forwards run concurrently on 4 streams; each member is bit-identical to one formed alone); members are sharded over ranks (weak scaling: `--steps`
-    members per rank), every rank evaluates its members on the 10,000-row test set, one all-reduce."""
+    refresh forwards run concurrently on 4 streams; each member is bit-identical to one formed alone). The `--steps` members
+    of the ensemble (30: BASELINE configs[3]) are SHARDED over the ranks as SURVEY.md 8(d) specifies — 30 -> {4,4,4,4,4,4,3,3} at
+    N = 8 (`distributed.shard`), `scaling: "strong"`, value = members / max-over-ranks time; `--c4-weak` gives every rank
+    `--steps` members instead. `--warmup` members per rank are formed first and discarded. Every rank evaluates its members on
+    the 10,000-row test set, one all-reduce."""
     from ursabench_amd import inference, models, tasks, util
     from ursabench_amd.data import synthetic
     dev, rank, world = job.dev, job.rank, job.world
@@ -634,14 +812,19 @@ def run_c4(a, job, legs, line):
     train = synthetic(n_train, (3, 32, 32), C, seed=0, device=dev, batch_size=batch)
     test = synthetic(n_test, (3, 32, 32), C, seed=1, device=dev, batch_size=batch)
     # hyperparams/WideResNet28x10CIFAR100/swag_hyperparams.json's keys; epochs cut to --c4-epochs
-    hyp = {'swag_lr': 0.01, 'swag_wd': 3e-4, 'lr_init': 0.1, 'num_samples': a.steps + a.warmup, 'momentum': 0.9,
+    from ursabench_amd.distributed import shard
+    mine = a.steps if a.c4_weak else len(shard(range(a.steps), rank, world))          # members this rank forms in the timed region
+    total = world * a.steps if a.c4_weak else a.steps
+    line['scaling'] = 'weak' if a.c4_weak else 'strong'
+    hyp = {'swag_lr': 0.01, 'swag_wd': 3e-4, 'lr_init': 0.1, 'num_samples': mine + a.warmup, 'momentum': 0.9,
            'burn_in_epochs': 1, 'num_iterates': max(1, a.c4_epochs - 1)}
     net = models.WideResNet(C, depth, widen).to(dev)
     s = inference.SWAG(hyp, net, train, device=dev, reference_quirks=False, seed=1000 + rank, **kw)
     N_TEST_ = n_test
     line['config'].update({'params': s.num_parameters, 'n_train': n_train, 'n_test': n_test, 'batch': batch, 'hyper': hyp,
-                           'members_per_rank': a.steps + a.warmup, 'members': world * (a.steps + a.warmup),
-                           'sharding': 'rank 0 trains, moments broadcast; members sharded over ranks; one all-reduce of [N*C + N]'})
+                           'members': total, 'members_on_rank0': mine, 'warmup_members_per_rank_discarded': a.warmup,
+                           'sharding': 'rank 0 trains, moments broadcast; the ensemble\'s members sharded over ranks '
+                                       '(distributed.shard: 30 -> 4,4,4,4,4,4,3,3 at N = 8); one all-reduce of [N*C + N]'})
 
     def trajectory():
         t0 = time.perf_counter()
@@ -658,23 +841,26 @@ def run_c4(a, job, legs, line):
 
     def members():
         if a.warmup:
-            ensemble.extend(s.sample(num_samples=a.warmup))
-        ens, dt = job.timed(lambda: s.sample(num_samples=a.steps))      # SWAG.sample: LANES members per pass over the training set
+            s.sample(num_samples=a.warmup)                               # MIOpen search / lane warm-up: not part of the ensemble
+        ens, dt = job.timed(lambda: s.sample(num_samples=mine) if mine else [])   # SWAG.sample: LANES members per pass over the training set
         ensemble.extend(ens)
-        line.update({'value': round(world * a.steps / dt, 4), 'unit': 'SWAG members/s', 'ms_per_step': round(1e3 * dt / a.steps, 2)})
+        line.update({'value': round(total / dt, 4), 'unit': 'SWAG members/s', 'ms_per_step': round(1e3 * dt / a.steps, 2)})
     legs.run('members', members)
 
     def bma():
         pred = tasks.Prediction({'in_distribution_test': test}, C, dev, 'ALL', **({'kernels': kw['kernels']} if kw else {}))
-        pred.update_statistics(ensemble[:1], output_performance=False)
+        # warm-up on this rank's own first member WITHOUT a collective (a rank may hold no member: its update below still
+        # takes part in the one all-reduce with zeros)
+        if ensemble:
+            pred._acc.accumulate(ensemble[:1])
         pred.reset()
+        pred._acc.reset(entropy_too=True)                         # (reset() keeps the entropy sums: prediction.py:33-35)
         _, dt = job.timed(lambda: pred.update_statistics(ensemble, output_performance=False))
         m = pred.get_performance_metrics()
         line.update({'bma_preds_per_s': round(N_TEST_ / dt, 1), 'bma_members': pred.num_samples_collected, 'bma_seconds': round(dt, 2),
                      'bma_member_forwards_per_s': round(pred.num_samples_collected * N_TEST_ / dt, 1),
                      'bma_nll': round(float(m['nll']), 5), 'bma_engine': dict(pred._acc.stats)})
-    if ensemble:
-        legs.run('bma', bma)
+    legs.run('bma', bma)                                          # every rank enters (the all-reduce is collective)
 
     def roofline():
         K, n = s.kernels, s.arena.n
@@ -684,8 +870,8 @@ def run_c4(a, job, legs, line):
         ms = batches[len(batches) // 2]                  # median of 5 event-timed batches of 10 launches
         ach = 12 * n / (ms * 1e-3) / 1e9
         line['roofline'] = {'bound': 'hbm', 'kernel': 'k_swag_draw_v (K3, one member)', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBPS,
-                            'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBPS, 4), 'traffic': pmc_traffic('swag_draw', n),
-                            'bytes_per_launch': 12 * n, 'us_per_launch': round(ms * 1e3, 2)}
+                            'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBPS, 4), 'traffic': pmc_traffic('swag_draw', n)[0],
+                            'traffic_source': pmc_traffic('swag_draw', n)[1], 'bytes_per_launch': 12 * n, 'us_per_launch': round(ms * 1e3, 2)}
         line['roofline_bma_kernel'] = bma_kernel_block(len(ensemble) or 30, N_TEST, C)
     if rank == 0 and not job.cpu:
         legs.run('roofline', roofline)
@@ -702,14 +888,20 @@ def run_c5(a, job, legs, line):
     C = 100
     local_chains = [c for c in range(a.c5_chains) if c % world == rank]
     line['metric'] = 'HMC proposals/sec and leapfrog steps/sec, PreResNet-164 / CIFAR-100-shaped, full-batch potential'
-    train = synthetic(a.c5_batch, (3, 32, 32), C, seed=0, device=dev, batch_size=BATCH)
+    n_full, depth, kw = a.c5_batch, 164, {}
+    if job.cpu:                                                  # --dry-run-cpu: control flow only (tests)
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        from oracle_kernels import OracleKernels
+        n_full, depth, kw = 32, 8, dict(kernels=OracleKernels(), use_graph=False)
+    train = synthetic(n_full, (3, 32, 32), C, seed=0, device=dev, batch_size=BATCH)
     hyp = {'step_size': 2e-4, 'num_samples': 1, 'L': a.c5_L, 'tau': 1.0, 'burn': 0, 'mass': 1.0}
     chains = []
     for c in local_chains:
         util.set_random_seed(c)
-        chains.append(inference.HMC(dict(hyp), models.PreResNet(C, 164).to(dev), train, device=dev, seed=c))
-    line['config'].update({'params': None, 'full_batch': a.c5_batch, 'hyper': hyp, 'chains': a.c5_chains,
-                           'chains_on_rank0': len(local_chains), 'sharding': 'chain c on rank c mod N; no communication'})
+        chains.append(inference.HMC(dict(hyp), models.PreResNet(C, depth).to(dev), train, device=dev, seed=c, **kw))
+    line['config'].update({'params': None, 'full_batch': n_full, 'hyper': hyp, 'chains': a.c5_chains,
+                           'chains_on_rank0': len(local_chains), 'ranks_without_a_chain': max(0, world - a.c5_chains),
+                           'sharding': 'chain c on rank c mod N; no communication; a rank without a chain only joins the barriers'})
 
     def proposals():
         for _ in range(a.warmup + 1):                          # MIOpen search, 2 eager evaluations, graph capture
@@ -720,7 +912,8 @@ def run_c5(a, job, legs, line):
         _, dt = job.timed(lambda: [h.sample() for _ in range(a.steps) for h in chains])
         n_prop = a.steps * a.c5_chains
         acc = sum(h.accepted for h in chains)
-        line['config']['params'] = chains[0].arena.num_parameters
+        if chains:
+            line['config']['params'] = chains[0].arena.num_parameters
         line.update({'value': round(n_prop / dt, 4), 'unit': 'HMC proposals/s (all chains)', 'ms_per_step': round(1e3 * dt / a.steps, 2),
                      'leapfrog_steps_per_s': round(n_prop * a.c5_L / dt, 3), 'accepted_rank0': acc,
                      'acceptance_rate_rank0': round(acc / max(1, a.steps * len(chains)), 3)})
@@ -746,8 +939,8 @@ def run_c5(a, job, legs, line):
         ach = 20 * big / (ms_l * 1e-3) / 1e9
         line['roofline'] = {'bound': 'hbm', 'kernel': 'k_leapfrog_v (K4 kick+drift), 2^26 elements', 'achieved': round(ach, 1),
                             'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBPS, 4), 'traffic': None,
-                            'bytes_per_launch': 20 * big, 'us_per_launch': round(ms_l * 1e3, 2)}
-    if rank == 0 and chains:
+                            'traffic_source': 'none', 'bytes_per_launch': 20 * big, 'us_per_launch': round(ms_l * 1e3, 2)}
+    if rank == 0 and chains and not job.cpu:
         legs.run('roofline', roofline)
 
 
@@ -762,8 +955,9 @@ def main(argv=None):
     try:
         legs.run('job', {'c2': run_c2, 'c4': run_c4, 'c5': run_c5}[a.config], a, job, legs, line)
     finally:
+        errors = job.gather_errors(legs.errors)
         if job.rank == 0:
-            line['errors'] = legs.errors
+            line['errors'] = errors
             print(json.dumps(line), flush=True)
         job.close()
     return 1 if legs.errors else 0

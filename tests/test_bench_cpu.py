@@ -64,8 +64,39 @@ def test_a_failing_leg_keeps_the_line(leg):
 def test_dry_run_c4_world_size_2_gloo():
     """BASELINE configs[3]'s N > 1 flow: rank 0 runs the SWAG trajectory, the moments are broadcast, every rank draws
     its own members and evaluates them, one all-reduce; toy WideResNet on CPU tensors."""
-    rc, line = run_bench(['--dry-run-cpu', '--config', 'c4', '--gpus', '2', '--steps', '2', '--warmup', '1', '--c4-epochs', '2'], world=2)
+    rc, line = run_bench(['--dry-run-cpu', '--config', 'c4', '--gpus', '2', '--steps', '2', '--warmup', '1', '--c4-epochs', '2', '--c4-weak'], world=2)
     assert rc == 0 and line['errors'] == {}, line['errors']
-    assert line['n_gpus'] == 2 and line['config']['members'] == 6 and line['bma_members'] == 6
+    assert line['n_gpus'] == 2 and line['config']['members'] == 4 and line['bma_members'] == 4 and line['scaling'] == 'weak'
     assert line['unit'] == 'SWAG members/s' and line['value'] > 0 and 'NOT a measurement' in line['data']
     assert line['value'] == pytest.approx(2 * 2 / (line['ms_per_step'] * 2 / 1e3), rel=1e-3)
+
+
+def test_dry_run_c4_shards_the_ensemble_world_size_4_gloo():
+    """the config's members are SHARDED over the ranks (30 -> 8, 8, 7, 7 at world size 4), scaling strong,
+    value = members / max-over-ranks time; the warm-up member of every rank is not part of the ensemble. Also 2 members on
+    4 ranks: two ranks hold none and still take part in the one all-reduce."""
+    rc, line = run_bench(['--dry-run-cpu', '--config', 'c4', '--gpus', '4', '--steps', '30', '--warmup', '1', '--c4-epochs', '2'], world=4)
+    assert rc == 0 and line['errors'] == {}, line['errors']
+    assert line['scaling'] == 'strong' and line['n_gpus'] == 4 and line['steps'] == 30
+    assert line['config']['members'] == 30 and line['config']['members_on_rank0'] == 8 and line['bma_members'] == 30
+    assert line['value'] == pytest.approx(30 / (line['ms_per_step'] * 30 / 1e3), rel=1e-3)
+    rc, line = run_bench(['--dry-run-cpu', '--config', 'c4', '--gpus', '4', '--steps', '2', '--warmup', '0', '--c4-epochs', '2'], world=4)
+    assert rc == 0 and line['errors'] == {}, line['errors']
+    assert line['bma_members'] == 2 and line['config']['members_on_rank0'] == 1
+
+
+@pytest.mark.parametrize('chains', [4, 2])
+def test_dry_run_c5_world_size_4_gloo(chains):
+    """BASELINE configs[4] on 4 ranks: chain c on rank c mod 4, no communication; with 2 chains two ranks hold none, skip
+    their legs cleanly and only join the barriers (round 2: IndexError on those ranks). value counts every chain's proposals."""
+    rc, line = run_bench(['--dry-run-cpu', '--config', 'c5', '--gpus', '4', '--steps', '2', '--warmup', '0', '--c5-chains', str(chains),
+                          '--c5-L', '2'], world=4)
+    assert rc == 0 and line['errors'] == {}, line['errors']
+    assert line['n_gpus'] == 4 and line['config']['chains'] == chains and line['config']['ranks_without_a_chain'] == 4 - chains
+    assert line['value'] == pytest.approx(chains * 2 / (line['ms_per_step'] * 2 / 1e3), rel=1e-3)
+    assert 0 <= line['acceptance_rate_rank0'] <= 1
+
+
+def test_a_leg_failing_on_another_rank_reaches_the_line():
+    rc, line = run_bench(['--dry-run-cpu', '--gpus', '2', '--steps', '1', '--warmup', '0', '--inject-failure', 'bma@1:after'], world=2)
+    assert rc != 0 and 'rank1:bma' in line['errors'] and 'injected failure' in line['errors']['rank1:bma']
