@@ -275,6 +275,25 @@ def test_tensors_without_gradient_are_skipped_like_the_reference():
     opt.step(add_langevin_noise=True)
     assert torch.equal(params[1], after1[1]) and not torch.equal(params[0], after1[0])
     assert float(opt.arena.grad_views[1].abs().sum()) == 0  # the previous step's gradient is gone, not re-applied
+    # the reference's host loop (sghmc.py:79-86): optimizer.zero_grad() [torch's default: set_to_none], backward, step.
+    # A layer the loss never touches keeps .grad = None and is left alone — no prior pull, no noise (with a
+    # memset-only zero_grad it saw a zero gradient and was updated on every step).
+    torch.manual_seed(1)
+    used, unused = torch.nn.Linear(6, 3), torch.nn.Linear(4, 2)
+    opt = inference.optimSGHMC(list(used.parameters()) + list(unused.parameters()), lr=0.1, momentum=0.5,
+                               num_training_samples=10, weight_decay=1.0, kernels=OracleKernels())
+    w0 = [p.detach().clone() for p in unused.parameters()]
+    ref = torch.nn.Linear(6, 3)
+    ref.load_state_dict(used.state_dict())
+    for k in range(3):
+        opt.zero_grad()
+        assert all(p.grad is None for p in unused.parameters())
+        used(torch.ones(2, 6)).sum().backward()
+        opt.step(add_langevin_noise=True)
+    assert all(torch.equal(a, b) for a, b in zip(unused.parameters(), w0))
+    assert not torch.equal(used.weight, ref.weight)
+    opt.zero_grad(set_to_none=False)                        # the memset form keeps the views bound
+    assert opt.arena.grads_bound() and float(opt.arena.grad.abs().sum()) == 0
 
 
 def _cyclic_replay(golden_dir, name, device, kernels=None, atol=0.0, use_graph=None, warmup_steps=None):

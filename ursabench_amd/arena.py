@@ -157,9 +157,11 @@ class FlatArena:
 
     def rebind(self):
         """Re-point parameters / grads / buffers at the arena if something replaced them
-        (optimizer.zero_grad(set_to_none=True), module.to(), load_state_dict keep data in place
-        but a user may assign p.grad). Values found outside the arena are copied in."""
+        (optimizer.zero_grad() sets .grad to None and autograd then hands out fresh tensors; module.to(),
+        load_state_dict keep data in place but a user may assign p.grad). Values found outside the arena are copied
+        in — the gradients with ONE multi-tensor copy."""
         with torch.no_grad():
+            src, dst = [], []
             for p, v, gv in zip(self.params, self.layout.views(self.theta), self.grad_views):
                 if p.data_ptr() != v.data_ptr():
                     v.copy_(p.detach())
@@ -168,8 +170,11 @@ class FlatArena:
                     gv.zero_()               # "no gradient": never re-apply the previous step's (optim_sghmc.py:44-45)
                     p.grad = gv
                 elif p.grad.data_ptr() != gv.data_ptr():
-                    gv.copy_(p.grad)
+                    src.append(p.grad)
+                    dst.append(gv)
                     p.grad = gv
+            if src:
+                torch._foreach_copy_(dst, src)
 
     def stash(self, indices):
         """Copies of the theta (and momentum) slices of the given tensors, to undo a flat update on them."""

@@ -1221,8 +1221,11 @@ int ursa_bma_accumulate_f32(const float* logits, float* proba_sum, float* ent_su
         }
         const int cp = C <= 4 ? 4 : C <= 8 ? 8 : C == 10 ? 10 : 16;
         const bool exact = C == cp;
-        const size_t lds = sizeof(float) * ((size_t)W * 4 * kRlRows * C
-                                            + (size_t)4 * W * (kRlRows * C * (risk_sum ? 2 : 1) + kRlRows));
+        auto lds_for = [&](int w) {
+            return sizeof(float) * ((size_t)w * 4 * kRlRows * C + (size_t)4 * w * (kRlRows * C * (risk_sum ? 2 : 1) + kRlRows));
+        };
+        while (W > 1 && lds_for(W) > 64 * 1024) W >>= 1;      // the default dynamic-LDS limit (a debug override could exceed it: ADVICE r2)
+        const size_t lds = lds_for(W);
         const dim3 grid((unsigned)bma_grid(B, kRlRows)), block(64 * W);
 #define URSA_RL2(CPV, EX, RK)                                                                                   \
         hipLaunchKernelGGL((k_bma_rowlane<CPV, EX, RK>), grid, block, lds, st, logits, proba_sum, ent_sum,      \

@@ -34,11 +34,27 @@ def increase_data_imbalance(label, x, y, remove_frac=0.9):
     return x[~drop], y[~drop]
 
 
+# the two CIFAR-10 class halves of `split_classes` (datasets.py:11-14)
+C10_CLASSES = ([0, 1, 2, 8, 9], [3, 4, 5, 6, 7])
+
+
+def _split(x, y, split_classes):
+    """datasets.py:224-242: keep the rows of the chosen class half and relabel them 0..4 by position in the half
+    (num_classes stays the dataset's: it is computed before the split, datasets.py:168)."""
+    half = torch.tensor(C10_CLASSES[split_classes])
+    mask = torch.isin(y, half)
+    y = (y[mask][:, None] == half[None, :]).nonzero()[:, 1]
+    return x[mask], y
+
+
 def loaders(dataset, path=None, batch_size=128, num_workers=0, transform_train=None, transform_test=None,
             use_validation=False, val_size=0.2, split_classes=None, shuffle_train=True, imbalance=False,
             device='cuda', train_size=None, test_size=None, seed=0, **kwargs):
     if dataset not in SHAPES:
         raise NotImplementedError(dataset)
+    if split_classes is not None:
+        assert dataset == 'CIFAR10'                       # datasets.py:225-226
+        assert split_classes in {0, 1}
     shape, classes, n_train, n_test = SHAPES[dataset]
     n_train, n_test = train_size or n_train, test_size or n_test
     cls = _named_dataset_cls(dataset)
@@ -57,8 +73,13 @@ def loaders(dataset, path=None, batch_size=128, num_workers=0, transform_train=N
             n = len(y)
         if split == 'train' and use_validation:
             n_val = int(n * val_size)
-            out['train'] = DeviceLoader(x[:-n_val].to(device), y[:-n_val].to(device), batch_size, shuffle_train, s, cls)
-            out['test'] = DeviceLoader(x[-n_val:].to(device), y[-n_val:].to(device), batch_size, False, s, cls)
+            (xt, yt), (xv, yv) = (x[:-n_val], y[:-n_val]), (x[-n_val:], y[-n_val:])
+            if split_classes is not None:
+                (xt, yt), (xv, yv) = _split(xt, yt, split_classes), _split(xv, yv, split_classes)
+            out['train'] = DeviceLoader(xt.to(device), yt.to(device), batch_size, shuffle_train, s, cls)
+            out['test'] = DeviceLoader(xv.to(device), yv.to(device), batch_size, False, s, cls)
             return out, classes
+        if split_classes is not None:
+            x, y = _split(x, y, split_classes)
         out[split] = DeviceLoader(x.to(device), y.to(device), batch_size, shuffle_train and split == 'train', s, cls)
     return out, classes

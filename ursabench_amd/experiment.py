@@ -84,13 +84,16 @@ def run(args, device=None, kernels=None):
             csv.writer(f, dialect='excel').writerow([args.dataset, args.model, args.seed, args.inference_method, args.task,
                                                      args.batch_size, *[hyperparams[k] for k in sorted(hyperparams)],
                                                      *[perf[k] for k in sorted(perf)]])
+    if use_val:
+        # experiment.py:113: the trial loop, the OOD / Decision tasks and the <save_path>results.csv / _tests.npy writes
+        # all sit under `if not args.use_val:` — a hyper-optimisation call costs ONE sampler run and writes ONE row
+        return perf if args.task == 'Prediction' else {}
     ood_loaders = []
-    if not use_val:                                               # experiment.py:113-160
-        if args.dataset not in OOD_SETS:
-            raise NotImplementedError
-        for name in OOD_SETS[args.dataset]:
-            l, _ = datasets.loaders(name, **ds)
-            ood_loaders.append({'data': name, 'in_distribution_test': test_loader, 'out_distribution_test': l['test']})
+    if args.dataset not in OOD_SETS:                              # experiment.py:113-160
+        raise NotImplementedError
+    for name in OOD_SETS[args.dataset]:
+        l, _ = datasets.loaders(name, **ds)
+        ood_loaders.append({'data': name, 'in_distribution_test': test_loader, 'out_distribution_test': l['test']})
 
     S = args.num_trials
     results, temp, costs = {}, {}, []
@@ -120,7 +123,7 @@ def run(args, device=None, kernels=None):
         # experiment.py:218-247: per seed, retrain on the class-imbalanced training set and decide on its test set
         for s in range(S):
             util.set_random_seed(s)
-            l, _ = datasets.loaders(args.dataset, imbalance=True, **ds)
+            l, _ = datasets.loaders(args.dataset, imbalance=True, split_classes=getattr(args, 'split_classes', None), **ds)
             sampler = inference_method(hyperparameters=hyperparams, model=model, train_loader=l['train'], device=device, **kw)
             dec = tasks.Decision(dataloader={'decision_data_test': l['test']}, num_classes=num_classes, device=device, **kw)
             dec.update_statistics(models=sampler.sample(), output_performance=False, smoothing=True)

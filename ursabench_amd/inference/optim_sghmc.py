@@ -78,10 +78,20 @@ class optimSGHMC(Optimizer):
         if old.seed == self.seed:
             self._step = old._step
 
-    def zero_grad(self, set_to_none=False):
-        """One memset of the flat gradient buffer (the grads are arena views and must survive)."""
+    def zero_grad(self, set_to_none=True):
+        """torch.optim.Optimizer.zero_grad's contract, default included. set_to_none=True (what the reference's bare
+        `optimizer.zero_grad()` means, sghmc.py:79): every .grad becomes None, so after backward() a tensor that received
+        no gradient is still None and step() skips it exactly like optim_sghmc.py:44-45 (no prior pull, no noise);
+        step() packs the fresh gradients into the arena with one multi-tensor copy. set_to_none=False: one memset of the
+        flat gradient buffer, the .grad views stay bound and autograd accumulates into the arena directly (fastest
+        drop-in loop, but an unused tensor then has a zero gradient, not None, and is updated by prior and noise)."""
         for a in self.arenas:
-            a.grad.zero_()
+            if set_to_none:
+                for p in a.params:
+                    p.grad = None
+            else:
+                a.rebind()
+                a.grad.zero_()
 
     def _register_momentum_views(self, gi):
         a = self.arenas[gi]

@@ -165,6 +165,10 @@ def bn_update_many(loader, models, subset=None, device=None, streams=None, **kwa
                         m.momentum = mom
                     if streams:
                         streams[k].wait_stream(cur)
+                        # the batch was allocated on `cur` (a shuffled gather, or the H2D copy of a host loader) and is
+                        # read on the side stream: tell the caching allocator, or the block is handed to a later
+                        # gather / copy on `cur` while this forward may still be reading it
+                        x.record_stream(streams[k])
                         with torch.cuda.stream(streams[k]):
                             model(x, **kwargs)
                     else:
