@@ -438,8 +438,14 @@ def roofline_kernels_block(dev, large_n):
     mean, sq, w, outb = (torch.randn(n, device=dev) for _ in range(4))
     sq.abs_().add_(mean * mean)
     entry('k2_swag_collect_36.5M', 20 * n, lambda: K.swag_collect(mean, sq, w, decay=0.75, denom=4.0), elements=n)
-    entry('k3_swag_draw_36.5M', 12 * n, lambda: K.swag_draw(outb, mean, sq, var_clamp=1e-30, scale=1.0, seed=3, draw=1), elements=n)
-    del mean, sq, w, outb
+    sd = torch.empty_like(mean)
+    entry('k3_swag_std_once_36.5M', 12 * n, lambda: K.swag_std(sd, mean, sq, var_clamp=1e-30, scale=1.0), elements=n,
+          launches='one per ensemble (the standard deviation is shared by every member)')
+    entry('k3_swag_draw_std_36.5M', 12 * n, lambda: K.swag_draw_std(outb, mean, sd, seed=3, draw=1), elements=n,
+          launches='one per member: what SWAG.sample() issues')
+    entry('k3_swag_draw_fused_36.5M', 12 * n, lambda: K.swag_draw(outb, mean, sq, var_clamp=1e-30, scale=1.0, seed=3, draw=1), elements=n,
+          launches='single-draw form (square roots inside the draw): VALU-co-limited, package-power-capped clocks')
+    del mean, sq, w, outb, sd
     # K4 as the HMC host issues it
     ws, acc = torch.zeros(_native.REDUCE_WS_FLOATS, device=dev), torch.zeros(1, device=dev)
     KD = _native.LEAP_KICK | _native.LEAP_DRIFT
@@ -865,13 +871,16 @@ def run_c4(a, job, legs, line):
     def roofline():
         K, n = s.kernels, s.arena.n
         out = torch.empty(n, device=dev)
-        fn = lambda: K.swag_draw(out, s._mean, s._sq, var_clamp=1e-30, scale=1.0, seed=3, draw=1)
+        if s._std is None:
+            s._std = torch.empty_like(s._mean)
+            K.swag_std(s._std, s._mean, s._sq, var_clamp=s.var_clamp, scale=1.0)
+        fn = lambda: K.swag_draw_std(out, s._mean, s._std, seed=3, draw=1)        # the launch SWAG.sample() issues per member
         batches = sorted(event_time_ms(fn, 10, torch.cuda.current_stream()) for _ in range(5))
         ms = batches[len(batches) // 2]                  # median of 5 event-timed batches of 10 launches
         ach = 12 * n / (ms * 1e-3) / 1e9
-        line['roofline'] = {'bound': 'hbm', 'kernel': 'k_swag_draw_v (K3, one member)', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBPS,
-                            'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBPS, 4), 'traffic': pmc_traffic('swag_draw', n)[0],
-                            'traffic_source': pmc_traffic('swag_draw', n)[1], 'bytes_per_launch': 12 * n, 'us_per_launch': round(ms * 1e3, 2)}
+        line['roofline'] = {'bound': 'hbm', 'kernel': 'k_swag_draw_std_v (K3, one member; std stored once per ensemble)', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBPS,
+                            'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBPS, 4), 'traffic': pmc_traffic('swag_draw_std', n)[0],
+                            'traffic_source': pmc_traffic('swag_draw_std', n)[1], 'bytes_per_launch': 12 * n, 'us_per_launch': round(ms * 1e3, 2)}
         line['roofline_bma_kernel'] = bma_kernel_block(len(ensemble) or 30, N_TEST, C)
     if rank == 0 and not job.cpu:
         legs.run('roofline', roofline)

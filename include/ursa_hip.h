@@ -147,6 +147,18 @@ int ursa_swag_draw_f32(float* theta_out, const float* mean, const float* sq,
                        const float* eps, int64_t n, float var_clamp, float scale,
                        uint64_t seed, uint64_t draw, ursa_stream_t stream);
 
+/* K3 for an ensemble: std = sqrt(max(sq - mean*mean, var_clamp)) * scale is the same for every member drawn
+ * from one pair of moment vectors (URSABench/inference/swag.py:131-147 draws num_samples members from them).
+ * ursa_swag_std_f32 stores it once (12 B/param, once); ursa_swag_draw_std_f32 is the per-member draw
+ *     theta = eps * std + mean
+ * — bit-identical to ursa_swag_draw_f32 on the same inputs (the same operations, the square roots hoisted out
+ * of the per-member launch). HBM traffic: 12 B/param/member. */
+int ursa_swag_std_f32(float* std_out, const float* mean, const float* sq, int64_t n,
+                      float var_clamp, float scale, ursa_stream_t stream);
+int ursa_swag_draw_std_f32(float* theta_out, const float* mean, const float* std,
+                           const float* eps /* NULL => Philox (seed, draw) */, int64_t n,
+                           uint64_t seed, uint64_t draw, ursa_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * K5  tasks accumulators         URSABench/tasks/prediction.py:57-63,
  *                                URSABench/tasks/ood_detection.py:59-65,

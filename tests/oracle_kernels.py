@@ -76,6 +76,14 @@ class OracleKernels:
     def swag_draw(self, out, mean, sq, *, var_clamp, scale=1.0, seed=0, draw=0, eps=None):
         O.swag_draw(_np(out), _np(mean), _np(sq), var_clamp=var_clamp, scale=scale, seed=seed, draw=draw, eps=_np(eps))
 
+    def swag_std(self, out, mean, sq, *, var_clamp, scale=1.0):
+        m, q = _np(mean), _np(sq)
+        _np(out)[:] = np.sqrt(np.maximum(q - m * m, np.float32(var_clamp))) * np.float32(scale)
+
+    def swag_draw_std(self, out, mean, std, *, seed=0, draw=0, eps=None):
+        e = _np(eps) if eps is not None else O.philox_normal(out.numel(), seed, draw)
+        _np(out)[:] = e * _np(std) + _np(mean)
+
     def bma_accumulate(self, logits, proba_sum, ent_sum=None, *, one_minus_gamma, gamma_over_c, smoothed,
                        risk_sum=None, cost=None):
         if logits.shape[0] == 0 or logits.shape[1] == 0:

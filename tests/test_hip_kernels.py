@@ -232,6 +232,11 @@ def test_k2_k3_bitwise_vs_reference_golden(K, golden_dir, mode):
     out = torch.empty_like(mean)
     K.swag_draw(out, mean, sq, var_clamp=1e-30, eps=dev(g[f'{mode}/eps']))
     assert np.array_equal(host(out), g[f'{mode}/draw'])
+    # the ensemble form (standard deviation stored once, square-root-free per-member draw) gives the same bits
+    sd, out2 = torch.empty_like(mean), torch.empty_like(mean)
+    K.swag_std(sd, mean, sq, var_clamp=1e-30)
+    K.swag_draw_std(out2, mean, sd, eps=dev(g[f'{mode}/eps']))
+    assert np.array_equal(host(out2), g[f'{mode}/draw'])
 
 
 @pytest.mark.parametrize('n', [1, 7, 1000, 36546980 // 16 + 3])
@@ -249,6 +254,13 @@ def test_k2_k3_bitwise_vs_oracle(K, n):
         O.swag_draw(o, mean, sq, var_clamp=1e-30, scale=0.5, seed=8, draw=2, eps=eps)
         K.swag_draw(d, dm, ds, var_clamp=1e-30, scale=0.5, seed=8, draw=2, eps=None if eps is None else dev(eps))
         assert np.array_equal(host(d), o)
+        for off in (0, 1):                                            # std hoisted out of the draw; float4 and 4-byte paths
+            buf = [torch.zeros(n + 8, device='cuda') for _ in range(4)]
+            m_, s_, sd, d2 = (b[off:off + n] for b in buf)
+            m_.copy_(dm); s_.copy_(ds)
+            K.swag_std(sd, m_, s_, var_clamp=1e-30, scale=0.5)
+            K.swag_draw_std(d2, m_, sd, seed=8, draw=2, eps=None if eps is None else dev(eps))
+            assert np.array_equal(host(d2), o), off
 
 
 @pytest.mark.parametrize('tag', ['c10', 'c100', 'mnist'])
@@ -518,3 +530,10 @@ def test_k2_k3_full_size_properties(K):
     t0 = (n // 4) * 4 - 1024
     assert np.array_equal(host(out[t0:]), O.philox_normal_range(t0, n - t0, 3, 1))
     assert abs(float(out.std()) - 1) < 1e-3
+    # the ensemble form at full size: same bits as the fused draw for a random pair of moments
+    mean, sq = torch.randn(n, device='cuda'), torch.rand(n, device='cuda') * 3
+    K.swag_draw(out, mean, sq, var_clamp=1e-30, seed=3, draw=7)
+    sd, out2 = torch.empty_like(mean), torch.empty_like(mean)
+    K.swag_std(sd, mean, sq, var_clamp=1e-30)
+    K.swag_draw_std(out2, mean, sd, seed=3, draw=7)
+    assert torch.equal(out, out2)

@@ -75,7 +75,11 @@ def point(n, state):
     mean, sq, eps, out = (torch.randn(n, device='cuda') for _ in range(4))
     sq.abs_().add_(mean * mean)
     res = {'elements': n, 'state': state}
+    sd = torch.empty_like(mean)
+    K.swag_std(sd, mean, sq, var_clamp=1e-30)
     for name, bpe, fn in (('philox', 12, lambda: K.swag_draw(out, mean, sq, var_clamp=1e-30, scale=1.0, seed=3, draw=1)),
+                          ('philox_std_hoisted', 12, lambda: K.swag_draw_std(out, mean, sd, seed=3, draw=1)),
+                          ('std_once', 12, lambda: K.swag_std(sd, mean, sq, var_clamp=1e-30)),
                           ('eps_ptr', 16, lambda: K.swag_draw(out, mean, sq, var_clamp=1e-30, scale=1.0, eps=eps)),
                           ('k2_collect', 20, lambda: K.swag_collect(mean, sq, eps, decay=0.75, denom=4.0)),
                           ('torch_copy', 8, lambda: out.copy_(mean))):
@@ -84,6 +88,7 @@ def point(n, state):
                      'TBps_median': round(bpe * n / med / 1e6, 3), 'frac_of_8TBps': round(bpe * n / med / 1e6 / 8, 4),
                      'Gelem_per_s': round(n / med / 1e3, 1)}
     res['smi_during_philox'] = smi_while(lambda: K.swag_draw(out, mean, sq, var_clamp=1e-30, scale=1.0, seed=3, draw=1))
+    res['smi_during_philox_std_hoisted'] = smi_while(lambda: K.swag_draw_std(out, mean, sd, seed=3, draw=1))
     return res
 
 
@@ -101,7 +106,7 @@ def main():
             a @ b
         torch.cuda.synchronize()
     results['smi_after_heat'] = smi()
-    for n in (arena, 1 << 26, 1 << 24, 1 << 25, 3 << 24, 1 << 27):
+    for n in (arena, 1 << 26, 1 << 24):
         results['points'].append(point(n, 'hot'))
         print(json.dumps(results['points'][-1]), flush=True)
     # output into a member-bank row layout ([theta_pad | fbuf_pad]) vs a fresh buffer: same kernel, different write target

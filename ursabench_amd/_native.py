@@ -41,6 +41,8 @@ SIGNATURES = {
     'ursa_philox_normal_f32': (ctypes.c_int, [_vp, _i64, _u64, _u64, _vp]),
     'ursa_swag_collect_f32': (ctypes.c_int, [_vp, _vp, _vp, _i64, _f, _f, _vp]),
     'ursa_swag_draw_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _f, _f, _u64, _u64, _vp]),
+    'ursa_swag_std_f32': (ctypes.c_int, [_vp, _vp, _vp, _i64, _f, _f, _vp]),
+    'ursa_swag_draw_std_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _u64, _u64, _vp]),
     'ursa_bma_accumulate_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _f, _f, _u32, _vp]),
     'ursa_leapfrog_f32': (ctypes.c_int, [_vp, _vp, _vp, _i64, _f, _f, _f, _u32, _vp, _vp, _vp]),
     'ursa_sumsq_f32': (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp]),
@@ -209,6 +211,22 @@ class HipKernels:
                                              _ptr(sq, 'sq', n, dev), _ptr(eps, 'eps', n, dev, optional=True), n,
                                              var_clamp, scale, seed, draw, _stream(dev))
         _check(self.lib, rc, 'ursa_swag_draw_f32')
+
+    def swag_std(self, out, mean, sq, *, var_clamp, scale=1.0):
+        """std = sqrt(max(sq - mean^2, var_clamp)) * scale, once per pair of moment vectors."""
+        n, dev = out.numel(), out.device
+        with torch.cuda.device(dev):
+            rc = self.lib.ursa_swag_std_f32(_ptr(out, 'std_out'), _ptr(mean, 'mean', n, dev), _ptr(sq, 'sq', n, dev), n,
+                                            var_clamp, scale, _stream(dev))
+        _check(self.lib, rc, 'ursa_swag_std_f32')
+
+    def swag_draw_std(self, out, mean, std, *, seed=0, draw=0, eps=None):
+        """theta = eps * std + mean: the per-member draw from a stored standard deviation."""
+        n, dev = out.numel(), out.device
+        with torch.cuda.device(dev):
+            rc = self.lib.ursa_swag_draw_std_f32(_ptr(out, 'theta_out'), _ptr(mean, 'mean', n, dev), _ptr(std, 'std', n, dev),
+                                                 _ptr(eps, 'eps', n, dev, optional=True), n, seed, draw, _stream(dev))
+        _check(self.lib, rc, 'ursa_swag_draw_std_f32')
 
     # K5 ------------------------------------------------------------------------------
     def bma_accumulate(self, logits, proba_sum, ent_sum=None, *, one_minus_gamma, gamma_over_c, smoothed,

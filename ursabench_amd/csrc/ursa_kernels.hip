@@ -451,6 +451,91 @@ __global__ __launch_bounds__(kBlock) void k_swag_draw_s(float* __restrict__ out,
     }
 }
 
+// K3 split for ensembles: the standard deviation sqrt(max(sq - mean^2, clamp)) * scale is the same for every member
+// drawn from one pair of moment vectors (30 members in BASELINE configs[3]); computing it inside every draw costs four
+// correctly rounded square roots per float4 — a fifth of the draw's VALU work, and the draw is VALU-co-limited (Philox +
+// Box-Muller in registers against only 12 B/param): under the 1,400 W package power cap the clock drops to ~1.8 GHz
+// and the fused draw reads 0.57 of the HBM peak (tools/exp/k3_spread.py). k_swag_std_v stores it once; k_swag_draw_std_v
+// is the per-member draw theta = eps * std + mean on the same 12 B/param, bit-identical to the fused kernel.
+template <bool NT>
+__global__ __launch_bounds__(kSBlock) void k_swag_std_v(float* __restrict__ out, const float* __restrict__ mean,
+                                                        const float* __restrict__ sq, int64_t n, float var_clamp, float scale)
+{
+    const int64_t n4 = n >> 2;
+    const int64_t i = (int64_t)blockIdx.x * kSBlock + threadIdx.x;
+    auto sd = [&](float m, float q) {
+        float var = q - m * m;
+        var = var < var_clamp ? var_clamp : var;
+        return __builtin_sqrtf(var) * scale;
+    };
+    if (i < n4) {
+        const float4 m = ld4<NT>(reinterpret_cast<const float4*>(mean) + i);
+        const float4 q = ld4<NT>(reinterpret_cast<const float4*>(sq) + i);
+        st4<NT>(reinterpret_cast<float4*>(out) + i, make_float4(sd(m.x, q.x), sd(m.y, q.y), sd(m.z, q.z), sd(m.w, q.w)));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t j = (n4 << 2) + threadIdx.x;
+        out[j] = sd(mean[j], sq[j]);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_swag_std_s(float* __restrict__ out, const float* __restrict__ mean,
+                                                       const float* __restrict__ sq, int64_t n, float var_clamp, float scale)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        float var = sq[i] - mean[i] * mean[i];
+        var = var < var_clamp ? var_clamp : var;
+        out[i] = __builtin_sqrtf(var) * scale;
+    }
+}
+
+template <bool PHILOX, bool NT>
+__global__ __launch_bounds__(kSBlock) void k_swag_draw_std_v(float* __restrict__ out, const float* __restrict__ mean,
+                                                             const float* __restrict__ sd, const float* __restrict__ eps,
+                                                             int64_t n, uint64_t seed, uint64_t draw)
+{
+    const int64_t n4 = n >> 2;
+    const int64_t i = (int64_t)blockIdx.x * kSBlock + threadIdx.x;
+    if (i < n4) {
+        const float4 m = ld4<NT>(reinterpret_cast<const float4*>(mean) + i);
+        const float4 s = ld4<NT>(reinterpret_cast<const float4*>(sd) + i);
+        const float4 e = PHILOX ? ursa::normal4(seed, draw, (uint64_t)i)
+                                : ld4<NT>(reinterpret_cast<const float4*>(eps) + i);
+        st4<NT>(reinterpret_cast<float4*>(out) + i, make_float4(e.x * s.x + m.x, e.y * s.y + m.y, e.z * s.z + m.z, e.w * s.w + m.w));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t j = (n4 << 2) + threadIdx.x;
+        float e;
+        if (PHILOX) {
+            const float4 z = ursa::normal4(seed, draw, (uint64_t)n4);
+            e = threadIdx.x == 0 ? z.x : threadIdx.x == 1 ? z.y : z.z;
+        } else {
+            e = eps[j];
+        }
+        out[j] = e * sd[j] + mean[j];
+    }
+}
+
+template <bool PHILOX>
+__global__ __launch_bounds__(kBlock) void k_swag_draw_std_s(float* __restrict__ out, const float* __restrict__ mean,
+                                                            const float* __restrict__ sd, const float* __restrict__ eps,
+                                                            int64_t n, uint64_t seed, uint64_t draw)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        float e;
+        if (PHILOX) {
+            const float4 z = ursa::normal4(seed, draw, (uint64_t)(i >> 2));
+            const int l = (int)(i & 3);
+            e = l == 0 ? z.x : l == 1 ? z.y : l == 2 ? z.z : z.w;
+        } else {
+            e = eps[i];
+        }
+        out[i] = e * sd[i] + mean[i];
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // K5: ensemble softmax-mean / entropy / risk accumulation (tasks/prediction.py:57-63,
 // ood_detection.py:59-65, decision_making.py:124-129, util.py:126-144).
@@ -1188,6 +1273,43 @@ int ursa_swag_draw_f32(float* theta_out, const float* mean, const float* sq, con
     if (vec && nt) { if (eps) URSA_LAUNCH((k_swag_draw_v<false, true>)); else URSA_LAUNCH((k_swag_draw_v<true, true>)); }
     else if (vec)  { if (eps) URSA_LAUNCH((k_swag_draw_v<false, false>)); else URSA_LAUNCH((k_swag_draw_v<true, false>)); }
     else           { if (eps) URSA_LAUNCH((k_swag_draw_s<false>)); else URSA_LAUNCH((k_swag_draw_s<true>)); }
+#undef URSA_LAUNCH
+    return launch_status();
+}
+
+int ursa_swag_std_f32(float* std_out, const float* mean, const float* sq, int64_t n, float var_clamp, float scale,
+                      ursa_stream_t stream)
+{
+    if (n < 0 || n > kMaxElems) return URSA_ESIZE;
+    if (n == 0) return URSA_OK;
+    if (!std_out || !mean || !sq) return URSA_ENULL;
+    if (!aligned4(std_out) || !aligned4(mean) || !aligned4(sq)) return URSA_EALIGN;
+    const bool vec = aligned16(std_out) && aligned16(mean) && aligned16(sq);
+    hipStream_t st = (hipStream_t)stream;
+    if (vec && n * 12ll > kNtBytes)
+        hipLaunchKernelGGL(k_swag_std_v<true>, dim3(sgrid(n >> 2)), dim3(kSBlock), 0, st, std_out, mean, sq, n, var_clamp, scale);
+    else if (vec)
+        hipLaunchKernelGGL(k_swag_std_v<false>, dim3(sgrid(n >> 2)), dim3(kSBlock), 0, st, std_out, mean, sq, n, var_clamp, scale);
+    else
+        hipLaunchKernelGGL(k_swag_std_s, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, st, std_out, mean, sq, n, var_clamp, scale);
+    return launch_status();
+}
+
+int ursa_swag_draw_std_f32(float* theta_out, const float* mean, const float* std, const float* eps, int64_t n,
+                           uint64_t seed, uint64_t draw, ursa_stream_t stream)
+{
+    if (n < 0 || n > kMaxElems) return URSA_ESIZE;
+    if (n == 0) return URSA_OK;
+    if (!theta_out || !mean || !std) return URSA_ENULL;
+    if (!aligned4(theta_out) || !aligned4(mean) || !aligned4(std) || !aligned4(eps)) return URSA_EALIGN;
+    const bool vec = aligned16(theta_out) && aligned16(mean) && aligned16(std) && aligned16(eps);
+    hipStream_t st = (hipStream_t)stream;
+    const bool nt = n * 12ll > kNtBytes;
+    const dim3 grid(vec ? sgrid(n >> 2) : grid_for(n, kBlock)), block(vec ? kSBlock : kBlock);
+#define URSA_LAUNCH(K) hipLaunchKernelGGL(K, grid, block, 0, st, theta_out, mean, std, eps, n, seed, draw)
+    if (vec && nt) { if (eps) URSA_LAUNCH((k_swag_draw_std_v<false, true>)); else URSA_LAUNCH((k_swag_draw_std_v<true, true>)); }
+    else if (vec)  { if (eps) URSA_LAUNCH((k_swag_draw_std_v<false, false>)); else URSA_LAUNCH((k_swag_draw_std_v<true, false>)); }
+    else           { if (eps) URSA_LAUNCH((k_swag_draw_std_s<false>)); else URSA_LAUNCH((k_swag_draw_std_s<true>)); }
 #undef URSA_LAUNCH
     return launch_status();
 }

@@ -92,6 +92,7 @@ class SWA(_Inference):
     def _reset_moments(self):
         self._mean = torch.zeros(self.arena.n, device=self.device)
         self._sq = torch.zeros(self.arena.n, device=self.device)
+        self._std = None                    # sqrt(clamp(sq - mean^2)) of the CURRENT moments, filled on first draw
         self.num_models_collected = torch.zeros(1, dtype=torch.long)
         self.burnt_in = False
         self.epochs_run = 0
@@ -120,6 +121,7 @@ class SWA(_Inference):
         """swa.py:79-90 — one K2 launch on the live arena; n = num_models_collected at call time."""
         n = self.num_models_collected.item()
         self.kernels.swag_collect(self._mean, self._sq, self.arena.theta, decay=n / (n + 1.0), denom=n + 1.0)
+        self._std = None                    # the moments moved
         self.subspace.collect_vector(None)
 
     def _schedule(self, epoch):
@@ -196,13 +198,21 @@ class SWAG(SWA):
         self.weight_variance = None
         self.num_samples = hyperparameters['num_samples']
 
+    def _draw(self, theta_out):
+        """One member: theta = mean + std * eps (swag.py:84-86 + swa.py:106-108). The standard deviation is the same for
+        every member drawn from these moments: computed once (K3 `ursa_swag_std_f32`) and kept, so the per-member launch
+        (`ursa_swag_draw_std_f32`, 12 B/param) carries no square roots — bit-identical to the fused draw."""
+        if self._std is None:
+            self._std = torch.empty_like(self._mean)
+            self.kernels.swag_std(self._std, self._mean, self._sq, var_clamp=self.var_clamp, scale=1.0)
+        eps = None if self.eps_provider is None else self.eps_provider(self._draws)
+        self.kernels.swag_draw_std(theta_out, self._mean, self._std, seed=self.seed, draw=self._draws, eps=eps)
+
     def _draw_into_swag_model(self):
         if self.reference_quirks:
             self.swag_arena.theta.copy_(self._mean)              # swag.py:98 — the draw is discarded
         else:
-            eps = None if self.eps_provider is None else self.eps_provider(self._draws)
-            self.kernels.swag_draw(self.swag_arena.theta, self._mean, self._sq, var_clamp=self.var_clamp, scale=1.0,
-                                   seed=self.seed, draw=self._draws, eps=eps)
+            self._draw(self.swag_arena.theta)
         self._draws += 1
 
     def run_trajectory(self, val_loader=None, debug_val_loss=False, wandb_debug=False):
@@ -220,6 +230,7 @@ class SWAG(SWA):
         """Mark the moments in self._mean / self._sq as final (after run_trajectory, or after another rank's
         moments were received into them): later sample_iterative calls only draw."""
         self.burnt_in = True
+        self._std = None
         _, self.weight_variance = self._get_mean_and_variance()
 
     def sample_iterative(self, update_bn=True, val_loader=None, debug_val_loss=False, wandb_debug=False,
@@ -258,9 +269,7 @@ class SWAG(SWA):
             if self.reference_quirks:
                 arena.theta.copy_(self._mean)                     # swag.py:98 — the draw is discarded
             else:
-                eps = None if self.eps_provider is None else self.eps_provider(self._draws)
-                self.kernels.swag_draw(arena.theta, self._mean, self._sq, var_clamp=self.var_clamp, scale=1.0,
-                                       seed=self.seed, draw=self._draws, eps=eps)
+                self._draw(arena.theta)
             self._draws += 1
         on_hip = torch.device(self.device).type == 'cuda'
         main = self.swag_arena
