@@ -67,7 +67,7 @@ for nn, tag in ((1726400, '1.73M'), (1 << 26, '2^26')):
     for _ in range(10):
         K.leapfrog(None, p4, g4, kick_coef=-1e-4, step_size=2e-4, inv_mass=1.0, flags=0x1, kinetic_out=acc, ws=ws)
     manifest.append(dict(pattern='k_leapfrog<', label=f'K4 kick + kinetic-energy reduction {tag}', algorithmic_bytes_per_launch=12 * nn,
-                         elements_total=nn))
+                         elements_total=nn, grid_threads=min((nn // 4 + 255) // 256, 2048) * 256))
     del t4, p4, g4
 # K5 at the shapes the tasks feed it
 for (S, B, C) in ((50, 10000, 10), (20, 9984, 10), (30, 10000, 100)):      # 9,984 rows: a grid of its own in the counter CSVs

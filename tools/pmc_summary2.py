@@ -29,6 +29,8 @@ for key, ctrs in sorted(acc.items()):
             m = cand
         if 'blocks' in cand and grid == cand['blocks'] * wg and cand.get('wg', wg) == wg:
             m = cand
+        if 'grid_threads' in cand and grid == cand['grid_threads']:
+            m = cand
     if m is not None:
         row.update({k: v for k, v in m.items() if k != 'pattern'})
     if 'FETCH_SIZE' in row and 'WRITE_SIZE' in row:
