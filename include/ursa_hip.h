@@ -127,6 +127,14 @@ int ursa_sgmcmc_step_multi_f32(float* theta, float* grad, float* mom, const floa
 int ursa_philox_normal_f32(float* out, int64_t n, uint64_t seed, uint64_t step,
                            ursa_stream_t stream);
 
+/* Device self-test of the generator arithmetic: the Box-Muller radius sqrt(-2 ln u) is computed in registers with a
+ * 6-instruction division and a 9-instruction square root that are correctly rounded on the argument ranges the
+ * generator feeds them; this launch recomputes the radius (and the logarithm) of EVERY one of the 2^32 possible Philox
+ * words with the compiler's general IEEE division / square root as well and adds the number of differing results to
+ * mismatches[0] (radius) and mismatches[1] (logarithm) — two uint64 in DEVICE memory, zeroed by the caller. Both must
+ * stay 0: that is what keeps the device's noise stream bit-identical to the CPU restatement. ~30 ms. */
+int ursa_selftest_rng_f32(uint64_t* mismatches /* device, [2], zero-initialised */, ursa_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * K2  SWA._collect_model         URSABench/inference/swa.py:81-88
  *     mean = mean * decay + w / denom ;  sq = sq * decay + (w * w) / denom

@@ -69,9 +69,51 @@ int main(void)
     for (int64_t i = 0; i < B * C; ++i) { double r = fabs(pd[i] - p[i]) / (fabs(p[i]) + 1e-8); if (r > worst) worst = r; }
     for (int64_t i = 0; i < B; ++i) { double r = fabs(ed[i] - e[i]) / (fabs(e[i]) + 1e-6); if (r > worst) worst = r; }
     if (worst > 1e-5) { printf("FAIL bma relative error %g\n", worst); return 1; }
+    /* ABI v2: two chains in ONE self-advancing launch over [2, stride] slabs, control blocks built by this C host.
+     * Chain k must equal the oracle's single-chain update with ctl[k]'s scalars / key / call index, for 3 steps. */
+    {
+        const int K = 2; const int64_t nc = 4096 + 8 + 2, stride = 4096 + 16;
+        const size_t sb = (size_t)K * stride * sizeof(float);
+        float *hth = malloc(sb), *hgr = malloc(sb), *hmo = malloc(sb), *hb = malloc(sb);
+        for (int64_t i = 0; i < K * stride; ++i) { hth[i] = frand(&seed); hgr[i] = frand(&seed); hmo[i] = 0.1f * frand(&seed); }
+        float *sth, *sgr, *smo; ursa_step_ctl hc[2], *dc;
+        CHECK(hipMalloc((void**)&sth, sb)); CHECK(hipMalloc((void**)&sgr, sb)); CHECK(hipMalloc((void**)&smo, sb));
+        CHECK(hipMalloc((void**)&dc, sizeof hc));
+        memset(hc, 0, sizeof hc);
+        for (int k = 0; k < K; ++k) {
+            hc[k].lr = 0.05f + 0.01f * k; hc[k].mu = k ? 0.0f : 0.9f; hc[k].c_wd = 8e-5f; hc[k].c_noise = 0.1f + 0.1f * k;
+            hc[k].n_train = 50000.0f; hc[k].flags = URSA_STEP_NOISE | URSA_STEP_WD | URSA_STEP_ADVANCE; hc[k].seed = 500 + k; hc[k].step = 10 * k;
+        }
+        CHECK(hipMemcpy(sth, hth, sb, hipMemcpyHostToDevice)); CHECK(hipMemcpy(sgr, hgr, sb, hipMemcpyHostToDevice));
+        CHECK(hipMemcpy(smo, hmo, sb, hipMemcpyHostToDevice)); CHECK(hipMemcpy(dc, hc, sizeof hc, hipMemcpyHostToDevice));
+        for (int it = 0; it < 3; ++it) {
+            CHECK(ursa_sgmcmc_step_multi_f32(sth, sgr, smo, NULL, NULL, nc, K, stride, dc, st));
+            for (int k = 0; k < K; ++k)
+                oracle_sgmcmc_step_f32(hth + k * stride, hgr + k * stride, hc[k].mu != 0.0f ? hmo + k * stride : NULL, NULL, NULL, nc,
+                                       hc[k].lr, hc[k].mu, hc[k].c_wd, hc[k].c_noise, hc[k].n_train, hc[k].seed, hc[k].step + it,
+                                       URSA_STEP_NOISE | URSA_STEP_WD);
+        }
+        CHECK(hipStreamSynchronize(st));
+        CHECK(hipMemcpy(hb, sth, sb, hipMemcpyDeviceToHost));
+        if (memcmp(hb, hth, sb)) { printf("FAIL multi-chain theta differs from the oracle\n"); return 1; }
+        CHECK(hipMemcpy(hb, smo, sb, hipMemcpyDeviceToHost));
+        if (memcmp(hb, hmo, (size_t)stride * sizeof(float))) { printf("FAIL multi-chain momentum differs from the oracle\n"); return 1; }
+        CHECK(hipMemcpy(hc, dc, sizeof hc, hipMemcpyDeviceToHost));
+        if (hc[0].step != 3 || hc[1].step != 13 || hc[0].ticket || hc[1].ticket) { printf("FAIL control blocks did not advance\n"); return 1; }
+    }
+    /* the generator's in-register division / square root against the IEEE forms, all 2^32 inputs, on this device */
+    {
+        uint64_t *dm, hm[2] = {1, 1};
+        CHECK(hipMalloc((void**)&dm, sizeof hm)); CHECK(hipMemset(dm, 0, sizeof hm));
+        CHECK(ursa_selftest_rng_f32(dm, st)); CHECK(hipStreamSynchronize(st));
+        CHECK(hipMemcpy(hm, dm, sizeof hm, hipMemcpyDeviceToHost));
+        if (hm[0] || hm[1]) { printf("FAIL generator self-test: %llu radius / %llu logarithm mismatches\n", (unsigned long long)hm[0], (unsigned long long)hm[1]); return 1; }
+    }
     /* argument errors come back as codes, not crashes */
     if (ursa_sgmcmc_step_f32(NULL, NULL, NULL, NULL, NULL, 8, 0, 0, 0, 0, 1, 0, 0, 0, st) != URSA_ENULL) { printf("FAIL enull\n"); return 1; }
     if (ursa_bma_accumulate_f32(dz, dp, de, NULL, NULL, S, B, 5000, omg, goc, 0, st) != URSA_EVALUE) { printf("FAIL evalue\n"); return 1; }
-    printf("C-ABI host OK: K1 bit-equal to the oracle over 3 steps (n=%lld), K5 max relative error %.2e\n", (long long)n, worst);
+    if (ursa_sgmcmc_step_multi_f32(dth, dgr, dmo, NULL, NULL, 64, 2, 62, NULL, st) != URSA_ESIZE) { printf("FAIL esize (stride < n)\n"); return 1; }
+    printf("C-ABI host OK: K1 bit-equal to the oracle over 3 steps (n=%lld), 2 chains in one self-advancing launch bit-equal, "
+           "generator self-test clean, K5 max relative error %.2e\n", (long long)n, worst);
     return 0;
 }

@@ -40,6 +40,13 @@ def test_philox_normal_bitwise_vs_oracle(K):
     assert np.array_equal(host(buf[1:1028]), O.philox_normal(1027, 9, 9))
 
 
+def test_generator_fast_math_is_ieee_exact_on_every_input(K):
+    """The in-register Box-Muller radius uses a 6-instruction division and a 9-instruction square root (csrc/ursa_rng.h).
+    On this device, for ALL 2^32 Philox words, radius and logarithm equal the ones computed with the compiler's IEEE
+    division / square root — the forms the scalar C oracle uses — bit for bit."""
+    assert K.selftest_rng() == (0, 0)
+
+
 K1_CASES = ['sghmc_wd_noise', 'sghmc_nowd_mixed', 'sghmc_sched', 'sgld_wd_noise', 'sgld_nonoise']
 
 

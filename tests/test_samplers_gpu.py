@@ -744,3 +744,31 @@ def test_hmc_fused_proposal_equals_oracle_substeps():
     assert np.isfinite(log[0]['H0']) and np.isfinite(log[0]['H1']) and abs(log[0]['H0'] - log[0]['H1']) < 1.0
     s._p.copy_(torch.from_numpy((O.philox_normal(n, 13, 0) * mask) * np.float32(np.sqrt(mass))).to(DEV))
     assert float(s._kinetic()) == pytest.approx(ke0, rel=2e-6)
+
+
+def test_swag_grouped_sampling_with_a_host_resident_loader():
+    """in the grouped BatchNorm refresh every batch is allocated on the current stream (here: the H2D copy of a
+    host-resident loader's batch) and read by member forwards on side streams; without `record_stream` the caching
+    allocator could hand the block to the next batch's copy while a forward still reads it. Grouped members must equal
+    the ones formed one at a time, on a loader whose batches are fresh device allocations."""
+    from ursabench_amd import util
+    hyp = {'swag_lr': 0.01, 'swag_wd': 1e-4, 'lr_init': 0.05, 'num_samples': 4, 'momentum': 0.9, 'burn_in_epochs': 1,
+           'num_iterates': 1}
+    g = torch.Generator().manual_seed(0)
+    x, y = torch.randn(1024, 3, 32, 32, generator=g), torch.randint(0, 10, (1024,), generator=g)
+    train = DataLoader(TensorDataset(x, y), batch_size=64, shuffle=False)            # host tensors: x.to(device) per batch
+    util.set_random_seed(3)
+    s = inference.SWAG(dict(hyp), models.PreResNet(10, 8).to(DEV), train, device=DEV, reference_quirks=False, seed=5)
+    s.run_trajectory()
+    s.LANES = 1
+    one = s.sample()
+    s._draws = 0
+    s.LANES, s.GROUP_MIN_PARAMS = 4, 0
+    for _ in range(3):                                        # a race is a matter of timing: several passes
+        s._draws = 0
+        grp = s.sample()
+        for a, b in zip(one, grp):
+            assert torch.equal(flat_params(a), flat_params(b))
+            for (ka, va), (kb, vb) in zip(a.named_buffers(), b.named_buffers()):
+                if va.dtype == torch.float32:
+                    np.testing.assert_allclose(va.cpu().numpy(), vb.cpu().numpy(), rtol=1e-5, atol=1e-6, err_msg=ka)

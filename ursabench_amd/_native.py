@@ -39,6 +39,7 @@ SIGNATURES = {
     'ursa_step_ctl_advance': (ctypes.c_int, [_vp, _i32, _vp]),
     'ursa_sgmcmc_step_multi_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp]),
     'ursa_philox_normal_f32': (ctypes.c_int, [_vp, _i64, _u64, _u64, _vp]),
+    'ursa_selftest_rng_f32': (ctypes.c_int, [_vp, _vp]),
     'ursa_swag_collect_f32': (ctypes.c_int, [_vp, _vp, _vp, _i64, _f, _f, _vp]),
     'ursa_swag_draw_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _f, _f, _u64, _u64, _vp]),
     'ursa_swag_std_f32': (ctypes.c_int, [_vp, _vp, _vp, _i64, _f, _f, _vp]),
@@ -195,6 +196,16 @@ class HipKernels:
         with torch.cuda.device(dev):
             rc = self.lib.ursa_philox_normal_f32(_ptr(out, 'out'), out.numel(), seed, step, _stream(dev))
         _check(self.lib, rc, 'ursa_philox_normal_f32')
+
+    def selftest_rng(self, device='cuda'):
+        """(radius mismatches, logarithm mismatches) of the generator's fast division / square root against the IEEE
+        forms over all 2^32 Philox words; both must be 0."""
+        dev = torch.device(device)
+        counts = torch.zeros(2, dtype=torch.int64, device=dev)
+        with torch.cuda.device(dev):
+            rc = self.lib.ursa_selftest_rng_f32(counts.data_ptr(), _stream(dev))
+        _check(self.lib, rc, 'ursa_selftest_rng_f32')
+        return tuple(int(v) for v in counts.cpu())
 
     # K2 / K3 -------------------------------------------------------------------------
     def swag_collect(self, mean, sq, w, *, decay, denom):

@@ -37,7 +37,38 @@ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
     return {c0, c1, c2, c3};
 }
 
+// Correctly rounded division and square root for the ARGUMENT RANGES this file feeds them, in 6 and 9 instructions
+// instead of the compiler's general 11 and 16 (no scaling of tiny / huge operands, no inf / nan fix-up): the draw
+// kernels are co-limited by this arithmetic under the package power cap (tools/exp/k3_spread.py). EXACT == true
+// selects the compiler's IEEE expansion; `ursa_selftest_rng_f32` compares the two forms on the device over every one
+// of the 2^32 inputs the generator can produce, and the test-suite requires zero mismatches — so the stream stays
+// bit-identical to the scalar C restatement in oracle/ursa_oracle.c, which uses `/` and sqrtf.
+template <bool EXACT>
+__device__ __forceinline__ float div_log(float f, float d)          // f in [-0.293, 0.415], d = 2 + f in [1.707, 2.415]
+{
+    if (EXACT) return f / d;
+    float y = __builtin_amdgcn_rcpf(d);                               // 1 ulp
+    const float e = __builtin_fmaf(-d, y, 1.0f);
+    y = __builtin_fmaf(e, y, y);                                      // Newton step: reciprocal to rounding accuracy
+    const float q = f * y;
+    const float r = __builtin_fmaf(-d, q, f);                         // exact residual
+    return __builtin_fmaf(r, y, q);                                   // Markstein correction: correctly rounded quotient
+}
+
+template <bool EXACT>
+__device__ __forceinline__ float sqrt_rad(float x)                   // x = -2 ln u in {-0} U [1.19e-7, 45.8]
+{
+    if (EXACT) return __builtin_sqrtf(x);
+    const float s = __builtin_amdgcn_sqrtf(x);                        // 1 ulp
+    const float s_dn = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_dn = __builtin_fmaf(-s_dn, s, x), r_up = __builtin_fmaf(-s_up, s, x);
+    float t = (0.0f >= r_dn) ? s_dn : s;                              // the neighbour test of the IEEE expansion, minus its
+    t = (0.0f < r_up) ? s_up : t;                                     // operand scaling and special-value fix-ups
+    return t;
+}
+
 // ln(u), u in (0, 1]; fdlibm-style reduction, degree-4 even/odd split in s = f/(2+f).
+template <bool EXACT = false>
 __device__ __forceinline__ float det_logf(float u)
 {
     uint32_t bits = __float_as_uint(u);
@@ -46,7 +77,7 @@ __device__ __forceinline__ float det_logf(float u)
     const bool big = m > 0x3504f3u;
     k += big ? 1 : 0;
     const float f = __uint_as_float(m | (big ? 0x3f000000u : 0x3f800000u)) - 1.0f;
-    const float s = f / (2.0f + f);
+    const float s = div_log<EXACT>(f, 2.0f + f);
     const float z = s * s;
     const float w = z * z;
     const float t1 = w * __builtin_fmaf(w, 0.24279078841f, 0.40000972152f);
@@ -89,19 +120,28 @@ __device__ __forceinline__ float4 normal4(uint64_t seed, uint64_t call, uint64_t
     float4 z;
     {
         const float u1 = __builtin_fmaf((float)x.x, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
-        const float rad = __builtin_sqrtf(-2.0f * det_logf(u1));
+        const float rad = sqrt_rad<false>(-2.0f * det_logf<false>(u1));
         float sn, cs;
         det_sincos2pi(x.y >> 9, sn, cs);
         z.x = rad * cs; z.y = rad * sn;
     }
     {
         const float u1 = __builtin_fmaf((float)x.z, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
-        const float rad = __builtin_sqrtf(-2.0f * det_logf(u1));
+        const float rad = sqrt_rad<false>(-2.0f * det_logf<false>(u1));
         float sn, cs;
         det_sincos2pi(x.w >> 9, sn, cs);
         z.z = rad * cs; z.w = rad * sn;
     }
     return z;
+}
+
+// The radius of the Box-Muller pair from Philox word `w`: every input the generator can produce is one of the 2^32
+// values of `w`, so the fast forms above can be checked against the IEEE ones exhaustively (ursa_selftest_rng_f32).
+template <bool EXACT>
+__device__ __forceinline__ float radius_of(uint32_t w)
+{
+    const float u1 = __builtin_fmaf((float)w, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+    return sqrt_rad<EXACT>(-2.0f * det_logf<EXACT>(u1));
 }
 
 }  // namespace ursa
