@@ -370,20 +370,26 @@ def given_equal_gradients_block(dev, train, depth=20):
     return out
 
 
-def roofline_block(sampler, large_n):
+def roofline_block(sampler, large_n, group=None):
     """Dominant kernel = the fused update (k_sgmcmc_step_ctl): identical launch to the one inside
-    the timed region (same arena, same control block), timed with HIP events on the stream it is
+    the timed region (same arena / slabs, same control block(s)), timed with HIP events on the stream it is
     launched on. Algorithmic bytes: SGHMC 20 B/param (theta, grad, mom read; theta, mom written) x
-    arena elements per launch."""
+    arena elements per launch (x chains for a ChainGroup's one multi-chain launch)."""
     opt, arena = sampler.optimizer, sampler.arena
     K = opt.kernels
     stream = torch.cuda.current_stream()
-    opt.ctl_begin(True)
-    ms = event_time_ms(lambda: K.sgmcmc_step_ctl(arena.theta, arena.grad, arena.mom, opt._ctl), 2048, stream,
-                       graph_batch=256)
-    bytes_per_launch = 20 * arena.n
+    if group is None:
+        opt.ctl_begin(True)
+        fn, chains = (lambda: K.sgmcmc_step_ctl(arena.theta, arena.grad, arena.mom, opt._ctl)), 1
+    else:
+        for s_ in group.samplers:
+            s_.optimizer.ctl_begin(True)
+        fn, chains = (lambda: K.sgmcmc_step_multi(group.theta, group.grad, group.mom, group.ctl)), len(group)
+    ms = event_time_ms(fn, 2048, stream, graph_batch=256)
+    bytes_per_launch = 20 * arena.n * chains
     achieved = bytes_per_launch / (ms * 1e-3) / 1e9
-    out = {'bound': 'hbm', 'kernel': 'k_sgmcmc_step_ctl', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS,
+    out = {'bound': 'hbm', 'kernel': 'k_sgmcmc_step_ctl' + (f' ({chains} chains in one launch)' if chains > 1 else ''),
+           'chains_per_launch': chains, 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS,
            'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': pmc_traffic('step_ctl', arena.n)[0],
            'traffic_source': pmc_traffic('step_ctl', arena.n)[1], 'bytes_per_launch': bytes_per_launch, 'us_per_launch': round(ms * 1e3, 3),
            'note': 'workload-sized launch (5.5 MB of state, L2/Infinity-Cache resident, one float4 per lane, 134 workgroups), '
@@ -778,7 +784,7 @@ def run_c2(a, job, legs, line):
         legs.run('bma', bma)
 
     if rank == 0 and not job.cpu:
-        r = legs.run('roofline', roofline_block, sampler, a.large_n)
+        r = legs.run('roofline', roofline_block, sampler, a.large_n, group)
         if r is not None:
             line['roofline'], line['roofline_large'] = r
         line['roofline_bma_kernel'] = legs.run('roofline_bma_kernel', bma_kernel_block, max(1, len(ensemble)), N_TEST, CLASSES)

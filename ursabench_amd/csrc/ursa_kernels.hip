@@ -236,16 +236,20 @@ __device__ __forceinline__ void ctl_advance(ursa_step_ctl* ctl)
 // fires at kernel start 5.4 and 3x worse for 16 chains (all tickets at once: 25-47 ns each). A streaming launch of
 // 100+ us does not want 11 ns x 18,000 workgroups: hosts self-advance up to URSA_SELF_ADVANCE_MAX_ELEMS per chain and
 // use the explicit advance launch beyond.
-template <bool NT>
+// MULTI: the launch carries several chains (blockIdx.y); a separate instantiation so that a profile tells the
+// single-chain launches of a sampler from the multi-chain launches of a ChainGroup by name.
+template <bool NT, bool MULTI>
 __global__ __launch_bounds__(1024) void k_sgmcmc_step_ctl(float* theta, float* grad, float* mom,
                                                           const float* eps, float* snapshot, int64_t n,
                                                           int64_t chain_stride, ursa_step_ctl* ctl_base)
 {
-    ursa_step_ctl* ctl = ctl_base + blockIdx.y;
-    const int64_t off = (int64_t)blockIdx.y * chain_stride;
-    theta += off; grad += off; mom += off;
-    if (eps) eps += off;
-    if (snapshot) snapshot += off;
+    ursa_step_ctl* ctl = ctl_base + (MULTI ? blockIdx.y : 0);
+    if (MULTI) {
+        const int64_t off = (int64_t)blockIdx.y * chain_stride;
+        theta += off; grad += off; mom += off;
+        if (eps) eps += off;
+        if (snapshot) snapshot += off;
+    }
     StepScalars s;
     s.lr = ctl->lr; s.mu = ctl->mu; s.c_wd = ctl->c_wd; s.c_noise = ctl->c_noise;
     s.n_train = ctl->n_train; s.flags = ctl->flags; s.seed = ctl->seed; s.step = ctl->step;
@@ -1039,8 +1043,10 @@ __global__ __launch_bounds__(kSBlock) void k_leapfrog_v(float* __restrict__ thet
     }
 }
 
-// Grid-stride form: also used when the kinetic energy is wanted (bounded number of block partials).
-template <bool VEC>
+// Grid-stride form: also used when the kinetic energy is wanted (bounded number of block partials). NT: non-temporal
+// accesses when the vectors touched exceed the Infinity Cache, as in the streaming form (round 2 left this form on
+// plain accesses: kick + kinetic read 0.63 of the HBM peak at 2^26 elements against 0.78 for the streaming kick).
+template <bool VEC, bool NT>
 __global__ __launch_bounds__(kBlock) void k_leapfrog(float* __restrict__ theta, float* __restrict__ mom,
                                                      const float* __restrict__ grad, int64_t n, float kick,
                                                      float drift, uint32_t flags, float* __restrict__ ws)
@@ -1051,36 +1057,20 @@ __global__ __launch_bounds__(kBlock) void k_leapfrog(float* __restrict__ theta, 
     float ke = 0.f;
     if (VEC) {
         const int64_t n4 = n >> 2;
-        // Four float4 per thread and trip: the loads of all four are issued before any arithmetic (a grid-stride loop
-        // with one dependent load chain per trip kept too few bytes in flight: kick + kinetic read 0.63 of the HBM peak at
-        // 2^26 elements against 0.81 for the plain kick). Each thread still adds its elements in index order.
-        auto one = [&](float4 p, float4 g, float4 t, int64_t i) {
+        for (int64_t i = tid; i < n4; i += stride) {
+            float4 p = ld4<NT>(reinterpret_cast<const float4*>(mom) + i);
             if (do_kick) {
+                const float4 g = ld4<NT>(reinterpret_cast<const float4*>(grad) + i);
                 p.x = p.x + kick * g.x; p.y = p.y + kick * g.y; p.z = p.z + kick * g.z; p.w = p.w + kick * g.w;
-                reinterpret_cast<float4*>(mom)[i] = p;
+                st4<NT>(reinterpret_cast<float4*>(mom) + i, p);
             }
             if (do_drift) {
+                float4 t = ld4<NT>(reinterpret_cast<const float4*>(theta) + i);
                 t.x = t.x + drift * p.x; t.y = t.y + drift * p.y; t.z = t.z + drift * p.z; t.w = t.w + drift * p.w;
-                reinterpret_cast<float4*>(theta)[i] = t;
+                st4<NT>(reinterpret_cast<float4*>(theta) + i, t);
             }
             ke += (p.x * p.x + p.y * p.y) + (p.z * p.z + p.w * p.w);
-        };
-        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        int64_t i = tid;
-        for (; i + 3 * stride < n4; i += 4 * stride) {
-            float4 p[4], g[4], t[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) p[u] = reinterpret_cast<const float4*>(mom)[i + u * stride];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) g[u] = do_kick ? reinterpret_cast<const float4*>(grad)[i + u * stride] : z4;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) t[u] = do_drift ? reinterpret_cast<const float4*>(theta)[i + u * stride] : z4;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) one(p[u], g[u], t[u], i + u * stride);
         }
-        for (; i < n4; i += stride)
-            one(reinterpret_cast<const float4*>(mom)[i], do_kick ? reinterpret_cast<const float4*>(grad)[i] : z4,
-                do_drift ? reinterpret_cast<const float4*>(theta)[i] : z4, i);
         if (tid < (n & 3)) {
             const int64_t i = (n4 << 2) + tid;
             float p = mom[i];
@@ -1203,10 +1193,11 @@ int ursa_sgmcmc_step_f32(float* theta, float* grad, float* mom, const float* eps
                       : launch_step<false>(ns, vec, nt, st, theta, grad, mom, eps, snapshot, n, s);
 }
 
-// Threads per workgroup of a control-block launch of n4 float4 per chain. Roofline-sized launches: 512 (one float4
-// per thread, kSBlock). A workload-sized chain (PreResNet-20: 68,352 float4 = 134 blocks of 512) would leave half
-// of the 256 CUs without a workgroup: smaller blocks spread the same lanes over every CU (debug override
-// URSA_CTL_BLOCK, tools/kbench.py).
+// Threads per workgroup of a control-block launch. One chain: 512 (one float4 per thread, 134 workgroups for
+// PreResNet-20: 4.06 us self-advancing; 256-thread workgroups double the tickets: 5.6 us; 1,024: 4.36). Several
+// chains per launch: 1,024 — half the tickets per chain, and with K x 67 workgroups there is no shortage of them
+// (8 chains: 8.99 us vs 10.41 at 512; 4 chains: 6.55 vs 6.76; tools/k1_ctl_bench.py, profiles/r03_k1_ctl_bench.json).
+// Debug override: URSA_CTL_BLOCK.
 inline int ctl_block(int64_t n4, int n_chains)
 {
     static const int forced = [] {
@@ -1215,8 +1206,8 @@ inline int ctl_block(int64_t n4, int n_chains)
         return (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) ? v : 0;
     }();
     if (forced) return forced;
-    (void)n4; (void)n_chains;
-    return kSBlock;
+    (void)n4;
+    return n_chains > 1 ? 1024 : kSBlock;
 }
 
 int ursa_sgmcmc_step_multi_f32(float* theta, float* grad, float* mom, const float* eps, float* snapshot,
@@ -1235,12 +1226,11 @@ int ursa_sgmcmc_step_multi_f32(float* theta, float* grad, float* mom, const floa
     int64_t gx = ((n >> 2) + block - 1) / block;
     if (gx < 1) gx = 1;
     const dim3 grid((unsigned)gx, (unsigned)n_chains);
-    if (n * 12ll * n_chains > kNtBytes)
-        hipLaunchKernelGGL(k_sgmcmc_step_ctl<true>, grid, dim3(block), 0, (hipStream_t)stream, theta, grad, mom, eps,
-                           snapshot, n, chain_stride, ctl);
-    else
-        hipLaunchKernelGGL(k_sgmcmc_step_ctl<false>, grid, dim3(block), 0, (hipStream_t)stream, theta, grad, mom, eps,
-                           snapshot, n, chain_stride, ctl);
+    const bool nt = n * 12ll * n_chains > kNtBytes;
+#define URSA_LAUNCH(K) hipLaunchKernelGGL(K, grid, dim3(block), 0, (hipStream_t)stream, theta, grad, mom, eps, snapshot, n, chain_stride, ctl)
+    if (n_chains > 1) { if (nt) URSA_LAUNCH((k_sgmcmc_step_ctl<true, true>)); else URSA_LAUNCH((k_sgmcmc_step_ctl<false, true>)); }
+    else              { if (nt) URSA_LAUNCH((k_sgmcmc_step_ctl<true, false>)); else URSA_LAUNCH((k_sgmcmc_step_ctl<false, false>)); }
+#undef URSA_LAUNCH
     return launch_status();
 }
 
@@ -1466,11 +1456,14 @@ int ursa_leapfrog_f32(float* theta, float* mom, const float* grad, int64_t n, fl
     else if (vec && !kinetic_out)
         hipLaunchKernelGGL(k_leapfrog_v<false>, dim3(sgrid(n >> 2)), dim3(kSBlock), 0, st, theta, mom, grad, n,
                            kick_coef, drift, flags);
+    else if (vec && n * 4ll * (1 + ((flags & URSA_LEAP_KICK) ? 1 : 0) + ((flags & URSA_LEAP_DRIFT) ? 1 : 0)) > kNtBytes)
+        hipLaunchKernelGGL((k_leapfrog<true, true>), dim3(grid), dim3(kBlock), 0, st, theta, mom, grad, n, kick_coef, drift,
+                           flags, wsp);
     else if (vec)
-        hipLaunchKernelGGL(k_leapfrog<true>, dim3(grid), dim3(kBlock), 0, st, theta, mom, grad, n, kick_coef, drift,
+        hipLaunchKernelGGL((k_leapfrog<true, false>), dim3(grid), dim3(kBlock), 0, st, theta, mom, grad, n, kick_coef, drift,
                            flags, wsp);
     else
-        hipLaunchKernelGGL(k_leapfrog<false>, dim3(grid), dim3(kBlock), 0, st, theta, mom, grad, n, kick_coef,
+        hipLaunchKernelGGL((k_leapfrog<false, false>), dim3(grid), dim3(kBlock), 0, st, theta, mom, grad, n, kick_coef,
                            drift, flags, wsp);
     if (kinetic_out)
         hipLaunchKernelGGL(k_finish_sum, dim3(1), dim3(kBlock), 0, st, ws, grid, 0.5f * inv_mass, kinetic_out);
