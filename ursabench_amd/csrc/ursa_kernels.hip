@@ -750,7 +750,13 @@ __global__ __launch_bounds__(kBlock) void k_bma_accumulate(const float* __restri
         for (int e = 0; e < (RISK ? EPL : 1); ++e) acc_r[e] = 0.f;
 
         // full chunks of U members, then the remainder one at a time: no per-member liveness masks anywhere
-        constexpr int U = EPL <= 2 ? 8 : EPL <= 4 ? 4 : EPL <= 8 ? 2 : 1;     // U * EPL <= 16 logits in flight per lane
+#ifndef URSA_BMA_U_EPL8
+#define URSA_BMA_U_EPL8 2
+#endif
+#ifndef URSA_BMA_U_EPL16
+#define URSA_BMA_U_EPL16 1
+#endif
+        constexpr int U = EPL <= 2 ? 8 : EPL <= 4 ? 4 : EPL <= 8 ? URSA_BMA_U_EPL8 : URSA_BMA_U_EPL16;   // members in flight per lane
         const float* zrow = logits + (row_ok ? b : 0) * (int64_t)C;          // rows past B recompute row 0 (never stored)
         int s0 = s_lo;
 #pragma unroll 1
