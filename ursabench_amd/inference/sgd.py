@@ -46,8 +46,10 @@ class SGD(_Inference):
         self.epochs = hyperparameters['epochs']
         self.momentum = hyperparameters['momentum']
         self.weight_decay = hyperparameters['weight_decay']
+        old = self.optimizer
         self.optimizer = FlatSGD(self.model.parameters(), lr=self.lr, momentum=self.momentum,
                                  weight_decay=self.weight_decay, kernels=self._kernels, arena=self.arena)
+        self.optimizer.adopt_device_state(old)      # keep the control block a captured graph may hold (like the chain samplers)
         self.engine.set_optimizer(self.optimizer)
         self.model = reset_model(self.model).to(self.device)
         self.burnt_in = False

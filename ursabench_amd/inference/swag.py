@@ -112,8 +112,10 @@ class SWA(_Inference):
         self._read_hyp(hyperparameters)
         self.model = reset_model(self.model)
         self.swag_model = reset_model(self.swag_model)
+        old = self.optimizer
         self.optimizer = FlatSGD(params=self.model.parameters(), lr=self.lr_init, momentum=self.momentum,
                                  weight_decay=self.swag_wd, kernels=self._kernels, arena=self.arena, seed=self.seed)
+        self.optimizer.adopt_device_state(old)      # keep the control block a captured graph may hold (like the chain samplers)
         self.engine.set_optimizer(self.optimizer)
 
     # -- the three SWA primitives ------------------------------------------------------------
