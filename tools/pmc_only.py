@@ -55,7 +55,7 @@ ctl4 = torch.frombuffer(bytearray(blocks), dtype=torch.uint8).cuda()
 for _ in range(20):
     K.sgmcmc_step_multi(ths, gs, ms_, ctl4)
 manifest.append(dict(pattern='k_sgmcmc_step_ctl', label='K1 4 chains x 273,408 in one launch', algorithmic_bytes_per_launch=20 * nc * 4,
-                     blocks=4 * ((nc // 4 + 511) // 512), wg=512, elements_total=4 * nc))
+                     blocks=4 * ((nc // 4 + 1023) // 1024), wg=1024, elements_total=4 * nc))     # multi-chain launches: 1,024-thread workgroups
 del ths, gs, ms_
 # K4 in the launch forms inference/hmc.py issues, at PreResNet-164's size and at 2^26
 ws, acc = torch.zeros(2048, device='cuda'), torch.zeros(1, device='cuda')
