@@ -85,3 +85,22 @@ def test_experiment_accepts_the_reference_flags(tmp_path, monkeypatch):
     for c in range(10):
         n, nf = int((y == c).sum()), int((yf == c).sum())
         assert n == (int(nf - 0.99 * nf) if c in (3, 7) else nf)
+
+
+def test_shipped_miopen_db_is_copied_privately(monkeypatch, tmp_path):
+    """ursabench_amd/tuning.py: every process gets a PRIVATE writable copy of the shipped tuned MIOpen databases (or an
+    empty private one), and a path the caller set is respected."""
+    from ursabench_amd import tuning
+    shipped = tmp_path / 'shipped'
+    shipped.mkdir()
+    (shipped / 'gfx950.udb.txt').write_text('x=y\n')
+    (shipped / 'README.md').write_text('not a database')
+    monkeypatch.setattr(tuning, 'SHIPPED', str(shipped))
+    monkeypatch.delenv('MIOPEN_USER_DB_PATH', raising=False)
+    monkeypatch.delenv('URSA_NO_SHIPPED_MIOPEN_DB', raising=False)
+    d = tuning.use_shipped_miopen_db()
+    assert os.environ['MIOPEN_USER_DB_PATH'] == d and os.listdir(d) == ['gfx950.udb.txt'] and d != str(shipped)
+    assert tuning.use_shipped_miopen_db() == d                         # already set: respected
+    monkeypatch.delenv('MIOPEN_USER_DB_PATH')
+    monkeypatch.setenv('URSA_NO_SHIPPED_MIOPEN_DB', '1')
+    assert os.listdir(tuning.use_shipped_miopen_db()) == []

@@ -772,3 +772,43 @@ def test_swag_grouped_sampling_with_a_host_resident_loader():
             for (ka, va), (kb, vb) in zip(a.named_buffers(), b.named_buffers()):
                 if va.dtype == torch.float32:
                     np.testing.assert_allclose(va.cpu().numpy(), vb.cpu().numpy(), rtol=1e-5, atol=1e-6, err_msg=ka)
+
+
+def test_chain_group_of_cyclic_samplers_replays_the_reference_run(golden_dir):
+    """G12 through the group path: two cSGHMC chains of one ChainGroup, both fed the reference's captured noise from its
+    initial weights, each reproduce the reference's cSGHMC trajectory — every chain's per-iteration (lr, noise scale)
+    table is walked by the ONE multi-chain update launch (its own `sched` pointer and call index in ctl[k]) under graph
+    replay, noise masks and collect epochs included."""
+    from test_samplers_cpu import tiny_loader, tiny_net
+    g = np.load(os.path.join(golden_dir, 'e2e_cyclic.npz'))
+    name = 'cSGHMC'
+    hyp = json.loads(str(g[f'{name}/hyper']))
+    loader = tiny_loader()
+    chains = []
+    for k in range(2):
+        net = tiny_net()
+        with torch.no_grad():
+            off = 0
+            for p in net.parameters():
+                p.copy_(torch.tensor(g[f'{name}/theta0'][off:off + p.numel()]).view_as(p))
+                off += p.numel()
+        chains.append(inference.cSGHMC(dict(hyp), net, loader, device=DEV, seed=k))
+    group = inference.ChainGroup(chains)
+    group.WARMUP_STEPS = 1
+
+    def provider(s):
+        def eps(k):
+            e = torch.zeros(s.arena.n, device=DEV)
+            e[s.arena.layout.gather_index(DEV)] = torch.tensor(g[f'{name}/eps'][k], device=DEV)
+            return e
+        return eps
+    for s in chains:
+        s.eps_provider = provider(s)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        per_chain = group.sample()
+    assert group.stats['graph_replays'] >= 8 and group.stats['update_launches'] == 16
+    for ens in per_chain:
+        assert len(ens) == len(g[f'{name}/samples'])
+        for m, ref in zip(ens, g[f'{name}/samples']):
+            np.testing.assert_allclose(flat_params(m).cpu().numpy(), ref, rtol=1e-4, atol=1e-5)

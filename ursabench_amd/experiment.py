@@ -140,6 +140,8 @@ def run(args, device=None, kernels=None):
 
 
 def main(argv=None):
+    from .tuning import use_shipped_miopen_db
+    use_shipped_miopen_db()                      # tuned MIOpen solver choices for the benchmark networks (tuning.py)
     res = run(build_parser().parse_args(argv))
     print(sorted(res.keys()))
     print(res)

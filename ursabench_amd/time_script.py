@@ -88,6 +88,8 @@ def run(args, device=None, kernels=None):
 
 
 def main(argv=None):
+    from .tuning import use_shipped_miopen_db
+    use_shipped_miopen_db()                      # tuned MIOpen solver choices for the benchmark networks (tuning.py)
     p = argparse.ArgumentParser()
     p.add_argument('--dataset', type=str, default='CIFAR10')
     p.add_argument('--model', type=str, required=True)
