@@ -674,29 +674,17 @@ def test_mcdropout_reference_run_on_gpu(golden_dir, monkeypatch):
     np.testing.assert_allclose(flat_params(s.sample_iterative()).cpu().numpy(), g['sample2'], rtol=1e-4, atol=1e-6)
 
 
-def test_hmc_fused_proposal_equals_oracle_substeps():
-    """One full HMC proposal (L = 3) at PreResNet-164's parameter count, P = 1,726,388, as the host issues it —
-    kinetic energy, fused half-kick + drift, two fused kick + drift launches, full kick, half-kick correction with the
-    kinetic-energy reduction: L + 3 K4 launches — against the oracle running hamiltorch's sub-step sequence (half kick;
-    L x (drift, gradient, kick); half-kick correction; call site URSABench/inference/hmc.py:71-75) on the gradients the
-    GPU produced: theta and momentum bit for bit, both energies within 2e-6 relative."""
+def _hmc_proposal_vs_oracle(model, train, L, eps, tau, mass, seed, use_graph, expect_params=None):
+    """Run ONE HMC proposal of `model` on the device, tapping the gradients of every potential evaluation and the K4
+    launches, then replay hamiltorch's sub-step sequence (half kick; L x (drift, gradient, kick); half-kick correction;
+    call site URSABench/inference/hmc.py:71-75) in the oracle on those gradients: theta and momentum bit for bit, both
+    kinetic energies within 2e-6 relative; the host issues L + 3 K4 launches."""
     from ursabench_amd import _native
-
-    class Wide(torch.nn.Module):                         # 3072 x 561 + 561 + 2435 = 1,726,388 parameters, cheap to evaluate
-        def __init__(self):
-            super().__init__()
-            self.lin = torch.nn.Linear(3072, 561)
-            self.extra = torch.nn.Parameter(torch.randn(2435) * 0.01)
-
-        def forward(self, x):
-            return self.lin(x.flatten(1))[:, :100] + self.extra[:100]
-    torch.manual_seed(0)
-    train = synthetic(256, (3, 32, 32), 100, seed=0, device=DEV, batch_size=128)
-    L, eps, tau, mass = 3, 2e-4, 1.0, 2.0
     s = inference.HMC({'step_size': eps, 'num_samples': 1, 'L': L, 'tau': tau, 'burn': 0, 'mass': mass},
-                      Wide().to(DEV), train, device=DEV, seed=13, use_graph=False)
+                      model, train, device=DEV, seed=seed, use_graph=use_graph)
     s._bind()
-    assert s.arena.num_parameters == 1726388
+    if expect_params is not None:
+        assert s.arena.num_parameters == expect_params
     th0 = s.arena.theta.cpu().numpy().copy()
     grads, launches = [], []
     orig_eval, orig_leap = s._neg_logp_and_grad, s.kernels.leapfrog
@@ -712,21 +700,20 @@ def test_hmc_fused_proposal_equals_oracle_substeps():
     s._neg_logp_and_grad = tap_eval
     import builtins
     log = []
-    monkey_print = builtins.print
+    real_print = builtins.print
     s.kernels.leapfrog = tap_leap
     try:
         builtins.print = lambda d, *a, **k: log.append(d)
         s.sample(debug=True)
     finally:
-        builtins.print = monkey_print
+        builtins.print = real_print
         s.kernels.leapfrog = orig_leap
     KD = _native.LEAP_KICK | _native.LEAP_DRIFT
-    assert launches == [0, KD, KD, KD, _native.LEAP_KICK, _native.LEAP_KICK] and len(launches) == L + 3
+    assert launches == [0] + [KD] * L + [_native.LEAP_KICK, _native.LEAP_KICK] and len(launches) == L + 3
     assert len(grads) == L + 1 and s.accepted == 1
-    # the oracle's sub-step sequence on the same gradients
     n = s.arena.n
     mask = s._mask.cpu().numpy()
-    p = (O.philox_normal(n, 13, 0) * mask) * np.float32(np.sqrt(mass))
+    p = (O.philox_normal(n, seed, 0) * mask) * np.float32(np.sqrt(mass))
     th = th0.copy()
     inv_mass = 1.0 / mass
     ke0 = O.leapfrog(None, p, None, kick_coef=0.0, step_size=0.0, inv_mass=inv_mass, flags=0, want_kinetic=True)
@@ -738,12 +725,74 @@ def test_hmc_fused_proposal_equals_oracle_substeps():
                      want_kinetic=True)
     assert np.array_equal(s.arena.theta.cpu().numpy(), th)            # accepted: the chain sits at the proposal
     assert np.array_equal(s._p.cpu().numpy(), p)
-    # energies: the fused kinetic-energy reduction of the closing launch, and K of the fresh momentum, against the
-    # oracle's float64 sums
-    assert float(s._acc[0]) == pytest.approx(ke1, rel=2e-6)
-    assert np.isfinite(log[0]['H0']) and np.isfinite(log[0]['H1']) and abs(log[0]['H0'] - log[0]['H1']) < 1.0
-    s._p.copy_(torch.from_numpy((O.philox_normal(n, 13, 0) * mask) * np.float32(np.sqrt(mass))).to(DEV))
+    assert float(s._acc[0]) == pytest.approx(ke1, rel=2e-6)           # the closing launch's fused kinetic-energy reduction
+    assert np.isfinite(log[0]['H0']) and np.isfinite(log[0]['H1'])
+    s._p.copy_(torch.from_numpy((O.philox_normal(n, seed, 0) * mask) * np.float32(np.sqrt(mass))).to(DEV))
     assert float(s._kinetic()) == pytest.approx(ke0, rel=2e-6)
+    return s, log[0]
+
+
+def test_hmc_fused_proposal_equals_oracle_substeps():
+    """One full HMC proposal (L = 3) at PreResNet-164's parameter count, P = 1,726,388, as the host issues it —
+    kinetic energy, fused half-kick + drift, two fused kick + drift launches, full kick, half-kick correction with the
+    kinetic-energy reduction: L + 3 K4 launches — against the oracle's sub-step sequence on the GPU's gradients."""
+    class Wide(torch.nn.Module):                         # 3072 x 561 + 561 + 2435 = 1,726,388 parameters, cheap to evaluate
+        def __init__(self):
+            super().__init__()
+            self.lin = torch.nn.Linear(3072, 561)
+            self.extra = torch.nn.Parameter(torch.randn(2435) * 0.01)
+
+        def forward(self, x):
+            return self.lin(x.flatten(1))[:, :100] + self.extra[:100]
+    torch.manual_seed(0)
+    train = synthetic(256, (3, 32, 32), 100, seed=0, device=DEV, batch_size=128)
+    _, rec = _hmc_proposal_vs_oracle(Wide().to(DEV), train, L=3, eps=2e-4, tau=1.0, mass=2.0, seed=13, use_graph=False,
+                                     expect_params=1726388)
+    assert abs(rec['H0'] - rec['H1']) < 1.0
+
+
+def test_hmc_sampler_on_preresnet164_equals_oracle_substeps():
+    """BASELINE configs[4]'s own network through the sampler on the GPU (no GPU test ran a PreResNet-164
+    sampler): PreResNet-164 / CIFAR-100-shaped, full-batch potential over 64 images (BatchNorm in training mode, as
+    hamiltorch runs the model), one proposal of L = 2 with the potential replayed from a hipGraph after two eager
+    evaluations — theta / momentum bit-identical to the oracle's sub-step sequence on the GPU's gradients."""
+    from ursabench_amd import util
+    util.set_random_seed(0)
+    train = synthetic(64, (3, 32, 32), 100, seed=0, device=DEV, batch_size=64)
+    s, rec = _hmc_proposal_vs_oracle(models.PreResNet(100, 164).to(DEV), train, L=2, eps=1e-4, tau=1.0, mass=1.0, seed=3,
+                                     use_graph=True, expect_params=1726388)
+    assert s._graph is not None                                       # the third evaluation was a graph replay
+
+
+def test_swag_sampler_on_wideresnet28_10_follows_the_oracle_draw():
+    """BASELINE configs[3]'s own network through the sampler on the GPU (no GPU test ran a WideResNet-28-10
+    sampler): WideResNet-28-10 (36,546,980 parameters), SWAG as published on a 256-image set — the SGD trajectory
+    through hipGraph replays with the roofline-sized K1 launch (non-temporal, explicit control-block advance), K2
+    moments, then two members: each equals, bit for bit, the oracle's draw from the moments the device holds (same
+    Philox key and draw index) through the ensemble form (std once + square-root-free draw); BatchNorm statistics
+    refreshed (grouped path: 2 members in one pass)."""
+    from ursabench_amd import util
+    from ursabench_amd._native import StepCtl
+    util.set_random_seed(0)
+    train = synthetic(256, (3, 32, 32), 100, seed=0, device=DEV, batch_size=64)
+    hyp = {'swag_lr': 0.01, 'swag_wd': 3e-4, 'lr_init': 0.05, 'num_samples': 2, 'momentum': 0.9, 'burn_in_epochs': 1,
+           'num_iterates': 2}
+    s = inference.SWAG(dict(hyp), models.WideResNet(100, 28, 10).to(DEV), train, device=DEV, reference_quirks=False, seed=21)
+    assert s.num_parameters == 36546980
+    ens = s.sample()
+    assert len(ens) == 2 and s.num_models_collected.item() == 2 and s.engine.stats['graph_replays'] > 0
+    assert s.optimizer.self_advance is False                          # 36.5 M elements: explicit advance launch
+    c = StepCtl.from_buffer_copy(bytes(s.optimizer._ctl.cpu().numpy()))
+    assert c.step == 3 * 4 and c.ticket == 0
+    mean, sq = s._mean.cpu().numpy(), s._sq.cpu().numpy()
+    for d, m in enumerate(ens):
+        want = np.empty_like(mean)
+        O.swag_draw(want, mean, sq, var_clamp=1e-30, scale=1.0, seed=21, draw=d)
+        got = m._ursa_row[:s.arena.n].cpu().numpy()
+        assert np.array_equal(got, want), d
+        bn = dict(m.named_buffers())
+        assert float(bn['bn1.running_var'].min()) > 0 and torch.isfinite(bn['bn1.running_mean']).all()
+    assert not torch.equal(ens[0]._ursa_row, ens[1]._ursa_row)
 
 
 def test_swag_grouped_sampling_with_a_host_resident_loader():
@@ -812,3 +861,37 @@ def test_chain_group_of_cyclic_samplers_replays_the_reference_run(golden_dir):
         assert len(ens) == len(g[f'{name}/samples'])
         for m, ref in zip(ens, g[f'{name}/samples']):
             np.testing.assert_allclose(flat_params(m).cpu().numpy(), ref, rtol=1e-4, atol=1e-5)
+
+
+def test_c3_partition_eight_chains_equals_one_ensemble():
+    """BASELINE configs[2] (8 independent SGHMC chains, members stay with their chain, ONE sum for the predictive) on
+    one GPU: 8 chains stepped as a ChainGroup (one multi-chain update launch per round), every chain's members
+    accumulated by its own Prediction task — what rank c of the 8-GPU job holds locally — and the sum of the 8 local
+    accumulators (the all-reduce is a sum) equals one Prediction over all 16 members to fp32 summation
+    order; the chains are distinct (seed = chain id, experiment.py:170)."""
+    from ursabench_amd import util
+    hyp = {'lr': 0.05, 'prior_std': 0.5, 'num_samples': 2, 'alpha': 0.5, 'burn_in_epochs': 0}
+    train = synthetic(640, (3, 32, 32), 10, seed=0, device=DEV, batch_size=128)
+    test = synthetic(512, (3, 32, 32), 10, seed=1, device=DEV, batch_size=128)
+    chains = []
+    for c in range(8):
+        util.set_random_seed(c)
+        chains.append(inference.SGHMC(dict(hyp), models.PreResNet(10, 8).to(DEV), train, device=DEV, seed=c))
+    group = inference.ChainGroup(chains)
+    per_chain = group.sample()
+    assert group.stats['update_launches'] == 2 * len(train) and len(per_chain) == 8 and all(len(e) == 2 for e in per_chain)
+    firsts = [flat_params(e[0]) for e in per_chain]
+    assert all(not torch.equal(firsts[0], f) for f in firsts[1:])
+    p_sum, e_sum = torch.zeros(512, 10), torch.zeros(512)
+    for ens in per_chain:                                   # "rank c": its own members only, no process group
+        t = tasks.Prediction({'in_distribution_test': test}, 10, DEV, 'ALL')
+        t.update_statistics(ens, output_performance=False)
+        assert t.num_samples_collected == 2
+        p_sum += t.ensemble_proba
+        e_sum += t.expected_data_uncertainty
+    whole = tasks.Prediction({'in_distribution_test': test}, 10, DEV, 'ALL')
+    whole.update_statistics([m for ens in per_chain for m in ens], output_performance=False)
+    assert whole.num_samples_collected == 16
+    np.testing.assert_allclose(p_sum.numpy(), whole.ensemble_proba.numpy(), rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(e_sum.numpy(), whole.expected_data_uncertainty.numpy(), rtol=2e-6, atol=1e-6)
+    np.testing.assert_allclose(whole.ensemble_proba.sum(1).numpy(), np.full(512, 16.0, np.float32), rtol=1e-6)
