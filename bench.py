@@ -777,7 +777,8 @@ def run_c2(a, job, legs, line):
     # ---- BMA predictive over the test set: members sharded over ranks, one all-reduce -------------
     def bma():
         pred = tasks.Prediction({'in_distribution_test': test}, CLASSES, dev, 'ALL', **kw)
-        pred._acc.accumulate(ensemble[:1])                        # warm up MIOpen eval-mode kernels / capture (local: no collective)
+        pred._acc.accumulate(ensemble)                            # untimed pass: MIOpen eval-mode search + the twin's graph captures for
+        #                                                           every (batch shape, lanes in use) this ensemble needs (local: no collective)
         pred.reset()
         pred._acc.reset(entropy_too=True)                         # (reset() keeps the entropy sums: prediction.py:33-35)
         _, dt_bma = job.timed(lambda: pred.update_statistics(ensemble, output_performance=False))
@@ -870,7 +871,7 @@ def run_c4(a, job, legs, line):
         # warm-up on this rank's own first member WITHOUT a collective (a rank may hold no member: its update below still
         # takes part in the one all-reduce with zeros)
         if ensemble:
-            pred._acc.accumulate(ensemble[:1])
+            pred._acc.accumulate(ensemble[:min(len(ensemble), 5)])    # untimed: a full lane group and a partial one (captures)
         pred.reset()
         pred._acc.reset(entropy_too=True)                         # (reset() keeps the entropy sums: prediction.py:33-35)
         _, dt = job.timed(lambda: pred.update_statistics(ensemble, output_performance=False))
