@@ -115,7 +115,8 @@ int ursa_step_ctl_advance(ursa_step_ctl* ctl /* [n_ctl] */, int32_t n_ctl, ursa_
  * start at element k * chain_stride of the base pointers — and their control blocks in ctl[K].
  * Chain k is updated exactly as ursa_sgmcmc_step_ctl_f32(theta + k*chain_stride, ..., n_per_chain,
  * ctl + k) would (own lr / flags / Philox key and call index; element i of chain k draws Philox
- * lane (i, ctl[k].step) of key ctl[k].seed), bit for bit. grid = (ceil(n_per_chain/2048), K).
+ * lane (i, ctl[k].step) of key ctl[k].seed), bit for bit. grid = (ceil(n_per_chain/4096), K): 1,024-thread
+ * workgroups, one float4 per thread (half the tickets per chain of a 512-thread launch).
  * chain_stride must be a multiple of 4 and >= n_per_chain; pointers 16-byte aligned. */
 int ursa_sgmcmc_step_multi_f32(float* theta, float* grad, float* mom, const float* eps,
                                float* snapshot, int64_t n_per_chain, int32_t n_chains,
