@@ -92,3 +92,19 @@ def test_update_hyp_on_group_members_invalidates_and_matches_single_chains():
     for (ma, sa), mb, c in zip(alone, together, chains):
         assert np.array_equal(flat(ma), flat(mb))
         assert sa.optimizer._step == c.optimizer._step
+
+
+def test_regrouping_a_chain_is_refused_by_the_old_group():
+    """A sampler lives in ONE group's slabs: putting it into a second ChainGroup re-homes its vectors, and the first
+    group must refuse to step (its one launch would update stale slab rows) instead of doing so silently."""
+    import pytest
+    K = OracleKernels()
+    hyp = {'lr': 0.05, 'prior_std': 1.0, 'num_samples': 1, 'alpha': 0.5, 'burn_in_epochs': 0}
+    loader = tiny_loader()
+    chains = [inference.SGHMC(dict(hyp), tiny_net(), loader, kernels=K, use_graph=False, seed=k) for k in range(3)]
+    g1 = inference.ChainGroup(chains[:2], use_graph=False)
+    g1.sample_iterative()
+    g2 = inference.ChainGroup(chains[1:], use_graph=False)
+    g2.sample_iterative()
+    with pytest.raises(RuntimeError):
+        g1.sample_iterative()

@@ -115,6 +115,9 @@ class ChainGroup:
             if s.optimizer._ctl.data_ptr() != self.ctl.data_ptr() + k * _native.CTL_BYTES:
                 raise RuntimeError(f'chain {k}: its optimizer was replaced without adopting the group\'s control block '
                                    '(use the sampler\'s update_hyp)')
+            if s.arena.theta.data_ptr() != self.theta[k].data_ptr() or s.arena.mom.data_ptr() != self.mom[k].data_ptr():
+                raise RuntimeError(f'chain {k} no longer lives in this group\'s slabs (was its sampler put into another '
+                                   'ChainGroup?): one launch over the slabs would step stale vectors')
         providers = [s._eps_for_epoch() for s in self.samplers]
         inject = any(p is not None for p in providers)
         if inject and not all(p is not None for p in providers):
