@@ -895,3 +895,22 @@ def test_c3_partition_eight_chains_equals_one_ensemble():
     np.testing.assert_allclose(p_sum.numpy(), whole.ensemble_proba.numpy(), rtol=2e-6, atol=1e-7)
     np.testing.assert_allclose(e_sum.numpy(), whole.expected_data_uncertainty.numpy(), rtol=2e-6, atol=1e-6)
     np.testing.assert_allclose(whole.ensemble_proba.sum(1).numpy(), np.full(512, 16.0, np.float32), rtol=1e-6)
+
+
+@pytest.mark.parametrize('use_graph', [False, True])
+def test_csghmc_across_update_hyp_vs_reference_on_gpu(golden_dir, use_graph):
+    """G15 on the HIP path: the reference's cSGHMC run, `update_hyp` (new optimizer adopting the control block and the
+    schedule table a captured graph holds; the Philox / update counter keeps counting), second run whose cyclical
+    schedule keeps the constructor's `total_iterations` (csghmc.py:48-62) — eager and through graph replay."""
+    from test_samplers_cpu import _cyclic_update_hyp_replay
+    s, ens, g, hyp2 = _cyclic_update_hyp_replay(golden_dir, DEV, use_graph=use_graph, warmup_steps=1 if use_graph else None)
+    for m, ref in zip(ens, g['samples']):
+        np.testing.assert_allclose(flat_params(m).cpu().numpy(), ref, rtol=1e-4, atol=1e-5)
+    # the device re-initialises from the HIP generator: continue from the reference's re-initialised weights
+    s.arena.load_flat(torch.tensor(g['theta1']))
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        ens2 = s.sample()
+    assert (s.engine.stats['graph_replays'] >= 15) if use_graph else (s.engine.stats['graph_replays'] == 0), s.engine.stats
+    for m, ref in zip(ens2, g['samples2']):
+        np.testing.assert_allclose(flat_params(m).cpu().numpy(), ref, rtol=1e-4, atol=1e-5)

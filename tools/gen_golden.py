@@ -447,6 +447,42 @@ def gen_e2e_cyclic():
     np.savez_compressed(os.path.join(OUT, 'e2e_cyclic.npz'), **out)
 
 
+def gen_cyclic_update_hyp():
+    """G15: the reference's cSGHMC across `update_hyp` (the hyper-optimisation loop's call, hyper_optimization.py:51-73):
+    constructor run, then update_hyp with another cycle layout and a second run. Pins the quirk that update_hyp does NOT
+    recompute `total_iterations` (csghmc.py:48-62 vs :42-44): the second run's cyclical schedule restarts where the
+    constructor's cycle arithmetic says, not where the new hyper-parameters would."""
+    loader = tiny_loader()
+    hyp = {'lr_0': 0.05, 'prior_std': 1.0, 'num_samples_per_cycle': 2, 'cycle_length': 4, 'burn_in_epochs': 1,
+           'num_cycles': 2, 'alpha': 0.5}
+    hyp2 = {'lr_0': 0.02, 'prior_std': 2.0, 'num_samples_per_cycle': 2, 'cycle_length': 5, 'burn_in_epochs': 2,
+            'num_cycles': 1, 'alpha': 0.3}
+    util.set_random_seed(3)
+    net = tiny_net()
+    out = {'theta0': flat(net.parameters()), 'hyper': json.dumps(hyp), 'hyper2': json.dumps(hyp2)}
+    s = inference.cSGHMC(dict(hyp), net, loader)
+    tap = NoiseTap(s.optimizer)
+    with quiet():
+        ens = s.sample()
+    out['eps'] = np.stack([r['eps'] for r in tap.records])
+    out['lr'] = np.array([r['lr'] for r in tap.records])
+    out['samples'] = np.stack([flat(m.parameters()) for m in ens])
+    util.set_random_seed(9)
+    s.update_hyp(dict(hyp2))
+    out['theta1'] = flat(s.model.parameters())
+    out['total_iterations_after'] = np.float64(s.total_iterations)
+    tap2 = NoiseTap(s.optimizer)
+    with quiet():
+        ens2 = s.sample()
+    out['eps2'] = np.stack([r['eps'] for r in tap2.records])
+    out['lr2'] = np.array([r['lr'] for r in tap2.records])
+    out['noise2'] = np.array([r['noise'] for r in tap2.records])
+    out['samples2'] = np.stack([flat(m.parameters()) for m in ens2])
+    np.savez_compressed(os.path.join(OUT, 'e2e_cyclic_update_hyp.npz'), **out)
+    print('G15 cyclic update_hyp: steps', len(tap.records), len(tap2.records), 'samples', len(ens), len(ens2),
+          'total_iterations', float(out['total_iterations_after']), 'lr2', out['lr2'][:4])
+
+
 def gen_sgd_sampler():
     """G13: the reference's SGD baseline sampler (inference/sgd.py) on a tiny MLP: constructor run (cosine to lr/100),
     then update_hyp (re-init, cosine to lr/2, loop still uses the constructor's epoch count) and a second run."""
@@ -625,8 +661,8 @@ def gen_model_keys():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['k1', 'sgd', 'sched', 'csghmc', 'tasks', 'swag', 'swag_e2e', 'e2e', 'e2e_preresnet', 'mcdropout', 'columns', 'cyclic', 'sgd_sampler', 'hmc_wrapper', 'keys']
+    which = sys.argv[1:] or ['k1', 'sgd', 'sched', 'csghmc', 'tasks', 'swag', 'swag_e2e', 'e2e', 'e2e_preresnet', 'mcdropout', 'columns', 'cyclic', 'cyclic_update_hyp', 'sgd_sampler', 'hmc_wrapper', 'keys']
     fns = dict(k1=gen_k1, sgd=gen_sgd, swag_e2e=gen_swag_e2e, e2e_preresnet=gen_e2e_preresnet, sched=gen_schedules, csghmc=gen_csghmc, tasks=gen_tasks, swag=gen_swag, e2e=gen_e2e,
-               keys=gen_model_keys, mcdropout=gen_mcdropout, columns=gen_experiment_columns, cyclic=gen_e2e_cyclic, sgd_sampler=gen_sgd_sampler, hmc_wrapper=gen_hmc_wrapper)
+               keys=gen_model_keys, mcdropout=gen_mcdropout, columns=gen_experiment_columns, cyclic=gen_e2e_cyclic, cyclic_update_hyp=gen_cyclic_update_hyp, sgd_sampler=gen_sgd_sampler, hmc_wrapper=gen_hmc_wrapper)
     for w in which:
         fns[w]()
