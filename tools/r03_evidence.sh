@@ -14,6 +14,7 @@ python3 tools/k1_ctl_bench.py > $out/k1_ctl_bench.log 2>&1; echo "k1_ctl_bench r
 python3 tools/exp/k3_spread.py > $out/k3_spread.log 2>&1; echo "k3_spread rc=$?"; cp gpurun_out/k3_spread.json $out/r03_k3_spread.json
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -- python3 $R/bench.py --steps 3 --warmup 1 > $out/bench_line_under_rocprof.json 2> $out/bench_under_rocprof.err; echo "bench under rocprof rc=$?"
+python3 $R/tools/exp/k1_in_workload.py /tmp/prof_bench $out/r03_k1_in_workload.json > /dev/null; echo "k1_in_workload rc=$?"
 python3 $R/tools/prof_summary.py /tmp/prof_bench $out/r03_bench_kernel_stats.csv > /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kb -- python3 $R/tools/kbench.py > /dev/null 2>&1; echo "kbench under rocprof rc=$?"
 python3 $R/tools/prof_summary.py /tmp/prof_kb $out/r03_kbench_kernel_stats.csv > /dev/null
