@@ -544,3 +544,33 @@ def test_k2_k3_full_size_properties(K):
     K.swag_std(sd, mean, sq, var_clamp=1e-30)
     K.swag_draw_std(out2, mean, sd, seed=3, draw=7)
     assert torch.equal(out, out2)
+
+
+def test_abi_v2_argument_errors_and_empty_inputs(K):
+    """The new entry points return URSA_E* codes (never crash, never launch) on bad arguments, and treat empty inputs
+    (n = 0, no chains, no control blocks) as a no-op that touches no pointer."""
+    lib = K.lib
+    E_NULL, E_SIZE, E_ALIGN = -1, -2, -3
+    th = torch.zeros(3, 64, device='cuda')
+    ctl = torch.zeros(3 * 64 + 8, dtype=torch.uint8, device='cuda')
+    p, c, st = th.data_ptr(), ctl.data_ptr(), torch.cuda.current_stream().cuda_stream
+    f = lib.ursa_sgmcmc_step_multi_f32
+    assert f(p, p, p, None, None, 0, 3, 64, c, st) == 0                      # n == 0
+    assert f(None, None, None, None, None, 64, 0, 64, None, st) == 0         # no chains
+    assert f(p, p, p, None, None, 64, 3, 60, c, st) == E_SIZE                # stride < n
+    assert f(p, p, p, None, None, 62, 3, 62, c, st) == E_SIZE                # stride not a multiple of 4
+    assert f(p, p, p, None, None, 64, 70000, 64, c, st) == E_SIZE            # more chains than a grid's y extent
+    assert f(p, p, None, None, None, 64, 3, 64, c, st) == E_NULL             # momentum is required (mu lives on the device)
+    assert f(p, p, p, None, None, 64, 3, 64, None, st) == E_NULL
+    assert f(p + 4, p, p, None, None, 60, 1, 0, c, st) == E_ALIGN            # float4-only launch
+    assert f(p, p, p, None, None, 64, 3, 64, c + 4, st) == E_ALIGN           # control blocks hold 64-bit fields
+    assert lib.ursa_step_ctl_advance(None, 1, st) == E_NULL
+    assert lib.ursa_step_ctl_advance(c, -1, st) == E_SIZE and lib.ursa_step_ctl_advance(c, 0, st) == 0
+    assert lib.ursa_swag_std_f32(None, p, p, 64, 1e-30, 1.0, st) == E_NULL
+    assert lib.ursa_swag_std_f32(p, p, p, 0, 1e-30, 1.0, st) == 0 and lib.ursa_swag_std_f32(p, p, p, -1, 1e-30, 1.0, st) == E_SIZE
+    assert lib.ursa_swag_draw_std_f32(p, p, None, None, 64, 1, 0, st) == E_NULL
+    assert lib.ursa_swag_draw_std_f32(p + 2, p, p, None, 64, 1, 0, st) == E_ALIGN
+    assert lib.ursa_selftest_rng_f32(None, st) == E_NULL
+    torch.cuda.synchronize()
+    assert not th.any() and not ctl.any()                                    # nothing was launched
+    assert lib.ursa_strerror(E_SIZE).decode() == 'invalid size'
