@@ -88,36 +88,41 @@ int ursa_sgmcmc_step_f32(float* theta, float* grad, float* mom /* NULL iff mu ==
  * the Philox call index, so it only ever grows.
  * With URSA_STEP_ADVANCE in ctl->flags the update launch advances its own block: every
  * workgroup takes a ticket once all of its waves hold a copy of the block, and the one that
- * draws the chain's last ticket does the advance (all others have read the block by then)
- * and re-arms the ticket — no second launch. ursa_step_ctl_advance is the same advance as a
- * launch of its own (one thread per block of ctl[n_ctl]), for roofline-sized chains and for
- * hosts that step a block without an update. `ticket` is device scratch: upload it as 0. */
+ * completes the chain's ticket tree does the advance (all others have read the block by then)
+ * and re-arms the tickets — no second launch. Tickets are relaxed agent-scope fetch-adds on a
+ * two-level tree: workgroup b counts on tickets[(b % 16) * 32], the last of each of those 16
+ * counters counts on tickets[16 * 32]. The counters sit on separate 128-byte lines because
+ * fetch-adds to ONE line serialise at ~11.5 ns each (1,024 workgroups: +10.7 us on one
+ * address, +0.6 us on 16 lines; tools/exp/ticket_probe.hip) — that is why the block is 2,304
+ * bytes. ursa_step_ctl_advance is the same advance as a launch of its own (one thread per
+ * block of ctl[n_ctl]), for hosts that step a block without an update. `tickets` is device
+ * scratch: upload it as zeros. Blocks of an array must be 128-byte aligned (so: the array). */
 #define URSA_STEP_ADVANCE   0x20u
+#define URSA_CTL_TICKET_LINES 16
 typedef struct ursa_step_ctl {
     float lr, mu, c_wd, c_noise, n_train;
     uint32_t flags;
     uint64_t seed, step, sched_base;
     const float* sched;       /* DEVICE pointer, [sched_len][2], or NULL */
     uint32_t sched_len;
-    uint32_t ticket;
-} ursa_step_ctl;              /* 64 bytes */
+    uint32_t reserved;
+    uint32_t pad[16];         /* the scalars own the first 128-byte line */
+    uint32_t tickets[(URSA_CTL_TICKET_LINES + 1) * 32];
+} ursa_step_ctl;              /* 2,304 bytes = 18 lines of 128 */
 
 int ursa_sgmcmc_step_ctl_f32(float* theta, float* grad, float* mom, const float* eps,
                              float* snapshot, int64_t n, ursa_step_ctl* ctl,
                              ursa_stream_t stream);
 int ursa_step_ctl_advance(ursa_step_ctl* ctl /* [n_ctl] */, int32_t n_ctl, ursa_stream_t stream);
-/* Self-advancing launches are for workload-sized chains (every workgroup takes a ticket, ~11 ns each on one
- * address): hosts use them up to this many elements per chain and the explicit advance launch beyond. */
-#define URSA_SELF_ADVANCE_MAX_ELEMS (1 << 20)
 
 /* K chains in ONE launch (SURVEY.md 8b `n_chains`, 8f-1): the K independent chains that share a GPU
  * keep their vectors in [K, chain_stride] slabs — chain k's theta / grad / mom (/ eps / snapshot)
  * start at element k * chain_stride of the base pointers — and their control blocks in ctl[K].
  * Chain k is updated exactly as ursa_sgmcmc_step_ctl_f32(theta + k*chain_stride, ..., n_per_chain,
  * ctl + k) would (own lr / flags / Philox key and call index; element i of chain k draws Philox
- * lane (i, ctl[k].step) of key ctl[k].seed), bit for bit. grid = (ceil(n_per_chain/4096), K): 1,024-thread
- * workgroups, one float4 per thread (half the tickets per chain of a 512-thread launch).
- * chain_stride must be a multiple of 4 and >= n_per_chain; pointers 16-byte aligned. */
+ * lane (i, ctl[k].step) of key ctl[k].seed), bit for bit. grid = (ceil(n_per_chain/2048), K): one float4 per
+ * thread, 512-thread workgroups.
+ * chain_stride must be a multiple of 4 and >= n_per_chain; pointers 16-byte aligned, ctl 128-byte aligned. */
 int ursa_sgmcmc_step_multi_f32(float* theta, float* grad, float* mom, const float* eps,
                                float* snapshot, int64_t n_per_chain, int32_t n_chains,
                                int64_t chain_stride, ursa_step_ctl* ctl /* [n_chains] */,

@@ -76,7 +76,7 @@ int main(void)
         const size_t sb = (size_t)K * stride * sizeof(float);
         float *hth = malloc(sb), *hgr = malloc(sb), *hmo = malloc(sb), *hb = malloc(sb);
         for (int64_t i = 0; i < K * stride; ++i) { hth[i] = frand(&seed); hgr[i] = frand(&seed); hmo[i] = 0.1f * frand(&seed); }
-        float *sth, *sgr, *smo; ursa_step_ctl hc[2], *dc;
+        float *sth, *sgr, *smo; static ursa_step_ctl hc[2]; ursa_step_ctl* dc;
         CHECK(hipMalloc((void**)&sth, sb)); CHECK(hipMalloc((void**)&sgr, sb)); CHECK(hipMalloc((void**)&smo, sb));
         CHECK(hipMalloc((void**)&dc, sizeof hc));
         memset(hc, 0, sizeof hc);
@@ -99,7 +99,9 @@ int main(void)
         CHECK(hipMemcpy(hb, smo, sb, hipMemcpyDeviceToHost));
         if (memcmp(hb, hmo, (size_t)stride * sizeof(float))) { printf("FAIL multi-chain momentum differs from the oracle\n"); return 1; }
         CHECK(hipMemcpy(hc, dc, sizeof hc, hipMemcpyDeviceToHost));
-        if (hc[0].step != 3 || hc[1].step != 13 || hc[0].ticket || hc[1].ticket) { printf("FAIL control blocks did not advance\n"); return 1; }
+        int armed = 0;
+        for (int k = 0; k < K; ++k) for (size_t w = 0; w < sizeof hc[k].tickets / 4; ++w) armed |= hc[k].tickets[w] != 0;
+        if (hc[0].step != 3 || hc[1].step != 13 || armed) { printf("FAIL control blocks did not advance / tickets not re-armed\n"); return 1; }
     }
     /* the generator's in-register division / square root against the IEEE forms, all 2^32 inputs, on this device */
     {

@@ -170,7 +170,7 @@ def test_k1_ctl_variant_and_advance(K, self_advance):
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and not gb.any(), k
         assert np.array_equal(host(b[0]), oth) and np.array_equal(host(b[1]), omo), k
     back = _ctl_back(ctl)
-    assert back.step == 5 and not (back.flags & O.STEP_FIRST) and back.lr == sched[5 % 3, 0] and back.ticket == 0
+    assert back.step == 5 and not (back.flags & O.STEP_FIRST) and back.lr == sched[5 % 3, 0] and back.tickets_clear()
     assert back.c_noise == sched[5 % 3, 1] and back.sched == dsched.data_ptr()
 
 
@@ -219,7 +219,7 @@ def test_k1_multi_chain_launch_bitwise(K, n, stride, inject):
             assert np.array_equal(got_mo[k, :n], mo[k, :n]), k
         assert np.array_equal(got_th[k, n:], th[k, n:]) and np.array_equal(got_mo[k, n:], mo[k, n:])     # row pads untouched
         b = _ctl_back(ctl, k)
-        assert b.step == 100 * k + steps and b.ticket == 0 and not (b.flags & O.STEP_FIRST)
+        assert b.step == 100 * k + steps and b.tickets_clear() and not (b.flags & O.STEP_FIRST)
     # argument checks happen on the host, before any launch
     with pytest.raises(ValueError):
         K.sgmcmc_step_multi(dth, dgr[:, :-4].contiguous(), dmo, ctl)
@@ -552,7 +552,7 @@ def test_abi_v2_argument_errors_and_empty_inputs(K):
     lib = K.lib
     E_NULL, E_SIZE, E_ALIGN = -1, -2, -3
     th = torch.zeros(3, 64, device='cuda')
-    ctl = torch.zeros(3 * 64 + 8, dtype=torch.uint8, device='cuda')
+    ctl = torch.zeros(3 * 2304 + 128, dtype=torch.uint8, device='cuda')
     p, c, st = th.data_ptr(), ctl.data_ptr(), torch.cuda.current_stream().cuda_stream
     f = lib.ursa_sgmcmc_step_multi_f32
     assert f(p, p, p, None, None, 0, 3, 64, c, st) == 0                      # n == 0
@@ -563,7 +563,7 @@ def test_abi_v2_argument_errors_and_empty_inputs(K):
     assert f(p, p, None, None, None, 64, 3, 64, c, st) == E_NULL             # momentum is required (mu lives on the device)
     assert f(p, p, p, None, None, 64, 3, 64, None, st) == E_NULL
     assert f(p + 4, p, p, None, None, 60, 1, 0, c, st) == E_ALIGN            # float4-only launch
-    assert f(p, p, p, None, None, 64, 3, 64, c + 4, st) == E_ALIGN           # control blocks hold 64-bit fields
+    assert f(p, p, p, None, None, 64, 3, 64, c + 64, st) == E_ALIGN          # ticket counters sit on separate 128-byte lines
     assert lib.ursa_step_ctl_advance(None, 1, st) == E_NULL
     assert lib.ursa_step_ctl_advance(c, -1, st) == E_SIZE and lib.ursa_step_ctl_advance(c, 0, st) == 0
     assert lib.ursa_swag_std_f32(None, p, p, 64, 1e-30, 1.0, st) == E_NULL

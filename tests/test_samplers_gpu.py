@@ -259,7 +259,7 @@ def test_csghmc_on_gpu_walks_the_device_schedule():
     assert len(ens) == 1 and s.epochs_run == 3 and s.engine.stats['graph_replays'] > 0
     from ursabench_amd._native import StepCtl
     c = StepCtl.from_buffer_copy(bytes(s.optimizer._ctl.cpu().numpy()))
-    assert c.step == 27 and c.ticket == 0
+    assert c.step == 27 and c.tickets_clear()
     want = s._adjust_learning_rate(s.optimizer, s.epochs_run - 1, len(s.train_loader) - 1)   # last iteration run
     assert s.lr == pytest.approx(want) and s.optimizer.param_groups[0]['lr'] == pytest.approx(want)
     assert np.isfinite(flat_params(ens[0]).cpu().numpy()).all()
@@ -656,7 +656,7 @@ def test_mcdropout_reference_run_on_gpu(golden_dir, monkeypatch):
         np.testing.assert_allclose(flat_params(m).cpu().numpy(), g['samples'][k], rtol=1e-4, atol=1e-6)
     from ursabench_amd._native import StepCtl
     c = StepCtl.from_buffer_copy(bytes(s.optimizer._ctl.cpu().numpy()))
-    assert c.step == len(g['lr_mom']) and c.ticket == 0
+    assert c.step == len(g['lr_mom']) and c.tickets_clear()
     s.model.eval()
     with torch.no_grad():
         mc = np.stack([s.model(torch.tensor(g['x_test']).to(DEV)).cpu().numpy() for _ in range(3)])
@@ -767,7 +767,8 @@ def test_hmc_sampler_on_preresnet164_equals_oracle_substeps():
 def test_swag_sampler_on_wideresnet28_10_follows_the_oracle_draw():
     """BASELINE configs[3]'s own network through the sampler on the GPU (no GPU test ran a WideResNet-28-10
     sampler): WideResNet-28-10 (36,546,980 parameters), SWAG as published on a 256-image set — the SGD trajectory
-    through hipGraph replays with the roofline-sized K1 launch (non-temporal, explicit control-block advance), K2
+    through hipGraph replays with the roofline-sized, self-advancing K1 launch (non-temporal; 17,846 workgroups on the
+    ticket tree), K2
     moments, then two members: each equals, bit for bit, the oracle's draw from the moments the device holds (same
     Philox key and draw index) through the ensemble form (std once + square-root-free draw); BatchNorm statistics
     refreshed (grouped path: 2 members in one pass)."""
@@ -781,9 +782,9 @@ def test_swag_sampler_on_wideresnet28_10_follows_the_oracle_draw():
     assert s.num_parameters == 36546980
     ens = s.sample()
     assert len(ens) == 2 and s.num_models_collected.item() == 2 and s.engine.stats['graph_replays'] > 0
-    assert s.optimizer.self_advance is False                          # 36.5 M elements: explicit advance launch
+    assert s.optimizer.self_advance is True                           # also at 36.5 M elements (17,846 workgroups on the ticket tree)
     c = StepCtl.from_buffer_copy(bytes(s.optimizer._ctl.cpu().numpy()))
-    assert c.step == 3 * 4 and c.ticket == 0
+    assert c.step == 3 * 4 and c.tickets_clear()
     mean, sq = s._mean.cpu().numpy(), s._sq.cpu().numpy()
     for d, m in enumerate(ens):
         want = np.empty_like(mean)

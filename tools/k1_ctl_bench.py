@@ -40,7 +40,7 @@ def one(block):
             byt = 20 * n * chains
             out.append(dict(block=block or 'auto', chains=chains, mode=mode, elements=n * chains, median_us=round(med * 1e6, 3),
                             best_us=round(best * 1e6, 3), GBps_median=round(byt / med / 1e9, 1),
-                            frac_of_8TBps=round(byt / med / 8e12, 4), ctl_step_after=back.step, ticket_after=back.ticket))
+                            frac_of_8TBps=round(byt / med / 8e12, 4), ctl_step_after=back.step, tickets_clear=back.tickets_clear()))
             print(json.dumps(out[-1]), flush=True)
     return out
 

@@ -24,7 +24,6 @@ STEP_NOISE, STEP_FIRST, STEP_ZERO_GRAD, STEP_WD, STEP_SGD, STEP_ADVANCE = 0x1, 0
 BMA_SMOOTHED = 0x1
 LEAP_KICK, LEAP_DRIFT = 0x1, 0x2
 REDUCE_WS_FLOATS = 2048
-SELF_ADVANCE_MAX_ELEMS = 1 << 20
 BMA_MAX_CLASSES = 1024
 
 _vp, _i64, _i32, _u64, _u32, _f = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_uint64,
@@ -50,21 +49,28 @@ SIGNATURES = {
 }
 
 
+CTL_TICKET_LINES = 16
+
+
 class StepCtl(ctypes.Structure):
-    """struct ursa_step_ctl (64 bytes). `sched` is a DEVICE address; `ticket` is device scratch (upload 0)."""
+    """struct ursa_step_ctl (2,304 bytes = 18 lines of 128). `sched` is a DEVICE address; `tickets` is device scratch
+    (upload zeros): the two-level ticket tree of the self-advancing launch, one counter per 128-byte line."""
     _fields_ = [('lr', _f), ('mu', _f), ('c_wd', _f), ('c_noise', _f), ('n_train', _f), ('flags', _u32),
                 ('seed', _u64), ('step', _u64), ('sched_base', _u64), ('sched', _u64), ('sched_len', _u32),
-                ('ticket', _u32)]
+                ('reserved', _u32), ('pad', _u32 * 16), ('tickets', _u32 * ((CTL_TICKET_LINES + 1) * 32))]
+
+    def tickets_clear(self):
+        return not any(self.tickets)
 
 
 CTL_BYTES = ctypes.sizeof(StepCtl)
-assert CTL_BYTES == 64
+assert CTL_BYTES == 2304
 
 
 def _ctl_ptr(ctl, n_chains=1):
     if not (isinstance(ctl, torch.Tensor) and ctl.is_cuda and ctl.dtype == torch.uint8
-            and ctl.numel() == n_chains * CTL_BYTES and ctl.is_contiguous() and ctl.data_ptr() % 8 == 0):
-        raise ValueError(f'ctl must be a contiguous 8-byte aligned uint8 HIP tensor of {n_chains} x sizeof(ursa_step_ctl) bytes')
+            and ctl.numel() == n_chains * CTL_BYTES and ctl.is_contiguous() and ctl.data_ptr() % 128 == 0):
+        raise ValueError(f'ctl must be a contiguous 128-byte aligned uint8 HIP tensor of {n_chains} x sizeof(ursa_step_ctl) bytes')
     return ctl.data_ptr()
 
 

@@ -138,11 +138,11 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 
 // `after_loads` runs once per thread right after the thread's vector loads (before the Philox arithmetic, the update
 // and the stores): the control-block launch takes its ticket there.
-template <bool MOM, int NOISE, bool NT, class Hook = NoHook>
+template <bool MOM, int NOISE, bool NT, class Hook = NoHook, class Hook2 = NoHook>
 __device__ __forceinline__ void step_body(float* __restrict__ theta, float* __restrict__ grad,
                                           float* __restrict__ mom, const float* __restrict__ eps,
                                           float* __restrict__ snapshot, int64_t n, const StepScalars& s,
-                                          Hook after_loads = Hook())
+                                          Hook after_loads = Hook(), Hook2 before_stores = Hook2())
 {
     const int64_t n4 = n >> 2;
     const bool zero_grad = s.flags & URSA_STEP_ZERO_GRAD;
@@ -165,12 +165,14 @@ __device__ __forceinline__ void step_body(float* __restrict__ theta, float* __re
         step_elem<MOM>(t.y, g.y, v.y, e.y, s, NOISE != kNoiseOff);
         step_elem<MOM>(t.z, g.z, v.z, e.z, s, NOISE != kNoiseOff);
         step_elem<MOM>(t.w, g.w, v.w, e.w, s, NOISE != kNoiseOff);
+        before_stores();
         st4<NT>(th4 + i, t);
         if (MOM) st4<NT>(m4 + i, v);
         if (zero_grad) st4<NT>(g4 + i, make_float4(0.f, 0.f, 0.f, 0.f));
         if (snapshot) st4<NT>(s4 + i, t);
     } else {
         after_loads();
+        before_stores();
     }
     // scalar tail (n % 4 elements): handled by the first lanes of block 0
     const int64_t tail0 = n4 << 2;
@@ -226,16 +228,20 @@ __device__ __forceinline__ void ctl_advance(ursa_step_ctl* ctl)
 // URSA_STEP_ADVANCE: the launch advances the chain's block itself (round 2: a second, 1-thread launch per step).
 // What has to be ordered is "every workgroup has READ *ctl" before "somebody WRITES *ctl". Each workgroup copies the
 // block into registers, passes a workgroup barrier (all of its waves hold their copy), and its thread 0 takes a ticket
-// (relaxed agent-scope fetch-add: tickets on one address are totally ordered) right after its vector loads, with the
-// next schedule row prefetched. The workgroup that drew the last ticket knows every workgroup of the chain holds its
-// copy: at its end it writes the next step's scalars and re-arms the ticket. Nobody waits on anybody else: no fence, no
-// spinning. Measured at the PreResNet-20 arena (134 workgroups of 512, tools/k1_ctl_bench.py, us per launch inside a
-// graph replay): no advance 2.8; ticket + advance at the END of the workgroup behind __threadfence() 6.5 (a release
-// fence is an L2 write-back per workgroup); same without fences 5.4; ticket right after the loads (this) 4.05 — the
-// launch grows by ~11 ns per workgroup (same-address atomics serialise); a dedicated ticket wave per workgroup that
-// fires at kernel start 5.4 and 3x worse for 16 chains (all tickets at once: 25-47 ns each). A streaming launch of
-// 100+ us does not want 11 ns x 18,000 workgroups: hosts self-advance up to URSA_SELF_ADVANCE_MAX_ELEMS per chain and
-// use the explicit advance launch beyond.
+// (relaxed agent-scope fetch-add) right after its vector loads, with the next schedule row prefetched. Tickets form a
+// two-level tree: workgroup b counts on tickets[(b % 16) * 32], the workgroup that draws the last ticket of such a
+// counter re-arms it and counts on tickets[16 * 32], and the one that draws the last ticket THERE knows every workgroup
+// of the chain holds its copy: it writes the next step's scalars and re-arms the top counter. Nobody waits on anybody
+// else: no fence, no spinning. Why a tree on separate 128-byte lines: fetch-adds to one line serialise at ~11.5 ns
+// each, whichever word of the line they hit (tools/exp/ticket_probe.hip, us per launch of an otherwise empty kernel,
+// 136 / 1,024 workgroups: empty 2.87 / 2.77; one address 3.46 / 13.5; 8 counters in ONE line 3.97 / 14.1; 8 counters
+// on 8 lines 2.84 / 4.18; 16 on 16 lines 2.78 / 3.37). History of this launch at the PreResNet-20 arena (134
+// workgroups of 512, tools/k1_ctl_bench.py, us per launch inside a graph replay): no advance 3.2; one-address ticket
+// + advance at the END of the workgroup behind __threadfence() 6.5 (a release fence is an L2 write-back per
+// workgroup); same without fences 5.4; one-address ticket right after the loads 4.06; a dedicated ticket wave firing at
+// kernel start 5.4 (3x worse for 16 chains: all tickets at once, 25-47 ns each); the tree 3.72; the tree with the top
+// ticket taken before the stores (this) 3.63 — 0.45 us above the launch that does not advance at all, and the same kernel
+// serves roofline-sized chains (WideResNet-28-10: 17,846 workgroups, ~1,100 tickets per line spread over a 108 us launch).
 // MULTI: the launch carries several chains (blockIdx.y); a separate instantiation so that a profile tells the
 // single-chain launches of a sampler from the multi-chain launches of a ChainGroup by name.
 template <bool NT, bool MULTI>
@@ -273,33 +279,51 @@ __global__ __launch_bounds__(1024) void k_sgmcmc_step_ctl(float* theta, float* g
     // The address goes through a VGPR the compiler must treat as lane-varying (with a provably uniform address its
     // atomic optimizer rewrites the add into a wave-aggregated one whose v_readfirstlane waits for the result at once)
     // and stays a GLOBAL pointer (a flat atomic forces vmcnt(0)/lgkmcnt(0) waits).
+    constexpr uint32_t kLines = URSA_CTL_TICKET_LINES;
+    const uint32_t line = blockIdx.x % kLines;          // this workgroup's first-level counter
     auto take_ticket = [&]() {
         if (advance && threadIdx.x == 0) {
             typedef __attribute__((address_space(1))) uint32_t gu32;
-            gu32* tp = (gu32*)&ctl->ticket;
+            gu32* tp = (gu32*)&ctl->tickets[line * 32];
             asm volatile("" : "+v"(tp));
             ticket = __hip_atomic_fetch_add(tp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
+    // Second level, taken between the arithmetic and the stores (the first-level ticket has been in flight since the
+    // loads: it is back by now), so that ITS round trip runs under the stores instead of after them.
+    uint32_t top = 0xFFFFFFFFu;
+    auto take_top_ticket = [&]() {
+        // workgroups counting on this line: those with blockIdx.x = line, line + 16, ... < gridDim.x
+        if (advance && threadIdx.x == 0 && ticket == (gridDim.x - line + kLines - 1) / kLines - 1) {
+            __hip_atomic_store(&ctl->tickets[line * 32], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            typedef __attribute__((address_space(1))) uint32_t gu32;
+            gu32* tp = (gu32*)&ctl->tickets[kLines * 32];
+            asm volatile("" : "+v"(tp));
+            top = __hip_atomic_fetch_add(tp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
     const bool noise = s.flags & URSA_STEP_NOISE;
     if (s.mu != 0.0f) {
-        if (!noise) step_body<true, kNoiseOff, NT>(theta, grad, mom, eps, snapshot, n, s, take_ticket);
-        else if (eps) step_body<true, kNoisePtr, NT>(theta, grad, mom, eps, snapshot, n, s, take_ticket);
-        else step_body<true, kNoisePhilox, NT>(theta, grad, mom, eps, snapshot, n, s, take_ticket);
+        if (!noise) step_body<true, kNoiseOff, NT>(theta, grad, mom, eps, snapshot, n, s, take_ticket, take_top_ticket);
+        else if (eps) step_body<true, kNoisePtr, NT>(theta, grad, mom, eps, snapshot, n, s, take_ticket, take_top_ticket);
+        else step_body<true, kNoisePhilox, NT>(theta, grad, mom, eps, snapshot, n, s, take_ticket, take_top_ticket);
     } else {
-        if (!noise) step_body<false, kNoiseOff, NT>(theta, grad, mom, eps, snapshot, n, s, take_ticket);
-        else if (eps) step_body<false, kNoisePtr, NT>(theta, grad, mom, eps, snapshot, n, s, take_ticket);
-        else step_body<false, kNoisePhilox, NT>(theta, grad, mom, eps, snapshot, n, s, take_ticket);
+        if (!noise) step_body<false, kNoiseOff, NT>(theta, grad, mom, eps, snapshot, n, s, take_ticket, take_top_ticket);
+        else if (eps) step_body<false, kNoisePtr, NT>(theta, grad, mom, eps, snapshot, n, s, take_ticket, take_top_ticket);
+        else step_body<false, kNoisePhilox, NT>(theta, grad, mom, eps, snapshot, n, s, take_ticket, take_top_ticket);
     }
-    if (advance && threadIdx.x == 0 && ticket == gridDim.x - 1) {      // same arithmetic as ctl_advance()
-        ctl->step = s.step + 1;
-        ctl->flags = s.flags & ~URSA_STEP_FIRST;
-        if (walk) {
-            ctl->lr = next_lr;
-            if (s.flags & URSA_STEP_SGD) ctl->mu = next_col;
-            else ctl->c_noise = next_col;
+    if (advance && threadIdx.x == 0) {
+        const uint32_t lines_in_use = gridDim.x < kLines ? gridDim.x : kLines;
+        if (top == lines_in_use - 1) {                   // every workgroup of the chain holds its copy of the block
+            ctl->step = s.step + 1;                      // same arithmetic as ctl_advance()
+            ctl->flags = s.flags & ~URSA_STEP_FIRST;
+            if (walk) {
+                ctl->lr = next_lr;
+                if (s.flags & URSA_STEP_SGD) ctl->mu = next_col;
+                else ctl->c_noise = next_col;
+            }
+            __hip_atomic_store(&ctl->tickets[kLines * 32], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        __hip_atomic_store(&ctl->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -1199,11 +1223,9 @@ int ursa_sgmcmc_step_f32(float* theta, float* grad, float* mom, const float* eps
                       : launch_step<false>(ns, vec, nt, st, theta, grad, mom, eps, snapshot, n, s);
 }
 
-// Threads per workgroup of a control-block launch. One chain: 512 (one float4 per thread, 134 workgroups for
-// PreResNet-20: 4.06 us self-advancing; 256-thread workgroups double the tickets: 5.6 us; 1,024: 4.36). Several
-// chains per launch: 1,024 — half the tickets per chain, and with K x 67 workgroups there is no shortage of them
-// (8 chains: 8.99 us vs 10.41 at 512; 4 chains: 6.55 vs 6.76; tools/k1_ctl_bench.py, profiles/r03_k1_ctl_bench.json).
-// Debug override: URSA_CTL_BLOCK.
+// Threads per workgroup of a control-block launch: 512, one float4 per thread (134 workgroups per PreResNet-20 chain).
+// With one-address tickets multi-chain launches were better off with 1,024 (half the tickets); on the ticket tree the
+// ticket count no longer matters (tools/k1_ctl_bench.py sweeps it through the debug override URSA_CTL_BLOCK).
 inline int ctl_block(int64_t n4, int n_chains)
 {
     static const int forced = [] {
@@ -1212,8 +1234,8 @@ inline int ctl_block(int64_t n4, int n_chains)
         return (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) ? v : 0;
     }();
     if (forced) return forced;
-    (void)n4;
-    return n_chains > 1 ? 1024 : kSBlock;
+    (void)n4; (void)n_chains;
+    return kSBlock;
 }
 
 int ursa_sgmcmc_step_multi_f32(float* theta, float* grad, float* mom, const float* eps, float* snapshot,
@@ -1227,7 +1249,7 @@ int ursa_sgmcmc_step_multi_f32(float* theta, float* grad, float* mom, const floa
     if (!theta || !grad || !mom || !ctl) return URSA_ENULL;   // mom always required: mu lives on the device
     if (!(aligned16(theta) && aligned16(grad) && aligned16(mom) && aligned16(eps) && aligned16(snapshot)))
         return URSA_EALIGN;                                    // the replayable form is float4-only
-    if (reinterpret_cast<uintptr_t>(ctl) & 7u) return URSA_EALIGN;
+    if (reinterpret_cast<uintptr_t>(ctl) & 127u) return URSA_EALIGN;   // ticket counters must sit on separate 128-byte lines
     const int block = ctl_block(n >> 2, n_chains);
     int64_t gx = ((n >> 2) + block - 1) / block;
     if (gx < 1) gx = 1;
@@ -1249,6 +1271,7 @@ int ursa_sgmcmc_step_ctl_f32(float* theta, float* grad, float* mom, const float*
 int ursa_step_ctl_advance(ursa_step_ctl* ctl, int32_t n_ctl, ursa_stream_t stream)
 {
     if (!ctl) return URSA_ENULL;
+    if (reinterpret_cast<uintptr_t>(ctl) & 7u) return URSA_EALIGN;
     if (n_ctl < 0) return URSA_ESIZE;
     if (n_ctl == 0) return URSA_OK;
     hipLaunchKernelGGL(k_step_ctl_advance, dim3((n_ctl + 63) / 64), dim3(64), 0, (hipStream_t)stream, ctl, (int)n_ctl);

@@ -66,7 +66,7 @@ class ChainGroup:
         self.kernels.sgmcmc_step_multi(self.theta, self.grad, self.mom, self.ctl,
                                        eps=self.eps if self._graph_eps else None)
         self.stats['update_launches'] += 1
-        if not self.samplers[0].optimizer.self_advance:       # roofline-sized chains: one explicit advance for all K blocks
+        if not self.samplers[0].optimizer.self_advance:       # (hosts that opt out of the self-advancing launch)
             self.kernels.step_ctl_advance(self.ctl)
         for s, keep in zip(self.samplers, keeps):
             s.engine.finish(keep)

@@ -53,7 +53,7 @@ class optimSGHMC(Optimizer):
         self._step = 0                 # Philox call index == number of updates applied so far
         self._ctl = None               # device control block (graph-replayable stepping)
         self._sched = None             # device (lr, c_noise) table for per-iteration schedules
-        self.self_advance = True       # control-block stepping: the update launch advances the block (set per epoch by ctl_begin)
+        self.self_advance = True       # control-block stepping: the update launch advances the block (False: explicit advance launch)
         self.ctl_zero_grad = True      # control-block stepping re-zeroes the flat gradient (fused)
         self.skip_grad_none = True     # reference semantics for tensors whose .grad is None (optim_sghmc.py:44-45)
 
@@ -175,15 +175,14 @@ class optimSGHMC(Optimizer):
             if self._sched.shape != sched.shape:
                 raise ValueError(f'schedule table changed shape {tuple(self._sched.shape)} -> {tuple(sched.shape)}')
             self._sched.copy_(sched)
-        # workload-sized chains: the update launch advances the block itself (no second launch per step);
-        # roofline-sized ones (WideResNet-28-10: 17,846 workgroups) use the explicit 1-thread advance launch
-        self.self_advance = a.n <= _native.SELF_ADVANCE_MAX_ELEMS
+        # the update launch advances the block itself (two-level ticket tree on separate cache lines): no second launch
+        self.self_advance = True
         c = _native.StepCtl(lr=sc['lr'], mu=sc['mu'], c_wd=sc['c_wd'], c_noise=sc['c_noise'], n_train=sc['n_train'],
                             flags=sc['flags'] | (_native.STEP_ADVANCE if self.self_advance else 0)
                             | (_native.STEP_ZERO_GRAD if self.ctl_zero_grad else 0),
                             seed=self.seed, step=self._step, sched_base=self._step,
                             sched=0 if self._sched is None else self._sched.data_ptr(),
-                            sched_len=0 if self._sched is None else self._sched.shape[0], ticket=0)
+                            sched_len=0 if self._sched is None else self._sched.shape[0])
         if sched is not None:
             c.lr = float(sched[0, 0])
             if sc['flags'] & _native.STEP_SGD:
@@ -198,7 +197,7 @@ class optimSGHMC(Optimizer):
 
     @torch.no_grad()
     def ctl_step(self, eps=None):
-        """The update and the advance of the control block: ONE launch for workload-sized chains."""
+        """The update and the advance of the control block: ONE launch."""
         a = self.arena
         self.kernels.sgmcmc_step_ctl(a.theta, a.grad, a.mom, self._ctl, eps=eps)
         if not self.self_advance:
