@@ -7,7 +7,7 @@ removed relative to the reference: 8 launches per parameter tensor per step (488
 PreResNet-20), `optimizer.zero_grad()` (fused into the update), the per-step host sync
 `loss.item()` (sghmc.py:82; the loss is accumulated on the device) and every host-side launch
 gap (graph replay). Per-step scalars (lr, noise scale, noise on/off, Philox counter) live in a
-64-byte device control block so the captured graph stays valid while they change; the update
+device control block so the captured graph stays valid while they change; the update
 launch advances the block itself.
 
 Injected noise (parity runs: `eps_per_step`) goes through ONE persistent device buffer that the
