@@ -11,6 +11,7 @@ git rev-parse HEAD > $out/HEAD.txt 2>/dev/null || sha256sum ursabench_amd/csrc/l
 sha256sum ursabench_amd/csrc/libursa_hip.so ursabench_amd/csrc/ursa_kernels.hip bench.py > $out/r03_sha256.txt
 python3 tools/kbench.py > $out/kbench.log 2>&1; echo "kbench rc=$?"; cp gpurun_out/kbench.json $out/r03_kbench.json
 python3 tools/k1_ctl_bench.py > $out/k1_ctl_bench.log 2>&1; echo "k1_ctl_bench rc=$?"; cp gpurun_out/k1_ctl_bench.json $out/r03_k1_ctl_bench.json
+(/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/ticket_probe tools/exp/ticket_probe.hip 2>/dev/null && /tmp/ticket_probe > $out/r03_ticket_probe.txt); echo "ticket_probe rc=$?"
 python3 tools/exp/k3_spread.py > $out/k3_spread.log 2>&1; echo "k3_spread rc=$?"; cp gpurun_out/k3_spread.json $out/r03_k3_spread.json
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -- python3 $R/bench.py --steps 3 --warmup 1 > $out/bench_line_under_rocprof.json 2> $out/bench_under_rocprof.err; echo "bench under rocprof rc=$?"
