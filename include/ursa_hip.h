@@ -115,7 +115,8 @@ int ursa_sgmcmc_step_ctl_f32(float* theta, float* grad, float* mom, const float*
                              ursa_stream_t stream);
 int ursa_step_ctl_advance(ursa_step_ctl* ctl /* [n_ctl] */, int32_t n_ctl, ursa_stream_t stream);
 
-/* K chains in ONE launch (SURVEY.md 8b `n_chains`, 8f-1): the K independent chains that share a GPU
+/* K chains in ONE launch (SURVEY.md 8b `n_chains`, 8f-1; the reference steps one chain per process, one parameter
+ * tensor at a time: URSABench/experiment.py:166-173 + optim_sghmc.py:43): the K independent chains that share a GPU
  * keep their vectors in [K, chain_stride] slabs — chain k's theta / grad / mom (/ eps / snapshot)
  * start at element k * chain_stride of the base pointers — and their control blocks in ctl[K].
  * Chain k is updated exactly as ursa_sgmcmc_step_ctl_f32(theta + k*chain_stride, ..., n_per_chain,
