@@ -10,7 +10,6 @@ are keyed by MIOpen build and gfx950; on any other stack MIOpen ignores them and
 
 A private copy per process also keeps the find-db hazard of DESIGN.md §6 away (a search recorded under other
 process-wide switches, e.g. deterministic mode, being reused)."""
-import atexit
 import os
 import shutil
 import tempfile
@@ -25,7 +24,6 @@ def use_shipped_miopen_db(prefix='ursa_miopen_'):
     if 'MIOPEN_USER_DB_PATH' in os.environ:
         return os.environ['MIOPEN_USER_DB_PATH']
     d = tempfile.mkdtemp(prefix=prefix)
-    atexit.register(shutil.rmtree, d, ignore_errors=True)       # the private copy lives as long as the process
     if os.environ.get('URSA_NO_SHIPPED_MIOPEN_DB') != '1' and os.path.isdir(SHIPPED):
         for f in os.listdir(SHIPPED):
             if f.endswith('.txt'):
