@@ -89,3 +89,41 @@ def test_sgd_sampler_equals_the_reference_run(golden_dir):
     m = s.sample()
     assert np.array_equal(flat(m[0]), g['sample2'])
     assert s.optimizer.param_groups[0]['lr'] == pytest.approx(float(g['lr_after2']), rel=1e-12)
+
+
+@pytest.mark.parametrize('name', ['SGHMC', 'SGLD', 'cSGHMC'])
+def test_chain_checkpoint_resume_is_bit_identical(tmp_path, name):
+    """A chain saved between two samples and resumed in a fresh sampler continues bit for bit: the update counter is the
+    Philox call index (counter-based noise), momentum / BatchNorm buffers / scheduler / epoch bookkeeping travel along.
+    (The reference has no resume for samplers: SURVEY.md §5.)"""
+    import ursabench_amd.inference as inference
+    from oracle_kernels import OracleKernels
+    from ursabench_amd import util
+    from test_swag_cpu import bn_loader, bn_net
+    hyp = {'SGHMC': {'lr': 0.05, 'prior_std': 1.0, 'num_samples': 4, 'alpha': 0.5, 'burn_in_epochs': 1},
+           'SGLD': {'lr': 0.05, 'prior_std': 1.0, 'num_samples': 4, 'alpha': 1.0, 'burn_in_epochs': 1},
+           'cSGHMC': {'lr_0': 0.05, 'prior_std': 1.0, 'num_samples_per_cycle': 2, 'cycle_length': 4, 'burn_in_epochs': 1,
+                      'num_cycles': 2, 'alpha': 0.5}}[name]
+    flat = lambda m: torch.cat([p.detach().reshape(-1) for p in m.parameters()] + [b.detach().float().reshape(-1) for b in m.buffers()])
+
+    def make():
+        util.set_random_seed(4)
+        return getattr(inference, name)(dict(hyp), bn_net(), bn_loader(), kernels=OracleKernels(), use_graph=False, seed=17)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        straight = make()
+        want = [flat(straight.sample_iterative()) for _ in range(4)]
+        first = make()
+        got = [flat(first.sample_iterative()) for _ in range(2)]
+        p = str(tmp_path / 'chain.pt')
+        checkpoint.save_chain(first, p)
+        resumed = make()                                   # fresh weights, fresh optimizer, counter at 0 ...
+        checkpoint.load_chain(resumed, p)                  # ... put where `first` stopped
+        assert resumed.optimizer._step == first.optimizer._step > 0
+        got += [flat(resumed.sample_iterative()) for _ in range(2)]
+    for a, b in zip(want, got):
+        assert torch.equal(a, b)
+    other = inference.SGHMC({'lr': 0.05, 'prior_std': 1.0, 'num_samples': 1, 'alpha': 0.5, 'burn_in_epochs': 0},
+                            torch.nn.Sequential(torch.nn.Flatten(), torch.nn.Linear(36, 4)), bn_loader(), kernels=OracleKernels(), use_graph=False)
+    with pytest.raises(ValueError):
+        checkpoint.load_chain(other, p)

@@ -143,3 +143,32 @@ def test_update_hyp_on_group_members_recaptures_on_gpu():
         assert sa.optimizer._step == c.optimizer._step == 16
         np.testing.assert_allclose(flat_params(ma).cpu().numpy(), flat_params(mb).cpu().numpy(), rtol=2e-3, atol=3e-4)
     assert abs(float(chains[0].optimizer.param_groups[0]['momentum']) - 0.7) < 1e-12
+
+
+def test_chain_checkpoint_resume_on_device(tmp_path):
+    """save_chain / load_chain on the HIP path: a PreResNet-8 SGHMC chain saved after two samples and resumed in a fresh
+    sampler has the same update counter (= Philox call index), learning rate and BatchNorm counters, and lands where the
+    uninterrupted chain lands up to MIOpen's run-to-run rounding (weight-gradient atomics), through graph replay."""
+    from ursabench_amd import inference
+    hyp = {'lr': 0.05, 'prior_std': 0.5, 'num_samples': 4, 'alpha': 0.5, 'burn_in_epochs': 0}
+    train = synthetic(640, (3, 32, 32), 10, seed=0, device=DEV, batch_size=128)
+
+    def make():
+        util.set_random_seed(2)
+        return inference.SGHMC(dict(hyp), models.PreResNet(10, 8).to(DEV), train, device=DEV, seed=31)
+    straight = make()
+    want = [flat_params(straight.sample_iterative()).clone() for _ in range(4)]
+    first = make()
+    for _ in range(2):
+        first.sample_iterative()
+    p = str(tmp_path / 'chain.pt')
+    checkpoint.save_chain(first, p)
+    resumed = checkpoint.load_chain(make(), p)
+    assert resumed.optimizer._step == first.optimizer._step == 10
+    assert resumed.optimizer.param_groups[0]['lr'] == first.optimizer.param_groups[0]['lr']
+    assert torch.equal(resumed.arena.theta, first.arena.theta) and torch.equal(resumed.arena.mom, first.arena.mom)
+    got = [flat_params(resumed.sample_iterative()) for _ in range(2)]
+    assert resumed.engine.stats['graph_replays'] > 0 and resumed.optimizer._step == straight.optimizer._step == 20
+    for a, b in zip(want[2:], got):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-3, atol=3e-4)
+    assert int(dict(resumed.model.named_buffers())['bn.num_batches_tracked']) == 20

@@ -2,7 +2,14 @@
 tensor names/shapes/offsets, so saving S posterior samples is one stacked tensor instead of S pickled
 modules, and a saved ensemble can be re-materialised on any model with the same state_dict layout.
 `to_state_dicts` bridges to the reference's intended per-sample `.pt` files
-(URSABench/experiment.py:77-80)."""
+(URSABench/experiment.py:77-80).
+
+Chain checkpoints (`save_chain` / `load_chain`): the reference has no resume for samplers — a long
+SG-MCMC run that dies starts over. Here a chain's whole state is a few flat vectors and counters: theta / momentum /
+BatchNorm buffers, the update counter (which IS the Philox call index: noise is counter-based, so the resumed chain draws
+exactly the noise the uninterrupted one would have drawn), the optimizer's scalars, the LR scheduler and the sampler's
+epoch bookkeeping. A chain resumed from a checkpoint continues bit-identically given the same minibatches and gradients
+(asserted on CPU, where gradients are deterministic)."""
 import torch
 
 from .arena import FlatArena, MemberBank
@@ -58,3 +65,54 @@ def load_ensemble(path, like, device=None):
 def to_state_dicts(members):
     """One ordinary `state_dict` (CPU clones) per member."""
     return [{k: v.detach().cpu().clone() for k, v in m.state_dict().items()} for m in members]
+
+
+CHAIN_FORMAT = 'ursabench-amd-chain-v1'
+_SAMPLER_FIELDS = ('burnt_in', 'epochs_run', 'lr', 'lr_0', 'lr_final')
+
+
+def save_chain(sampler, path):
+    """Everything SGLD / SGHMC / cSGLD / cSGHMC needs to continue where it is (between two `sample_iterative` calls)."""
+    a, opt = sampler.arena, sampler.optimizer
+    cpu = lambda t: None if t is None else t.detach().cpu().clone()
+    sched = getattr(sampler, 'optimizer_scheduler', None)
+    torch.save({'format': CHAIN_FORMAT, 'kind': type(sampler).__name__, 'n': a.n, 'param_names': list(a.param_names),
+                'theta': cpu(a.theta), 'mom': cpu(a.mom), 'fbuf': cpu(a.fbuf), 'ibufs': [cpu(b) for _, b in a.ibufs],
+                'step': opt._step, 'has_mom': list(opt._has_mom), 'seed': opt.seed,
+                'param_groups': [{k: v for k, v in g.items() if k != 'params'} for g in opt.param_groups],
+                'scheduler': None if sched is None else sched.state_dict(),
+                'fields': {k: getattr(sampler, k) for k in _SAMPLER_FIELDS if hasattr(sampler, k)}}, path)
+
+
+def load_chain(sampler, path):
+    """Put a freshly constructed sampler (same class, model architecture, loader, hyper-parameters) into the saved state."""
+    ck = torch.load(path, weights_only=False)
+    if ck.get('format') != CHAIN_FORMAT:
+        raise ValueError(f'unknown chain checkpoint format {ck.get("format")}')
+    a, opt = sampler.arena, sampler.optimizer
+    if ck['kind'] != type(sampler).__name__ or ck['n'] != a.n or ck['param_names'] != list(a.param_names):
+        raise ValueError('chain checkpoint does not match this sampler (class / model layout)')
+    with torch.no_grad():
+        a.theta.copy_(ck['theta'])
+        if ck['mom'] is not None:
+            a.ensure_mom().copy_(ck['mom'])
+        if ck['fbuf'] is not None and a.fbuf is not None:
+            a.fbuf.copy_(ck['fbuf'])
+        for (_, b), v in zip(a.ibufs, ck['ibufs']):
+            b.copy_(v)
+    opt.seed, opt._step = ck['seed'], ck['step']
+    opt._has_mom = list(ck['has_mom'])
+    for gi, has in enumerate(opt._has_mom):
+        if has:
+            opt._register_momentum_views(gi)
+    for g, saved in zip(opt.param_groups, ck['param_groups']):
+        g.update(saved)
+    sched = getattr(sampler, 'optimizer_scheduler', None)
+    if sched is not None and ck['scheduler'] is not None:
+        sched.load_state_dict(ck['scheduler'])
+    for k, v in ck['fields'].items():
+        setattr(sampler, k, v)
+    if hasattr(sampler, 'seed'):
+        sampler.seed = ck['seed']
+    sampler.engine.invalidate()            # a captured graph is still valid address-wise, but keep the contract simple
+    return sampler
