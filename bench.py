@@ -713,11 +713,18 @@ class Job:
                 pass
 
 
+def _abi_version():
+    from ursabench_amd import _native
+    return _native.load_library().ursa_abi_version()
+
+
 def base_line(a, job, metric, unit, workload):
     return {'metric': metric, 'value': None, 'unit': unit, 'n_gpus': job.world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': None, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
             'data': 'synthetic' if not job.cpu else 'DRY RUN on CPU tensors with the tests\' oracle kernel set: control flow only, NOT a measurement',
-            'config': {'workload': workload, 'miopen_user_db': 'shipped tuned databases (ursabench_amd/miopen_db, MIOPEN_FIND_ENFORCE=3 search; stock MIOpen solvers)'
+            'config': {'workload': workload, 'device': (torch.cuda.get_device_name(job.dev) if not job.cpu else 'cpu'),
+                       'torch': torch.__version__, 'hip': torch.version.hip, 'abi': None if job.cpu else _abi_version(),
+                       'miopen_user_db': 'shipped tuned databases (ursabench_amd/miopen_db, MIOPEN_FIND_ENFORCE=3 search; stock MIOpen solvers)'
                        if any(f.endswith('.txt') for f in os.listdir(MIOPEN_DB)) else 'empty private database (quick search per layer)'}}
 
 
