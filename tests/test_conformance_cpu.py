@@ -127,3 +127,31 @@ def test_chain_checkpoint_resume_is_bit_identical(tmp_path, name):
                             torch.nn.Sequential(torch.nn.Flatten(), torch.nn.Linear(36, 4)), bn_loader(), kernels=OracleKernels(), use_graph=False)
     with pytest.raises(ValueError):
         checkpoint.load_chain(other, p)
+
+
+def test_swag_checkpoint_resume_is_bit_identical(tmp_path):
+    """SWAG (as published) saved after its trajectory and first member, resumed in a fresh sampler: the moments, the
+    collected count and the Philox draw index travel along, so the next members are the uninterrupted run's, bit for bit
+    (parameters and refreshed BatchNorm statistics)."""
+    import ursabench_amd.inference as inference
+    from oracle_kernels import OracleKernels
+    from ursabench_amd import util
+    from test_swag_cpu import bn_loader, bn_net
+    hyp = {'swag_lr': 0.01, 'swag_wd': 1e-4, 'lr_init': 0.05, 'num_samples': 3, 'momentum': 0.9, 'burn_in_epochs': 1,
+           'num_iterates': 2}
+    flat = lambda m: torch.cat([p.detach().reshape(-1) for p in m.parameters()] + [b.detach().float().reshape(-1) for b in m.buffers()])
+
+    def make():
+        util.set_random_seed(4)
+        return inference.SWAG(dict(hyp), bn_net(), bn_loader(), kernels=OracleKernels(), use_graph=False, reference_quirks=False, seed=23)
+    straight = make()
+    want = [flat(straight.sample_iterative()) for _ in range(3)]
+    first = make()
+    got = [flat(first.sample_iterative())]
+    p = str(tmp_path / 'swag.pt')
+    checkpoint.save_chain(first, p)
+    resumed = checkpoint.load_chain(make(), p)
+    assert resumed.burnt_in and resumed._draws == 1 and resumed.num_models_collected.item() == 2
+    got += [flat(resumed.sample_iterative()) for _ in range(2)]
+    for a, b in zip(want, got):
+        assert torch.equal(a, b)

@@ -68,11 +68,12 @@ def to_state_dicts(members):
 
 
 CHAIN_FORMAT = 'ursabench-amd-chain-v1'
-_SAMPLER_FIELDS = ('burnt_in', 'epochs_run', 'lr', 'lr_0', 'lr_final')
+_SAMPLER_FIELDS = ('burnt_in', 'epochs_run', 'lr', 'lr_0', 'lr_final', '_draws')      # '_draws': SWAG's Philox draw index
 
 
 def save_chain(sampler, path):
-    """Everything SGLD / SGHMC / cSGLD / cSGHMC needs to continue where it is (between two `sample_iterative` calls)."""
+    """Everything SGLD / SGHMC / cSGLD / cSGHMC / SWA / SWAG needs to continue where it is (between two
+    `sample_iterative` calls); for SWA / SWAG that includes the two moment vectors and the collected count."""
     a, opt = sampler.arena, sampler.optimizer
     cpu = lambda t: None if t is None else t.detach().cpu().clone()
     sched = getattr(sampler, 'optimizer_scheduler', None)
@@ -81,6 +82,10 @@ def save_chain(sampler, path):
                 'step': opt._step, 'has_mom': list(opt._has_mom), 'seed': opt.seed,
                 'param_groups': [{k: v for k, v in g.items() if k != 'params'} for g in opt.param_groups],
                 'scheduler': None if sched is None else sched.state_dict(),
+                'swag': None if not hasattr(sampler, '_mean') else {'mean': cpu(sampler._mean), 'sq': cpu(sampler._sq),
+                                                                   'collected': sampler.num_models_collected.clone(),
+                                                                   # swag_model's BatchNorm step counters keep counting across members (util.py:195-199)
+                                                                   'swag_ibufs': [cpu(b) for _, b in sampler.swag_arena.ibufs]},
                 'fields': {k: getattr(sampler, k) for k in _SAMPLER_FIELDS if hasattr(sampler, k)}}, path)
 
 
@@ -112,6 +117,17 @@ def load_chain(sampler, path):
         sched.load_state_dict(ck['scheduler'])
     for k, v in ck['fields'].items():
         setattr(sampler, k, v)
+    if ck.get('swag') is not None:
+        with torch.no_grad():
+            sampler._mean.copy_(ck['swag']['mean'])
+            sampler._sq.copy_(ck['swag']['sq'])
+        sampler.num_models_collected = ck['swag']['collected'].clone()
+        with torch.no_grad():
+            for (_, b), v in zip(sampler.swag_arena.ibufs, ck['swag']['swag_ibufs']):
+                b.copy_(v)
+        sampler._std = None
+        if ck['fields'].get('burnt_in') and hasattr(sampler, 'adopt_moments'):
+            sampler.adopt_moments()
     if hasattr(sampler, 'seed'):
         sampler.seed = ck['seed']
     sampler.engine.invalidate()            # a captured graph is still valid address-wise, but keep the contract simple
