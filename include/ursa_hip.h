@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define URSA_ABI_VERSION 2
+#define URSA_ABI_VERSION 3
 
 typedef void* ursa_stream_t; /* hipStream_t */
 
@@ -231,6 +231,53 @@ int ursa_leapfrog_f32(float* theta, float* mom, const float* grad, int64_t n,
 
 /* out[0] += sum x[i]^2  (prior term tau/2*||theta||^2 and kinetic energy). 4 B/param. */
 int ursa_sumsq_f32(const float* x, int64_t n, float* out, float* ws, ursa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K6  BatchNorm2d (+ ReLU) of the pre-activation blocks      URSABench/models/preresnet.py:40-41,
+ *     45-46,76-85,146; wideresnet.py:47,49,117 (`relu(bn(x))` = torch.nn.functional.batch_norm
+ *     followed by relu; backward = threshold_backward + native_batch_norm_backward).
+ *     x, y, dy, dx: contiguous NCHW fp32, [N, C, HW]. float4 accesses when HW % 4 == 0 and the
+ *     pointers are 16-byte aligned, 4-byte accesses otherwise (same results).
+ *
+ *   training forward (two launches: per-channel partial sums in double; merge + normalise):
+ *     mean_c = (float) (sum x / n), var_c = sum x^2 / n - mean^2 (double; biased), invstd_c =
+ *     (float) (1 / sqrt(var_c + eps)) : correctly rounded, like torch's CPU kernel (double accumulation)
+ *     alpha_c = invstd_c * gamma_c ; beta'_c = fmaf(-mean_c, alpha_c, beta_c)
+ *     y = fmaf(x, alpha_c, beta'_c) ; RELU: y = y < 0 ? 0 : y
+ *         (the association of torch 2.10's CPU BatchNorm, bit for bit given x / mean / invstd: the
+ *          ReLU gate of a pre-activation near zero must not depend on which device ran it)
+ *     save_mean[c] = mean_c ; save_invstd[c] = invstd_c
+ *     running_mean != NULL:  running_mean[c] = momentum * mean_c + (1 - momentum) * running_mean[c]
+ *                            running_var[c]  = momentum * var_c * n/(n-1) + (1 - momentum) * running_var[c]
+ *   evaluation forward (one launch): the same with mean / var = running_mean / running_var.
+ *   backward (two launches; torch's CPU association, native_batch_norm_backward in training mode):
+ *     g = RELU ? (fmaf(x, alpha_c, beta'_c) > 0 ? dy : 0) : dy        (the forward's gate, recomputed)
+ *     sum = sum g ; dotp = sum g * (x - mean_c)                      (double)
+ *     dbeta[c] = sum ; dgamma[c] = dotp * invstd_c ; gm = sum / n ; k = dotp * invstd_c^2 / n
+ *     dx = (((g - gm) - (x - mean_c) * k) * invstd_c) * gamma_c       (n = N * HW)
+ * ws: scratch, URSA_BN_WS_FLOATS(C) floats, 16-byte aligned, no initialisation needed; partial
+ * results of the first launch of a call, consumed by its second launch.
+ * Deterministic (no atomics); fp32 throughout. Error vs exact arithmetic: a few ulp on y / dx
+ * (tests compare with float64 BatchNorm at 2e-6 relative to the activation scale).
+ * Traffic: forward 12 B/element (x twice, y once), backward 20 B/element, evaluation 8 B/element.
+ */
+#define URSA_BN_RELU      0x1u
+#define URSA_BN_ALLFLAGS  0x1u
+#define URSA_BN_WS_FLOATS(C) ((int64_t)(C) * 64 * 4)
+
+int ursa_bn_relu_fwd_f32(const float* x, float* y, const float* gamma, const float* beta,
+                         float* running_mean /* or NULL */, float* running_var /* or NULL */,
+                         float* save_mean, float* save_invstd, float* ws, int64_t N, int64_t C,
+                         int64_t HW, float eps, float momentum, uint32_t flags, ursa_stream_t stream);
+
+int ursa_bn_relu_eval_f32(const float* x, float* y, const float* gamma, const float* beta,
+                          const float* running_mean, const float* running_var, int64_t N, int64_t C,
+                          int64_t HW, float eps, uint32_t flags, ursa_stream_t stream);
+
+int ursa_bn_relu_bwd_f32(const float* x, const float* dy, float* dx, const float* gamma,
+                         const float* beta, const float* save_mean, const float* save_invstd,
+                         float* dgamma, float* dbeta, float* ws, int64_t N, int64_t C, int64_t HW,
+                         uint32_t flags, ursa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------ */
 int ursa_abi_version(void);

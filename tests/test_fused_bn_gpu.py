@@ -1,0 +1,306 @@
+"""K6 (relu(bn(x)) as gfx950 launches) against torch's own BatchNorm + ReLU — the ops the reference's networks run
+(URSABench/models/preresnet.py:40-41,76-85,146; wideresnet.py:47,49,117) — evaluated in float64 on the host.
+Floating-point reductions: the bar is a few fp32 ulp of the activation scale (2e-6 relative to max |y|, written below),
+an order of magnitude inside north_star's 1e-5; the stock fp32 GPU path's own distance to float64 is measured beside it."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 2e-6          # of max |reference| per tensor
+
+
+@pytest.fixture(scope='module')
+def K():
+    from ursabench_amd import _native
+    assert torch.cuda.is_available(), 'gpu tests need a HIP device'
+    return _native.default_kernels()
+
+
+def _ref64(x, w, b, eps, relu, dy=None, mask=None):
+    """float64 BatchNorm(+ReLU) forward / backward on the host. `mask`: which ReLUs count as open in the backward
+    (the device's own decision: an element whose pre-activation sits within fp32 rounding of zero may legitimately
+    fall on either side, and a flipped element moves dx by O(dy), not by rounding)."""
+    x = x.double().cpu().requires_grad_(True)
+    w = w.double().cpu().requires_grad_(True)
+    b = b.double().cpu().requires_grad_(True)
+    y = F.batch_norm(x, None, None, w, b, True, 0.0, eps)
+    if relu:
+        y = F.relu(y) if mask is None else y * mask.double().cpu()
+    out = dict(y=y.detach())
+    dims = [0] + list(range(2, x.dim()))
+    out['mean'] = x.detach().mean(dims)
+    out['var'] = x.detach().var(dims, unbiased=False)
+    if dy is not None:
+        y.backward(dy.double().cpu())
+        out.update(dx=x.grad, dw=w.grad, db=b.grad)
+    return out
+
+
+def _close(got, ref, what, rtol=RTOL):
+    ref = ref.float()
+    scale = max(float(ref.abs().max()), 1e-30)
+    err = float((got.cpu() - ref).abs().max()) / scale
+    assert err <= rtol, f'{what}: {err:.3e} of the tensor scale (bar {rtol:.1e})'
+    return err
+
+
+SHAPES = [(128, 16, 32, 32), (128, 32, 16, 16), (128, 64, 8, 8),      # PreResNet-20's three stages
+          (16, 160, 32, 32), (16, 640, 8, 8),                          # WideResNet-28-10 widths
+          (7, 5, 3, 3), (2, 3, 1, 2), (33, 2, 5, 4), (1, 4, 2, 2),     # ragged: 4-byte path, tiny, one image
+          (3, 1, 257, 4), (2, 70000 // 64, 8, 8)]                      # one channel; more channels than workgroup target
+
+
+@pytest.mark.parametrize('shape', SHAPES)
+@pytest.mark.parametrize('relu', [True, False])
+def test_training_forward_backward_vs_float64(K, shape, relu):
+    g = torch.Generator().manual_seed(hash(shape) % 1000)
+    C = shape[1]
+    x = (torch.randn(shape, generator=g) * 1.7 + 0.3).cuda()
+    w = (torch.rand(C, generator=g) + 0.5).cuda()
+    b = (torch.randn(C, generator=g) * 0.2).cuda()
+    dy = torch.randn(shape, generator=g).cuda()
+    rm, rv = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
+    eps, mom = 1e-5, 0.1
+    from ursabench_amd import _native
+    y = torch.full_like(x, float('nan'))
+    sm, si = torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
+    ws = torch.empty(_native.bn_ws_floats(C), device='cuda')
+    K.bn_relu_forward(x, y, w, b, rm, rv, sm, si, ws, eps=eps, momentum=mom, relu=relu)
+    ref = _ref64(x, w, b, eps, relu, dy, mask=(y > 0) if relu else None)
+    _close(y, ref['y'], 'y')
+    _close(sm, ref['mean'], 'save_mean')
+    _close(si, 1.0 / torch.sqrt(ref['var'] + eps), 'save_invstd')
+    n = x.numel() // C
+    _close(rm, mom * ref['mean'], 'running_mean')
+    _close(rv, mom * ref['var'] * n / (n - 1) + (1 - mom), 'running_var')
+    dx = torch.full_like(x, float('nan'))
+    dw, db = torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
+    K.bn_relu_backward(x, dy, dx, w, b, sm, si, dw, db, ws, relu=relu)
+    _close(db, ref['db'], 'dbeta', 2e-5)
+    _close(dw, ref['dw'], 'dgamma', 2e-5)
+    _close(dx, ref['dx'], 'dx', 2e-5)
+    # the stock fp32 path on the same device, for scale
+    ys = F.batch_norm(x, None, None, w, b, True, 0.0, eps)
+    ys = F.relu(ys) if relu else ys
+    _close(ys, ref['y'], 'stock y', 1e-5)
+
+
+def test_large_mean_small_spread(K):
+    """Activations with |mean| >> std (mean 300, std 0.01): E[x^2] - E[x]^2 in fp32 cancels to noise; the double
+    accumulators do not. y follows torch's CPU association (x * alpha + beta'), whose own cancellation against the
+    folded shift is the reference's arithmetic: compared with the CPU kernel, not with float64."""
+    from ursabench_amd import _native
+    g = torch.Generator().manual_seed(5)
+    shape, C = (64, 8, 16, 16), 8
+    x = (torch.randn(shape, generator=g) * 0.01 + 300.0).cuda()
+    w, b = torch.ones(C, device='cuda'), torch.zeros(C, device='cuda')
+    y = torch.empty_like(x)
+    sm, si = torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
+    ws = torch.empty(_native.bn_ws_floats(C), device='cuda')
+    K.bn_relu_forward(x, y, w, b, None, None, sm, si, ws, eps=1e-5, momentum=0.0, relu=False)
+    ref = _ref64(x, w, b, 1e-5, False)
+    assert torch.equal(sm.cpu(), ref['mean'].float())
+    assert float((si.cpu().double() * torch.sqrt(ref['var'] + 1e-5) - 1).abs().max()) < 2e-7
+    y_c, m_c, i_c = torch.native_batch_norm(x.cpu(), w.cpu(), b.cpu(), None, None, True, 0.0, 1e-5)
+    same = (si.cpu() == i_c) & (sm.cpu() == m_c)
+    assert torch.equal(y.cpu()[:, same], y_c[:, same])
+    assert float((y.cpu() - y_c).abs().max()) < 1e-2       # channels whose invstd differs in the last bit: 30000 * 2^-23
+
+
+@pytest.mark.parametrize('shape', [(128, 16, 32, 32), (128, 32, 16, 16), (128, 64, 8, 8), (7, 5, 3, 3)])
+def test_forward_is_torch_cpu_batchnorm_bit_for_bit(K, shape):
+    """The reference's path is torch's CPU BatchNorm. Same x: the batch mean is the same float in every channel, invstd
+    in most (torch's own variance is not exact; ours is the correctly rounded one), and wherever both agree every
+    output element has the same bits - so the ReLU gates agree."""
+    from ursabench_amd import _native
+    g = torch.Generator().manual_seed(11)
+    C = shape[1]
+    x = (torch.randn(shape, generator=g) * 1.3 - 0.2)
+    w, b = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    y_c, m_c, i_c = torch.native_batch_norm(x, w, b, None, None, True, 0.0, 1e-5)
+    xd = x.cuda()
+    y = torch.empty_like(xd)
+    sm, si = torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
+    ws = torch.empty(_native.bn_ws_floats(C), device='cuda')
+    K.bn_relu_forward(xd, y, w.cuda(), b.cuda(), None, None, sm, si, ws, eps=1e-5, momentum=0.0, relu=True)
+    assert torch.equal(sm.cpu(), m_c)
+    same = si.cpu() == i_c
+    assert int(same.sum()) >= 0.7 * C, f'invstd equal in only {int(same.sum())} of {C} channels'
+    assert float((si.cpu() / i_c - 1).abs().max()) < 1.3e-7          # the others: one unit in the last place
+    assert torch.equal(y.cpu()[:, same], F.relu(y_c)[:, same])
+
+
+def test_unaligned_pointers_take_the_scalar_path(K):
+    from ursabench_amd import _native
+    g = torch.Generator().manual_seed(9)
+    shape, C = (8, 6, 4, 4), 6
+    buf = torch.randn(8 * 6 * 16 + 1, generator=g).cuda()
+    x = buf[1:].view(shape)                       # contiguous, 4-byte aligned only
+    assert x.data_ptr() % 16 != 0
+    w, b = torch.rand(C, device='cuda') + 0.5, torch.randn(C, device='cuda')
+    out = []
+    for xx in (x, x.clone()):
+        y = torch.empty_like(xx)
+        sm, si = torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
+        ws = torch.empty(_native.bn_ws_floats(C), device='cuda')
+        K.bn_relu_forward(xx, y, w, b, None, None, sm, si, ws, eps=1e-5, momentum=0.0, relu=True)
+        out.append((y, sm, si))
+    ref = _ref64(x, w, b, 1e-5, True)
+    _close(out[0][0], ref['y'], 'y (unaligned)')
+    _close(out[1][0], ref['y'], 'y (aligned)')
+
+
+@pytest.mark.parametrize('shape', [(128, 16, 32, 32), (5, 3, 3, 3), (100, 64, 8, 8)])
+def test_evaluation_mode_vs_float64(K, shape):
+    g = torch.Generator().manual_seed(3)
+    C = shape[1]
+    x = torch.randn(shape, generator=g).cuda()
+    w, b = (torch.rand(C, generator=g) + 0.5).cuda(), torch.randn(C, generator=g).cuda()
+    rm, rv = torch.randn(C, generator=g).cuda(), (torch.rand(C, generator=g) + 0.2).cuda()
+    y = torch.empty_like(x)
+    K.bn_relu_eval(x, y, w, b, rm, rv, eps=1e-5, relu=True)
+    ref = F.relu(F.batch_norm(x.double().cpu(), rm.double().cpu(), rv.double().cpu(), w.double().cpu(), b.double().cpu(),
+                              False, 0.0, 1e-5))
+    _close(y, ref, 'eval y')
+
+
+def test_module_semantics_follow_nn_batchnorm():
+    """bn_relu(bn, x) against relu(bn_stock(x)) on twin modules: running statistics, the batch counter, train / eval,
+    the cases that must take the stock path, and the in-place contract (x is never modified)."""
+    from ursabench_amd import fused_bn
+    torch.manual_seed(0)
+    x = torch.randn(32, 8, 8, 8, device='cuda')
+    a, s = nn.BatchNorm2d(8).cuda(), nn.BatchNorm2d(8).cuda()
+    with torch.no_grad():
+        a.weight.uniform_(0.5, 1.5)
+        a.bias.normal_()
+    s.load_state_dict(a.state_dict())
+    for it in range(3):
+        xi = x + it
+        keep = xi.clone()
+        ya = fused_bn.bn_relu(a, xi)
+        ys = F.relu(s(xi))
+        assert torch.equal(xi, keep)
+        assert torch.allclose(ya, ys, rtol=0, atol=2e-6 * float(ys.abs().max()))
+        assert torch.allclose(a.running_mean, s.running_mean, rtol=1e-6, atol=1e-7)
+        assert torch.allclose(a.running_var, s.running_var, rtol=1e-6, atol=1e-7)
+        assert int(a.num_batches_tracked) == int(s.num_batches_tracked) == it + 1
+    a.eval(), s.eval()
+    with torch.no_grad():
+        ya, ys = fused_bn.bn_relu(a, x), F.relu(s(x))
+    assert torch.allclose(ya, ys, rtol=0, atol=5e-6 * float(ys.abs().max()))
+    assert int(a.num_batches_tracked) == 3
+    # gradients through an evaluation-mode layer: stock path (same numbers as torch, by construction)
+    xg = x.clone().requires_grad_(True)
+    fused_bn.bn_relu(a, xg).sum().backward()
+    assert xg.grad is not None
+    # momentum=None (cumulative average) and host tensors: stock path
+    c = nn.BatchNorm2d(8, momentum=None).cuda()
+    c2 = nn.BatchNorm2d(8, momentum=None).cuda()
+    assert torch.equal(fused_bn.bn_relu(c, x), F.relu(c2(x)))
+    h, h2 = nn.BatchNorm2d(8), nn.BatchNorm2d(8)
+    assert torch.equal(fused_bn.bn_relu(h, x.cpu()), F.relu(h2(x.cpu())))
+    # the switch
+    old = fused_bn.enabled(False)
+    try:
+        a.train(), s.train()
+        assert torch.equal(fused_bn.bn_relu(a, x), F.relu(s(x)))
+    finally:
+        fused_bn.enabled(old)
+    with pytest.raises(ValueError):
+        fused_bn.bn_relu(nn.BatchNorm2d(8).cuda(), torch.randn(1, 8, 1, 1, device='cuda'))
+
+
+def test_autograd_through_the_fused_layer_vs_stock():
+    from ursabench_amd import fused_bn
+    torch.manual_seed(1)
+    x0 = torch.randn(64, 16, 16, 16, device='cuda')
+    res = []
+    for fused in (True, False):
+        bn = nn.BatchNorm2d(16).cuda()
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, 16))
+            bn.bias.copy_(torch.linspace(-0.3, 0.3, 16))
+        x = x0.clone().requires_grad_(True)
+        old = fused_bn.enabled(fused)
+        try:
+            y = fused_bn.bn_relu(bn, x)
+            (y * torch.linspace(0, 1, y.numel(), device='cuda').view_as(y)).sum().backward()
+        finally:
+            fused_bn.enabled(old)
+        res.append((y.detach(), x.grad, bn.weight.grad, bn.bias.grad))
+    for got, ref, what in zip(res[0], res[1], ('y', 'dx', 'dgamma', 'dbeta')):
+        scale = float(ref.abs().max())
+        assert float((got - ref).abs().max()) <= 2e-5 * scale, what
+
+
+@pytest.mark.parametrize('name', ['PreResNet20', 'PreResNet164', 'WideResNet28x10'])
+def test_networks_fused_vs_stock(name):
+    """The benchmark networks end to end, train mode, fused vs stock launches from identical weights. The logits are a
+    continuous function of every intermediate rounding: tight. The gradients are not: a pre-activation within rounding
+    of zero opens its ReLU gate on one side and not on the other (tools/exp/bn_gate_diag.py: ~2 of 24M gates per
+    forward between ANY two of {CPU, MIOpen launches, K6}), which moves the gradients it touches by ~1/sqrt(elements per
+    channel) - so they are compared at that scale only; the per-layer tests above carry the tight gradient bars."""
+    from ursabench_amd import fused_bn, models
+    cfg = getattr(models, name)
+    classes = 10 if name == 'PreResNet20' else 100
+    torch.manual_seed(0)
+    ref_model = cfg.base(num_classes=classes, **cfg.kwargs).cuda()
+    B = 32 if name == 'PreResNet20' else 8
+    x = torch.randn(B, 3, 32, 32, device='cuda')
+    t = torch.randint(0, classes, (B,), device='cuda')
+    out = []
+    for fused in (True, False):
+        m = cfg.base(num_classes=classes, **cfg.kwargs).cuda()
+        m.load_state_dict(ref_model.state_dict())
+        m.train()
+        old = fused_bn.enabled(fused)
+        try:
+            logits = m(x)
+            F.cross_entropy(logits, t).backward()
+        finally:
+            fused_bn.enabled(old)
+        out.append((logits.detach(), [p.grad for p in m.parameters()], [b.clone() for b in m.buffers()]))
+    (la, ga, ba), (ls, gs, bs) = out
+    deep = name != 'PreResNet20'       # 164 / 28 layers: rounding differences compound through the depth
+    assert float((la - ls).abs().max()) <= (2e-4 if deep else 2e-5) * float(ls.abs().max())
+    for a, s in zip(ga, gs):
+        assert float((a - s).abs().max()) <= 0.1 * max(float(s.abs().max()), 1e-6)
+    for a, s in zip(ba, bs):
+        assert torch.allclose(a.float(), s.float(), rtol=1e-4, atol=1e-5)
+
+
+def test_fused_layers_replay_inside_a_hipgraph():
+    from ursabench_amd import models
+    from ursabench_amd._capture import capture
+    torch.manual_seed(0)
+    m = models.PreResNet(num_classes=10, depth=8).cuda().train()
+    x = torch.randn(16, 3, 32, 32, device='cuda')
+    t = torch.randint(0, 10, (16,), device='cuda')
+
+    def step():
+        for p in m.parameters():
+            p.grad = None
+        F.cross_entropy(m(x), t).backward()
+        return [p.grad for p in m.parameters()]
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream().wait_stream(s)
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+    eager = [g.clone() for g in step()]
+    m.load_state_dict(state)
+    g = torch.cuda.CUDAGraph()
+    with capture(g):
+        grads = step()
+    m.load_state_dict(state)
+    g.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(grads, eager):      # MIOpen's split-K weight gradients add with atomics: not bit-reproducible
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6 * float(b.abs().max()))

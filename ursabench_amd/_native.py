@@ -17,13 +17,19 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libursa_hip.so')
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # flags (mirror include/ursa_hip.h)
 STEP_NOISE, STEP_FIRST, STEP_ZERO_GRAD, STEP_WD, STEP_SGD, STEP_ADVANCE = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
 BMA_SMOOTHED = 0x1
 LEAP_KICK, LEAP_DRIFT = 0x1, 0x2
 REDUCE_WS_FLOATS = 2048
+BN_RELU = 0x1
+
+
+def bn_ws_floats(channels):
+    """URSA_BN_WS_FLOATS(C): scratch of one BatchNorm call."""
+    return int(channels) * 64 * 4
 BMA_MAX_CLASSES = 1024
 
 _vp, _i64, _i32, _u64, _u32, _f = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_uint64,
@@ -46,6 +52,9 @@ SIGNATURES = {
     'ursa_bma_accumulate_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _f, _f, _u32, _vp]),
     'ursa_leapfrog_f32': (ctypes.c_int, [_vp, _vp, _vp, _i64, _f, _f, _f, _u32, _vp, _vp, _vp]),
     'ursa_sumsq_f32': (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp]),
+    'ursa_bn_relu_fwd_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f, _f, _u32, _vp]),
+    'ursa_bn_relu_eval_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f, _u32, _vp]),
+    'ursa_bn_relu_bwd_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _u32, _vp]),
 }
 
 
@@ -282,6 +291,54 @@ class HipKernels:
             rc = self.lib.ursa_sumsq_f32(_ptr(x, 'x'), x.numel(), _ptr(out, 'out', 1, dev), _ptr(ws, 'ws', None, dev),
                                          _stream(dev))
         _check(self.lib, rc, 'ursa_sumsq_f32')
+
+    # K6 ------------------------------------------------------------------------------
+    @staticmethod
+    def _bn_dims(x):
+        if x.dim() < 2:
+            raise ValueError(f'BatchNorm input must be [N, C, ...], got {tuple(x.shape)}')
+        N, C = x.shape[0], x.shape[1]
+        return N, C, x.numel() // max(N * C, 1)
+
+    def bn_relu_forward(self, x, y, gamma, beta, running_mean, running_var, save_mean, save_invstd, ws, *, eps,
+                        momentum, relu=True):
+        """Training-mode BatchNorm (+ ReLU) of a contiguous [N, C, *] tensor: batch statistics, running statistics
+        updated in place (skipped when both are None), mean / invstd saved for the backward."""
+        N, C, HW = self._bn_dims(x)
+        dev, n = x.device, x.numel()
+        if ws.numel() < bn_ws_floats(C):
+            raise ValueError(f'ws must hold {bn_ws_floats(C)} floats')
+        with torch.cuda.device(dev):
+            rc = self.lib.ursa_bn_relu_fwd_f32(
+                _ptr(x, 'x'), _ptr(y, 'y', n, dev), _ptr(gamma, 'gamma', C, dev), _ptr(beta, 'beta', C, dev),
+                _ptr(running_mean, 'running_mean', C, dev, optional=True),
+                _ptr(running_var, 'running_var', C, dev, optional=True), _ptr(save_mean, 'save_mean', C, dev),
+                _ptr(save_invstd, 'save_invstd', C, dev), _ptr(ws, 'ws', None, dev), N, C, HW, eps, momentum,
+                BN_RELU if relu else 0, _stream(dev))
+        _check(self.lib, rc, 'ursa_bn_relu_fwd_f32')
+
+    def bn_relu_eval(self, x, y, gamma, beta, running_mean, running_var, *, eps, relu=True):
+        N, C, HW = self._bn_dims(x)
+        dev, n = x.device, x.numel()
+        with torch.cuda.device(dev):
+            rc = self.lib.ursa_bn_relu_eval_f32(
+                _ptr(x, 'x'), _ptr(y, 'y', n, dev), _ptr(gamma, 'gamma', C, dev), _ptr(beta, 'beta', C, dev),
+                _ptr(running_mean, 'running_mean', C, dev), _ptr(running_var, 'running_var', C, dev), N, C, HW, eps,
+                BN_RELU if relu else 0, _stream(dev))
+        _check(self.lib, rc, 'ursa_bn_relu_eval_f32')
+
+    def bn_relu_backward(self, x, dy, dx, gamma, beta, save_mean, save_invstd, dgamma, dbeta, ws, *, relu=True):
+        N, C, HW = self._bn_dims(x)
+        dev, n = x.device, x.numel()
+        if ws.numel() < bn_ws_floats(C):
+            raise ValueError(f'ws must hold {bn_ws_floats(C)} floats')
+        with torch.cuda.device(dev):
+            rc = self.lib.ursa_bn_relu_bwd_f32(
+                _ptr(x, 'x'), _ptr(dy, 'dy', n, dev), _ptr(dx, 'dx', n, dev), _ptr(gamma, 'gamma', C, dev),
+                _ptr(beta, 'beta', C, dev), _ptr(save_mean, 'save_mean', C, dev),
+                _ptr(save_invstd, 'save_invstd', C, dev), _ptr(dgamma, 'dgamma', C, dev), _ptr(dbeta, 'dbeta', C, dev),
+                _ptr(ws, 'ws', None, dev), N, C, HW, BN_RELU if relu else 0, _stream(dev))
+        _check(self.lib, rc, 'ursa_bn_relu_bwd_f32')
 
 
 _default = None

@@ -1,0 +1,489 @@
+// ursa_bn.hip — K6: BatchNorm2d (+ ReLU) of the benchmark networks' pre-activation blocks, NCHW fp32, gfx950.
+//
+// Every BatchNorm of PreResNet / WideResNet is followed by a ReLU (URSABench/models/preresnet.py:40-41,45-46,
+// 76-85,146; wideresnet.py:47,49,117). Stock PyTorch-ROCm runs that pair as 2-4 MIOpen launches + 1 ATen clamp
+// forward and 2-4 MIOpen launches + 1 ATen threshold backward per layer: 31 % of the kernel time of a PreResNet-20
+// training step (profiles/r03_bench_kernel_stats.csv), at 5-19 us per launch on 2-8 MB activations. Here: two
+// launches forward (per-channel partial statistics; normalise + ReLU), two backward (partial sums of dy' and
+// dy'*xhat with the ReLU mask recomputed from x; dx), one in evaluation mode. All are HBM / cache streaming
+// kernels: float4 per lane, 256-thread workgroups, grid = (splits, channels) with the channel's N*H*W run cut into
+// `splits` contiguous chunks so that >= 512 workgroups stream even for 16-channel layers.
+//
+// Arithmetic = torch's CPU BatchNorm (the reference's path), bit for bit given the same x, mean and invstd:
+//     alpha = invstd * gamma ; beta' = fma(-mean, alpha, beta) ; y = fma(x, alpha, beta')
+// (found by probing torch 2.10's CPU kernel: 0 of 2,097,152 outputs differ with this form, 20-50 % with any other
+// association). That matters beyond rounding: the ReLU that follows turns a last-bit difference of a
+// pre-activation near zero into an open / closed gate, i.e. an O(1) change of that element's gradient.
+// Statistics: torch's CPU kernel accumulates in double and its batch mean is the correctly rounded exact mean;
+// here every thread accumulates sum x and sum x^2 in DOUBLE (gfx950's vector fp64 rate makes that free next to the
+// loads), the workgroup partials {s1, s2} are doubles, and the prologue of EVERY workgroup of the second launch
+// (<= 64 partials per channel: one wave) merges them in double in a fixed lane order: mean and invstd come out
+// correctly rounded (mean always equal to torch's, invstd in > 90 % of channels - torch's own variance is not exact),
+// all workgroups of a channel normalise with identical scalars, and no atomics, grid sync or third launch are
+// needed. Deterministic. In double there is no cancellation in s2/n - mean^2 up to |mean| / std ~ 1e6.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ursa_hip.h"
+
+namespace {
+
+constexpr int kBnBlock = 256;
+constexpr int kBnMaxSplit = 64;     // partials per channel: merged by one wave
+constexpr int kBnTargetWgs = 1024;  // 4 workgroups per CU
+
+struct BnGeom {
+    int C;            // channels
+    int hw;           // H*W / V  (V = 4: float4 units, V = 1: floats)
+    int hw_shift;     // log2(hw) if hw is a power of two, else -1
+    int chunk;        // units per workgroup (multiple of kBnBlock)
+    int64_t per_ch;   // N * hw
+};
+
+template <int V> struct Vec;
+template <> struct Vec<4> { using T = float4; };
+template <> struct Vec<1> { using T = float; };
+
+__device__ inline float comp(const float4& v, int k) { return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w; }
+__device__ inline float comp(const float& v, int) { return v; }
+__device__ inline void setc(float4& v, int k, float a) { if (k == 0) v.x = a; else if (k == 1) v.y = a; else if (k == 2) v.z = a; else v.w = a; }
+__device__ inline void setc(float& v, int, float a) { v = a; }
+
+// unit index i of channel c -> unit offset in the NCHW tensor
+__device__ inline int64_t bn_off(const BnGeom& g, int c, int64_t i)
+{
+    int64_t n;
+    if (g.hw_shift >= 0) n = i >> g.hw_shift; else n = i / g.hw;
+    const int64_t j = i - n * g.hw;
+    return (n * g.C + c) * (int64_t)g.hw + j;
+}
+
+// Sum of a double over the 64 lanes of a wave on the VALU (DPP butterflies inside a 16-lane row, v_readlane across
+// rows: no LDS round trip per step as with ds_bpermute-based __shfl_xor); every lane ends with the same bits, fixed tree.
+template <int CTRL>
+__device__ __forceinline__ float bn_dpp(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ double bn_wave_sum(double v)
+{
+    // the same tree on both 32-bit halves of the double
+#define URSA_BN_DPP64(CTRL) do { \
+        const long long b = __builtin_bit_cast(long long, v); \
+        const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xF, 0xF, true); \
+        const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, true); \
+        v += __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo); } while (0)
+    URSA_BN_DPP64(0xB1);
+    URSA_BN_DPP64(0x4E);
+    URSA_BN_DPP64(0x141);
+    URSA_BN_DPP64(0x140);
+#undef URSA_BN_DPP64
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+    double r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        r[k] = __builtin_bit_cast(double, ((long long)__builtin_amdgcn_readlane(hi, 16 * k) << 32) |
+                                              (unsigned int)__builtin_amdgcn_readlane(lo, 16 * k));
+    return (r[0] + r[1]) + (r[2] + r[3]);
+}
+
+// sums of two values over the workgroup, same bits in every thread, fixed order; sh: 2 * kBnBlock/64 floats
+template <class F>
+__device__ __forceinline__ void bn_block_sum2(F& a, F& b, F* sh)
+{
+    a = bn_wave_sum(a);
+    b = bn_wave_sum(b);
+    if ((threadIdx.x & 63) == 0) { sh[2 * (threadIdx.x >> 6)] = a; sh[2 * (threadIdx.x >> 6) + 1] = b; }
+    __syncthreads();
+    a = b = F(0);
+#pragma unroll
+    for (int w = 0; w < kBnBlock / 64; ++w) { a += sh[2 * w]; b += sh[2 * w + 1]; }
+}
+
+__device__ inline float bn_relu_fwd(float v) { return v < 0.f ? 0.f : v; }   // NaN stays NaN
+
+// ---- forward, launch 1: partial statistics --------------------------------------------------------------------
+template <int V>
+__global__ __launch_bounds__(kBnBlock) void k_bn_stats(const float* __restrict__ x, double2* __restrict__ partial, BnGeom g)
+{
+    using T = typename Vec<V>::T;
+    __shared__ double sh[2 * kBnBlock / 64];
+    const T* __restrict__ xv = reinterpret_cast<const T*>(x);
+    const int c = blockIdx.y;
+    const int64_t lo = (int64_t)blockIdx.x * g.chunk;
+    const int64_t hi = lo + g.chunk < g.per_ch ? lo + g.chunk : g.per_ch;
+    double s1 = 0.0, s2 = 0.0;
+    int64_t i = lo + threadIdx.x;
+    for (; i + 3 * kBnBlock < hi; i += 4 * kBnBlock) {      // four loads in flight
+        T v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = xv[bn_off(g, c, i + u * kBnBlock)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < V; ++k) { const double d = (double)comp(v[u], k); s1 += d; s2 = fma(d, d, s2); }
+    }
+    for (; i < hi; i += kBnBlock) {
+        const T v = xv[bn_off(g, c, i)];
+#pragma unroll
+        for (int k = 0; k < V; ++k) { const double d = (double)comp(v, k); s1 += d; s2 = fma(d, d, s2); }
+    }
+    bn_block_sum2(s1, s2, sh);
+    if (threadIdx.x == 0) partial[(int64_t)c * gridDim.x + blockIdx.x] = make_double2(s1, s2);
+}
+
+// Merge of a channel's partials by wave 0 of the calling workgroup, in double; same result in lanes 0..63.
+__device__ inline void bn_merge(const double2* __restrict__ partial, int c, int S, double n, double& mean, double& var)
+{
+    double a = 0.0, b = 0.0;
+    if ((int)threadIdx.x < S) { const double2 p = partial[(int64_t)c * S + threadIdx.x]; a = p.x; b = p.y; }
+    a = bn_wave_sum(a);
+    b = bn_wave_sum(b);
+    mean = a / n;
+    var = b / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+}
+
+// ---- forward, launch 2: merge, normalise (+ ReLU), running statistics ------------------------------------------
+template <int V, bool RELU>
+__global__ __launch_bounds__(kBnBlock) void k_bn_fwd_apply(const float* __restrict__ x, float* __restrict__ y,
+                                                           const double2* __restrict__ partial, int S,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                           float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                           float eps, float momentum, BnGeom g)
+{
+    using T = typename Vec<V>::T;
+    __shared__ float sh[2];
+    const int c = blockIdx.y;
+    if (threadIdx.x < 64) {
+        double mean, var;
+        const double n = (double)g.per_ch * V;
+        bn_merge(partial, c, S, n, mean, var);
+        if (threadIdx.x == 0) {
+            const float meanf = (float)mean;
+            const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+            const float alpha = invstd * gamma[c];
+            sh[0] = alpha;
+            sh[1] = fmaf(-meanf, alpha, beta[c]);
+            if (blockIdx.x == 0) {
+                save_mean[c] = meanf;
+                save_invstd[c] = invstd;
+                if (running_mean) {      // torch: running = momentum * batch + (1 - momentum) * running, unbiased variance
+                    running_mean[c] = momentum * meanf + (1.0f - momentum) * running_mean[c];
+                    running_var[c] = momentum * (float)(var * (n / (n - 1.0))) + (1.0f - momentum) * running_var[c];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const float scale = sh[0], shift = sh[1];
+    const T* __restrict__ xv = reinterpret_cast<const T*>(x);
+    T* __restrict__ yv = reinterpret_cast<T*>(y);
+    const int64_t lo = (int64_t)blockIdx.x * g.chunk;
+    const int64_t hi = lo + g.chunk < g.per_ch ? lo + g.chunk : g.per_ch;
+    int64_t i = lo + threadIdx.x;
+    for (; i + 3 * kBnBlock < hi; i += 4 * kBnBlock) {
+        T v[4];
+        int64_t o[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { o[u] = bn_off(g, c, i + u * kBnBlock); v[u] = xv[o[u]]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) { const float t = fmaf(comp(v[u], k), scale, shift); setc(v[u], k, RELU ? bn_relu_fwd(t) : t); }
+            yv[o[u]] = v[u];
+        }
+    }
+    for (; i < hi; i += kBnBlock) {
+        const int64_t o = bn_off(g, c, i);
+        T v = xv[o];
+#pragma unroll
+        for (int k = 0; k < V; ++k) { const float t = fmaf(comp(v, k), scale, shift); setc(v, k, RELU ? bn_relu_fwd(t) : t); }
+        yv[o] = v;
+    }
+}
+
+// ---- evaluation mode: y = relu(gamma * (x - running_mean) / sqrt(running_var + eps) + beta), one launch ------------
+template <int V, bool RELU>
+__global__ __launch_bounds__(kBnBlock) void k_bn_eval(const float* __restrict__ x, float* __restrict__ y,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ running_mean,
+                                                      const float* __restrict__ running_var, float eps, BnGeom g)
+{
+    using T = typename Vec<V>::T;
+    const int c = blockIdx.y;
+    const float invstd = 1.0f / sqrtf(running_var[c] + eps);
+    const float scale = invstd * gamma[c];
+    const float shift = fmaf(-running_mean[c], scale, beta[c]);
+    const T* __restrict__ xv = reinterpret_cast<const T*>(x);
+    T* __restrict__ yv = reinterpret_cast<T*>(y);
+    const int64_t lo = (int64_t)blockIdx.x * g.chunk;
+    const int64_t hi = lo + g.chunk < g.per_ch ? lo + g.chunk : g.per_ch;
+    int64_t i = lo + threadIdx.x;
+    for (; i + 3 * kBnBlock < hi; i += 4 * kBnBlock) {
+        T v[4];
+        int64_t o[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { o[u] = bn_off(g, c, i + u * kBnBlock); v[u] = xv[o[u]]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) { const float t = fmaf(comp(v[u], k), scale, shift); setc(v[u], k, RELU ? bn_relu_fwd(t) : t); }
+            yv[o[u]] = v[u];
+        }
+    }
+    for (; i < hi; i += kBnBlock) {
+        const int64_t o = bn_off(g, c, i);
+        T v = xv[o];
+#pragma unroll
+        for (int k = 0; k < V; ++k) { const float t = fmaf(comp(v, k), scale, shift); setc(v, k, RELU ? bn_relu_fwd(t) : t); }
+        yv[o] = v;
+    }
+}
+
+// ---- backward, launch 1: partial sums of dy' and dy' * (x - mean), in double (dy' = dy where the ReLU was open) ------
+template <int V, bool RELU>
+__global__ __launch_bounds__(kBnBlock) void k_bn_bwd_reduce(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ save_mean,
+                                                            const float* __restrict__ save_invstd,
+                                                            double2* __restrict__ partial, BnGeom g)
+{
+    using T = typename Vec<V>::T;
+    __shared__ double sh[2 * kBnBlock / 64];
+    const int c = blockIdx.y;
+    const float mean = save_mean[c], invstd = save_invstd[c];
+    const float scale = invstd * gamma[c];                   // the forward's own expressions: same bits, same gates
+    const float shift = fmaf(-mean, scale, beta[c]);
+    const double meand = (double)mean;
+    const T* __restrict__ xv = reinterpret_cast<const T*>(x);
+    const T* __restrict__ dv = reinterpret_cast<const T*>(dy);
+    const int64_t lo = (int64_t)blockIdx.x * g.chunk;
+    const int64_t hi = lo + g.chunk < g.per_ch ? lo + g.chunk : g.per_ch;
+    double s1 = 0.0, s2 = 0.0;
+    int64_t i = lo + threadIdx.x;
+    for (; i + kBnBlock < hi; i += 2 * kBnBlock) {           // four loads in flight
+        T a[2], b[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const int64_t o = bn_off(g, c, i + u * kBnBlock); a[u] = xv[o]; b[u] = dv[o]; }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const float xe = comp(a[u], k);
+                float ge = comp(b[u], k);
+                if (RELU && !(fmaf(xe, scale, shift) > 0.f)) ge = 0.f;
+                s1 += (double)ge;
+                s2 = fma((double)ge, (double)xe - meand, s2);
+            }
+    }
+    for (; i < hi; i += kBnBlock) {
+        const int64_t o = bn_off(g, c, i);
+        const T a = xv[o], b = dv[o];
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float xe = comp(a, k);
+            float ge = comp(b, k);
+            if (RELU && !(fmaf(xe, scale, shift) > 0.f)) ge = 0.f;
+            s1 += (double)ge;
+            s2 = fma((double)ge, (double)xe - meand, s2);
+        }
+    }
+    bn_block_sum2(s1, s2, sh);
+    if (threadIdx.x == 0) partial[(int64_t)c * gridDim.x + blockIdx.x] = make_double2(s1, s2);
+}
+
+// ---- backward, launch 2: torch's CPU association (native_batch_norm_backward, training):
+//      sum = sum dy' ; dotp = sum dy' (x - mean)                      (double, merged here)
+//      dbeta = sum ; dgamma = dotp * invstd ; gm = sum / n ; k = dotp * invstd^2 / n
+//      dx = ((dy' - gm) - (x - mean) * k) * invstd * gamma
+template <int V, bool RELU>
+__global__ __launch_bounds__(kBnBlock) void k_bn_bwd_dx(const float* __restrict__ x, const float* __restrict__ dy,
+                                                        float* __restrict__ dx, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const float* __restrict__ save_mean,
+                                                        const float* __restrict__ save_invstd,
+                                                        const double2* __restrict__ partial, int S,
+                                                        float* __restrict__ dgamma, float* __restrict__ dbeta, BnGeom g)
+{
+    using T = typename Vec<V>::T;
+    __shared__ float sh[2];
+    const int c = blockIdx.y;
+    const float mean = save_mean[c], invstd = save_invstd[c], w = gamma[c];
+    if (threadIdx.x < 64) {
+        double a = 0.0, b = 0.0;
+        if ((int)threadIdx.x < S) { const double2 p = partial[(int64_t)c * S + threadIdx.x]; a = p.x; b = p.y; }
+        a = bn_wave_sum(a);
+        b = bn_wave_sum(b);
+        if (threadIdx.x == 0) {
+            const double n = (double)g.per_ch * V, iv = (double)invstd;
+            sh[0] = (float)(a / n);
+            sh[1] = (float)(b * iv * iv / n);
+            if (blockIdx.x == 0) { dbeta[c] = (float)a; dgamma[c] = (float)(b * iv); }
+        }
+    }
+    __syncthreads();
+    const float gm = sh[0], kk = sh[1];
+    const float scale = invstd * w;
+    const float shift = fmaf(-mean, scale, beta[c]);
+    const T* __restrict__ xv = reinterpret_cast<const T*>(x);
+    const T* __restrict__ dv = reinterpret_cast<const T*>(dy);
+    T* __restrict__ ov = reinterpret_cast<T*>(dx);
+    const int64_t lo = (int64_t)blockIdx.x * g.chunk;
+    const int64_t hi = lo + g.chunk < g.per_ch ? lo + g.chunk : g.per_ch;
+    int64_t i = lo + threadIdx.x;
+    for (; i + kBnBlock < hi; i += 2 * kBnBlock) {
+        T a[2], b[2];
+        int64_t o[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { o[u] = bn_off(g, c, i + u * kBnBlock); a[u] = xv[o[u]]; b[u] = dv[o[u]]; }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const float xe = comp(a[u], k);
+                float ge = comp(b[u], k);
+                if (RELU && !(fmaf(xe, scale, shift) > 0.f)) ge = 0.f;
+                setc(b[u], k, (((ge - gm) - (xe - mean) * kk) * invstd) * w);
+            }
+            ov[o[u]] = b[u];
+        }
+    }
+    for (; i < hi; i += kBnBlock) {
+        const int64_t o = bn_off(g, c, i);
+        const T a = xv[o];
+        T b = dv[o];
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float xe = comp(a, k);
+            float ge = comp(b, k);
+            if (RELU && !(fmaf(xe, scale, shift) > 0.f)) ge = 0.f;
+            setc(b, k, (((ge - gm) - (xe - mean) * kk) * invstd) * w);
+        }
+        ov[o] = b;
+    }
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------
+struct BnPlan {
+    BnGeom g;
+    int S;       // workgroups (= partials) per channel
+    int V;
+};
+
+inline bool bn_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline bool bn_aligned4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
+
+// One geometry per (N, C, HW): the backward's partials are laid out by the same S as its own first launch, and the
+// forward's by its own; nothing is shared between calls except through `ws` within one call.
+inline int bn_plan(int64_t N, int64_t C, int64_t HW, bool vec_ok, BnPlan* p)
+{
+    if (N <= 0 || C <= 0 || HW <= 0 || C > 65535 || HW > (1 << 30) || N > (1ll << 31)) return URSA_ESIZE;
+    if (N * C > (1ll << 40) / HW) return URSA_ESIZE;
+    const int V = (vec_ok && (HW & 3) == 0) ? 4 : 1;
+    const int64_t hw = HW / V;
+    const int64_t per_ch = N * hw;
+    int64_t S = (kBnTargetWgs + C - 1) / C;
+    if (S > kBnMaxSplit) S = kBnMaxSplit;
+    if (S < 1) S = 1;
+    int64_t chunk = (per_ch + S - 1) / S;
+    chunk = (chunk + kBnBlock - 1) / kBnBlock * kBnBlock;
+    if (chunk > (1ll << 30)) return URSA_ESIZE;
+    S = (per_ch + chunk - 1) / chunk;
+    p->V = V;
+    p->S = (int)S;
+    p->g.C = (int)C;
+    p->g.hw = (int)hw;
+    p->g.hw_shift = -1;
+    for (int s = 0; s < 31; ++s) if ((1ll << s) == hw) p->g.hw_shift = s;
+    p->g.chunk = (int)chunk;
+    p->g.per_ch = per_ch;
+    return URSA_OK;
+}
+
+inline int bn_launch_status() { return (int)hipGetLastError(); }
+
+}  // namespace
+
+extern "C" {
+
+int ursa_bn_relu_fwd_f32(const float* x, float* y, const float* gamma, const float* beta, float* running_mean,
+                         float* running_var, float* save_mean, float* save_invstd, float* ws, int64_t N, int64_t C,
+                         int64_t HW, float eps, float momentum, uint32_t flags, ursa_stream_t stream)
+{
+    if (flags & ~URSA_BN_ALLFLAGS) return URSA_EFLAGS;
+    if (N == 0 || C == 0 || HW == 0) return (N < 0 || C < 0 || HW < 0) ? URSA_ESIZE : URSA_OK;
+    if (!x || !y || !gamma || !beta || !save_mean || !save_invstd || !ws) return URSA_ENULL;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return URSA_ENULL;
+    if (!bn_aligned4(x) || !bn_aligned4(y) || !bn_aligned16(ws)) return URSA_EALIGN;
+    if (N > 0 && HW > 0 && N * HW < 2) return URSA_EVALUE;        // torch: "Expected more than 1 value per channel"
+    BnPlan p;
+    const int rc = bn_plan(N, C, HW, bn_aligned16(x) && bn_aligned16(y), &p);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(p.S, p.g.C), block(kBnBlock);
+    double2* part = reinterpret_cast<double2*>(ws);
+    const bool relu = flags & URSA_BN_RELU;
+#define URSA_BN_FWD(V, R) \
+    hipLaunchKernelGGL((k_bn_fwd_apply<V, R>), grid, block, 0, st, x, y, part, p.S, gamma, beta, running_mean, running_var, \
+                       save_mean, save_invstd, eps, momentum, p.g)
+    if (p.V == 4) {
+        hipLaunchKernelGGL(k_bn_stats<4>, grid, block, 0, st, x, part, p.g);
+        if (relu) URSA_BN_FWD(4, true); else URSA_BN_FWD(4, false);
+    } else {
+        hipLaunchKernelGGL(k_bn_stats<1>, grid, block, 0, st, x, part, p.g);
+        if (relu) URSA_BN_FWD(1, true); else URSA_BN_FWD(1, false);
+    }
+#undef URSA_BN_FWD
+    return bn_launch_status();
+}
+
+int ursa_bn_relu_eval_f32(const float* x, float* y, const float* gamma, const float* beta, const float* running_mean,
+                          const float* running_var, int64_t N, int64_t C, int64_t HW, float eps, uint32_t flags,
+                          ursa_stream_t stream)
+{
+    if (flags & ~URSA_BN_ALLFLAGS) return URSA_EFLAGS;
+    if (N == 0 || C == 0 || HW == 0) return (N < 0 || C < 0 || HW < 0) ? URSA_ESIZE : URSA_OK;
+    if (!x || !y || !gamma || !beta || !running_mean || !running_var) return URSA_ENULL;
+    if (!bn_aligned4(x) || !bn_aligned4(y)) return URSA_EALIGN;
+    BnPlan p;
+    const int rc = bn_plan(N, C, HW, bn_aligned16(x) && bn_aligned16(y), &p);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(p.S, p.g.C), block(kBnBlock);
+    const bool relu = flags & URSA_BN_RELU;
+#define URSA_BN_EVAL(V, R) \
+    hipLaunchKernelGGL((k_bn_eval<V, R>), grid, block, 0, st, x, y, gamma, beta, running_mean, running_var, eps, p.g)
+    if (p.V == 4) { if (relu) URSA_BN_EVAL(4, true); else URSA_BN_EVAL(4, false); }
+    else          { if (relu) URSA_BN_EVAL(1, true); else URSA_BN_EVAL(1, false); }
+#undef URSA_BN_EVAL
+    return bn_launch_status();
+}
+
+int ursa_bn_relu_bwd_f32(const float* x, const float* dy, float* dx, const float* gamma, const float* beta,
+                         const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, float* ws,
+                         int64_t N, int64_t C, int64_t HW, uint32_t flags, ursa_stream_t stream)
+{
+    if (flags & ~URSA_BN_ALLFLAGS) return URSA_EFLAGS;
+    if (N == 0 || C == 0 || HW == 0) return (N < 0 || C < 0 || HW < 0) ? URSA_ESIZE : URSA_OK;
+    if (!x || !dy || !dx || !gamma || !beta || !save_mean || !save_invstd || !dgamma || !dbeta || !ws) return URSA_ENULL;
+    if (!bn_aligned4(x) || !bn_aligned4(dy) || !bn_aligned4(dx) || !bn_aligned16(ws)) return URSA_EALIGN;
+    BnPlan p;
+    const int rc = bn_plan(N, C, HW, bn_aligned16(x) && bn_aligned16(dy) && bn_aligned16(dx), &p);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(p.S, p.g.C), block(kBnBlock);
+    double2* part = reinterpret_cast<double2*>(ws);
+    const bool relu = flags & URSA_BN_RELU;
+#define URSA_BN_BWD(V, R) do { \
+    hipLaunchKernelGGL((k_bn_bwd_reduce<V, R>), grid, block, 0, st, x, dy, gamma, beta, save_mean, save_invstd, part, p.g); \
+    hipLaunchKernelGGL((k_bn_bwd_dx<V, R>), grid, block, 0, st, x, dy, dx, gamma, beta, save_mean, save_invstd, part, p.S, \
+                       dgamma, dbeta, p.g); } while (0)
+    if (p.V == 4) { if (relu) URSA_BN_BWD(4, true); else URSA_BN_BWD(4, false); }
+    else          { if (relu) URSA_BN_BWD(1, true); else URSA_BN_BWD(1, false); }
+#undef URSA_BN_BWD
+    return bn_launch_status();
+}
+
+}  // extern "C"
