@@ -486,8 +486,9 @@ def roofline_kernels_block(dev, large_n):
     median of 5 batches: K2 / K3 at the WideResNet-28-10 arena (36,546,980 parameters); K4 in exactly the launch forms
     inference/hmc.py issues (kinetic-only, fused kick+drift, kick, kick + kinetic-energy reduction) at PreResNet-164's
     1,726,388 parameters (cache-resident: latency-bound, graph-batched timing) and at 2^26 elements (HBM-bound); K5 at
-    C4's (30, 10^4, 100); K1 for 4 and 8 PreResNet-20 chains in ONE multi-chain launch. bytes = algorithmic bytes per
-    launch; frac = bytes / time / 8 TB/s."""
+    C4's (30, 10^4, 100); K1 for 4 and 8 PreResNet-20 chains in ONE multi-chain launch; K6 (relu(bn(x)) forward /
+    backward / evaluation) at the workload's layer shapes and at roofline-sized layers of the C4 / C5 networks. bytes =
+    algorithmic bytes per call; frac = bytes / time / 8 TB/s."""
     from ursabench_amd import _native
     K = _native.default_kernels()
     stream = torch.cuda.current_stream()
@@ -553,6 +554,27 @@ def roofline_kernels_block(dev, large_n):
         entry(f'k1_multi_{chains}x273408', 20 * n * chains, lambda: K.sgmcmc_step_multi(th, g, m, ctl), cache_resident=True,
               elements=n * chains, chains=chains)
         del th, g, m
+    # K6: relu(bn(x)) forward (2 launches), backward (2 launches), evaluation (1 launch) per layer: PreResNet-20's first
+    # stage at the workload batch (8 MB activations: cache-resident, latency-bound) and the layers of the C4 / C5 networks
+    # whose activations do not fit the Infinity Cache. Algorithmic bytes: forward 12 B/element (x twice, y once),
+    # backward 20 B/element (x and dy twice, dx once), evaluation 8 B/element.
+    for label, shape, resident in (('128x16x32x32', (128, 16, 32, 32), True), ('128x64x8x8', (128, 64, 8, 8), True),
+                                   ('128x160x32x32', (128, 160, 32, 32), False), ('1024x64x32x32', (1024, 64, 32, 32), False)):
+        C = shape[1]
+        x, dy = torch.randn(shape, device=dev), torch.randn(shape, device=dev)
+        y, dx = torch.empty_like(x), torch.empty_like(x)
+        w, b = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev)
+        rm, rv, sm, si, dg, db = (torch.zeros(C, device=dev) for _ in range(6))
+        rv.fill_(1.0)
+        wsb = torch.empty(_native.bn_ws_floats(C), device=dev)
+        e = x.numel()
+        entry(f'k6_bn_relu_fwd_{label}', 12 * e, lambda: K.bn_relu_forward(x, y, w, b, rm, rv, sm, si, wsb, eps=1e-5, momentum=0.1),
+              cache_resident=resident, shape=list(shape), launches=2)
+        entry(f'k6_bn_relu_bwd_{label}', 20 * e, lambda: K.bn_relu_backward(x, dy, dx, w, b, sm, si, dg, db, wsb),
+              cache_resident=resident, shape=list(shape), launches=2)
+        entry(f'k6_bn_relu_eval_{label}', 8 * e, lambda: K.bn_relu_eval(x, y, w, b, rm, rv, eps=1e-5),
+              cache_resident=resident, shape=list(shape), launches=1)
+        del x, dy, y, dx
     return out
 
 

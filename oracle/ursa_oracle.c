@@ -9,6 +9,10 @@
  * within 1e-5 relative (ATen's vectorised softmax/sum order is not reproducible in scalar C).
  * HMC (oracle_leapfrog_f32) follows hamiltorch's published leapfrog: PARITY UNPINNED
  * (hamiltorch is an un-vendored, un-pinned dependency that is absent from /root/reference).
+ * K6 (oracle_bn_relu_*: the networks' relu(bn(x)), models/preresnet.py:40-41,76-85,146) restates
+ * torch's CPU BatchNorm + ReLU, which is what the reference executes there; pinned in
+ * tests/test_oracle_golden.py against torch's CPU kernels themselves on seeded inputs (the batch
+ * mean bit for bit, the outputs bit for bit in every channel whose invstd agrees).
  *
  * Build: make -C oracle   (gcc -O2 -mfma -ffp-contract=off: the two fmaf() per update are
  * the only fused operations, exactly where ATen's add(alpha=) fuses — SURVEY.md A.1).
@@ -280,5 +284,100 @@ int oracle_sumsq_f32(const float* x, int64_t n, double* out)
     double acc = 0.0;
     for (int64_t i = 0; i < n; ++i) acc += (double)x[i] * (double)x[i];
     *out += acc;
+    return 0;
+}
+
+/* ---------------------------------------------------------------------------------------
+ * K6  relu(bn(x)), training mode      URSABench/models/preresnet.py:40-41,45-46,76-85,146;
+ *     wideresnet.py:47,49,117 -> torch.nn.functional.batch_norm + relu on the CPU path.
+ * torch 2.10's CPU kernel (probed, see include/ursa_hip.h K6): statistics accumulated in double,
+ *     alpha = invstd * gamma ; beta' = fma(-mean, alpha, beta) ; y = fma(x, alpha, beta')
+ * and its backward (native_batch_norm_backward, training):
+ *     sum = sum g ; dotp = sum g (x - mean) ; dbeta = sum ; dgamma = dotp * invstd
+ *     dx = (((g - sum/n) - (x - mean) * (dotp * invstd^2 / n)) * invstd) * gamma
+ * with g = dy where the ReLU output is > 0 (threshold_backward). x, y, dy, dx: [N, C, HW].
+ */
+int oracle_bn_relu_fwd_f32(const float* x, float* y, const float* gamma, const float* beta, float* running_mean,
+                           float* running_var, float* save_mean, float* save_invstd, int64_t N, int64_t C, int64_t HW,
+                           float eps, float momentum, int relu)
+{
+    const double n = (double)N * (double)HW;
+    for (int64_t c = 0; c < C; ++c) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int64_t i = 0; i < N; ++i)
+            for (int64_t j = 0; j < HW; ++j) {
+                const double d = (double)x[(i * C + c) * HW + j];
+                s1 += d;
+                s2 += d * d;
+            }
+        const double mean = s1 / n;
+        double var = s2 / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float meanf = (float)mean;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float alpha = invstd * gamma[c];
+        const float shift = fmaf(-meanf, alpha, beta[c]);
+        for (int64_t i = 0; i < N; ++i)
+            for (int64_t j = 0; j < HW; ++j) {
+                const int64_t o = (i * C + c) * HW + j;
+                const float t = fmaf(x[o], alpha, shift);
+                y[o] = (relu && t < 0.0f) ? 0.0f : t;
+            }
+        save_mean[c] = meanf;
+        save_invstd[c] = invstd;
+        if (running_mean) {
+            running_mean[c] = momentum * meanf + (1.0f - momentum) * running_mean[c];
+            running_var[c] = momentum * (float)(var * (n / (n - 1.0))) + (1.0f - momentum) * running_var[c];
+        }
+    }
+    return 0;
+}
+
+int oracle_bn_relu_bwd_f32(const float* x, const float* dy, float* dx, const float* gamma, const float* beta,
+                           const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, int64_t N,
+                           int64_t C, int64_t HW, int relu)
+{
+    const double n = (double)N * (double)HW;
+    for (int64_t c = 0; c < C; ++c) {
+        const float mean = save_mean[c], invstd = save_invstd[c], w = gamma[c];
+        const float alpha = invstd * w;
+        const float shift = fmaf(-mean, alpha, beta[c]);
+        double sum = 0.0, dotp = 0.0;
+        for (int64_t i = 0; i < N; ++i)
+            for (int64_t j = 0; j < HW; ++j) {
+                const int64_t o = (i * C + c) * HW + j;
+                const float g = (relu && !(fmaf(x[o], alpha, shift) > 0.0f)) ? 0.0f : dy[o];
+                sum += (double)g;
+                dotp += (double)g * ((double)x[o] - (double)mean);
+            }
+        const float gm = (float)(sum / n);
+        const float k = (float)(dotp * (double)invstd * (double)invstd / n);
+        for (int64_t i = 0; i < N; ++i)
+            for (int64_t j = 0; j < HW; ++j) {
+                const int64_t o = (i * C + c) * HW + j;
+                const float g = (relu && !(fmaf(x[o], alpha, shift) > 0.0f)) ? 0.0f : dy[o];
+                dx[o] = (((g - gm) - (x[o] - mean) * k) * invstd) * w;
+            }
+        dbeta[c] = (float)sum;
+        dgamma[c] = (float)(dotp * (double)invstd);
+    }
+    return 0;
+}
+
+/* evaluation mode: torch's CPU kernel computes invstd in float here (probed: 0 of 262,144 outputs differ) */
+int oracle_bn_relu_eval_f32(const float* x, float* y, const float* gamma, const float* beta, const float* running_mean,
+                            const float* running_var, int64_t N, int64_t C, int64_t HW, float eps, int relu)
+{
+    for (int64_t c = 0; c < C; ++c) {
+        const float invstd = 1.0f / sqrtf(running_var[c] + eps);
+        const float alpha = invstd * gamma[c];
+        const float shift = fmaf(-running_mean[c], alpha, beta[c]);
+        for (int64_t i = 0; i < N; ++i)
+            for (int64_t j = 0; j < HW; ++j) {
+                const int64_t o = (i * C + c) * HW + j;
+                const float t = fmaf(x[o], alpha, shift);
+                y[o] = (relu && t < 0.0f) ? 0.0f : t;
+            }
+    }
     return 0;
 }

@@ -18,6 +18,11 @@ int oracle_sgmcmc_step_f32(float*, float*, float*, const float*, float*, int64_t
 int oracle_bma_accumulate_f32(const float*, float*, float*, float*, const float*, int32_t, int64_t, int32_t, float,
                               float, uint32_t);
 
+int oracle_bn_relu_fwd_f32(const float*, float*, const float*, const float*, float*, float*, float*, float*, int64_t,
+                           int64_t, int64_t, float, float, int);
+int oracle_bn_relu_bwd_f32(const float*, const float*, float*, const float*, const float*, const float*, const float*,
+                           float*, float*, int64_t, int64_t, int64_t, int);
+
 #define CHECK(x) do { int rc_ = (x); if (rc_) { printf("FAIL %s -> %d (%s)\n", #x, rc_, ursa_strerror(rc_)); return 1; } } while (0)
 
 static float frand(unsigned* s) { *s = *s * 1664525u + 1013904223u; return ((*s >> 8) / 8388608.0f) - 1.0f; }
@@ -111,11 +116,44 @@ int main(void)
         CHECK(hipMemcpy(hm, dm, sizeof hm, hipMemcpyDeviceToHost));
         if (hm[0] || hm[1]) { printf("FAIL generator self-test: %llu radius / %llu logarithm mismatches\n", (unsigned long long)hm[0], (unsigned long long)hm[1]); return 1; }
     }
+    /* K6: relu(bn(x)) forward + backward, [N, C, HW] = [24, 6, 36], against the oracle: the statistics and every
+     * output / gate / parameter gradient are the same floats (both sides round exact double sums once) */
+    {
+        const int64_t N = 24, C = 6, HW = 36, tot = N * C * HW;
+        float *hx = malloc(tot * 4), *hdy = malloc(tot * 4), *hy = malloc(tot * 4), *hdx = malloc(tot * 4);
+        float *oy = malloc(tot * 4), *odx = malloc(tot * 4);
+        float hg[6], hb[6], osm[6], osi[6], odg[6], odb[6], gsm[6], gsi[6], gdg[6], gdb[6];
+        unsigned sd = 99u;
+        for (int64_t i = 0; i < tot; ++i) { hx[i] = 1.5f * frand(&sd) + 0.3f; hdy[i] = frand(&sd); }
+        for (int c = 0; c < C; ++c) { hg[c] = 1.0f + 0.5f * frand(&sd); hb[c] = 0.3f * frand(&sd); }
+        oracle_bn_relu_fwd_f32(hx, oy, hg, hb, NULL, NULL, osm, osi, N, C, HW, 1e-5f, 0.0f, 1);
+        oracle_bn_relu_bwd_f32(hx, hdy, odx, hg, hb, osm, osi, odg, odb, N, C, HW, 1);
+        float *dx_, *ddy, *dy_, *ddx, *dg_, *db_, *dsm, *dsi, *ddg, *ddb, *dws;
+        CHECK(hipMalloc((void**)&dx_, tot * 4)); CHECK(hipMalloc((void**)&ddy, tot * 4));
+        CHECK(hipMalloc((void**)&dy_, tot * 4)); CHECK(hipMalloc((void**)&ddx, tot * 4));
+        CHECK(hipMalloc((void**)&dg_, 24)); CHECK(hipMalloc((void**)&db_, 24)); CHECK(hipMalloc((void**)&dsm, 24));
+        CHECK(hipMalloc((void**)&dsi, 24)); CHECK(hipMalloc((void**)&ddg, 24)); CHECK(hipMalloc((void**)&ddb, 24));
+        CHECK(hipMalloc((void**)&dws, URSA_BN_WS_FLOATS(C) * 4));
+        CHECK(hipMemcpy(dx_, hx, tot * 4, hipMemcpyHostToDevice)); CHECK(hipMemcpy(ddy, hdy, tot * 4, hipMemcpyHostToDevice));
+        CHECK(hipMemcpy(dg_, hg, 24, hipMemcpyHostToDevice)); CHECK(hipMemcpy(db_, hb, 24, hipMemcpyHostToDevice));
+        CHECK(ursa_bn_relu_fwd_f32(dx_, dy_, dg_, db_, NULL, NULL, dsm, dsi, dws, N, C, HW, 1e-5f, 0.0f, URSA_BN_RELU, st));
+        CHECK(ursa_bn_relu_bwd_f32(dx_, ddy, ddx, dg_, db_, dsm, dsi, ddg, ddb, dws, N, C, HW, URSA_BN_RELU, st));
+        CHECK(hipStreamSynchronize(st));
+        CHECK(hipMemcpy(hy, dy_, tot * 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(hdx, ddx, tot * 4, hipMemcpyDeviceToHost));
+        CHECK(hipMemcpy(gsm, dsm, 24, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(gsi, dsi, 24, hipMemcpyDeviceToHost));
+        CHECK(hipMemcpy(gdg, ddg, 24, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(gdb, ddb, 24, hipMemcpyDeviceToHost));
+        if (memcmp(gsm, osm, 24) || memcmp(gsi, osi, 24)) { printf("FAIL K6 batch statistics differ from the oracle\n"); return 1; }
+        if (memcmp(hy, oy, tot * 4)) { printf("FAIL K6 forward differs from the oracle\n"); return 1; }
+        if (memcmp(gdg, odg, 24) || memcmp(gdb, odb, 24)) { printf("FAIL K6 dgamma / dbeta differ from the oracle\n"); return 1; }
+        if (memcmp(hdx, odx, tot * 4)) { printf("FAIL K6 dx differs from the oracle\n"); return 1; }
+        if (ursa_bn_relu_fwd_f32(dx_, dy_, dg_, db_, NULL, NULL, dsm, dsi, dws, 1, C, 1, 1e-5f, 0.0f, 0, st) != URSA_EVALUE) { printf("FAIL K6 evalue\n"); return 1; }
+        if (ursa_bn_relu_fwd_f32(dx_, dy_, dg_, db_, NULL, NULL, dsm, dsi, dws, N, C, HW, 1e-5f, 0.0f, 0x8u, st) != URSA_EFLAGS) { printf("FAIL K6 eflags\n"); return 1; }
+    }
     /* argument errors come back as codes, not crashes */
     if (ursa_sgmcmc_step_f32(NULL, NULL, NULL, NULL, NULL, 8, 0, 0, 0, 0, 1, 0, 0, 0, st) != URSA_ENULL) { printf("FAIL enull\n"); return 1; }
     if (ursa_bma_accumulate_f32(dz, dp, de, NULL, NULL, S, B, 5000, omg, goc, 0, st) != URSA_EVALUE) { printf("FAIL evalue\n"); return 1; }
     if (ursa_sgmcmc_step_multi_f32(dth, dgr, dmo, NULL, NULL, 64, 2, 62, NULL, st) != URSA_ESIZE) { printf("FAIL esize (stride < n)\n"); return 1; }
     printf("C-ABI host OK: K1 bit-equal to the oracle over 3 steps (n=%lld), 2 chains in one self-advancing launch bit-equal, "
-           "generator self-test clean, K5 max relative error %.2e\n", (long long)n, worst);
+           "generator self-test clean, K5 max relative error %.2e, K6 forward + backward bit-equal\n", (long long)n, worst);
     return 0;
 }

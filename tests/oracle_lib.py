@@ -28,6 +28,9 @@ _L.oracle_swag_draw_f32.argtypes = [_vp, _vp, _vp, _vp, _i64, _f, _f, _u64, _u64
 _L.oracle_bma_accumulate_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _f, _f, _u32]
 _L.oracle_leapfrog_f32.argtypes = [_vp, _vp, _vp, _i64, _f, _f, _f, _u32, _vp]
 _L.oracle_sumsq_f32.argtypes = [_vp, _i64, _vp]
+_L.oracle_bn_relu_fwd_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f, _f, _i32]
+_L.oracle_bn_relu_bwd_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32]
+_L.oracle_bn_relu_eval_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f, _i32]
 
 
 def _p(a):
@@ -100,3 +103,37 @@ def step_scalars(lr, momentum, weight_decay, n_train):
     import math
     return dict(lr=lr, mu=momentum, c_wd=(weight_decay / n_train) if weight_decay != 0 else 0.0,
                 c_noise=math.sqrt(2 * (1 - momentum) * lr), n_train=float(n_train))
+
+
+def _bn_dims(x):
+    N, C = x.shape[0], x.shape[1]
+    return N, C, x.size // (N * C)
+
+
+def bn_relu_fwd(x, gamma, beta, running_mean=None, running_var=None, *, eps=1e-5, momentum=0.1, relu=True):
+    """K6 forward: returns (y, save_mean, save_invstd); running statistics are updated in place when given."""
+    N, C, HW = _bn_dims(x)
+    y, sm, si = np.empty_like(x), np.empty(C, np.float32), np.empty(C, np.float32)
+    rc = _L.oracle_bn_relu_fwd_f32(_p(x), _p(y), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(sm), _p(si),
+                                   N, C, HW, eps, momentum, int(relu))
+    assert rc == 0
+    return y, sm, si
+
+
+def bn_relu_bwd(x, dy, gamma, beta, save_mean, save_invstd, *, relu=True):
+    """K6 backward: returns (dx, dgamma, dbeta)."""
+    N, C, HW = _bn_dims(x)
+    dx, dg, db = np.empty_like(x), np.empty(C, np.float32), np.empty(C, np.float32)
+    rc = _L.oracle_bn_relu_bwd_f32(_p(x), _p(dy), _p(dx), _p(gamma), _p(beta), _p(save_mean), _p(save_invstd), _p(dg),
+                                   _p(db), N, C, HW, int(relu))
+    assert rc == 0
+    return dx, dg, db
+
+
+def bn_relu_eval(x, gamma, beta, running_mean, running_var, *, eps=1e-5, relu=True):
+    N, C, HW = _bn_dims(x)
+    y = np.empty_like(x)
+    rc = _L.oracle_bn_relu_eval_f32(_p(x), _p(y), _p(gamma), _p(beta), _p(running_mean), _p(running_var), N, C, HW, eps,
+                                    int(relu))
+    assert rc == 0
+    return y

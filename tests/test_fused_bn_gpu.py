@@ -304,3 +304,44 @@ def test_fused_layers_replay_inside_a_hipgraph():
     torch.cuda.synchronize()
     for a, b in zip(grads, eager):      # MIOpen's split-K weight gradients add with atomics: not bit-reproducible
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-6 * float(b.abs().max()))
+
+
+@pytest.mark.parametrize('shape', [(128, 16, 32, 32), (128, 64, 8, 8), (33, 6, 5, 3), (16, 160, 16, 16)])
+@pytest.mark.parametrize('relu', [True, False])
+def test_k6_vs_oracle(K, shape, relu):
+    """K6 through the C ABI against oracle/ursa_oracle.c (scalar C, sequential double sums) on the same seeded inputs:
+    both round exact double statistics once, so mean / invstd - and with them every output, every ReLU gate, dbeta and
+    dgamma - are the same floats (the double sums differ in association only: 1e-16 relative before the one rounding;
+    a tie-straddling channel is allowed for, none observed); dx is elementwise float arithmetic on equal scalars."""
+    import oracle_lib as O
+    from ursabench_amd import _native
+    g = torch.Generator().manual_seed(sum(shape) + relu)
+    C = shape[1]
+    x = (torch.randn(shape, generator=g) * 1.4 + 0.25)
+    w, b = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    dy = torch.randn(shape, generator=g)
+    rm, rv = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    rm_o, rv_o = rm.numpy().copy(), rv.numpy().copy()
+    y_o, sm_o, si_o = O.bn_relu_fwd(x.numpy(), w.numpy(), b.numpy(), rm_o, rv_o, eps=1e-5, momentum=0.1, relu=relu)
+    xd, wd, bd, dyd, rmd, rvd = (t.cuda() for t in (x, w, b, dy, rm, rv))
+    y = torch.empty_like(xd)
+    sm, si = torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
+    ws = torch.empty(_native.bn_ws_floats(C), device='cuda')
+    K.bn_relu_forward(xd, y, wd, bd, rmd, rvd, sm, si, ws, eps=1e-5, momentum=0.1, relu=relu)
+    same = (sm.cpu().numpy() == sm_o) & (si.cpu().numpy() == si_o)
+    assert same.sum() >= C - 1, f'{C - same.sum()} of {C} channels differ in mean / invstd'
+    assert np.array_equal(y.cpu().numpy()[:, same], y_o[:, same])
+    np.testing.assert_allclose(rmd.cpu().numpy(), rm_o, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(rvd.cpu().numpy(), rv_o, rtol=1e-6, atol=1e-7)
+    dx_o, dg_o, db_o = O.bn_relu_bwd(x.numpy(), dy.numpy(), w.numpy(), b.numpy(), sm_o, si_o, relu=relu)
+    dx = torch.empty_like(xd)
+    dw, db = torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
+    K.bn_relu_backward(xd, dyd, dx, wd, bd, torch.from_numpy(sm_o).cuda(), torch.from_numpy(si_o).cuda(), dw, db, ws, relu=relu)
+    assert np.count_nonzero(db.cpu().numpy() != db_o) <= 1 and np.count_nonzero(dw.cpu().numpy() != dg_o) <= 1
+    np.testing.assert_allclose(db.cpu().numpy(), db_o, rtol=2e-7, atol=0)
+    np.testing.assert_allclose(dw.cpu().numpy(), dg_o, rtol=2e-7, atol=0)
+    ok = (db.cpu().numpy() == db_o) & (dw.cpu().numpy() == dg_o)
+    assert np.array_equal(dx.cpu().numpy()[:, ok], dx_o[:, ok])
+    y_e = torch.empty_like(xd)
+    K.bn_relu_eval(xd, y_e, wd, bd, rmd, rvd, eps=1e-5, relu=relu)
+    assert np.array_equal(y_e.cpu().numpy(), O.bn_relu_eval(x.numpy(), w.numpy(), b.numpy(), rmd.cpu().numpy(), rvd.cpu().numpy(), eps=1e-5, relu=relu))

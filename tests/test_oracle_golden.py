@@ -163,3 +163,41 @@ def test_sgd_mode_bitwise_vs_torch_sgd(golden_dir, case):
         assert np.array_equal(theta, g[f'{case}/theta'][k]), (case, k)
         if momentum != 0:
             assert np.array_equal(mom, g[f'{case}/mom'][k]), (case, k)
+
+
+@pytest.mark.parametrize('shape', [(32, 16, 16, 16), (16, 8, 8, 8), (7, 5, 3, 3), (64, 4, 1, 6)])
+def test_bn_relu_restatement_vs_torch_cpu_batchnorm(shape):
+    """K6's restatement against the ops the reference's networks execute on the CPU path (models/preresnet.py:40-41:
+    torch's BatchNorm + ReLU and their autograd backward), on seeded inputs: the batch mean is the same float in every
+    channel; invstd in most (torch's own variance is not exactly rounded) and within one unit in the last place in the
+    rest; wherever both agree every output has the same bits; evaluation mode has the same bits everywhere."""
+    import torch
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(sum(shape))
+    C = shape[1]
+    x = torch.randn(shape, generator=g) * 1.5 + 0.4
+    w, b = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    dy = torch.randn(shape, generator=g)
+    rm, rv = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    rm_t, rv_t = rm.clone(), rv.clone()
+    xt, wt, bt = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    out_t, m_t, i_t = torch.native_batch_norm(xt, wt, bt, rm_t, rv_t, True, 0.1, 1e-5)
+    y_t = F.relu(out_t)
+    y_t.backward(dy)
+    rm_o, rv_o = rm.numpy().copy(), rv.numpy().copy()
+    y, sm, si = O.bn_relu_fwd(x.numpy(), w.numpy(), b.numpy(), rm_o, rv_o, eps=1e-5, momentum=0.1, relu=True)
+    assert np.array_equal(sm, m_t.detach().numpy())
+    same = si == i_t.detach().numpy()
+    assert same.sum() >= 0.6 * C, f'invstd equal in only {same.sum()} of {C} channels'
+    np.testing.assert_allclose(si, i_t.detach().numpy(), rtol=1.3e-7)
+    assert np.array_equal(y[:, same], y_t.detach().numpy()[:, same])
+    np.testing.assert_allclose(rm_o, rm_t.numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(rv_o, rv_t.numpy(), rtol=1e-6, atol=1e-7)
+    # backward from torch's own saved statistics: same gates, sums in double on both sides
+    dx, dg, db = O.bn_relu_bwd(x.numpy(), dy.numpy(), w.numpy(), b.numpy(), m_t.detach().numpy(), i_t.detach().numpy(), relu=True)
+    # (torch's channel sums carry float accumulation error, ours are exact doubles: compare at the tensor's scale)
+    np.testing.assert_allclose(db, bt.grad.numpy(), rtol=0, atol=1e-6 * float(bt.grad.abs().max()))
+    np.testing.assert_allclose(dg, wt.grad.numpy(), rtol=0, atol=1e-6 * float(wt.grad.abs().max()))
+    np.testing.assert_allclose(dx, xt.grad.numpy(), rtol=0, atol=1e-6 * float(xt.grad.abs().max()))
+    y_e = O.bn_relu_eval(x.numpy(), w.numpy(), b.numpy(), rm.numpy(), rv.numpy(), eps=1e-5, relu=True)
+    assert np.array_equal(y_e, F.relu(F.batch_norm(x, rm, rv, w, b, False, 0.0, 1e-5)).numpy())
