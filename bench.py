@@ -209,7 +209,7 @@ def first_step_gate_flips(net0, x, dev):
     import copy
     import ursabench_amd.models as M
     rec = {}
-    orig = M.bn_relu
+    orig, orig_add = M.bn_relu, M.add_bn_relu
     try:
         for name in ('cpu', 'gpu'):
             got = rec.setdefault(name, [])
@@ -218,12 +218,17 @@ def first_step_gate_flips(net0, x, dev):
                 y = orig(bn, xx, relu)
                 _got.append((y.detach() > 0).cpu())
                 return y
-            M.bn_relu = spy
+
+            def spy_add(bn, xx, relu=True, _got=got):
+                z, y = orig_add(bn, xx, relu)
+                _got.append((y.detach() > 0).cpu())
+                return z, y
+            M.bn_relu, M.add_bn_relu = spy, spy_add
             net = copy.deepcopy(net0).to('cpu' if name == 'cpu' else dev).train()
             with torch.no_grad():
                 net(x.to('cpu' if name == 'cpu' else dev))
     finally:
-        M.bn_relu = orig
+        M.bn_relu, M.add_bn_relu = orig, orig_add
     return (int(sum(int((a != b).sum()) for a, b in zip(rec['cpu'], rec['gpu']))),
             int(sum(a.numel() for a in rec['cpu'])))
 

@@ -255,26 +255,35 @@ int ursa_sumsq_f32(const float* x, int64_t n, float* out, float* ws, ursa_stream
  *     sum = sum g ; dotp = sum g * (x - mean_c)                      (double)
  *     dbeta[c] = sum ; dgamma[c] = dotp * invstd_c ; gm = sum / n ; k = dotp * invstd_c^2 / n
  *     dx = (((g - gm) - (x - mean_c) * k) * invstd_c) * gamma_c       (n = N * HW)
+ *   residual form (the blocks end `out += residual`, preresnet.py:49-52,87-90, and the next block's first op is
+ *   relu(bn(out))): with addend != NULL the forward / evaluation launches normalise z = x + addend (one fp32 add,
+ *   as torch's) and also store z to z_out - the add launch folded into the statistics pass; with dz != NULL the
+ *   backward returns dx + dz, dz being the gradient that reaches z on its other path (the next residual sum or
+ *   the downsampling convolution) - the accumulation autograd would otherwise run as its own add launch.
  * ws: scratch, URSA_BN_WS_FLOATS(C) floats, 16-byte aligned, no initialisation needed; partial
  * results of the first launch of a call, consumed by its second launch.
  * Deterministic (no atomics); fp32 throughout. Error vs exact arithmetic: a few ulp on y / dx
  * (tests compare with float64 BatchNorm at 2e-6 relative to the activation scale).
- * Traffic: forward 12 B/element (x twice, y once), backward 20 B/element, evaluation 8 B/element.
+ * Traffic: forward 12 B/element (x twice, y once), backward 20 B/element, evaluation 8 B/element;
+ * residual form: forward 20, backward 24, evaluation 16.
  */
 #define URSA_BN_RELU      0x1u
 #define URSA_BN_ALLFLAGS  0x1u
 #define URSA_BN_WS_FLOATS(C) ((int64_t)(C) * 64 * 4)
 
-int ursa_bn_relu_fwd_f32(const float* x, float* y, const float* gamma, const float* beta,
+int ursa_bn_relu_fwd_f32(const float* x, const float* addend /* or NULL */, float* z_out /* iff addend */,
+                         float* y, const float* gamma, const float* beta,
                          float* running_mean /* or NULL */, float* running_var /* or NULL */,
                          float* save_mean, float* save_invstd, float* ws, int64_t N, int64_t C,
                          int64_t HW, float eps, float momentum, uint32_t flags, ursa_stream_t stream);
 
-int ursa_bn_relu_eval_f32(const float* x, float* y, const float* gamma, const float* beta,
+int ursa_bn_relu_eval_f32(const float* x, const float* addend /* or NULL */, float* z_out /* iff addend */,
+                          float* y, const float* gamma, const float* beta,
                           const float* running_mean, const float* running_var, int64_t N, int64_t C,
                           int64_t HW, float eps, uint32_t flags, ursa_stream_t stream);
 
-int ursa_bn_relu_bwd_f32(const float* x, const float* dy, float* dx, const float* gamma,
+int ursa_bn_relu_bwd_f32(const float* x /* the normalised input: z_out if the forward had an addend */,
+                         const float* dy, const float* dz /* or NULL */, float* dx, const float* gamma,
                          const float* beta, const float* save_mean, const float* save_invstd,
                          float* dgamma, float* dbeta, float* ws, int64_t N, int64_t C, int64_t HW,
                          uint32_t flags, ursa_stream_t stream);

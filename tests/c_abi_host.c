@@ -136,8 +136,8 @@ int main(void)
         CHECK(hipMalloc((void**)&dws, URSA_BN_WS_FLOATS(C) * 4));
         CHECK(hipMemcpy(dx_, hx, tot * 4, hipMemcpyHostToDevice)); CHECK(hipMemcpy(ddy, hdy, tot * 4, hipMemcpyHostToDevice));
         CHECK(hipMemcpy(dg_, hg, 24, hipMemcpyHostToDevice)); CHECK(hipMemcpy(db_, hb, 24, hipMemcpyHostToDevice));
-        CHECK(ursa_bn_relu_fwd_f32(dx_, dy_, dg_, db_, NULL, NULL, dsm, dsi, dws, N, C, HW, 1e-5f, 0.0f, URSA_BN_RELU, st));
-        CHECK(ursa_bn_relu_bwd_f32(dx_, ddy, ddx, dg_, db_, dsm, dsi, ddg, ddb, dws, N, C, HW, URSA_BN_RELU, st));
+        CHECK(ursa_bn_relu_fwd_f32(dx_, NULL, NULL, dy_, dg_, db_, NULL, NULL, dsm, dsi, dws, N, C, HW, 1e-5f, 0.0f, URSA_BN_RELU, st));
+        CHECK(ursa_bn_relu_bwd_f32(dx_, ddy, NULL, ddx, dg_, db_, dsm, dsi, ddg, ddb, dws, N, C, HW, URSA_BN_RELU, st));
         CHECK(hipStreamSynchronize(st));
         CHECK(hipMemcpy(hy, dy_, tot * 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(hdx, ddx, tot * 4, hipMemcpyDeviceToHost));
         CHECK(hipMemcpy(gsm, dsm, 24, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(gsi, dsi, 24, hipMemcpyDeviceToHost));
@@ -146,8 +146,8 @@ int main(void)
         if (memcmp(hy, oy, tot * 4)) { printf("FAIL K6 forward differs from the oracle\n"); return 1; }
         if (memcmp(gdg, odg, 24) || memcmp(gdb, odb, 24)) { printf("FAIL K6 dgamma / dbeta differ from the oracle\n"); return 1; }
         if (memcmp(hdx, odx, tot * 4)) { printf("FAIL K6 dx differs from the oracle\n"); return 1; }
-        if (ursa_bn_relu_fwd_f32(dx_, dy_, dg_, db_, NULL, NULL, dsm, dsi, dws, 1, C, 1, 1e-5f, 0.0f, 0, st) != URSA_EVALUE) { printf("FAIL K6 evalue\n"); return 1; }
-        if (ursa_bn_relu_fwd_f32(dx_, dy_, dg_, db_, NULL, NULL, dsm, dsi, dws, N, C, HW, 1e-5f, 0.0f, 0x8u, st) != URSA_EFLAGS) { printf("FAIL K6 eflags\n"); return 1; }
+        if (ursa_bn_relu_fwd_f32(dx_, NULL, NULL, dy_, dg_, db_, NULL, NULL, dsm, dsi, dws, 1, C, 1, 1e-5f, 0.0f, 0, st) != URSA_EVALUE) { printf("FAIL K6 evalue\n"); return 1; }
+        if (ursa_bn_relu_fwd_f32(dx_, NULL, NULL, dy_, dg_, db_, NULL, NULL, dsm, dsi, dws, N, C, HW, 1e-5f, 0.0f, 0x8u, st) != URSA_EFLAGS) { printf("FAIL K6 eflags\n"); return 1; }
     }
     /* argument errors come back as codes, not crashes */
     if (ursa_sgmcmc_step_f32(NULL, NULL, NULL, NULL, NULL, 8, 0, 0, 0, 0, 1, 0, 0, 0, st) != URSA_ENULL) { printf("FAIL enull\n"); return 1; }

@@ -345,3 +345,84 @@ def test_k6_vs_oracle(K, shape, relu):
     y_e = torch.empty_like(xd)
     K.bn_relu_eval(xd, y_e, wd, bd, rmd, rvd, eps=1e-5, relu=relu)
     assert np.array_equal(y_e.cpu().numpy(), O.bn_relu_eval(x.numpy(), w.numpy(), b.numpy(), rmd.cpu().numpy(), rvd.cpu().numpy(), eps=1e-5, relu=relu))
+
+
+@pytest.mark.parametrize('shape', [(128, 16, 32, 32), (64, 64, 8, 8), (9, 5, 3, 3)])
+def test_residual_form_equals_add_then_k6(K, shape):
+    """addend / dz (the residual sum folded into the statistics pass, the gradient accumulation into the backward's
+    second pass): z is torch's a + b bit for bit, y / statistics are those of the plain form on z, and the backward is
+    the plain form's dx plus dz with one fp32 add - the same bits as running the two add launches separately."""
+    from ursabench_amd import _native
+    g = torch.Generator().manual_seed(sum(shape))
+    C = shape[1]
+    a, b, dy, dz = (torch.randn(shape, generator=g).cuda() for _ in range(4))
+    w, bb = (torch.rand(C, generator=g) + 0.5).cuda(), torch.randn(C, generator=g).cuda()
+    ws = torch.empty(_native.bn_ws_floats(C), device='cuda')
+
+    def stats():
+        return torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
+    z, y = torch.empty_like(a), torch.empty_like(a)
+    sm, si = stats()
+    rm, rv = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
+    K.bn_relu_forward(a, y, w, bb, rm, rv, sm, si, ws, eps=1e-5, momentum=0.1, addend=b, z_out=z)
+    z_ref = a + b
+    assert torch.equal(z, z_ref)
+    y2 = torch.empty_like(a)
+    sm2, si2 = stats()
+    rm2, rv2 = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
+    K.bn_relu_forward(z_ref, y2, w, bb, rm2, rv2, sm2, si2, ws, eps=1e-5, momentum=0.1)
+    assert torch.equal(y, y2) and torch.equal(sm, sm2) and torch.equal(si, si2) and torch.equal(rm, rm2) and torch.equal(rv, rv2)
+    dx, dx2 = torch.empty_like(a), torch.empty_like(a)
+    dw, db = stats()
+    dw2, db2 = stats()
+    K.bn_relu_backward(z, dy, dx, w, bb, sm, si, dw, db, ws, dz=dz)
+    K.bn_relu_backward(z, dy, dx2, w, bb, sm, si, dw2, db2, ws)
+    assert torch.equal(dx, dz + dx2) and torch.equal(dw, dw2) and torch.equal(db, db2)
+    ze, ye, ye2 = torch.empty_like(a), torch.empty_like(a), torch.empty_like(a)
+    K.bn_relu_eval(a, ye, w, bb, rm, rv, eps=1e-5, addend=b, z_out=ze)
+    K.bn_relu_eval(z_ref, ye2, w, bb, rm, rv, eps=1e-5)
+    assert torch.equal(ze, z_ref) and torch.equal(ye, ye2)
+    with pytest.raises(ValueError):
+        K.bn_relu_forward(a, y, w, bb, rm, rv, sm, si, ws, eps=1e-5, momentum=0.1, addend=b)
+
+
+def test_add_bn_relu_autograd_vs_stock_ops():
+    """(z, y) = add_bn_relu(bn, (a, b)) with z feeding a second consumer, against torch's add / BatchNorm / relu:
+    gradients of a and b (equal), of gamma / beta; the unused-output cases (dz None, dy None)."""
+    from ursabench_amd import fused_bn
+    torch.manual_seed(3)
+    a0, b0 = torch.randn(32, 8, 8, 8, device='cuda'), torch.randn(32, 8, 8, 8, device='cuda')
+    wz = torch.randn(32, 8, 8, 8, device='cuda')
+    out = []
+    for fused in (True, False):
+        bn = nn.BatchNorm2d(8).cuda()
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, 8))
+            bn.bias.copy_(torch.linspace(-0.3, 0.3, 8))
+        a, b = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        old = fused_bn.enabled(fused)
+        try:
+            z, y = fused_bn.add_bn_relu(bn, (a, b))
+            ((z * wz).sum() + (y * y).sum()).backward()
+        finally:
+            fused_bn.enabled(old)
+        out.append((z.detach(), y.detach(), a.grad, b.grad, bn.weight.grad, bn.bias.grad))
+    assert torch.equal(out[0][0], out[1][0])
+    for got, ref, what in zip(out[0][1:], out[1][1:], ('y', 'da', 'db', 'dgamma', 'dbeta')):
+        assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), what
+    assert torch.equal(out[0][2], out[0][3])
+    bn = nn.BatchNorm2d(8).cuda()
+    a, b = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+    z, y = fused_bn.add_bn_relu(bn, (a, b))
+    y.sum().backward()                                   # z unused: no dz
+    assert a.grad is not None and torch.equal(a.grad, b.grad)
+    a.grad = b.grad = None
+    z, y = fused_bn.add_bn_relu(bn, (a, b))
+    (z * wz).sum().backward()                            # y unused: the sum's own gradient only
+    assert torch.equal(a.grad, wz) and torch.equal(b.grad, wz)
+    # a plain tensor passes through; host tensors take torch's ops
+    z, y = fused_bn.add_bn_relu(bn, a0)
+    assert z is a0
+    h = nn.BatchNorm2d(8)
+    z, y = fused_bn.add_bn_relu(h, (a0.cpu(), b0.cpu()))
+    assert torch.equal(z, a0.cpu() + b0.cpu())

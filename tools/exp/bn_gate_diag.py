@@ -19,7 +19,7 @@ def main():
     g = torch.Generator().manual_seed(4243)
     x = torch.randn(128, 3, 32, 32, generator=g)
     runs = {}
-    orig = M.bn_relu
+    orig, orig_add = M.bn_relu, M.add_bn_relu
     for name in ('cpu', 'fused', 'stock'):
         rec = []
 
@@ -28,7 +28,13 @@ def main():
             _rec.append((xx.detach().cpu().clone(), y.detach().cpu().clone(), bn.weight.detach().cpu().clone(),
                          bn.bias.detach().cpu().clone()))
             return y
-        M.bn_relu = spy
+
+        def spy_add(bn, xx, relu=True, _rec=rec):
+            z, y = orig_add(bn, xx, relu)
+            _rec.append((z.detach().cpu().clone(), y.detach().cpu().clone(), bn.weight.detach().cpu().clone(),
+                         bn.bias.detach().cpu().clone()))
+            return z, y
+        M.bn_relu, M.add_bn_relu = spy, spy_add
         mm = models.PreResNet(10, 20)
         mm.load_state_dict(m0.state_dict())
         dev = 'cpu' if name == 'cpu' else 'cuda'
@@ -37,7 +43,7 @@ def main():
         with torch.no_grad():
             mm(x.to(dev))
         runs[name] = rec
-    M.bn_relu = orig
+    M.bn_relu, M.add_bn_relu = orig, orig_add
     fused_bn.enabled(True)
     for li, (xc, yc, w, b) in enumerate(runs['cpu']):
         line = f'layer {li:2d} {tuple(xc.shape)}'

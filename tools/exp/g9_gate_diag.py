@@ -22,14 +22,20 @@ def replay(dev, g, fused):
     hyp = json.loads(str(g['hyper']))
     train, test = _preresnet8_inputs(g)
     gates = []
-    orig = M.bn_relu
+    orig, orig_add = M.bn_relu, M.add_bn_relu
 
     def spy(bn, x, relu=True):
         y = orig(bn, x, relu)
         if bn.training:
             gates.append((y.detach() > 0).cpu())
         return y
-    M.bn_relu = spy
+
+    def spy_add(bn, x, relu=True):
+        z, y = orig_add(bn, x, relu)
+        if bn.training:
+            gates.append((y.detach() > 0).cpu())
+        return z, y
+    M.bn_relu, M.add_bn_relu = spy, spy_add
     fused_bn.enabled(fused)
     try:
         if dev == 'cpu':
@@ -50,7 +56,7 @@ def replay(dev, g, fused):
             pred = tasks.Prediction({'in_distribution_test': test}, 10, torch.device('cuda'), 'ALL')
         pred.update_statistics(ens, output_performance=False)
     finally:
-        M.bn_relu = orig
+        M.bn_relu, M.add_bn_relu = orig, orig_add
         fused_bn.enabled(True)
     return gates, pred.ensemble_proba.numpy()
 

@@ -52,9 +52,9 @@ SIGNATURES = {
     'ursa_bma_accumulate_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _f, _f, _u32, _vp]),
     'ursa_leapfrog_f32': (ctypes.c_int, [_vp, _vp, _vp, _i64, _f, _f, _f, _u32, _vp, _vp, _vp]),
     'ursa_sumsq_f32': (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp]),
-    'ursa_bn_relu_fwd_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f, _f, _u32, _vp]),
-    'ursa_bn_relu_eval_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f, _u32, _vp]),
-    'ursa_bn_relu_bwd_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _u32, _vp]),
+    'ursa_bn_relu_fwd_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f, _f, _u32, _vp]),
+    'ursa_bn_relu_eval_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f, _u32, _vp]),
+    'ursa_bn_relu_bwd_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _u32, _vp]),
 }
 
 
@@ -301,40 +301,49 @@ class HipKernels:
         return N, C, x.numel() // max(N * C, 1)
 
     def bn_relu_forward(self, x, y, gamma, beta, running_mean, running_var, save_mean, save_invstd, ws, *, eps,
-                        momentum, relu=True):
+                        momentum, relu=True, addend=None, z_out=None):
         """Training-mode BatchNorm (+ ReLU) of a contiguous [N, C, *] tensor: batch statistics, running statistics
-        updated in place (skipped when both are None), mean / invstd saved for the backward."""
+        updated in place (skipped when both are None), mean / invstd saved for the backward. With `addend` the
+        normalised tensor is z = x + addend, also stored to `z_out` (the residual sum folded into the statistics pass)."""
+        if (addend is None) != (z_out is None):
+            raise ValueError('addend and z_out go together')
         N, C, HW = self._bn_dims(x)
         dev, n = x.device, x.numel()
         if ws.numel() < bn_ws_floats(C):
             raise ValueError(f'ws must hold {bn_ws_floats(C)} floats')
         with torch.cuda.device(dev):
             rc = self.lib.ursa_bn_relu_fwd_f32(
-                _ptr(x, 'x'), _ptr(y, 'y', n, dev), _ptr(gamma, 'gamma', C, dev), _ptr(beta, 'beta', C, dev),
+                _ptr(x, 'x'), _ptr(addend, 'addend', n, dev, optional=True), _ptr(z_out, 'z_out', n, dev, optional=True),
+                _ptr(y, 'y', n, dev), _ptr(gamma, 'gamma', C, dev), _ptr(beta, 'beta', C, dev),
                 _ptr(running_mean, 'running_mean', C, dev, optional=True),
                 _ptr(running_var, 'running_var', C, dev, optional=True), _ptr(save_mean, 'save_mean', C, dev),
                 _ptr(save_invstd, 'save_invstd', C, dev), _ptr(ws, 'ws', None, dev), N, C, HW, eps, momentum,
                 BN_RELU if relu else 0, _stream(dev))
         _check(self.lib, rc, 'ursa_bn_relu_fwd_f32')
 
-    def bn_relu_eval(self, x, y, gamma, beta, running_mean, running_var, *, eps, relu=True):
+    def bn_relu_eval(self, x, y, gamma, beta, running_mean, running_var, *, eps, relu=True, addend=None, z_out=None):
+        if (addend is None) != (z_out is None):
+            raise ValueError('addend and z_out go together')
         N, C, HW = self._bn_dims(x)
         dev, n = x.device, x.numel()
         with torch.cuda.device(dev):
             rc = self.lib.ursa_bn_relu_eval_f32(
-                _ptr(x, 'x'), _ptr(y, 'y', n, dev), _ptr(gamma, 'gamma', C, dev), _ptr(beta, 'beta', C, dev),
+                _ptr(x, 'x'), _ptr(addend, 'addend', n, dev, optional=True), _ptr(z_out, 'z_out', n, dev, optional=True),
+                _ptr(y, 'y', n, dev), _ptr(gamma, 'gamma', C, dev), _ptr(beta, 'beta', C, dev),
                 _ptr(running_mean, 'running_mean', C, dev), _ptr(running_var, 'running_var', C, dev), N, C, HW, eps,
                 BN_RELU if relu else 0, _stream(dev))
         _check(self.lib, rc, 'ursa_bn_relu_eval_f32')
 
-    def bn_relu_backward(self, x, dy, dx, gamma, beta, save_mean, save_invstd, dgamma, dbeta, ws, *, relu=True):
+    def bn_relu_backward(self, x, dy, dx, gamma, beta, save_mean, save_invstd, dgamma, dbeta, ws, *, relu=True, dz=None):
+        """`x` is the tensor the forward normalised (z_out in the residual form); with `dz` the result is dx + dz."""
         N, C, HW = self._bn_dims(x)
         dev, n = x.device, x.numel()
         if ws.numel() < bn_ws_floats(C):
             raise ValueError(f'ws must hold {bn_ws_floats(C)} floats')
         with torch.cuda.device(dev):
             rc = self.lib.ursa_bn_relu_bwd_f32(
-                _ptr(x, 'x'), _ptr(dy, 'dy', n, dev), _ptr(dx, 'dx', n, dev), _ptr(gamma, 'gamma', C, dev),
+                _ptr(x, 'x'), _ptr(dy, 'dy', n, dev), _ptr(dz, 'dz', n, dev, optional=True), _ptr(dx, 'dx', n, dev),
+                _ptr(gamma, 'gamma', C, dev),
                 _ptr(beta, 'beta', C, dev), _ptr(save_mean, 'save_mean', C, dev),
                 _ptr(save_invstd, 'save_invstd', C, dev), _ptr(dgamma, 'dgamma', C, dev), _ptr(dbeta, 'dbeta', C, dev),
                 _ptr(ws, 'ws', None, dev), N, C, HW, BN_RELU if relu else 0, _stream(dev))

@@ -49,6 +49,9 @@ __device__ inline float comp(const float& v, int) { return v; }
 __device__ inline void setc(float4& v, int k, float a) { if (k == 0) v.x = a; else if (k == 1) v.y = a; else if (k == 2) v.z = a; else v.w = a; }
 __device__ inline void setc(float& v, int, float a) { v = a; }
 
+__device__ inline float4 vadd(const float4& a, const float4& b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ inline float vadd(const float& a, const float& b) { return a + b; }
+
 // unit index i of channel c -> unit offset in the NCHW tensor
 __device__ inline int64_t bn_off(const BnGeom& g, int c, int64_t i)
 {
@@ -103,29 +106,37 @@ __device__ __forceinline__ void bn_block_sum2(F& a, F& b, F* sh)
 
 __device__ inline float bn_relu_fwd(float v) { return v < 0.f ? 0.f : v; }   // NaN stays NaN
 
-// ---- forward, launch 1: partial statistics --------------------------------------------------------------------
-template <int V>
-__global__ __launch_bounds__(kBnBlock) void k_bn_stats(const float* __restrict__ x, double2* __restrict__ partial, BnGeom g)
+// ---- forward, launch 1: partial statistics (ADD: of z = x + addend, the residual sum, which is written out) --------
+template <int V, bool ADD>
+__global__ __launch_bounds__(kBnBlock) void k_bn_stats(const float* __restrict__ x, const float* __restrict__ addend,
+                                                       float* __restrict__ z, double2* __restrict__ partial, BnGeom g)
 {
     using T = typename Vec<V>::T;
     __shared__ double sh[2 * kBnBlock / 64];
     const T* __restrict__ xv = reinterpret_cast<const T*>(x);
+    const T* __restrict__ av = reinterpret_cast<const T*>(addend);
+    T* __restrict__ zv = reinterpret_cast<T*>(z);
     const int c = blockIdx.y;
     const int64_t lo = (int64_t)blockIdx.x * g.chunk;
     const int64_t hi = lo + g.chunk < g.per_ch ? lo + g.chunk : g.per_ch;
     double s1 = 0.0, s2 = 0.0;
     int64_t i = lo + threadIdx.x;
-    for (; i + 3 * kBnBlock < hi; i += 4 * kBnBlock) {      // four loads in flight
-        T v[4];
+    for (; i + 3 * kBnBlock < hi; i += 4 * kBnBlock) {      // four (ADD: eight) loads in flight
+        T v[4], w[4];
+        int64_t o[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = xv[bn_off(g, c, i + u * kBnBlock)];
+        for (int u = 0; u < 4; ++u) { o[u] = bn_off(g, c, i + u * kBnBlock); v[u] = xv[o[u]]; if (ADD) w[u] = av[o[u]]; }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < 4; ++u) {
+            if (ADD) { v[u] = vadd(v[u], w[u]); zv[o[u]] = v[u]; }
 #pragma unroll
             for (int k = 0; k < V; ++k) { const double d = (double)comp(v[u], k); s1 += d; s2 = fma(d, d, s2); }
+        }
     }
     for (; i < hi; i += kBnBlock) {
-        const T v = xv[bn_off(g, c, i)];
+        const int64_t o = bn_off(g, c, i);
+        T v = xv[o];
+        if (ADD) { v = vadd(v, av[o]); zv[o] = v; }
 #pragma unroll
         for (int k = 0; k < V; ++k) { const double d = (double)comp(v, k); s1 += d; s2 = fma(d, d, s2); }
     }
@@ -205,9 +216,11 @@ __global__ __launch_bounds__(kBnBlock) void k_bn_fwd_apply(const float* __restri
     }
 }
 
-// ---- evaluation mode: y = relu(gamma * (x - running_mean) / sqrt(running_var + eps) + beta), one launch ------------
-template <int V, bool RELU>
-__global__ __launch_bounds__(kBnBlock) void k_bn_eval(const float* __restrict__ x, float* __restrict__ y,
+// ---- evaluation mode: y = relu(gamma * (x - running_mean) / sqrt(running_var + eps) + beta), one launch;
+//      ADD: of z = x + addend, which is written out too -----------------------------------------------------------
+template <int V, bool RELU, bool ADD>
+__global__ __launch_bounds__(kBnBlock) void k_bn_eval(const float* __restrict__ x, const float* __restrict__ addend,
+                                                      float* __restrict__ z, float* __restrict__ y,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       const float* __restrict__ running_mean,
                                                       const float* __restrict__ running_var, float eps, BnGeom g)
@@ -218,17 +231,20 @@ __global__ __launch_bounds__(kBnBlock) void k_bn_eval(const float* __restrict__ 
     const float scale = invstd * gamma[c];
     const float shift = fmaf(-running_mean[c], scale, beta[c]);
     const T* __restrict__ xv = reinterpret_cast<const T*>(x);
+    const T* __restrict__ av = reinterpret_cast<const T*>(addend);
+    T* __restrict__ zv = reinterpret_cast<T*>(z);
     T* __restrict__ yv = reinterpret_cast<T*>(y);
     const int64_t lo = (int64_t)blockIdx.x * g.chunk;
     const int64_t hi = lo + g.chunk < g.per_ch ? lo + g.chunk : g.per_ch;
     int64_t i = lo + threadIdx.x;
     for (; i + 3 * kBnBlock < hi; i += 4 * kBnBlock) {
-        T v[4];
+        T v[4], w[4];
         int64_t o[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { o[u] = bn_off(g, c, i + u * kBnBlock); v[u] = xv[o[u]]; }
+        for (int u = 0; u < 4; ++u) { o[u] = bn_off(g, c, i + u * kBnBlock); v[u] = xv[o[u]]; if (ADD) w[u] = av[o[u]]; }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
+            if (ADD) { v[u] = vadd(v[u], w[u]); zv[o[u]] = v[u]; }
 #pragma unroll
             for (int k = 0; k < V; ++k) { const float t = fmaf(comp(v[u], k), scale, shift); setc(v[u], k, RELU ? bn_relu_fwd(t) : t); }
             yv[o[u]] = v[u];
@@ -237,6 +253,7 @@ __global__ __launch_bounds__(kBnBlock) void k_bn_eval(const float* __restrict__ 
     for (; i < hi; i += kBnBlock) {
         const int64_t o = bn_off(g, c, i);
         T v = xv[o];
+        if (ADD) { v = vadd(v, av[o]); zv[o] = v; }
 #pragma unroll
         for (int k = 0; k < V; ++k) { const float t = fmaf(comp(v, k), scale, shift); setc(v, k, RELU ? bn_relu_fwd(t) : t); }
         yv[o] = v;
@@ -298,10 +315,11 @@ __global__ __launch_bounds__(kBnBlock) void k_bn_bwd_reduce(const float* __restr
 // ---- backward, launch 2: torch's CPU association (native_batch_norm_backward, training):
 //      sum = sum dy' ; dotp = sum dy' (x - mean)                      (double, merged here)
 //      dbeta = sum ; dgamma = dotp * invstd ; gm = sum / n ; k = dotp * invstd^2 / n
-//      dx = ((dy' - gm) - (x - mean) * k) * invstd * gamma
-template <int V, bool RELU>
+//      dx = ((dy' - gm) - (x - mean) * k) * invstd * gamma     (RES: + dz, the gradient that reaches the residual sum
+//      z = x on its other path: the accumulation autograd would run as a separate add launch)
+template <int V, bool RELU, bool RES>
 __global__ __launch_bounds__(kBnBlock) void k_bn_bwd_dx(const float* __restrict__ x, const float* __restrict__ dy,
-                                                        float* __restrict__ dx, const float* __restrict__ gamma,
+                                                        const float* __restrict__ dz, float* __restrict__ dx, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const float* __restrict__ save_mean,
                                                         const float* __restrict__ save_invstd,
                                                         const double2* __restrict__ partial, int S,
@@ -329,15 +347,16 @@ __global__ __launch_bounds__(kBnBlock) void k_bn_bwd_dx(const float* __restrict_
     const float shift = fmaf(-mean, scale, beta[c]);
     const T* __restrict__ xv = reinterpret_cast<const T*>(x);
     const T* __restrict__ dv = reinterpret_cast<const T*>(dy);
+    const T* __restrict__ rv = reinterpret_cast<const T*>(dz);
     T* __restrict__ ov = reinterpret_cast<T*>(dx);
     const int64_t lo = (int64_t)blockIdx.x * g.chunk;
     const int64_t hi = lo + g.chunk < g.per_ch ? lo + g.chunk : g.per_ch;
     int64_t i = lo + threadIdx.x;
     for (; i + kBnBlock < hi; i += 2 * kBnBlock) {
-        T a[2], b[2];
+        T a[2], b[2], r[2];
         int64_t o[2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) { o[u] = bn_off(g, c, i + u * kBnBlock); a[u] = xv[o[u]]; b[u] = dv[o[u]]; }
+        for (int u = 0; u < 2; ++u) { o[u] = bn_off(g, c, i + u * kBnBlock); a[u] = xv[o[u]]; b[u] = dv[o[u]]; if (RES) r[u] = rv[o[u]]; }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
 #pragma unroll
@@ -347,7 +366,7 @@ __global__ __launch_bounds__(kBnBlock) void k_bn_bwd_dx(const float* __restrict_
                 if (RELU && !(fmaf(xe, scale, shift) > 0.f)) ge = 0.f;
                 setc(b[u], k, (((ge - gm) - (xe - mean) * kk) * invstd) * w);
             }
-            ov[o[u]] = b[u];
+            ov[o[u]] = RES ? vadd(r[u], b[u]) : b[u];
         }
     }
     for (; i < hi; i += kBnBlock) {
@@ -361,7 +380,7 @@ __global__ __launch_bounds__(kBnBlock) void k_bn_bwd_dx(const float* __restrict_
             if (RELU && !(fmaf(xe, scale, shift) > 0.f)) ge = 0.f;
             setc(b, k, (((ge - gm) - (xe - mean) * kk) * invstd) * w);
         }
-        ov[o] = b;
+        ov[o] = RES ? vadd(rv[o], b) : b;
     }
 }
 
@@ -408,69 +427,78 @@ inline int bn_launch_status() { return (int)hipGetLastError(); }
 
 extern "C" {
 
-int ursa_bn_relu_fwd_f32(const float* x, float* y, const float* gamma, const float* beta, float* running_mean,
-                         float* running_var, float* save_mean, float* save_invstd, float* ws, int64_t N, int64_t C,
-                         int64_t HW, float eps, float momentum, uint32_t flags, ursa_stream_t stream)
+int ursa_bn_relu_fwd_f32(const float* x, const float* addend, float* z_out, float* y, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, float* save_mean, float* save_invstd, float* ws,
+                         int64_t N, int64_t C, int64_t HW, float eps, float momentum, uint32_t flags, ursa_stream_t stream)
 {
     if (flags & ~URSA_BN_ALLFLAGS) return URSA_EFLAGS;
     if (N == 0 || C == 0 || HW == 0) return (N < 0 || C < 0 || HW < 0) ? URSA_ESIZE : URSA_OK;
     if (!x || !y || !gamma || !beta || !save_mean || !save_invstd || !ws) return URSA_ENULL;
     if ((running_mean == nullptr) != (running_var == nullptr)) return URSA_ENULL;
-    if (!bn_aligned4(x) || !bn_aligned4(y) || !bn_aligned16(ws)) return URSA_EALIGN;
+    if ((addend == nullptr) != (z_out == nullptr)) return URSA_ENULL;
+    if (!bn_aligned4(x) || !bn_aligned4(y) || !bn_aligned4(addend) || !bn_aligned4(z_out) || !bn_aligned16(ws)) return URSA_EALIGN;
     if (N > 0 && HW > 0 && N * HW < 2) return URSA_EVALUE;        // torch: "Expected more than 1 value per channel"
     BnPlan p;
-    const int rc = bn_plan(N, C, HW, bn_aligned16(x) && bn_aligned16(y), &p);
+    const int rc = bn_plan(N, C, HW, bn_aligned16(x) && bn_aligned16(y) && bn_aligned16(addend) && bn_aligned16(z_out), &p);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(p.S, p.g.C), block(kBnBlock);
     double2* part = reinterpret_cast<double2*>(ws);
     const bool relu = flags & URSA_BN_RELU;
+    const float* in2 = addend ? z_out : x;                        // what the second launch normalises
 #define URSA_BN_FWD(V, R) \
-    hipLaunchKernelGGL((k_bn_fwd_apply<V, R>), grid, block, 0, st, x, y, part, p.S, gamma, beta, running_mean, running_var, \
+    hipLaunchKernelGGL((k_bn_fwd_apply<V, R>), grid, block, 0, st, in2, y, part, p.S, gamma, beta, running_mean, running_var, \
                        save_mean, save_invstd, eps, momentum, p.g)
+#define URSA_BN_STATS(V) do { \
+    if (addend) hipLaunchKernelGGL((k_bn_stats<V, true>), grid, block, 0, st, x, addend, z_out, part, p.g); \
+    else hipLaunchKernelGGL((k_bn_stats<V, false>), grid, block, 0, st, x, addend, z_out, part, p.g); } while (0)
     if (p.V == 4) {
-        hipLaunchKernelGGL(k_bn_stats<4>, grid, block, 0, st, x, part, p.g);
+        URSA_BN_STATS(4);
         if (relu) URSA_BN_FWD(4, true); else URSA_BN_FWD(4, false);
     } else {
-        hipLaunchKernelGGL(k_bn_stats<1>, grid, block, 0, st, x, part, p.g);
+        URSA_BN_STATS(1);
         if (relu) URSA_BN_FWD(1, true); else URSA_BN_FWD(1, false);
     }
+#undef URSA_BN_STATS
 #undef URSA_BN_FWD
     return bn_launch_status();
 }
 
-int ursa_bn_relu_eval_f32(const float* x, float* y, const float* gamma, const float* beta, const float* running_mean,
-                          const float* running_var, int64_t N, int64_t C, int64_t HW, float eps, uint32_t flags,
-                          ursa_stream_t stream)
+int ursa_bn_relu_eval_f32(const float* x, const float* addend, float* z_out, float* y, const float* gamma, const float* beta,
+                          const float* running_mean, const float* running_var, int64_t N, int64_t C, int64_t HW, float eps,
+                          uint32_t flags, ursa_stream_t stream)
 {
     if (flags & ~URSA_BN_ALLFLAGS) return URSA_EFLAGS;
     if (N == 0 || C == 0 || HW == 0) return (N < 0 || C < 0 || HW < 0) ? URSA_ESIZE : URSA_OK;
     if (!x || !y || !gamma || !beta || !running_mean || !running_var) return URSA_ENULL;
-    if (!bn_aligned4(x) || !bn_aligned4(y)) return URSA_EALIGN;
+    if ((addend == nullptr) != (z_out == nullptr)) return URSA_ENULL;
+    if (!bn_aligned4(x) || !bn_aligned4(y) || !bn_aligned4(addend) || !bn_aligned4(z_out)) return URSA_EALIGN;
     BnPlan p;
-    const int rc = bn_plan(N, C, HW, bn_aligned16(x) && bn_aligned16(y), &p);
+    const int rc = bn_plan(N, C, HW, bn_aligned16(x) && bn_aligned16(y) && bn_aligned16(addend) && bn_aligned16(z_out), &p);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(p.S, p.g.C), block(kBnBlock);
     const bool relu = flags & URSA_BN_RELU;
-#define URSA_BN_EVAL(V, R) \
-    hipLaunchKernelGGL((k_bn_eval<V, R>), grid, block, 0, st, x, y, gamma, beta, running_mean, running_var, eps, p.g)
-    if (p.V == 4) { if (relu) URSA_BN_EVAL(4, true); else URSA_BN_EVAL(4, false); }
-    else          { if (relu) URSA_BN_EVAL(1, true); else URSA_BN_EVAL(1, false); }
+#define URSA_BN_EVAL(V, R, A) \
+    hipLaunchKernelGGL((k_bn_eval<V, R, A>), grid, block, 0, st, x, addend, z_out, y, gamma, beta, running_mean, running_var, eps, p.g)
+#define URSA_BN_EVAL2(V, R) do { if (addend) URSA_BN_EVAL(V, R, true); else URSA_BN_EVAL(V, R, false); } while (0)
+    if (p.V == 4) { if (relu) URSA_BN_EVAL2(4, true); else URSA_BN_EVAL2(4, false); }
+    else          { if (relu) URSA_BN_EVAL2(1, true); else URSA_BN_EVAL2(1, false); }
+#undef URSA_BN_EVAL2
 #undef URSA_BN_EVAL
     return bn_launch_status();
 }
 
-int ursa_bn_relu_bwd_f32(const float* x, const float* dy, float* dx, const float* gamma, const float* beta,
+int ursa_bn_relu_bwd_f32(const float* x, const float* dy, const float* dz, float* dx, const float* gamma, const float* beta,
                          const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, float* ws,
                          int64_t N, int64_t C, int64_t HW, uint32_t flags, ursa_stream_t stream)
 {
     if (flags & ~URSA_BN_ALLFLAGS) return URSA_EFLAGS;
     if (N == 0 || C == 0 || HW == 0) return (N < 0 || C < 0 || HW < 0) ? URSA_ESIZE : URSA_OK;
     if (!x || !dy || !dx || !gamma || !beta || !save_mean || !save_invstd || !dgamma || !dbeta || !ws) return URSA_ENULL;
-    if (!bn_aligned4(x) || !bn_aligned4(dy) || !bn_aligned4(dx) || !bn_aligned16(ws)) return URSA_EALIGN;
+    if (!bn_aligned4(x) || !bn_aligned4(dy) || !bn_aligned4(dz) || !bn_aligned4(dx) || !bn_aligned16(ws)) return URSA_EALIGN;
     BnPlan p;
-    const int rc = bn_plan(N, C, HW, bn_aligned16(x) && bn_aligned16(dy) && bn_aligned16(dx), &p);
+    const int rc = bn_plan(N, C, HW, bn_aligned16(x) && bn_aligned16(dy) && bn_aligned16(dz) && bn_aligned16(dx), &p);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(p.S, p.g.C), block(kBnBlock);
@@ -478,8 +506,10 @@ int ursa_bn_relu_bwd_f32(const float* x, const float* dy, float* dx, const float
     const bool relu = flags & URSA_BN_RELU;
 #define URSA_BN_BWD(V, R) do { \
     hipLaunchKernelGGL((k_bn_bwd_reduce<V, R>), grid, block, 0, st, x, dy, gamma, beta, save_mean, save_invstd, part, p.g); \
-    hipLaunchKernelGGL((k_bn_bwd_dx<V, R>), grid, block, 0, st, x, dy, dx, gamma, beta, save_mean, save_invstd, part, p.S, \
-                       dgamma, dbeta, p.g); } while (0)
+    if (dz) hipLaunchKernelGGL((k_bn_bwd_dx<V, R, true>), grid, block, 0, st, x, dy, dz, dx, gamma, beta, save_mean, save_invstd, \
+                               part, p.S, dgamma, dbeta, p.g); \
+    else hipLaunchKernelGGL((k_bn_bwd_dx<V, R, false>), grid, block, 0, st, x, dy, dz, dx, gamma, beta, save_mean, save_invstd, \
+                            part, p.S, dgamma, dbeta, p.g); } while (0)
     if (p.V == 4) { if (relu) URSA_BN_BWD(4, true); else URSA_BN_BWD(4, false); }
     else          { if (relu) URSA_BN_BWD(1, true); else URSA_BN_BWD(1, false); }
 #undef URSA_BN_BWD

@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .fused_bn import bn_relu
+from .fused_bn import add_bn_relu, bn_relu
 
 __all__ = ['LeNet5', 'MLP', 'MLP_dropout', 'PreResNet', 'PreResNet_dropout', 'WideResNet', 'MLP200MNIST',
            'MLP200MNIST_dropout', 'LeNet5MNIST', 'PreResNet8', 'PreResNet20', 'PreResNet164', 'WideResNet28x10']
@@ -89,9 +89,13 @@ class _PreActBasic(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        y = self.conv1(bn_relu(self.bn1, x))
+        """`x`: a tensor or the pending sum (a, b) the previous block returned; returns the pending sum
+        (conv output, shortcut): the `out += residual` of preresnet.py:49-52 is done by whoever consumes it - the next
+        block's bn1 or the network's final bn (`fused_bn.add_bn_relu`: same values, one launch less each way)."""
+        x, h = add_bn_relu(self.bn1, x)
+        y = self.conv1(h)
         y = self.conv2(bn_relu(self.bn2, y))
-        return y + (x if self.downsample is None else self.downsample(x))
+        return y, (x if self.downsample is None else self.downsample(x))
 
 
 class _PreActBottleneck(nn.Module):
@@ -109,10 +113,11 @@ class _PreActBottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        y = self.conv1(bn_relu(self.bn1, x))
+        x, h = add_bn_relu(self.bn1, x)                 # pending sums in and out, as in _PreActBasic
+        y = self.conv1(h)
         y = self.conv2(bn_relu(self.bn2, y))
         y = self.conv3(bn_relu(self.bn3, y))
-        return y + (x if self.downsample is None else self.downsample(x))
+        return y, (x if self.downsample is None else self.downsample(x))
 
 
 def _pool8(x, pool=None):
@@ -166,8 +171,8 @@ class PreResNet(nn.Module):
         return nn.Sequential(*blocks)
 
     def forward(self, x):
-        x = self.layer3(self.layer2(self.layer1(self.conv1(x))))
-        return self.fc(_pool8(bn_relu(self.bn, x), self.avgpool))
+        x = self.layer3(self.layer2(self.layer1(self.conv1(x))))     # the last block's pending sum
+        return self.fc(_pool8(add_bn_relu(self.bn, x)[1], self.avgpool))
 
 
 class PreResNet_dropout(PreResNet):
@@ -181,7 +186,7 @@ class PreResNet_dropout(PreResNet):
 
     def forward(self, x):
         x = self.layer3(self.layer2(self.layer1(self.conv1(x))))
-        return self.fc(F.dropout(_pool8(bn_relu(self.bn, x), self.avgpool), p=self.dropout))
+        return self.fc(F.dropout(_pool8(add_bn_relu(self.bn, x)[1], self.avgpool), p=self.dropout))
 
 
 # ---- wide ResNet -------------------------------------------------------------------------
@@ -198,9 +203,10 @@ class _WideBlock(nn.Module):
             self.shortcut = nn.Sequential(nn.Conv2d(cin, planes, 1, stride, bias=True))
 
     def forward(self, x):
-        y = self.dropout(self.conv1(bn_relu(self.bn1, x)))
+        x, h = add_bn_relu(self.bn1, x)                 # pending sums in and out, as in _PreActBasic
+        y = self.dropout(self.conv1(h))
         y = self.conv2(bn_relu(self.bn2, y))
-        return y + self.shortcut(x)
+        return y, self.shortcut(x)
 
 
 class WideResNet(nn.Module):
@@ -226,7 +232,7 @@ class WideResNet(nn.Module):
 
     def forward(self, x):
         x = self.layer3(self.layer2(self.layer1(self.conv1(x))))
-        return self.linear(_pool8(bn_relu(self.bn1, x)))
+        return self.linear(_pool8(add_bn_relu(self.bn1, x)[1]))
 
 
 # ---- config classes: `.base/.args/.kwargs` like URSABench/models (preresnet.py:154-169) ----
