@@ -559,12 +559,14 @@ def roofline_kernels_block(dev, large_n):
         entry(f'k1_multi_{chains}x273408', 20 * n * chains, lambda: K.sgmcmc_step_multi(th, g, m, ctl), cache_resident=True,
               elements=n * chains, chains=chains)
         del th, g, m
-    # K6: relu(bn(x)) forward (2 launches), backward (2 launches), evaluation (1 launch) per layer: PreResNet-20's first
-    # stage at the workload batch (8 MB activations: cache-resident, latency-bound) and the layers of the C4 / C5 networks
-    # whose activations do not fit the Infinity Cache. Algorithmic bytes: forward 12 B/element (x twice, y once),
-    # backward 20 B/element (x and dy twice, dx once), evaluation 8 B/element.
+    # K6: relu(bn(x)) forward, backward, evaluation per layer: PreResNet-20's first stage (two-launch form) and last stage
+    # (one-pass form) at the workload batch (8 / 2 MB activations: cache-resident, latency-bound) and layers of the C4 / C5
+    # networks whose activations do not fit the Infinity Cache. bytes = the ALGORITHMIC minimum of the operation: forward
+    # 8 B/element (x in, y out), backward 12 (x, dy in, dx out), evaluation 8; form_bytes = what the launched form moves
+    # (the two-launch form reads its inputs twice: 12 / 20).
     for label, shape, resident in (('128x16x32x32', (128, 16, 32, 32), True), ('128x64x8x8', (128, 64, 8, 8), True),
-                                   ('128x160x32x32', (128, 160, 32, 32), False), ('1024x64x32x32', (1024, 64, 32, 32), False)):
+                                   ('128x160x32x32', (128, 160, 32, 32), False), ('128x640x8x8', (128, 640, 8, 8), False),
+                                   ('1024x64x32x32', (1024, 64, 32, 32), False)):
         C = shape[1]
         x, dy = torch.randn(shape, device=dev), torch.randn(shape, device=dev)
         y, dx = torch.empty_like(x), torch.empty_like(x)
@@ -573,12 +575,14 @@ def roofline_kernels_block(dev, large_n):
         rv.fill_(1.0)
         wsb = torch.empty(_native.bn_ws_floats(C), device=dev)
         e = x.numel()
-        entry(f'k6_bn_relu_fwd_{label}', 12 * e, lambda: K.bn_relu_forward(x, y, w, b, rm, rv, sm, si, wsb, eps=1e-5, momentum=0.1),
-              cache_resident=resident, shape=list(shape), launches=2)
-        entry(f'k6_bn_relu_bwd_{label}', 20 * e, lambda: K.bn_relu_backward(x, dy, dx, w, b, sm, si, dg, db, wsb),
-              cache_resident=resident, shape=list(shape), launches=2)
+        one = C >= 48 and e // C <= 32768                       # csrc/ursa_bn.hip bn_one_pass
+        form = dict(form='one-pass (1 launch)' if one else 'two-launch')
+        entry(f'k6_bn_relu_fwd_{label}', 8 * e, lambda: K.bn_relu_forward(x, y, w, b, rm, rv, sm, si, wsb, eps=1e-5, momentum=0.1),
+              cache_resident=resident, shape=list(shape), form_bytes=(8 if one else 12) * e, **form)
+        entry(f'k6_bn_relu_bwd_{label}', 12 * e, lambda: K.bn_relu_backward(x, dy, dx, w, b, sm, si, dg, db, wsb),
+              cache_resident=resident, shape=list(shape), form_bytes=(12 if one else 20) * e, **form)
         entry(f'k6_bn_relu_eval_{label}', 8 * e, lambda: K.bn_relu_eval(x, y, w, b, rm, rv, eps=1e-5),
-              cache_resident=resident, shape=list(shape), launches=1)
+              cache_resident=resident, shape=list(shape), form_bytes=8 * e, form='1 launch')
         del x, dy, y, dx
     return out
 

@@ -255,6 +255,10 @@ int ursa_sumsq_f32(const float* x, int64_t n, float* out, float* ws, ursa_stream
  *     sum = sum g ; dotp = sum g * (x - mean_c)                      (double)
  *     dbeta[c] = sum ; dgamma[c] = dotp * invstd_c ; gm = sum / n ; k = dotp * invstd_c^2 / n
  *     dx = (((g - gm) - (x - mean_c) * k) * invstd_c) * gamma_c       (n = N * HW)
+ *   one-pass form: when a channel fits one 1,024-thread workgroup's registers (N*HW <= 32,768, 16-byte
+ *   aligned float4 accesses) and there are >= 48 channels (= workgroups) the forward and the backward are
+ *   ONE launch each, grid = C: the channel is read once, reduced in the workgroup and written - same
+ *   arithmetic and the same floats as the two-launch form (URSA_BN_TWO_LAUNCH keeps that one).
  *   residual form (the blocks end `out += residual`, preresnet.py:49-52,87-90, and the next block's first op is
  *   relu(bn(out))): with addend != NULL the forward / evaluation launches normalise z = x + addend (one fp32 add,
  *   as torch's) and also store z to z_out - the add launch folded into the statistics pass; with dz != NULL the
@@ -267,8 +271,9 @@ int ursa_sumsq_f32(const float* x, int64_t n, float* out, float* ws, ursa_stream
  * Traffic: forward 12 B/element (x twice, y once), backward 20 B/element, evaluation 8 B/element;
  * residual form: forward 20, backward 24, evaluation 16.
  */
-#define URSA_BN_RELU      0x1u
-#define URSA_BN_ALLFLAGS  0x1u
+#define URSA_BN_RELU        0x1u
+#define URSA_BN_TWO_LAUNCH  0x2u   /* keep the two-launch form where the one-pass form would apply (A/B, tests) */
+#define URSA_BN_ALLFLAGS    0x3u
 #define URSA_BN_WS_FLOATS(C) ((int64_t)(C) * 64 * 4)
 
 int ursa_bn_relu_fwd_f32(const float* x, const float* addend /* or NULL */, float* z_out /* iff addend */,

@@ -426,3 +426,39 @@ def test_add_bn_relu_autograd_vs_stock_ops():
     h = nn.BatchNorm2d(8)
     z, y = fused_bn.add_bn_relu(h, (a0.cpu(), b0.cpu()))
     assert torch.equal(z, a0.cpu() + b0.cpu())
+
+
+@pytest.mark.parametrize('shape', [(128, 64, 8, 8), (128, 64, 16, 16), (16, 640, 8, 8), (2, 48, 2, 2), (30, 50, 12, 12), (64, 96, 8, 8)])
+@pytest.mark.parametrize('relu', [True, False])
+def test_one_pass_form_equals_two_launch_form(K, shape, relu):
+    """A channel that fits one workgroup's registers takes the one-pass kernels (one launch forward, one backward); the
+    arithmetic is the two-launch form's: statistics, outputs, gates, parameter gradients and dx are the same floats
+    (double sums rounded once on both sides), plain and residual forms."""
+    from ursabench_amd import _native
+    g = torch.Generator().manual_seed(sum(shape) + 7 * relu)
+    C = shape[1]
+    a, b, dy, dz = (torch.randn(shape, generator=g).cuda() for _ in range(4))
+    w, bb = (torch.rand(C, generator=g) + 0.5).cuda(), torch.randn(C, generator=g).cuda()
+    ws = torch.empty(_native.bn_ws_floats(C), device='cuda')
+    outs = []
+    for two in (False, True):
+        for resid in (False, True):
+            z, y, dx = torch.full_like(a, float('nan')), torch.full_like(a, float('nan')), torch.full_like(a, float('nan'))
+            sm, si, dw, db = (torch.empty(C, device='cuda') for _ in range(4))
+            rm, rv = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
+            K.bn_relu_forward(a, y, w, bb, rm, rv, sm, si, ws, eps=1e-5, momentum=0.1, relu=relu, two_launch=two,
+                              **(dict(addend=b, z_out=z) if resid else {}))
+            K.bn_relu_backward(z if resid else a, dy, dx, w, bb, sm, si, dw, db, ws, relu=relu, two_launch=two,
+                               dz=dz if resid else None)
+            outs.append((resid, [y, sm, si, rm, rv, dx, dw, db] + ([z] if resid else [])))
+    for (r1, o1), (r2, o2) in ((outs[0], outs[2]), (outs[1], outs[3])):
+        assert r1 == r2
+        for t1, t2, name in zip(o1, o2, ('y', 'mean', 'invstd', 'running_mean', 'running_var', 'dx', 'dgamma', 'dbeta', 'z')):
+            assert not torch.isnan(t1).any(), name
+            if name in ('dgamma', 'dbeta', 'mean', 'invstd', 'running_mean', 'running_var'):
+                assert int((t1 != t2).sum()) <= 1 and torch.allclose(t1, t2, rtol=2e-7, atol=0), name
+            elif name in ('dx', 'y'):
+                ok = (o1[1] == o2[1]) & (o1[2] == o2[2]) & (o1[6] == o2[6]) & (o1[7] == o2[7])
+                assert torch.equal(t1[:, ok], t2[:, ok]), name
+            else:
+                assert torch.equal(t1, t2), name

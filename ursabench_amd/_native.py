@@ -24,7 +24,7 @@ STEP_NOISE, STEP_FIRST, STEP_ZERO_GRAD, STEP_WD, STEP_SGD, STEP_ADVANCE = 0x1, 0
 BMA_SMOOTHED = 0x1
 LEAP_KICK, LEAP_DRIFT = 0x1, 0x2
 REDUCE_WS_FLOATS = 2048
-BN_RELU = 0x1
+BN_RELU, BN_TWO_LAUNCH = 0x1, 0x2
 
 
 def bn_ws_floats(channels):
@@ -301,7 +301,7 @@ class HipKernels:
         return N, C, x.numel() // max(N * C, 1)
 
     def bn_relu_forward(self, x, y, gamma, beta, running_mean, running_var, save_mean, save_invstd, ws, *, eps,
-                        momentum, relu=True, addend=None, z_out=None):
+                        momentum, relu=True, addend=None, z_out=None, two_launch=False):
         """Training-mode BatchNorm (+ ReLU) of a contiguous [N, C, *] tensor: batch statistics, running statistics
         updated in place (skipped when both are None), mean / invstd saved for the backward. With `addend` the
         normalised tensor is z = x + addend, also stored to `z_out` (the residual sum folded into the statistics pass)."""
@@ -318,7 +318,7 @@ class HipKernels:
                 _ptr(running_mean, 'running_mean', C, dev, optional=True),
                 _ptr(running_var, 'running_var', C, dev, optional=True), _ptr(save_mean, 'save_mean', C, dev),
                 _ptr(save_invstd, 'save_invstd', C, dev), _ptr(ws, 'ws', None, dev), N, C, HW, eps, momentum,
-                BN_RELU if relu else 0, _stream(dev))
+                (BN_RELU if relu else 0) | (BN_TWO_LAUNCH if two_launch else 0), _stream(dev))
         _check(self.lib, rc, 'ursa_bn_relu_fwd_f32')
 
     def bn_relu_eval(self, x, y, gamma, beta, running_mean, running_var, *, eps, relu=True, addend=None, z_out=None):
@@ -334,7 +334,7 @@ class HipKernels:
                 BN_RELU if relu else 0, _stream(dev))
         _check(self.lib, rc, 'ursa_bn_relu_eval_f32')
 
-    def bn_relu_backward(self, x, dy, dx, gamma, beta, save_mean, save_invstd, dgamma, dbeta, ws, *, relu=True, dz=None):
+    def bn_relu_backward(self, x, dy, dx, gamma, beta, save_mean, save_invstd, dgamma, dbeta, ws, *, relu=True, dz=None, two_launch=False):
         """`x` is the tensor the forward normalised (z_out in the residual form); with `dz` the result is dx + dz."""
         N, C, HW = self._bn_dims(x)
         dev, n = x.device, x.numel()
@@ -346,7 +346,8 @@ class HipKernels:
                 _ptr(gamma, 'gamma', C, dev),
                 _ptr(beta, 'beta', C, dev), _ptr(save_mean, 'save_mean', C, dev),
                 _ptr(save_invstd, 'save_invstd', C, dev), _ptr(dgamma, 'dgamma', C, dev), _ptr(dbeta, 'dbeta', C, dev),
-                _ptr(ws, 'ws', None, dev), N, C, HW, BN_RELU if relu else 0, _stream(dev))
+                _ptr(ws, 'ws', None, dev), N, C, HW, (BN_RELU if relu else 0) | (BN_TWO_LAUNCH if two_launch else 0),
+                _stream(dev))
         _check(self.lib, rc, 'ursa_bn_relu_bwd_f32')
 
 

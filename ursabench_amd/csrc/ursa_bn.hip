@@ -384,6 +384,161 @@ __global__ __launch_bounds__(kBnBlock) void k_bn_bwd_dx(const float* __restrict_
     }
 }
 
+// ---- one-pass forms: a channel that fits one workgroup's registers (N*H*W <= 4 * kOneBlock * kOneEpt elements: the
+//      16x16 and 8x8 stages at batch 128) is read ONCE - one launch instead of two, no partials, no second read.
+//      Same arithmetic (double sums, one rounding), so the same floats as the two-launch form. -----------------------
+constexpr int kOneBlock = 1024;
+constexpr int kOneEpt = 8;          // most float4 per thread held in registers (2, 4 or 8 by channel size)
+constexpr int kOneMinC = 48;        // fewer channels = fewer workgroups than that: the two-launch form spreads wider
+
+// 32-bit form of bn_off for tensors the host has checked to hold < 2^31 float4 (one-pass kernels: saves the 64-bit
+// address arithmetic's registers)
+__device__ __forceinline__ int bn_off32(const BnGeom& g, int c, int i)
+{
+    const int n = g.hw_shift >= 0 ? (i >> g.hw_shift) : (i / g.hw);
+    return (n * g.C + c) * g.hw + (i - n * g.hw);
+}
+
+__device__ __forceinline__ void bn_block_sum2_one(double& a, double& b, double* sh /* 2 * kOneBlock/64 */)
+{
+    a = bn_wave_sum(a);
+    b = bn_wave_sum(b);
+    if ((threadIdx.x & 63) == 0) { sh[2 * (threadIdx.x >> 6)] = a; sh[2 * (threadIdx.x >> 6) + 1] = b; }
+    __syncthreads();
+    a = b = 0.0;
+#pragma unroll
+    for (int w = 0; w < kOneBlock / 64; ++w) { a += sh[2 * w]; b += sh[2 * w + 1]; }
+}
+
+template <bool RELU, bool ADD, int EPT>
+__global__ __launch_bounds__(kOneBlock) void k_bn_fwd_one(const float* __restrict__ x, const float* __restrict__ addend,
+                                                         float* __restrict__ z, float* __restrict__ y,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                         float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                         float eps, float momentum, BnGeom g)
+{
+    __shared__ double sh[2 * kOneBlock / 64];
+    __shared__ float shf[2];
+    const float4* __restrict__ xv = reinterpret_cast<const float4*>(x);
+    const float4* __restrict__ av = reinterpret_cast<const float4*>(addend);
+    float4* __restrict__ zv = reinterpret_cast<float4*>(z);
+    float4* __restrict__ yv = reinterpret_cast<float4*>(y);
+    const int c = blockIdx.x, per_ch = (int)g.per_ch;
+    float4 v[EPT];
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) {
+        const int i = threadIdx.x + u * kOneBlock;
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < per_ch) {
+            const int o = bn_off32(g, c, i);
+            v[u] = xv[o];
+            if (ADD) v[u] = vadd(v[u], av[o]);
+        }
+    }
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) {             // lanes beyond the channel hold zeros: they add nothing
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const double d = (double)comp(v[u], k); s1 += d; s2 = fma(d, d, s2); }
+    }
+    bn_block_sum2_one(s1, s2, sh);
+    if (threadIdx.x == 0) {
+        const double n = (double)g.per_ch * 4.0;
+        const double mean = s1 / n;
+        double var = s2 / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float meanf = (float)mean;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float alpha = invstd * gamma[c];
+        shf[0] = alpha;
+        shf[1] = fmaf(-meanf, alpha, beta[c]);
+        save_mean[c] = meanf;
+        save_invstd[c] = invstd;
+        if (running_mean) {
+            running_mean[c] = momentum * meanf + (1.0f - momentum) * running_mean[c];
+            running_var[c] = momentum * (float)(var * (n / (n - 1.0))) + (1.0f - momentum) * running_var[c];
+        }
+    }
+    __syncthreads();
+    const float scale = shf[0], shift = shf[1];
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) {
+        const int i = threadIdx.x + u * kOneBlock;
+        if (i < per_ch) {
+            const int o = bn_off32(g, c, i);
+            if (ADD) zv[o] = v[u];
+            float4 r = v[u];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float t = fmaf(comp(v[u], k), scale, shift); setc(r, k, RELU ? bn_relu_fwd(t) : t); }
+            yv[o] = r;
+        }
+    }
+}
+
+template <bool RELU, bool RES, int EPT>
+__global__ __launch_bounds__(kOneBlock) void k_bn_bwd_one(const float* __restrict__ x, const float* __restrict__ dy,
+                                                         const float* __restrict__ dz, float* __restrict__ dx,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const float* __restrict__ save_mean,
+                                                         const float* __restrict__ save_invstd, float* __restrict__ dgamma,
+                                                         float* __restrict__ dbeta, BnGeom g)
+{
+    __shared__ double sh[2 * kOneBlock / 64];
+    __shared__ float shf[2];
+    const float4* __restrict__ xv = reinterpret_cast<const float4*>(x);
+    const float4* __restrict__ dv = reinterpret_cast<const float4*>(dy);
+    const float4* __restrict__ rv = reinterpret_cast<const float4*>(dz);
+    float4* __restrict__ ov = reinterpret_cast<float4*>(dx);
+    const int c = blockIdx.x, per_ch = (int)g.per_ch;
+    const float mean = save_mean[c], invstd = save_invstd[c], w = gamma[c];
+    const float scale = invstd * w;
+    const float shift = fmaf(-mean, scale, beta[c]);
+    const double meand = (double)mean;
+    float4 a[EPT], b[EPT];
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) {
+        const int i = threadIdx.x + u * kOneBlock;
+        a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        b[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < per_ch) { const int o = bn_off32(g, c, i); a[u] = xv[o]; b[u] = dv[o]; }
+    }
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float xe = comp(a[u], k);
+            float ge = comp(b[u], k);                // zero beyond the channel: adds nothing
+            if (RELU && !(fmaf(xe, scale, shift) > 0.f)) ge = 0.f;
+            setc(b[u], k, ge);
+            s1 += (double)ge;
+            s2 = fma((double)ge, (double)xe - meand, s2);
+        }
+    }
+    bn_block_sum2_one(s1, s2, sh);
+    if (threadIdx.x == 0) {
+        const double n = (double)g.per_ch * 4.0, iv = (double)invstd;
+        shf[0] = (float)(s1 / n);
+        shf[1] = (float)(s2 * iv * iv / n);
+        dbeta[c] = (float)s1;
+        dgamma[c] = (float)(s2 * iv);
+    }
+    __syncthreads();
+    const float gm = shf[0], kk = shf[1];
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) {
+        const int i = threadIdx.x + u * kOneBlock;
+        if (i < per_ch) {
+            const int o = bn_off32(g, c, i);
+            float4 r = b[u];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) setc(r, k, (((comp(b[u], k) - gm) - (comp(a[u], k) - mean) * kk) * invstd) * w);
+            ov[o] = RES ? vadd(rv[o], r) : r;
+        }
+    }
+}
+
 // ---- host side ----------------------------------------------------------------------------------------------------
 struct BnPlan {
     BnGeom g;
@@ -423,6 +578,16 @@ inline int bn_plan(int64_t N, int64_t C, int64_t HW, bool vec_ok, BnPlan* p)
 
 inline int bn_launch_status() { return (int)hipGetLastError(); }
 
+// One-pass form: float4 accesses, the channel fits one workgroup's registers, 32-bit float4 offsets suffice, and there
+// are enough channels (= workgroups) to spread over the CUs. Measured (tools/exp/bn_fused_bench.py): [128,64,8,8] forward
+// 6.7 -> 5.8 us, backward 5.4 -> 3.8; [128,320,16,16] 23 -> 19 / 34 -> 26; with only 32 channels ([128,32,16,16]) the
+// two-launch form is as fast forward and faster backward.
+inline bool bn_one_pass(const BnPlan& p, uint32_t flags)
+{
+    return p.V == 4 && p.g.per_ch <= (int64_t)kOneBlock * kOneEpt && p.g.C >= kOneMinC && p.g.per_ch * p.g.C < (1ll << 31) &&
+           !(flags & URSA_BN_TWO_LAUNCH);
+}
+
 }  // namespace
 
 extern "C" {
@@ -445,6 +610,18 @@ int ursa_bn_relu_fwd_f32(const float* x, const float* addend, float* z_out, floa
     const dim3 grid(p.S, p.g.C), block(kBnBlock);
     double2* part = reinterpret_cast<double2*>(ws);
     const bool relu = flags & URSA_BN_RELU;
+    if (bn_one_pass(p, flags)) {
+        const dim3 g1(p.g.C), b1(kOneBlock);
+#define URSA_BN_ONE_E(R, A, E) hipLaunchKernelGGL((k_bn_fwd_one<R, A, E>), g1, b1, 0, st, x, addend, z_out, y, gamma, beta, running_mean, \
+                                                  running_var, save_mean, save_invstd, eps, momentum, p.g)
+#define URSA_BN_ONE(R, A) do { if (p.g.per_ch <= 2 * kOneBlock) URSA_BN_ONE_E(R, A, 2); else if (p.g.per_ch <= 4 * kOneBlock) URSA_BN_ONE_E(R, A, 4); \
+                               else URSA_BN_ONE_E(R, A, 8); } while (0)
+        if (relu) { if (addend) URSA_BN_ONE(true, true); else URSA_BN_ONE(true, false); }
+        else      { if (addend) URSA_BN_ONE(false, true); else URSA_BN_ONE(false, false); }
+#undef URSA_BN_ONE
+#undef URSA_BN_ONE_E
+        return bn_launch_status();
+    }
     const float* in2 = addend ? z_out : x;                        // what the second launch normalises
 #define URSA_BN_FWD(V, R) \
     hipLaunchKernelGGL((k_bn_fwd_apply<V, R>), grid, block, 0, st, in2, y, part, p.S, gamma, beta, running_mean, running_var, \
@@ -504,6 +681,18 @@ int ursa_bn_relu_bwd_f32(const float* x, const float* dy, const float* dz, float
     const dim3 grid(p.S, p.g.C), block(kBnBlock);
     double2* part = reinterpret_cast<double2*>(ws);
     const bool relu = flags & URSA_BN_RELU;
+    if (bn_one_pass(p, flags)) {
+        const dim3 g1(p.g.C), b1(kOneBlock);
+#define URSA_BN_ONE_E(R, A, E) hipLaunchKernelGGL((k_bn_bwd_one<R, A, E>), g1, b1, 0, st, x, dy, dz, dx, gamma, beta, save_mean, save_invstd, \
+                                                  dgamma, dbeta, p.g)
+#define URSA_BN_ONE(R, A) do { if (p.g.per_ch <= 2 * kOneBlock) URSA_BN_ONE_E(R, A, 2); else if (p.g.per_ch <= 4 * kOneBlock) URSA_BN_ONE_E(R, A, 4); \
+                               else URSA_BN_ONE_E(R, A, 8); } while (0)
+        if (relu) { if (dz) URSA_BN_ONE(true, true); else URSA_BN_ONE(true, false); }
+        else      { if (dz) URSA_BN_ONE(false, true); else URSA_BN_ONE(false, false); }
+#undef URSA_BN_ONE
+#undef URSA_BN_ONE_E
+        return bn_launch_status();
+    }
 #define URSA_BN_BWD(V, R) do { \
     hipLaunchKernelGGL((k_bn_bwd_reduce<V, R>), grid, block, 0, st, x, dy, gamma, beta, save_mean, save_invstd, part, p.g); \
     if (dz) hipLaunchKernelGGL((k_bn_bwd_dx<V, R, true>), grid, block, 0, st, x, dy, dz, dx, gamma, beta, save_mean, save_invstd, \

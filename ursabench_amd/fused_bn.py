@@ -14,7 +14,8 @@ torch.nn.modules.batchnorm._BatchNorm.forward); only the launches differ:
   evaluation-mode layer):                          `F.relu(bn(x))`, the stock path
 
 On a HIP tensor the fused path needs csrc/libursa_hip.so (no silent fallback: a missing library raises).
-`URSA_FUSED_BN=0` in the environment, or `enabled(False)`, selects the stock path everywhere (A/B runs).
+`URSA_FUSED_BN=0` in the environment, or `enabled(False)`, selects the stock path everywhere (A/B runs);
+`URSA_BN_TWO_LAUNCH=1` keeps the two-launch kernels where the one-pass form would apply.
 """
 import os
 
@@ -25,6 +26,7 @@ from torch.autograd.function import once_differentiable
 from . import _native
 
 _on = os.environ.get('URSA_FUSED_BN', '1') != '0'
+_two_launch = os.environ.get('URSA_BN_TWO_LAUNCH', '0') == '1'     # A/B: never take the one-pass form
 
 
 def enabled(flag=None):
@@ -45,7 +47,7 @@ class _BNReLUTrain(torch.autograd.Function):
         stats = x.new_empty(2, C)                       # save_mean, save_invstd
         ws = x.new_empty(_native.bn_ws_floats(C))
         K.bn_relu_forward(x, y, weight, bias, running_mean, running_var, stats[0], stats[1], ws, eps=eps,
-                          momentum=momentum, relu=relu)
+                          momentum=momentum, relu=relu, two_launch=_two_launch)
         ctx.save_for_backward(x, weight, bias, stats)
         ctx.relu = relu
         return y
@@ -60,7 +62,8 @@ class _BNReLUTrain(torch.autograd.Function):
         dx = torch.empty_like(x)
         dwb = x.new_empty(2, C)
         ws = x.new_empty(_native.bn_ws_floats(C))
-        K.bn_relu_backward(x, dy, dx, weight, bias, stats[0], stats[1], dwb[0], dwb[1], ws, relu=ctx.relu)
+        K.bn_relu_backward(x, dy, dx, weight, bias, stats[0], stats[1], dwb[0], dwb[1], ws, relu=ctx.relu,
+                           two_launch=_two_launch)
         return dx, dwb[0], dwb[1], None, None, None, None, None
 
 
@@ -76,7 +79,7 @@ class _AddBNReLUTrain(torch.autograd.Function):
         stats = a.new_empty(2, C)
         ws = a.new_empty(_native.bn_ws_floats(C))
         K.bn_relu_forward(a, y, weight, bias, running_mean, running_var, stats[0], stats[1], ws, eps=eps,
-                          momentum=momentum, relu=relu, addend=b, z_out=z)
+                          momentum=momentum, relu=relu, addend=b, z_out=z, two_launch=_two_launch)
         ctx.save_for_backward(z, weight, bias, stats)
         ctx.relu = relu
         return z, y
@@ -94,7 +97,8 @@ class _AddBNReLUTrain(torch.autograd.Function):
         dx = torch.empty_like(z)
         dwb = z.new_empty(2, C)
         ws = z.new_empty(_native.bn_ws_floats(C))
-        K.bn_relu_backward(z, dy, dx, weight, bias, stats[0], stats[1], dwb[0], dwb[1], ws, relu=ctx.relu, dz=dz)
+        K.bn_relu_backward(z, dy, dx, weight, bias, stats[0], stats[1], dwb[0], dwb[1], ws, relu=ctx.relu, dz=dz,
+                           two_launch=_two_launch)
         return dx, dx, dwb[0], dwb[1], None, None, None, None, None
 
 
