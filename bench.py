@@ -813,6 +813,16 @@ def _abi_version():
     return _native.load_library().ursa_abi_version()
 
 
+def _bn_relu_path(job):
+    from ursabench_amd import fused_bn
+    if job.cpu:
+        return 'torch ops (host tensors)'
+    if not fused_bn.enabled():
+        return 'stock MIOpen / ATen launches (URSA_FUSED_BN=0)'
+    return ('K6 launches (ursabench_amd/fused_bn.py: relu(bn(x)) and the residual sums around it)'
+            + (', two-launch form only (URSA_BN_TWO_LAUNCH=1)' if fused_bn._two_launch else ''))
+
+
 def base_line(a, job, metric, unit, workload):
     return {'metric': metric, 'value': None, 'unit': unit, 'n_gpus': job.world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': None, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
@@ -820,7 +830,8 @@ def base_line(a, job, metric, unit, workload):
             'config': {'workload': workload, 'device': (torch.cuda.get_device_name(job.dev) if not job.cpu else 'cpu'),
                        'torch': torch.__version__, 'hip': torch.version.hip, 'abi': None if job.cpu else _abi_version(),
                        'miopen_user_db': 'shipped tuned databases (ursabench_amd/miopen_db, MIOPEN_FIND_ENFORCE=3 search; stock MIOpen solvers)'
-                       if any(f.endswith('.txt') for f in os.listdir(MIOPEN_DB)) else 'empty private database (quick search per layer)'}}
+                       if any(f.endswith('.txt') for f in os.listdir(MIOPEN_DB)) else 'empty private database (quick search per layer)',
+                       'bn_relu': _bn_relu_path(job)}}
 
 
 def run_c2(a, job, legs, line):

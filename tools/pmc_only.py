@@ -78,5 +78,41 @@ for (S, B, C) in ((50, 10000, 10), (20, 9984, 10), (30, 10000, 100)):      # 9,9
     grid = (B + 15) // 16 if C <= 16 else (B + 3) // 4
     wg = 64 * (4 if S >= 12 else 2 if S >= 5 else 1) if C <= 16 else 256
     note('k_bma_', f'K5 S={S} B={B} C={C}', 4 * S * B * C + 8 * B * (C + 1), shape=[S, B, C], blocks=grid, wg=wg)
+del z, p, e
+# K6 relu(bn(x)): the two-launch form on a 268 MB activation (PreResNet-164's first stage at the HMC batch: beyond the
+# Infinity Cache) and the one-pass form on an 84 MB one (WideResNet-28-10's last stage at 4x the batch)
+for shape, one in (((1024, 64, 32, 32), False), ((512, 640, 8, 8), True)):
+    C = shape[1]
+    x, dy = torch.randn(shape, device='cuda'), torch.randn(shape, device='cuda')
+    y, dx = torch.empty_like(x), torch.empty_like(x)
+    w, b = torch.rand(C, device='cuda') + 0.5, torch.randn(C, device='cuda')
+    rm, rv, sm, si, dg, db = (torch.zeros(C, device='cuda') for _ in range(6))
+    rv.fill_(1.0)
+    wsb = torch.empty(_native.bn_ws_floats(C), device='cuda')
+    for _ in range(10):
+        K.bn_relu_forward(x, y, w, b, rm, rv, sm, si, wsb, eps=1e-5, momentum=0.1)
+        K.bn_relu_backward(x, dy, dx, w, b, sm, si, dg, db, wsb)
+        K.bn_relu_eval(x, y, w, b, rm, rv, eps=1e-5)
+    e = x.numel()
+    tag = 'x'.join(str(v) for v in shape)
+    if one:
+        manifest.append(dict(pattern='k_bn_fwd_one', label=f'K6 forward, one-pass form {tag}', algorithmic_bytes_per_launch=8 * e, blocks=C, wg=1024))
+        manifest.append(dict(pattern='k_bn_bwd_one', label=f'K6 backward, one-pass form {tag}', algorithmic_bytes_per_launch=12 * e, blocks=C, wg=1024))
+        S = 2
+    else:
+        S = min(64, -(-1024 // C))
+        per = e // C // 4
+        chunk = -(-(-(-per // S)) // 256) * 256
+        S = -(-per // chunk)
+        manifest.append(dict(pattern='k_bn_stats', label=f'K6 forward launch 1 (statistics) {tag}', algorithmic_bytes_per_launch=4 * e, blocks=S * C, wg=256))
+        manifest.append(dict(pattern='k_bn_fwd_apply', label=f'K6 forward launch 2 (normalise + ReLU) {tag}', algorithmic_bytes_per_launch=8 * e, blocks=S * C, wg=256))
+        manifest.append(dict(pattern='k_bn_bwd_reduce', label=f'K6 backward launch 1 (sums) {tag}', algorithmic_bytes_per_launch=8 * e, blocks=S * C, wg=256))
+        manifest.append(dict(pattern='k_bn_bwd_dx', label=f'K6 backward launch 2 (dx) {tag}', algorithmic_bytes_per_launch=12 * e, blocks=S * C, wg=256))
+    Se = min(64, -(-1024 // C))
+    per = e // C // 4
+    chunk = -(-(-(-per // Se)) // 256) * 256
+    Se = -(-per // chunk)
+    manifest.append(dict(pattern='k_bn_eval', label=f'K6 evaluation {tag}', algorithmic_bytes_per_launch=8 * e, blocks=Se * C, wg=256))
+    del x, dy, y, dx
 torch.cuda.synchronize()
 json.dump(manifest, open(sys.argv[1], 'w'), indent=1)
