@@ -23,9 +23,10 @@ def main():
     rec = []
     orig = K.bn_relu_backward
 
-    def spy(x_, dy, dx, gamma, beta, sm, si, dg, db, ws, relu=True):
-        orig(x_, dy, dx, gamma, beta, sm, si, dg, db, ws, relu=relu)
-        rec.append([v.detach().clone() for v in (x_, dy, dx, gamma, beta, sm, si, dg, db)])
+    def spy(x_, dy, dx, gamma, beta, sm, si, dg, db, ws, relu=True, dz=None, **kw):
+        orig(x_, dy, dx, gamma, beta, sm, si, dg, db, ws, relu=relu, dz=dz, **kw)
+        plain = dx if dz is None else dx - dz           # the BatchNorm's own dx (the residual form adds dz)
+        rec.append([v.detach().clone() for v in (x_, dy, plain, gamma, beta, sm, si, dg, db)])
     K.bn_relu_backward = spy
     grads = {}
     for name in ('fused', 'stock', 'cpu'):

@@ -21,7 +21,7 @@ a)  # kernel micro-benchmarks and diagnostics
   python3 tools/exp/bn_mask_flips.py > $out/r03_bn_same_input_vs_cpu.json 2> $out/bn_mask_flips.err; echo "bn_mask_flips rc=$?"
   python3 tools/exp/bn_gate_diag.py > $out/r03_bn_gate_diag.txt 2> $out/bn_gate_diag.err; echo "bn_gate_diag rc=$?"
   python3 tools/exp/g9_gate_diag.py > $out/r03_g9_gate_diag.txt 2> $out/g9_gate_diag.err; echo "g9_gate_diag rc=$?"
-  python3 tools/exp/bn_grad_diag.py > $out/r03_bn_grad_diag.txt 2> $out/bn_grad_diag.err; echo "bn_grad_diag rc=$?"
+
   cd /tmp && export TMPDIR=/tmp
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kb -- python3 $R/tools/kbench.py > /dev/null 2>&1; echo "kbench under rocprof rc=$?"
   python3 $R/tools/prof_summary.py /tmp/prof_kb $out/r03_kbench_kernel_stats.csv > /dev/null
@@ -49,6 +49,7 @@ c)  # the bench lines and the harness drivers
   python3 bench.py --chains-per-gpu 4 --no-cpu-baseline --ref-style-steps 0 --multi-chain-probe 0 > $out/r03_bench_line_4chains.json 2> $out/bench4.err; echo "4-chain bench rc=$?"
   python3 -m ursabench_amd.time_script --dataset CIFAR10 --model PreResNet20 --save_path $out/r03_time_script_preresnet20 --samples 3 --trials 10 --discard_first \
       --methods SGLD SGHMC cSGLD cSGHMC SWAG MCdropout SGD > $out/time_script.log 2>&1; echo "time_script rc=$?"
+  python3 tools/exp/bn_grad_diag.py > $out/r03_bn_grad_diag.txt 2> $out/bn_grad_diag.err; echo "bn_grad_diag rc=$?"
   python3 -m ursabench_amd.experiment --dataset CIFAR10 --model PreResNet20 --inference_method SGHMC --hyperparams_path tools/hyperparams/preresnet20_sghmc.json \
       --save_path $out/r03_experiment_ --num_trials 2 > $out/experiment.log 2>&1; echo "experiment rc=$?"
   ;;
