@@ -716,14 +716,19 @@ def reference_style_gpu_block(steps, dev):
                 state[p] = d_p
         return total
 
+    from ursabench_amd import fused_bn
     net.train()
-    for k in range(10):
-        step(k)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(steps):
-        step(k)
-    torch.cuda.synchronize()
+    was = fused_bn.enabled(False)            # the reference's networks run torch's own BatchNorm / ReLU / add launches
+    try:
+        for k in range(10):
+            step(k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            step(k)
+        torch.cuda.synchronize()
+    finally:
+        fused_bn.enabled(was)
     t_step = (time.perf_counter() - t0) / steps
     t0 = time.perf_counter()
     snap = copy.deepcopy(net.cpu())

@@ -23,6 +23,7 @@
 // needed. Deterministic. In double there is no cancellation in s2/n - mean^2 up to |mean| / std ~ 1e6.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/ursa_hip.h"
 
@@ -558,7 +559,8 @@ inline int bn_plan(int64_t N, int64_t C, int64_t HW, bool vec_ok, BnPlan* p)
     const int V = (vec_ok && (HW & 3) == 0) ? 4 : 1;
     const int64_t hw = HW / V;
     const int64_t per_ch = N * hw;
-    int64_t S = (kBnTargetWgs + C - 1) / C;
+    static const int target = [] { const char* e = getenv("URSA_BN_TARGET_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : kBnTargetWgs; }();
+    int64_t S = (target + C - 1) / C;      // URSA_BN_TARGET_WGS: geometry experiments (tools/exp/bn_fused_bench.py)
     if (S > kBnMaxSplit) S = kBnMaxSplit;
     if (S < 1) S = 1;
     int64_t chunk = (per_ch + S - 1) / S;

@@ -103,9 +103,13 @@ class _AddBNReLUTrain(torch.autograd.Function):
 
 
 def _fusable(bn, x):
+    """Plain BatchNorm1d/2d/3d (SyncBatchNorm's statistics span processes: stock path) with affine parameters on a
+    contiguous fp32 [N, C, *] HIP tensor; the launch grid carries the channel index in its y dimension."""
     return (_on and x.is_cuda and x.dtype == torch.float32 and x.dim() >= 3 and x.is_contiguous() and x.numel() > 0
-            and isinstance(bn, torch.nn.modules.batchnorm._BatchNorm) and bn.affine
-            and bn.weight.dtype == torch.float32 and bn.weight.device == x.device)
+            and x.shape[1] <= 65535
+            and isinstance(bn, torch.nn.modules.batchnorm._BatchNorm) and not isinstance(bn, torch.nn.SyncBatchNorm)
+            and bn.affine and bn.weight.dtype == torch.float32 and bn.weight.device == x.device
+            and bn.weight.is_contiguous() and bn.bias.is_contiguous())
 
 
 def _stock(bn, x, relu):
