@@ -20,7 +20,7 @@ DEV = torch.device('cuda', 0)
 # convolutions differ by ~1e-6, so a pre-activation within that of zero opens its ReLU gate on one device and not on the
 # other; every such gate moves the gradients it feeds by ~1/sqrt(N*H*W) and the trajectories apart, which creates more
 # of them: tools/exp/g9_gate_diag.py counts 3 (K6 launches) / 2 (MIOpen's BatchNorm launches) differing gates of 9.4M in
-# the first step and 385 / 112 of 37.7M over the four, and 1.12e-5 / 2.9e-6 on the predictive — for arithmetic that is
+# the first step and 385 / 113 of 37.7M over the four, and 1.12e-5 / 2.9e-6 on the predictive — for arithmetic that is
 # torch's CPU BatchNorm bit for bit given the same input (test_fused_bn_gpu.py). Which side of 1e-5 a 4-step run lands on
 # is decided by where those gates fall, not by the implementation; one step with equal gates is held to 1e-5 in
 # bench.py's parity leg, runs without BatchNorm (LeNet-5 below, cyclic samplers, SWAG, SGD, MCdropout) stay at 1e-5 / 1e-4.
