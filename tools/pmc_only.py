@@ -13,75 +13,81 @@ def note(pattern, label, alg_bytes, **kw):
     manifest.append(dict(pattern=pattern, label=label, algorithmic_bytes_per_launch=alg_bytes, **kw))
 
 
-# K1 at the PreResNet-20 arena size through the control-block entry point (the workload's launch)
-n = 273408
-th, g, m = (torch.randn(n, device='cuda') for _ in range(3))
-c = _native.StepCtl(lr=0.1, mu=0.5, c_wd=8e-5, c_noise=0.3, n_train=50000.0, flags=0x1 | 0x8 | 0x20, seed=1, step=0)     # NOISE | WD | ADVANCE
-ctl = torch.frombuffer(bytearray(bytes(c)), dtype=torch.uint8).cuda()
-for _ in range(20):
-    K.sgmcmc_step_ctl(th, g, m, ctl)               # advances its own control block
-note('k_sgmcmc_step_ctl', 'K1 workload size (control block)', 20 * n, elements=n)
-# K1 at 2^26
-n = 1 << 26
-th, g, m = (torch.randn(n, device='cuda') for _ in range(3))
-for k in range(10):
-    K.sgmcmc_step(th, g, m, lr=0.1, mu=0.5, c_wd=8e-5, c_noise=0.3, n_train=50000.0, flags=0x1 | 0x8, seed=1, step=k)
-note('k_sgmcmc_step<', 'K1 2^26 elements (SGHMC + Philox)', 20 * n, elements=n)
-# K2 / K3 at the WideResNet-28-10 arena size
-n = 36546980 + (-36546980) % 4
-out = torch.empty(n, device='cuda')
-m[:n].abs_().add_(th[:n] * th[:n])
-sd = torch.empty(n, device='cuda')
-for k in range(10):
-    K.swag_std(sd, th[:n], m[:n], var_clamp=1e-30, scale=1.0)
-note('k_swag_std_v', 'K3 standard deviation, once per ensemble (WideResNet-28-10)', 12 * n, elements=n)
-for k in range(10):
-    K.swag_draw_std(out, th[:n], sd, seed=3, draw=k)
-note('k_swag_draw_std_v', 'K3 WideResNet-28-10 member draw (Philox, std stored)', 12 * n, elements=n)
-for k in range(10):
-    K.swag_draw(out, th[:n], m[:n], var_clamp=1e-30, scale=1.0, seed=3, draw=k)
-note('k_swag_draw_v', 'K3 fused single-draw form (Philox)', 12 * n, elements=n)
-del sd
-for k in range(10):
-    K.swag_collect(th[:n], m[:n], g[:n], decay=0.75, denom=4.0)
-note('k_swag_collect', 'K2 WideResNet-28-10 moment update', 20 * n, elements=n)
-del th, g, m, out
-# K1: 4 PreResNet-20 chains in one self-advancing multi-chain launch
-nc = 273408
-ths, gs, ms_ = (torch.randn(4, nc, device='cuda') for _ in range(3))
-blocks = b''.join(bytes(_native.StepCtl(lr=0.1, mu=0.5, c_wd=8e-5, c_noise=0.3, n_train=50000.0, flags=0x1 | 0x8 | 0x20, seed=1 + k, step=0))
-                  for k in range(4))
-ctl4 = torch.frombuffer(bytearray(blocks), dtype=torch.uint8).cuda()
-for _ in range(20):
-    K.sgmcmc_step_multi(ths, gs, ms_, ctl4)
-manifest.append(dict(pattern='k_sgmcmc_step_ctl', label='K1 4 chains x 273,408 in one launch', algorithmic_bytes_per_launch=20 * nc * 4,
-                     blocks=4 * ((nc // 4 + 1023) // 1024), wg=1024, elements_total=4 * nc))     # multi-chain launches: 1,024-thread workgroups
-del ths, gs, ms_
-# K4 in the launch forms inference/hmc.py issues, at PreResNet-164's size and at 2^26
-ws, acc = torch.zeros(2048, device='cuda'), torch.zeros(1, device='cuda')
-for nn, tag in ((1726400, '1.73M'), (1 << 26, '2^26')):
-    t4, p4, g4 = (torch.randn(nn, device='cuda') for _ in range(3))
-    for _ in range(10):
-        K.leapfrog(t4, p4, g4, kick_coef=1e-4, step_size=2e-4, inv_mass=1.0, flags=0x3)
-    note('k_leapfrog_v', f'K4 fused kick+drift {tag}', 20 * nn, elements=nn)
-    for _ in range(10):
-        K.leapfrog(None, p4, g4, kick_coef=-1e-4, step_size=2e-4, inv_mass=1.0, flags=0x1, kinetic_out=acc, ws=ws)
-    manifest.append(dict(pattern='k_leapfrog<', label=f'K4 kick + kinetic-energy reduction {tag}', algorithmic_bytes_per_launch=12 * nn,
-                         elements_total=nn, grid_threads=min((nn // 4 + 255) // 256, 2048) * 256))
-    del t4, p4, g4
-# K5 at the shapes the tasks feed it
-for (S, B, C) in ((50, 10000, 10), (20, 9984, 10), (30, 10000, 100)):      # 9,984 rows: a grid of its own in the counter CSVs
-    z = torch.randn(S, B, C, device='cuda') * 3
-    p, e = torch.zeros(B, C, device='cuda'), torch.zeros(B, device='cuda')
-    for _ in range(10):
-        K.bma_accumulate(z, p, e, one_minus_gamma=0.9999, gamma_over_c=1e-4 / C, smoothed=False)
-    grid = (B + 15) // 16 if C <= 16 else (B + 3) // 4
-    wg = 64 * (4 if S >= 12 else 2 if S >= 5 else 1) if C <= 16 else 256
-    note('k_bma_', f'K5 S={S} B={B} C={C}', 4 * S * B * C + 8 * B * (C + 1), shape=[S, B, C], blocks=grid, wg=wg)
-del z, p, e
+# `python3 tools/pmc_only.py <manifest.json> k6_workload`: only K6 at the workload's own first / last stage (their launch
+# grids coincide with the roofline-sized shapes' below, and the summary keys counters by kernel + grid: a pass of their own)
+K6_ONLY = len(sys.argv) > 2 and sys.argv[2] == 'k6_workload'
+K6_SHAPES = ((((128, 16, 32, 32), False), ((128, 64, 8, 8), True)) if K6_ONLY
+             else (((1024, 64, 32, 32), False), ((512, 640, 8, 8), True)))
+if not K6_ONLY:
+    # K1 at the PreResNet-20 arena size through the control-block entry point (the workload's launch)
+    n = 273408
+    th, g, m = (torch.randn(n, device='cuda') for _ in range(3))
+    c = _native.StepCtl(lr=0.1, mu=0.5, c_wd=8e-5, c_noise=0.3, n_train=50000.0, flags=0x1 | 0x8 | 0x20, seed=1, step=0)     # NOISE | WD | ADVANCE
+    ctl = torch.frombuffer(bytearray(bytes(c)), dtype=torch.uint8).cuda()
+    for _ in range(20):
+        K.sgmcmc_step_ctl(th, g, m, ctl)               # advances its own control block
+    note('k_sgmcmc_step_ctl', 'K1 workload size (control block)', 20 * n, elements=n)
+    # K1 at 2^26
+    n = 1 << 26
+    th, g, m = (torch.randn(n, device='cuda') for _ in range(3))
+    for k in range(10):
+        K.sgmcmc_step(th, g, m, lr=0.1, mu=0.5, c_wd=8e-5, c_noise=0.3, n_train=50000.0, flags=0x1 | 0x8, seed=1, step=k)
+    note('k_sgmcmc_step<', 'K1 2^26 elements (SGHMC + Philox)', 20 * n, elements=n)
+    # K2 / K3 at the WideResNet-28-10 arena size
+    n = 36546980 + (-36546980) % 4
+    out = torch.empty(n, device='cuda')
+    m[:n].abs_().add_(th[:n] * th[:n])
+    sd = torch.empty(n, device='cuda')
+    for k in range(10):
+        K.swag_std(sd, th[:n], m[:n], var_clamp=1e-30, scale=1.0)
+    note('k_swag_std_v', 'K3 standard deviation, once per ensemble (WideResNet-28-10)', 12 * n, elements=n)
+    for k in range(10):
+        K.swag_draw_std(out, th[:n], sd, seed=3, draw=k)
+    note('k_swag_draw_std_v', 'K3 WideResNet-28-10 member draw (Philox, std stored)', 12 * n, elements=n)
+    for k in range(10):
+        K.swag_draw(out, th[:n], m[:n], var_clamp=1e-30, scale=1.0, seed=3, draw=k)
+    note('k_swag_draw_v', 'K3 fused single-draw form (Philox)', 12 * n, elements=n)
+    del sd
+    for k in range(10):
+        K.swag_collect(th[:n], m[:n], g[:n], decay=0.75, denom=4.0)
+    note('k_swag_collect', 'K2 WideResNet-28-10 moment update', 20 * n, elements=n)
+    del th, g, m, out
+    # K1: 4 PreResNet-20 chains in one self-advancing multi-chain launch
+    nc = 273408
+    ths, gs, ms_ = (torch.randn(4, nc, device='cuda') for _ in range(3))
+    blocks = b''.join(bytes(_native.StepCtl(lr=0.1, mu=0.5, c_wd=8e-5, c_noise=0.3, n_train=50000.0, flags=0x1 | 0x8 | 0x20, seed=1 + k, step=0))
+                      for k in range(4))
+    ctl4 = torch.frombuffer(bytearray(blocks), dtype=torch.uint8).cuda()
+    for _ in range(20):
+        K.sgmcmc_step_multi(ths, gs, ms_, ctl4)
+    manifest.append(dict(pattern='k_sgmcmc_step_ctl', label='K1 4 chains x 273,408 in one launch', algorithmic_bytes_per_launch=20 * nc * 4,
+                         blocks=4 * ((nc // 4 + 1023) // 1024), wg=1024, elements_total=4 * nc))     # multi-chain launches: 1,024-thread workgroups
+    del ths, gs, ms_
+    # K4 in the launch forms inference/hmc.py issues, at PreResNet-164's size and at 2^26
+    ws, acc = torch.zeros(2048, device='cuda'), torch.zeros(1, device='cuda')
+    for nn, tag in ((1726400, '1.73M'), (1 << 26, '2^26')):
+        t4, p4, g4 = (torch.randn(nn, device='cuda') for _ in range(3))
+        for _ in range(10):
+            K.leapfrog(t4, p4, g4, kick_coef=1e-4, step_size=2e-4, inv_mass=1.0, flags=0x3)
+        note('k_leapfrog_v', f'K4 fused kick+drift {tag}', 20 * nn, elements=nn)
+        for _ in range(10):
+            K.leapfrog(None, p4, g4, kick_coef=-1e-4, step_size=2e-4, inv_mass=1.0, flags=0x1, kinetic_out=acc, ws=ws)
+        manifest.append(dict(pattern='k_leapfrog<', label=f'K4 kick + kinetic-energy reduction {tag}', algorithmic_bytes_per_launch=12 * nn,
+                             elements_total=nn, grid_threads=min((nn // 4 + 255) // 256, 2048) * 256))
+        del t4, p4, g4
+    # K5 at the shapes the tasks feed it
+    for (S, B, C) in ((50, 10000, 10), (20, 9984, 10), (30, 10000, 100)):      # 9,984 rows: a grid of its own in the counter CSVs
+        z = torch.randn(S, B, C, device='cuda') * 3
+        p, e = torch.zeros(B, C, device='cuda'), torch.zeros(B, device='cuda')
+        for _ in range(10):
+            K.bma_accumulate(z, p, e, one_minus_gamma=0.9999, gamma_over_c=1e-4 / C, smoothed=False)
+        grid = (B + 15) // 16 if C <= 16 else (B + 3) // 4
+        wg = 64 * (4 if S >= 12 else 2 if S >= 5 else 1) if C <= 16 else 256
+        note('k_bma_', f'K5 S={S} B={B} C={C}', 4 * S * B * C + 8 * B * (C + 1), shape=[S, B, C], blocks=grid, wg=wg)
+    del z, p, e
 # K6 relu(bn(x)): the two-launch form on a 268 MB activation (PreResNet-164's first stage at the HMC batch: beyond the
 # Infinity Cache) and the one-pass form on an 84 MB one (WideResNet-28-10's last stage at 4x the batch)
-for shape, one in (((1024, 64, 32, 32), False), ((512, 640, 8, 8), True)):
+for shape, one in K6_SHAPES:
     C = shape[1]
     x, dy = torch.randn(shape, device='cuda'), torch.randn(shape, device='cuda')
     y, dx = torch.empty_like(x), torch.empty_like(x)
