@@ -38,6 +38,25 @@ def test_argument_errors_do_not_need_a_gpu():
     assert lib.ursa_sgmcmc_step_f32(None, None, None, None, None, 0, 0, 0, 0, 0, 1, 0, 0, 0, None) == 0     # n == 0: no-op
     assert lib.ursa_bma_accumulate_f32(None, None, None, None, None, 1, 1, 0, 0, 0, 0, None) == -5           # C out of range
     assert lib.ursa_bma_accumulate_f32(None, None, None, None, None, 1, 1, 2000, 0, 0, 0, None) == -5
+    # K6: flags, sizes, NULLs, the addend / z_out pairing and torch's "more than 1 value per channel" rule
+    import ctypes
+    buf = (ctypes.c_float * 64)()                       # a 16-byte aligned HOST address: never dereferenced before the checks
+    p = ctypes.addressof(buf)
+    p -= p % 16
+    fwd, bwd, ev = lib.ursa_bn_relu_fwd_f32, lib.ursa_bn_relu_bwd_f32, lib.ursa_bn_relu_eval_f32
+    assert fwd(None, None, None, None, None, None, None, None, None, None, None, 2, 3, 4, 1e-5, 0.1, 0x8, None) == -4   # EFLAGS
+    assert fwd(p, None, None, p, p, p, None, None, p, p, p, -1, 3, 4, 1e-5, 0.1, 0, None) == -2                         # ESIZE
+    assert fwd(None, None, None, None, None, None, None, None, None, None, None, 0, 3, 4, 1e-5, 0.1, 0, None) == 0      # empty: no-op
+    assert fwd(None, None, None, None, None, None, None, None, None, None, None, 2, 3, 4, 1e-5, 0.1, 1, None) == -1     # ENULL
+    assert fwd(p, p, None, p, p, p, None, None, p, p, p, 2, 3, 4, 1e-5, 0.1, 1, None) == -1          # addend without z_out
+    assert fwd(p, None, None, p, p, p, p, None, p, p, p, 2, 3, 4, 1e-5, 0.1, 1, None) == -1          # running_mean without running_var
+    assert fwd(p, None, None, p, p, p, None, None, p, p, p, 1, 3, 1, 1e-5, 0.1, 1, None) == -5       # one value per channel
+    assert fwd(p, None, None, p, p, p, None, None, p, p, p, 2, 70000, 4, 1e-5, 0.1, 1, None) == -2   # channels beyond the grid
+    assert fwd(p + 2, None, None, p, p, p, None, None, p, p, p, 2, 3, 4, 1e-5, 0.1, 1, None) == -3   # EALIGN
+    assert bwd(None, None, None, None, None, None, None, None, None, None, None, 2, 3, 4, 1, None) == -1
+    assert bwd(None, None, None, None, None, None, None, None, None, None, None, 2, 3, 4, 0x10, None) == -4
+    assert ev(None, None, None, None, None, None, None, None, 2, 3, 4, 1e-5, 1, None) == -1
+    assert ev(p, None, p, p, p, p, p, p, 2, 3, 4, 1e-5, 1, None) == -1                              # z_out without addend
 
 
 def test_wrappers_refuse_cpu_tensors():
