@@ -333,6 +333,52 @@ int oracle_bn_relu_fwd_f32(const float* x, float* y, const float* gamma, const f
     return 0;
 }
 
+/* gate of element o: listed (ascending gate_idx, INT32_MAX = padding) -> gate_open, else the forward's own
+ * (twin of ursa_bn_relu_bwd_gated_f32, include/ursa_hip.h: the parity instrument) */
+static int oracle_gate(int computed, int64_t o, const int32_t* gate_idx, const uint8_t* gate_open, int64_t n_gates)
+{
+    int64_t lo = 0, hi = n_gates;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) / 2;
+        if ((int64_t)gate_idx[mid] < o) lo = mid + 1; else hi = mid;
+    }
+    return (lo < n_gates && (int64_t)gate_idx[lo] == o) ? gate_open[lo] != 0 : computed;
+}
+
+int oracle_bn_relu_bwd_gated_f32(const float* x, const float* dy, float* dx, const float* gamma, const float* beta,
+                                 const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, int64_t N,
+                                 int64_t C, int64_t HW, int relu, const int32_t* gate_idx, const uint8_t* gate_open,
+                                 int64_t n_gates)
+{
+    const double n = (double)N * (double)HW;
+    for (int64_t c = 0; c < C; ++c) {
+        const float mean = save_mean[c], invstd = save_invstd[c], w = gamma[c];
+        const float alpha = invstd * w;
+        const float shift = fmaf(-mean, alpha, beta[c]);
+        double sum = 0.0, dotp = 0.0;
+        for (int64_t i = 0; i < N; ++i)
+            for (int64_t j = 0; j < HW; ++j) {
+                const int64_t o = (i * C + c) * HW + j;
+                const int open = oracle_gate(fmaf(x[o], alpha, shift) > 0.0f, o, gate_idx, gate_open, n_gates);
+                const float g = (relu && !open) ? 0.0f : dy[o];
+                sum += (double)g;
+                dotp += (double)g * ((double)x[o] - (double)mean);
+            }
+        const float gm = (float)(sum / n);
+        const float k = (float)(dotp * (double)invstd * (double)invstd / n);
+        for (int64_t i = 0; i < N; ++i)
+            for (int64_t j = 0; j < HW; ++j) {
+                const int64_t o = (i * C + c) * HW + j;
+                const int open = oracle_gate(fmaf(x[o], alpha, shift) > 0.0f, o, gate_idx, gate_open, n_gates);
+                const float g = (relu && !open) ? 0.0f : dy[o];
+                dx[o] = (((g - gm) - (x[o] - mean) * k) * invstd) * w;
+            }
+        dbeta[c] = (float)sum;
+        dgamma[c] = (float)(dotp * (double)invstd);
+    }
+    return 0;
+}
+
 int oracle_bn_relu_bwd_f32(const float* x, const float* dy, float* dx, const float* gamma, const float* beta,
                            const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, int64_t N,
                            int64_t C, int64_t HW, int relu)

@@ -30,6 +30,7 @@ _L.oracle_leapfrog_f32.argtypes = [_vp, _vp, _vp, _i64, _f, _f, _f, _u32, _vp]
 _L.oracle_sumsq_f32.argtypes = [_vp, _i64, _vp]
 _L.oracle_bn_relu_fwd_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f, _f, _i32]
 _L.oracle_bn_relu_bwd_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32]
+_L.oracle_bn_relu_bwd_gated_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _i64]
 _L.oracle_bn_relu_eval_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f, _i32]
 
 
@@ -120,10 +121,16 @@ def bn_relu_fwd(x, gamma, beta, running_mean=None, running_var=None, *, eps=1e-5
     return y, sm, si
 
 
-def bn_relu_bwd(x, dy, gamma, beta, save_mean, save_invstd, *, relu=True):
-    """K6 backward: returns (dx, dgamma, dbeta)."""
+def bn_relu_bwd(x, dy, gamma, beta, save_mean, save_invstd, *, relu=True, gates=None):
+    """K6 backward: returns (dx, dgamma, dbeta). gates=(idx int32 ascending, open uint8): listed elements' ReLU gates given."""
     N, C, HW = _bn_dims(x)
     dx, dg, db = np.empty_like(x), np.empty(C, np.float32), np.empty(C, np.float32)
+    if gates is not None:
+        gi, go = np.ascontiguousarray(gates[0], np.int32), np.ascontiguousarray(gates[1], np.uint8)
+        rc = _L.oracle_bn_relu_bwd_gated_f32(_p(x), _p(dy), _p(dx), _p(gamma), _p(beta), _p(save_mean), _p(save_invstd),
+                                             _p(dg), _p(db), N, C, HW, int(relu), gi.ctypes.data, go.ctypes.data, gi.size)
+        assert rc == 0
+        return dx, dg, db
     rc = _L.oracle_bn_relu_bwd_f32(_p(x), _p(dy), _p(dx), _p(gamma), _p(beta), _p(save_mean), _p(save_invstd), _p(dg),
                                    _p(db), N, C, HW, int(relu))
     assert rc == 0

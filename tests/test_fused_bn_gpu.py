@@ -462,3 +462,62 @@ def test_one_pass_form_equals_two_launch_form(K, shape, relu):
                 assert torch.equal(t1[:, ok], t2[:, ok]), name
             else:
                 assert torch.equal(t1, t2), name
+
+
+@pytest.mark.parametrize('shape', [(128, 16, 32, 32), (64, 64, 8, 8), (7, 5, 3, 3), (3, 1, 257, 4)])
+@pytest.mark.parametrize('residual', [False, True])
+def test_gated_backward_equals_oracle(K, shape, residual):
+    """ursa_bn_relu_bwd_gated_f32 (the parity instrument, include/ursa_hip.h): listed gates are taken as given, unlisted
+    ones recomputed; == the oracle's gated backward (dgamma / dbeta: both round exact double sums once; dx: same
+    floats), == the plain backward when the list is empty, only padding, or every listed gate is the element's own."""
+    import oracle_lib as O
+    from ursabench_amd import _native
+    g = torch.Generator().manual_seed(11)
+    C = shape[1]
+    x = torch.randn(shape, generator=g) * 1.3 + 0.2
+    dy, dz = torch.randn(shape, generator=g), torch.randn(shape, generator=g)
+    w, b = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    y, sm, si = O.bn_relu_fwd(x.numpy(), w.numpy(), b.numpy(), momentum=0.0)
+    n = x.numel()
+    pick = np.sort(np.random.default_rng(5).choice(n, size=min(n, 97), replace=False)).astype(np.int32)
+    own = (y.reshape(-1)[pick] > 0).astype(np.uint8)
+    flipped = own.copy()
+    flipped[::2] ^= 1
+    pad = np.full(31, 2 ** 31 - 1, np.int32)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    dX, dDY, dW, dB, dSM, dSI = (t.cuda() for t in (x, dy, w, b, torch.from_numpy(sm), torch.from_numpy(si)))
+    dDZ = dz.cuda() if residual else None
+    ws = torch.empty(_native.bn_ws_floats(C), device='cuda')
+
+    def run(gates):
+        dx = torch.full_like(dX, float('nan'))
+        dg, db = torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
+        K.bn_relu_backward(dX, dDY, dx, dW, dB, dSM, dSI, dg, db, ws, relu=True, dz=dDZ, two_launch=True, gates=gates)
+        return dx.cpu().numpy(), dg.cpu().numpy(), db.cpu().numpy()
+    plain = run(None)
+    for gates in ((dev(pad[:0]), dev(np.zeros(0, np.uint8))), (dev(pad), dev(np.ones(31, np.uint8))),
+                  (dev(np.concatenate([pick, pad])), dev(np.concatenate([own, np.ones(31, np.uint8)])))):
+        for a, c in zip(plain, run(gates)):
+            assert np.array_equal(a, c)
+    got = run((dev(np.concatenate([pick, pad])), dev(np.concatenate([flipped, np.zeros(31, np.uint8)]))))
+    odx, odg, odb = O.bn_relu_bwd(x.numpy(), dy.numpy(), w.numpy(), b.numpy(), sm, si, gates=(pick, flipped))
+    if residual:
+        odx = odx + dz.numpy()
+    assert np.array_equal(got[1], odg) and np.array_equal(got[2], odb)
+    np.testing.assert_allclose(got[0], odx, rtol=0, atol=2e-7 * float(np.abs(odx).max()))
+    assert not np.array_equal(got[0], plain[0])
+
+
+def test_gated_backward_argument_errors(K):
+    from ursabench_amd import _native
+    x = torch.randn(4, 3, 2, 2, device='cuda')
+    C = 3
+    v = torch.ones(C, device='cuda')
+    ws = torch.empty(_native.bn_ws_floats(C), device='cuda')
+    gi, go = torch.zeros(2, dtype=torch.int32, device='cuda'), torch.zeros(2, dtype=torch.uint8, device='cuda')
+    with pytest.raises(ValueError):
+        K.bn_relu_backward(x, x, torch.empty_like(x), v, v, v, v, v.clone(), v.clone(), ws, relu=False, gates=(gi, go))   # needs RELU
+    with pytest.raises(ValueError):
+        K.bn_relu_backward(x, x, torch.empty_like(x), v, v, v, v, v.clone(), v.clone(), ws, relu=True, gates=(gi, go[:1]))
+    with pytest.raises(ValueError):
+        K.bn_relu_backward(x, x, torch.empty_like(x), v, v, v, v, v.clone(), v.clone(), ws, relu=True, gates=(gi.long(), go))

@@ -422,6 +422,75 @@ def gen_e2e_preresnet():
     print('G9 e2e_preresnet8 steps', out['eps'].shape)
 
 
+PRERESNET8_SEEDS = 8
+
+
+def preresnet8_seed_inputs(sd):
+    """Inputs of seed `sd` of G16 (the GPU tests regenerate them from the same CPU generators)."""
+    g = torch.Generator().manual_seed(9000 + sd)
+    xtr, ytr = torch.randn(128, 3, 32, 32, generator=g), torch.randint(0, 10, (128,), generator=g)
+    xte, yte = torch.randn(64, 3, 32, 32, generator=g), torch.randint(0, 10, (64,), generator=g)
+    return xtr, ytr, xte, yte
+
+
+def gen_e2e_preresnet_seeds():
+    """G16: the reference's SGHMC on its own PreResNet-8 for 8 seeds, 4 samples of ONE 128-row minibatch step each (so
+    the ensemble IS the trajectory after 1, 2, 3, 4 steps), with, per step and per BatchNorm call,
+    the pre-activations the reference computed within 1e-4 of zero and the ReLU gate it took there. The GPU tests
+    (tests/test_gate_parity_gpu.py) replay every seed and assert north_star's 1e-5 on the predictive after every step
+    that took the reference's gates, naturally or with the listed gates given to the backward launch; they also
+    compare K6 with MIOpen's BatchNorm launches seed by seed. Only outputs travel: the inputs, the initial weights and
+    the Langevin noise are regenerated from torch's CPU generator (checksums in the fixture); the noise of step k is
+    what the reference's own `torch.randn_like` calls (optim_sghmc.py:64) draw after torch.manual_seed(5000+100*seed+k)."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import copy
+    from gate_lists import NearZeroGates, TAU, pack
+    hyp = {'lr': 0.05, 'prior_std': 0.5, 'num_samples': 4, 'alpha': 0.5, 'burn_in_epochs': 0}
+    out = {'hyper': json.dumps(hyp), 'seeds': np.arange(PRERESNET8_SEEDS), 'tau': np.array(TAU)}
+    for sd in range(PRERESNET8_SEEDS):
+        xtr, ytr, xte, yte = preresnet8_seed_inputs(sd)
+        train = DataLoader(TensorDataset(xtr, ytr), batch_size=128, shuffle=False)
+        test = DataLoader(TensorDataset(xte, yte), batch_size=64, shuffle=False)
+        util.set_random_seed(sd)
+        net = models.PreResNet8.base(num_classes=10, depth=8)
+        util.set_random_seed(sd)
+        ours = our_models.PreResNet(10, 8)
+        assert np.array_equal(flat(net.parameters()), flat(ours.parameters())), 'our class initialises differently'
+        theta0 = flat(net.parameters())
+        log = NearZeroGates(net)
+        s = inference.SGHMC(dict(hyp), net, train)
+        orig, eps_sums, steps = s.optimizer.step, [], []
+
+        def step(add_langevin_noise=True, closure=None, _k=[0], _sd=sd, _orig=orig):
+            steps.append(log.take())
+            torch.manual_seed(5000 + 100 * _sd + _k[0])
+            state = torch.get_rng_state()
+            eps_sums.append(float(sum(torch.randn_like(p).double().sum() for p in s.optimizer.param_groups[0]['params'])))
+            torch.set_rng_state(state)
+            _k[0] += 1
+            return _orig(add_langevin_noise=add_langevin_noise, closure=closure)
+        s.optimizer.step = step
+        with quiet():
+            ens = s.sample()
+        assert len(ens) == 4 and len(steps) == 4 and all(len(c) == 7 for c in steps)
+        probas, ents = [], []
+        for m in ens:
+            pred = tasks.Prediction({'in_distribution_test': test}, 10, torch.device('cpu'), 'ALL')
+            pred.update_statistics([m], output_performance=False)
+            probas.append(pred.ensemble_proba.numpy().copy())
+            ents.append(pred.expected_data_uncertainty.numpy().copy())
+        pre = f's{sd}/'
+        out[pre + 'checksums'] = np.array([float(xtr.double().sum()), float(ytr.sum()), float(xte.double().sum()),
+                                           float(yte.sum()), float(theta0.astype(np.float64).sum())] + eps_sums)
+        out[pre + 'proba_step'], out[pre + 'ent_step'] = np.stack(probas), np.stack(ents)
+        out[pre + 'theta_final_sum'] = np.array(float(flat(ens[-1].parameters()).astype(np.float64).sum()))
+        for k, v in pack(steps).items():
+            out[pre + k] = v
+        print('G16 seed', sd, 'near-zero pre-activations per step', out[pre + 'gate_counts'].sum(1).tolist(),
+              'of', int(out[pre + 'numel'].sum()))
+    np.savez_compressed(os.path.join(OUT, 'e2e_preresnet8_seeds.npz'), **out)
+
+
 def gen_e2e_cyclic():
     """G12: the reference's cSGHMC and cSGLD end to end on a tiny MLP: per-iteration cyclical lr, noise only in the
     tail of each cycle, samples only from the last epochs of a cycle — parameters of every emitted sample with the
@@ -661,8 +730,8 @@ def gen_model_keys():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['k1', 'sgd', 'sched', 'csghmc', 'tasks', 'swag', 'swag_e2e', 'e2e', 'e2e_preresnet', 'mcdropout', 'columns', 'cyclic', 'cyclic_update_hyp', 'sgd_sampler', 'hmc_wrapper', 'keys']
-    fns = dict(k1=gen_k1, sgd=gen_sgd, swag_e2e=gen_swag_e2e, e2e_preresnet=gen_e2e_preresnet, sched=gen_schedules, csghmc=gen_csghmc, tasks=gen_tasks, swag=gen_swag, e2e=gen_e2e,
+    which = sys.argv[1:] or ['k1', 'sgd', 'sched', 'csghmc', 'tasks', 'swag', 'swag_e2e', 'e2e', 'e2e_preresnet', 'e2e_preresnet_seeds', 'mcdropout', 'columns', 'cyclic', 'cyclic_update_hyp', 'sgd_sampler', 'hmc_wrapper', 'keys']
+    fns = dict(k1=gen_k1, sgd=gen_sgd, swag_e2e=gen_swag_e2e, e2e_preresnet=gen_e2e_preresnet, e2e_preresnet_seeds=gen_e2e_preresnet_seeds, sched=gen_schedules, csghmc=gen_csghmc, tasks=gen_tasks, swag=gen_swag, e2e=gen_e2e,
                keys=gen_model_keys, mcdropout=gen_mcdropout, columns=gen_experiment_columns, cyclic=gen_e2e_cyclic, cyclic_update_hyp=gen_cyclic_update_hyp, sgd_sampler=gen_sgd_sampler, hmc_wrapper=gen_hmc_wrapper)
     for w in which:
         fns[w]()

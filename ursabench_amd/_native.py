@@ -17,7 +17,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libursa_hip.so')
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # flags (mirror include/ursa_hip.h)
 STEP_NOISE, STEP_FIRST, STEP_ZERO_GRAD, STEP_WD, STEP_SGD, STEP_ADVANCE = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
@@ -55,6 +55,8 @@ SIGNATURES = {
     'ursa_bn_relu_fwd_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f, _f, _u32, _vp]),
     'ursa_bn_relu_eval_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f, _u32, _vp]),
     'ursa_bn_relu_bwd_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _u32, _vp]),
+    'ursa_bn_relu_bwd_gated_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _u32,
+                                                  _vp, _vp, _i64, _vp]),
 }
 
 
@@ -334,20 +336,32 @@ class HipKernels:
                 BN_RELU if relu else 0, _stream(dev))
         _check(self.lib, rc, 'ursa_bn_relu_eval_f32')
 
-    def bn_relu_backward(self, x, dy, dx, gamma, beta, save_mean, save_invstd, dgamma, dbeta, ws, *, relu=True, dz=None, two_launch=False):
-        """`x` is the tensor the forward normalised (z_out in the residual form); with `dz` the result is dx + dz."""
+    def bn_relu_backward(self, x, dy, dx, gamma, beta, save_mean, save_invstd, dgamma, dbeta, ws, *, relu=True, dz=None,
+                         two_launch=False, gates=None):
+        """`x` is the tensor the forward normalised (z_out in the residual form); with `dz` the result is dx + dz.
+        `gates=(idx int32 [n], open uint8 [n])`: the parity instrument ursa_bn_relu_bwd_gated_f32 - the ReLU gates of the
+        listed element offsets (ascending; INT32_MAX = padding) are taken from `open` instead of recomputed."""
         N, C, HW = self._bn_dims(x)
         dev, n = x.device, x.numel()
         if ws.numel() < bn_ws_floats(C):
             raise ValueError(f'ws must hold {bn_ws_floats(C)} floats')
-        with torch.cuda.device(dev):
-            rc = self.lib.ursa_bn_relu_bwd_f32(
-                _ptr(x, 'x'), _ptr(dy, 'dy', n, dev), _ptr(dz, 'dz', n, dev, optional=True), _ptr(dx, 'dx', n, dev),
-                _ptr(gamma, 'gamma', C, dev),
-                _ptr(beta, 'beta', C, dev), _ptr(save_mean, 'save_mean', C, dev),
+        args = (_ptr(x, 'x'), _ptr(dy, 'dy', n, dev), _ptr(dz, 'dz', n, dev, optional=True), _ptr(dx, 'dx', n, dev),
+                _ptr(gamma, 'gamma', C, dev), _ptr(beta, 'beta', C, dev), _ptr(save_mean, 'save_mean', C, dev),
                 _ptr(save_invstd, 'save_invstd', C, dev), _ptr(dgamma, 'dgamma', C, dev), _ptr(dbeta, 'dbeta', C, dev),
-                _ptr(ws, 'ws', None, dev), N, C, HW, (BN_RELU if relu else 0) | (BN_TWO_LAUNCH if two_launch else 0),
-                _stream(dev))
+                _ptr(ws, 'ws', None, dev), N, C, HW, (BN_RELU if relu else 0) | (BN_TWO_LAUNCH if two_launch else 0))
+        if gates is not None:
+            gi, go = gates
+            for t, dt, nm in ((gi, torch.int32, 'gate idx'), (go, torch.uint8, 'gate open')):
+                if not (isinstance(t, torch.Tensor) and t.is_cuda and t.device == dev and t.dtype == dt and t.is_contiguous()):
+                    raise ValueError(f'{nm} must be a contiguous {dt} tensor on {dev}')
+            if gi.numel() != go.numel():
+                raise ValueError('gate idx / open lengths differ')
+            with torch.cuda.device(dev):
+                rc = self.lib.ursa_bn_relu_bwd_gated_f32(*args, gi.data_ptr(), go.data_ptr(), gi.numel(), _stream(dev))
+            _check(self.lib, rc, 'ursa_bn_relu_bwd_gated_f32')
+            return
+        with torch.cuda.device(dev):
+            rc = self.lib.ursa_bn_relu_bwd_f32(*args, _stream(dev))
         _check(self.lib, rc, 'ursa_bn_relu_bwd_f32')
 
 

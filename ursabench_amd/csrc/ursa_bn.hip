@@ -261,13 +261,33 @@ __global__ __launch_bounds__(kBnBlock) void k_bn_eval(const float* __restrict__ 
     }
 }
 
+// ---- parity instrument (ursa_bn_relu_bwd_gated_f32): a sorted list of element offsets whose ReLU gate is GIVEN instead
+//      of recomputed - the reference CPU run's gates at the pre-activations within rounding of zero, where MIOpen's and
+//      oneDNN's convolutions (inputs of this layer) decide the sign by their last bits. Binary search per element: this
+//      form is for comparisons against the reference, never for the timed path.
+struct BnGates {
+    const int32_t* idx;     // ascending element offsets into the [N, C, HW] tensor; entries == INT32_MAX are padding
+    const uint8_t* open;    // 1: dy passes, 0: blocked
+    int n;
+};
+
+__device__ inline bool bn_gate(bool computed, int64_t e, const BnGates& gt)
+{
+    int lo = 0, hi = gt.n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if ((int64_t)gt.idx[mid] < e) lo = mid + 1; else hi = mid;
+    }
+    return (lo < gt.n && (int64_t)gt.idx[lo] == e) ? gt.open[lo] != 0 : computed;
+}
+
 // ---- backward, launch 1: partial sums of dy' and dy' * (x - mean), in double (dy' = dy where the ReLU was open) ------
-template <int V, bool RELU>
+template <int V, bool RELU, bool GATED = false>
 __global__ __launch_bounds__(kBnBlock) void k_bn_bwd_reduce(const float* __restrict__ x, const float* __restrict__ dy,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const float* __restrict__ save_mean,
                                                             const float* __restrict__ save_invstd,
-                                                            double2* __restrict__ partial, BnGeom g)
+                                                            double2* __restrict__ partial, BnGeom g, BnGates gt = BnGates{})
 {
     using T = typename Vec<V>::T;
     __shared__ double sh[2 * kBnBlock / 64];
@@ -284,15 +304,18 @@ __global__ __launch_bounds__(kBnBlock) void k_bn_bwd_reduce(const float* __restr
     int64_t i = lo + threadIdx.x;
     for (; i + kBnBlock < hi; i += 2 * kBnBlock) {           // four loads in flight
         T a[2], b[2];
+        int64_t o[2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) { const int64_t o = bn_off(g, c, i + u * kBnBlock); a[u] = xv[o]; b[u] = dv[o]; }
+        for (int u = 0; u < 2; ++u) { o[u] = bn_off(g, c, i + u * kBnBlock); a[u] = xv[o[u]]; b[u] = dv[o[u]]; }
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int k = 0; k < V; ++k) {
                 const float xe = comp(a[u], k);
                 float ge = comp(b[u], k);
-                if (RELU && !(fmaf(xe, scale, shift) > 0.f)) ge = 0.f;
+                bool open = fmaf(xe, scale, shift) > 0.f;
+                if (GATED) open = bn_gate(open, o[u] * V + k, gt);
+                if (RELU && !open) ge = 0.f;
                 s1 += (double)ge;
                 s2 = fma((double)ge, (double)xe - meand, s2);
             }
@@ -304,7 +327,9 @@ __global__ __launch_bounds__(kBnBlock) void k_bn_bwd_reduce(const float* __restr
         for (int k = 0; k < V; ++k) {
             const float xe = comp(a, k);
             float ge = comp(b, k);
-            if (RELU && !(fmaf(xe, scale, shift) > 0.f)) ge = 0.f;
+            bool open = fmaf(xe, scale, shift) > 0.f;
+            if (GATED) open = bn_gate(open, o * V + k, gt);
+            if (RELU && !open) ge = 0.f;
             s1 += (double)ge;
             s2 = fma((double)ge, (double)xe - meand, s2);
         }
@@ -318,13 +343,14 @@ __global__ __launch_bounds__(kBnBlock) void k_bn_bwd_reduce(const float* __restr
 //      dbeta = sum ; dgamma = dotp * invstd ; gm = sum / n ; k = dotp * invstd^2 / n
 //      dx = ((dy' - gm) - (x - mean) * k) * invstd * gamma     (RES: + dz, the gradient that reaches the residual sum
 //      z = x on its other path: the accumulation autograd would run as a separate add launch)
-template <int V, bool RELU, bool RES>
+template <int V, bool RELU, bool RES, bool GATED = false>
 __global__ __launch_bounds__(kBnBlock) void k_bn_bwd_dx(const float* __restrict__ x, const float* __restrict__ dy,
                                                         const float* __restrict__ dz, float* __restrict__ dx, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const float* __restrict__ save_mean,
                                                         const float* __restrict__ save_invstd,
                                                         const double2* __restrict__ partial, int S,
-                                                        float* __restrict__ dgamma, float* __restrict__ dbeta, BnGeom g)
+                                                        float* __restrict__ dgamma, float* __restrict__ dbeta, BnGeom g,
+                                                        BnGates gt = BnGates{})
 {
     using T = typename Vec<V>::T;
     __shared__ float sh[2];
@@ -364,7 +390,9 @@ __global__ __launch_bounds__(kBnBlock) void k_bn_bwd_dx(const float* __restrict_
             for (int k = 0; k < V; ++k) {
                 const float xe = comp(a[u], k);
                 float ge = comp(b[u], k);
-                if (RELU && !(fmaf(xe, scale, shift) > 0.f)) ge = 0.f;
+                bool open = fmaf(xe, scale, shift) > 0.f;
+                if (GATED) open = bn_gate(open, o[u] * V + k, gt);
+                if (RELU && !open) ge = 0.f;
                 setc(b[u], k, (((ge - gm) - (xe - mean) * kk) * invstd) * w);
             }
             ov[o[u]] = RES ? vadd(r[u], b[u]) : b[u];
@@ -378,7 +406,9 @@ __global__ __launch_bounds__(kBnBlock) void k_bn_bwd_dx(const float* __restrict_
         for (int k = 0; k < V; ++k) {
             const float xe = comp(a, k);
             float ge = comp(b, k);
-            if (RELU && !(fmaf(xe, scale, shift) > 0.f)) ge = 0.f;
+            bool open = fmaf(xe, scale, shift) > 0.f;
+            if (GATED) open = bn_gate(open, o * V + k, gt);
+            if (RELU && !open) ge = 0.f;
             setc(b, k, (((ge - gm) - (xe - mean) * kk) * invstd) * w);
         }
         ov[o] = RES ? vadd(rv[o], b) : b;
@@ -668,9 +698,9 @@ int ursa_bn_relu_eval_f32(const float* x, const float* addend, float* z_out, flo
     return bn_launch_status();
 }
 
-int ursa_bn_relu_bwd_f32(const float* x, const float* dy, const float* dz, float* dx, const float* gamma, const float* beta,
-                         const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, float* ws,
-                         int64_t N, int64_t C, int64_t HW, uint32_t flags, ursa_stream_t stream)
+static int bn_bwd_impl(const float* x, const float* dy, const float* dz, float* dx, const float* gamma, const float* beta,
+                       const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, float* ws,
+                       int64_t N, int64_t C, int64_t HW, uint32_t flags, const BnGates* gates, ursa_stream_t stream)
 {
     if (flags & ~URSA_BN_ALLFLAGS) return URSA_EFLAGS;
     if (N == 0 || C == 0 || HW == 0) return (N < 0 || C < 0 || HW < 0) ? URSA_ESIZE : URSA_OK;
@@ -683,6 +713,19 @@ int ursa_bn_relu_bwd_f32(const float* x, const float* dy, const float* dz, float
     const dim3 grid(p.S, p.g.C), block(kBnBlock);
     double2* part = reinterpret_cast<double2*>(ws);
     const bool relu = flags & URSA_BN_RELU;
+    if (gates) {                                                  // parity instrument: always the two-launch kernels
+        if (!relu) return URSA_EFLAGS;
+        const BnGates gt = *gates;
+#define URSA_BN_BWD_G(V) do { \
+    hipLaunchKernelGGL((k_bn_bwd_reduce<V, true, true>), grid, block, 0, st, x, dy, gamma, beta, save_mean, save_invstd, part, p.g, gt); \
+    if (dz) hipLaunchKernelGGL((k_bn_bwd_dx<V, true, true, true>), grid, block, 0, st, x, dy, dz, dx, gamma, beta, save_mean, \
+                               save_invstd, part, p.S, dgamma, dbeta, p.g, gt); \
+    else hipLaunchKernelGGL((k_bn_bwd_dx<V, true, false, true>), grid, block, 0, st, x, dy, dz, dx, gamma, beta, save_mean, \
+                            save_invstd, part, p.S, dgamma, dbeta, p.g, gt); } while (0)
+        if (p.V == 4) URSA_BN_BWD_G(4); else URSA_BN_BWD_G(1);
+#undef URSA_BN_BWD_G
+        return bn_launch_status();
+    }
     if (bn_one_pass(p, flags)) {
         const dim3 g1(p.g.C), b1(kOneBlock);
 #define URSA_BN_ONE_E(R, A, E) hipLaunchKernelGGL((k_bn_bwd_one<R, A, E>), g1, b1, 0, st, x, dy, dz, dx, gamma, beta, save_mean, save_invstd, \
@@ -696,15 +739,35 @@ int ursa_bn_relu_bwd_f32(const float* x, const float* dy, const float* dz, float
         return bn_launch_status();
     }
 #define URSA_BN_BWD(V, R) do { \
-    hipLaunchKernelGGL((k_bn_bwd_reduce<V, R>), grid, block, 0, st, x, dy, gamma, beta, save_mean, save_invstd, part, p.g); \
+    hipLaunchKernelGGL((k_bn_bwd_reduce<V, R>), grid, block, 0, st, x, dy, gamma, beta, save_mean, save_invstd, part, p.g, BnGates{}); \
     if (dz) hipLaunchKernelGGL((k_bn_bwd_dx<V, R, true>), grid, block, 0, st, x, dy, dz, dx, gamma, beta, save_mean, save_invstd, \
-                               part, p.S, dgamma, dbeta, p.g); \
+                               part, p.S, dgamma, dbeta, p.g, BnGates{}); \
     else hipLaunchKernelGGL((k_bn_bwd_dx<V, R, false>), grid, block, 0, st, x, dy, dz, dx, gamma, beta, save_mean, save_invstd, \
-                            part, p.S, dgamma, dbeta, p.g); } while (0)
+                            part, p.S, dgamma, dbeta, p.g, BnGates{}); } while (0)
     if (p.V == 4) { if (relu) URSA_BN_BWD(4, true); else URSA_BN_BWD(4, false); }
     else          { if (relu) URSA_BN_BWD(1, true); else URSA_BN_BWD(1, false); }
 #undef URSA_BN_BWD
     return bn_launch_status();
+}
+
+int ursa_bn_relu_bwd_f32(const float* x, const float* dy, const float* dz, float* dx, const float* gamma, const float* beta,
+                         const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, float* ws,
+                         int64_t N, int64_t C, int64_t HW, uint32_t flags, ursa_stream_t stream)
+{
+    return bn_bwd_impl(x, dy, dz, dx, gamma, beta, save_mean, save_invstd, dgamma, dbeta, ws, N, C, HW, flags, nullptr, stream);
+}
+
+int ursa_bn_relu_bwd_gated_f32(const float* x, const float* dy, const float* dz, float* dx, const float* gamma,
+                               const float* beta, const float* save_mean, const float* save_invstd, float* dgamma,
+                               float* dbeta, float* ws, int64_t N, int64_t C, int64_t HW, uint32_t flags,
+                               const int32_t* gate_idx, const uint8_t* gate_open, int64_t n_gates, ursa_stream_t stream)
+{
+    if (n_gates < 0 || n_gates > (1 << 30)) return URSA_ESIZE;
+    if (n_gates > 0 && (!gate_idx || !gate_open)) return URSA_ENULL;
+    if (!bn_aligned4(gate_idx)) return URSA_EALIGN;
+    if (N > 0 && C > 0 && HW > 0 && N * C > (int64_t)0x7ffffffe / HW) return URSA_ESIZE;      // 32-bit element offsets
+    const BnGates gt{gate_idx, gate_open, (int)n_gates};
+    return bn_bwd_impl(x, dy, dz, dx, gamma, beta, save_mean, save_invstd, dgamma, dbeta, ws, N, C, HW, flags, &gt, stream);
 }
 
 }  // extern "C"

@@ -16,6 +16,7 @@ path that is timed — is the path the reference comparisons execute.
 """
 import torch
 
+from .. import fused_bn
 from .._capture import capture, side_streams
 from ..util import deferred_bn_counters
 
@@ -39,6 +40,8 @@ class ChainEngine:
         self._static = None
         self._eps_static = None
         self._eager_full_steps = 0
+        self.gate_probe = None           # fused_bn.GateProbe: parity runs against the reference CPU path only
+        self._graph_probe = None
         self.stats = dict(graph_replays=0, eager_steps=0, captures=0)
 
     def invalidate(self):
@@ -53,7 +56,7 @@ class ChainEngine:
     def forward_backward(self, x, y):
         """Forward + loss + backward, gradients packed into the arena. Returns what `finish` needs to put back
         the tensors that received no gradient (None almost always)."""
-        with deferred_bn_counters(self.model):       # 19 one-element counter kernels -> one multi-tensor add
+        with deferred_bn_counters(self.model), fused_bn.probing(self.gate_probe):   # 19 one-element counter kernels -> one multi-tensor add
             logits = self.model(x)
         loss = self.crit(logits, y)
         # Gradients: with p.grad = None autograd hands over its freshly computed tensors (no kernel);
@@ -100,11 +103,14 @@ class ChainEngine:
         with capture(g):
             self._train_step(*self._static, eps=self._eps_static if self._graph_eps else None)
         self._graph = g
+        self._graph_probe = self.gate_probe
         self.stats['captures'] += 1
 
-    def run_epoch(self, loader, add_langevin_noise, sched=None, eps_per_step=None):
+    def run_epoch(self, loader, add_langevin_noise, sched=None, eps_per_step=None, gates_per_step=None):
         """One pass over `loader`. Returns the number of examples seen; self.loss_acc holds the
-        summed loss (read it with .item() only when debugging: that is the one host sync)."""
+        summed loss (read it with .item() only when debugging: that is the one host sync).
+        gates_per_step(k) -> the reference run's near-zero gate lists of minibatch step k for `self.gate_probe`
+        (parity runs; loaded into the probe's persistent buffers before the step, observations collected after it)."""
         self.model.train()
         self.loss_acc.zero_()
         self.opt.ctl_begin(add_langevin_noise, sched)
@@ -113,9 +119,11 @@ class ChainEngine:
         inject = eps_per_step is not None
         if inject and self._eps_static is None:
             self._eps_static = torch.zeros_like(self.opt.arena.theta)
-        if self._graph is not None and self._graph_eps != inject:
-            self._graph = None                       # the captured launch reads / does not read the noise buffer
+        if self._graph is not None and (self._graph_eps != inject or self._graph_probe is not self.gate_probe):
+            self._graph = None                       # the captured launches read / do not read the noise / gate buffers
         self._graph_eps = inject
+        if gates_per_step is not None and self.gate_probe is None:
+            raise ValueError('gates_per_step needs engine.gate_probe')
         eps_buf = self._eps_static if inject else None
         for bi, (x, y) in enumerate(loader):
             x = x.to(self.device, non_blocking=True)
@@ -123,6 +131,8 @@ class ChainEngine:
             b = x.shape[0]
             if inject:
                 self._eps_static.copy_(eps_per_step(steps))
+            if gates_per_step is not None:
+                self.gate_probe.load(gates_per_step(steps))
             if self.use_graph and b == full:
                 if self._graph is None and self._eager_full_steps >= self.WARMUP_STEPS:
                     self._capture(x, y)            # records the step; the replay below executes it
@@ -145,6 +155,8 @@ class ChainEngine:
             else:
                 self._train_step(x, y, eps_buf)
                 self.stats['eager_steps'] += 1
+            if gates_per_step is not None:
+                self.gate_probe.collect()
             seen += b
             steps += 1
         self.opt.ctl_end(steps)

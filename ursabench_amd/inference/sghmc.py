@@ -49,6 +49,8 @@ class _ChainSampler(_Inference):
         self.engine = ChainEngine(self.model, self.optimizer, self.loss_criterion, device, use_graph)
         self.bank = MemberBank(self.arena)
         self.eps_provider = None        # callable(step_in_epoch) -> flat eps tensor: parity runs only
+        self.gate_provider = None       # callable(step) -> the reference run's near-zero ReLU gate lists (with
+        #                                 engine.gate_probe = fused_bn.GateProbe(...)): parity runs only
 
     def _new_optimizer(self, lr, momentum, weight_decay):
         """update_hyp rebuilds the optimizer (sghmc.py:57-58); the arena, the device control block and
@@ -71,12 +73,19 @@ class _ChainSampler(_Inference):
         base = self.optimizer._step
         return lambda k: self.eps_provider(base + k)
 
+    def _gates_for_epoch(self):
+        if self.gate_provider is None:
+            return None
+        base = self.optimizer._step
+        return lambda k: self.gate_provider(base + k)
+
     def _drive(self, epochs):
         """Run one sampler's epoch generator on its own engine and snapshot when it is exhausted."""
         try:
             noise, sched = next(epochs)
             while True:
-                seen = self.engine.run_epoch(self.train_loader, noise, sched=sched, eps_per_step=self._eps_for_epoch())
+                seen = self.engine.run_epoch(self.train_loader, noise, sched=sched, eps_per_step=self._eps_for_epoch(),
+                                             gates_per_step=self._gates_for_epoch())
                 noise, sched = epochs.send(seen)
         except StopIteration:
             pass
