@@ -51,7 +51,6 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBPS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); measured float4 copy ceiling: 6290
 HBM_COPY_GBPS = 6290.0
 PARITY_RTOL = 1e-5              # north_star: fp32 predictive probabilities within 1e-5 relative of the CPU path
-MAX_PARITY_SEEDS = 8            # parity_block: seeds tried for one whose first step takes equal ReLU gates on both devices
 
 # C2 hyper-parameters: URSABench/hyperparams/ResNet50CIFAR10/sghmc_hyperparams.json (no PreResNet-20
 # file exists in the reference), burn-in forced to 0 as time_script.py:89-90 does.
@@ -198,189 +197,201 @@ def pmc_traffic(kernel_key, elements):
 
 
 # ---- c2 legs ------------------------------------------------------------------------------------------
-def first_step_gate_flips(net0, x, dev):
-    """ReLU gates after every BatchNorm of the FIRST minibatch step, GPU launches vs the CPU path, from the same
-    weights and batch: (gates that differ, gates). MIOpen's and oneDNN's convolutions differ by ~1e-6, so a
-    pre-activation within that of zero is open on one device and closed on the other - for any BatchNorm
-    implementation, ~2 of the 24M gates of a 128-row PreResNet-20 forward (tools/exp/bn_gate_diag.py; K6's own
-    arithmetic is torch's CPU BatchNorm bit for bit given the same input, tests/test_fused_bn_gpu.py). A differing gate
-    changes nothing in the forward pass and O(dy) in that element's gradient: ~1/sqrt(N*H*W) relative on the
-    gradients it feeds, 1e-4 on the next predictive. Networks without BatchNorm+ReLU pairs report (0, 0)."""
+def load_gate_lists():
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import gate_lists
+    return gate_lists
+
+
+def parity_trial(dev, seed_offset, steps_per_sample=1, samples=3, rows=128, test_rows=64, depth=20, n_noise=N_TRAIN,
+                 given_gates=True):
+    """One (rows, seed) of parity_block: the torch-CPU port once (recording its near-zero ReLU gates), then the GPU path
+    on the same init / inputs / noise - `natural` (gates as the GPU's own convolutions decide them; differing ones
+    counted against the port's lists) and, if `given_gates`, `given` (the port's gates handed to the backward launches)."""
     import copy
-    import ursabench_amd.models as M
-    rec = {}
-    orig, orig_add = M.bn_relu, M.add_bn_relu
-    try:
-        for name in ('cpu', 'gpu'):
-            got = rec.setdefault(name, [])
-
-            def spy(bn, xx, relu=True, _got=got):
-                y = orig(bn, xx, relu)
-                _got.append((y.detach() > 0).cpu())
-                return y
-
-            def spy_add(bn, xx, relu=True, _got=got):
-                z, y = orig_add(bn, xx, relu)
-                _got.append((y.detach() > 0).cpu())
-                return z, y
-            M.bn_relu, M.add_bn_relu = spy, spy_add
-            net = copy.deepcopy(net0).to('cpu' if name == 'cpu' else dev).train()
-            with torch.no_grad():
-                net(x.to('cpu' if name == 'cpu' else dev))
-    finally:
-        M.bn_relu, M.add_bn_relu = orig, orig_add
-    return (int(sum(int((a != b).sum()) for a, b in zip(rec['cpu'], rec['gpu']))),
-            int(sum(a.numel() for a in rec['cpu'])))
-
-
-def parity_trial(dev, seed_offset, steps_per_sample=1, samples=3, rows=128, test_rows=64, depth=20, n_noise=N_TRAIN):
-    """One seed of parity_block (below): returns the errors and the number of first-step ReLU gates that differ."""
-    import copy
-    from ursabench_amd import inference, models, tasks
+    from torch.optim.lr_scheduler import CosineAnnealingLR
+    from ursabench_amd import fused_bn, inference, models, tasks
     from ursabench_amd.data import DeviceLoader
-    port = load_port()
+    port, GL = load_port(), load_gate_lists()
     torch.manual_seed(4242 + seed_offset)
-    net_cpu = models.PreResNet(CLASSES, depth)
-    net_gpu = copy.deepcopy(net_cpu)
-    net0 = copy.deepcopy(net_cpu)
+    net0 = models.PreResNet(CLASSES, depth)
     g = torch.Generator().manual_seed(4243 + seed_offset)
     n_tr = rows * steps_per_sample
     xtr, ytr = torch.randn(n_tr, 3, 32, 32, generator=g), torch.randint(0, CLASSES, (n_tr,), generator=g)
     xte, yte = torch.randn(test_rows, 3, 32, 32, generator=g), torch.randint(0, CLASSES, (test_rows,), generator=g)
     hyp = dict(HYP, num_samples=samples)
-    # the noise the port will draw: torch.randn_like per tensor, in parameters() order, from the global generator
     total = samples * steps_per_sample
+    # the noise the port will draw: torch.randn_like per tensor, in parameters() order, from the global generator
     torch.manual_seed(777 + seed_offset)
-    eps_steps = [[torch.randn_like(p) for p in net_cpu.parameters()] for _ in range(total)]
-    # GPU: the product path with that noise injected through the kernel's eps input
-    train = DeviceLoader(xtr.to(dev), ytr.to(dev), rows)
-    test = DeviceLoader(xte.to(dev), yte.to(dev), test_rows)
-    s = inference.SGHMC(dict(hyp), net_gpu, train, device=dev, seed=1, use_graph=True)
-    s.optimizer.param_groups[0]['num_training_samples'] = n_noise     # the N of optim_sghmc.py:48,64: the workload's 50,000
-    idx = s.arena.layout.gather_index(dev)
-
-    def eps(k):
-        e = torch.zeros(s.arena.n, device=dev)
-        e[idx] = torch.cat([t.reshape(-1) for t in eps_steps[k % total]]).to(dev)
-        return e
-    s.eps_provider = eps
-    # Compare the path that is TIMED: hipGraph replays reading the injected noise from the engine's persistent
-    # buffer. Capture needs one eager warm-up step (MIOpen's solver search cannot run inside a capture): take it
-    # and the capture on this very chain, then put the chain back to its initial state, so that EVERY compared
-    # minibatch step below — the first sample included — is a graph replay.
-    a = s.arena
-    saved = (a.theta.clone(), None if a.fbuf is None else a.fbuf.clone(), [b.clone() for _, b in a.ibufs])
-    s.engine.WARMUP_STEPS = 1
-    for _ in range(2):                                                # eager warm-up step, then capture + first replay
-        s.engine.run_epoch(train, True, eps_per_step=eps)
-    assert s.engine.stats['captures'] == 1 and s.engine.stats['graph_replays'] >= 1, s.engine.stats
-    with torch.no_grad():
-        a.theta.copy_(saved[0])
-        if saved[1] is not None:
-            a.fbuf.copy_(saved[1])
-        for (_, b), v in zip(a.ibufs, saved[2]):
-            b.copy_(v)
-        a.mom.zero_()
-    s.optimizer._step, s.optimizer._has_mom = 0, [False]              # first-step rule and Philox call index as at construction
-    s.optimizer.state.clear()
-    s.engine.stats.update(graph_replays=0, eager_steps=0)
-    lrs, ens = [], []
+    eps_steps = [[torch.randn_like(p) for p in net0.parameters()] for _ in range(total)]
+    # the learning rate of each sample: CosineAnnealingLR moves it once per sample (sghmc.py:44,87)
+    dummy = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=HYP['lr'])
+    sch, lrs = CosineAnnealingLR(dummy, T_max=samples), []
     for _ in range(samples):
-        lrs.append(s.optimizer.param_groups[0]['lr'])         # CosineAnnealingLR moves it once per sample (sghmc.py:44,87)
-        ens.append(s.sample_iterative())
-    # CPU: the port, same generator state -> same noise
+        lrs.append(dummy.param_groups[0]['lr'])
+        dummy.step()
+        sch.step()
+
+    # ---- CPU: the port, same generator state -> same noise; its near-zero pre-activations and gates per step
+    net_cpu = copy.deepcopy(net0)
+    log = GL.NearZeroGates(net_cpu)
+    n_bn = len(log._handles)
     torch.manual_seed(777 + seed_offset)
-    state, cpu_members = {}, []
+    state, cpu_members, gate_steps = {}, [], []
     batches = [(xtr[i:i + rows], ytr[i:i + rows]) for i in range(0, n_tr, rows)]
     for lr in lrs:
         port.sghmc_epoch(net_cpu, batches, state, lr=lr, momentum=1 - HYP['alpha'],
                          weight_decay=1 / HYP['prior_std'] ** 2, num_training_samples=n_noise)
+        calls = log.take()
+        gate_steps += [calls[i:i + n_bn] for i in range(0, len(calls), n_bn)]
         cpu_members.append(copy.deepcopy(net_cpu))
+    log.remove()
+    assert len(gate_steps) == total
+    lists = [[(c['idx'], c['open']) for c in calls] for calls in gate_steps]
+    cap = max(len(c['idx']) for calls in gate_steps for c in calls) + 1
+    rel = lambda a, b: ((a - b).abs() / b.abs()).max().item()
+    test = DeviceLoader(xte.to(dev), yte.to(dev), test_rows)
+
+    def cpu_predictive(members):
+        p, e, _, _ = port.prediction_accumulate(members, [(xte, yte)], CLASSES, test_rows)
+        return p, e
 
     def gpu_predictive(members):
         pred = tasks.Prediction({'in_distribution_test': test}, CLASSES, dev, 'ALL')
         pred.update_statistics(members, output_performance=False)
         return pred.ensemble_proba, pred.expected_data_uncertainty
 
-    def cpu_predictive(members):
-        p, e, _, _ = port.prediction_accumulate(members, [(xte, yte)], CLASSES, test_rows)
-        return p, e
+    def gpu_run(force):
+        # the product path with the port's noise injected through the kernel's eps input
+        train = DeviceLoader(xtr.to(dev), ytr.to(dev), rows)
+        s = inference.SGHMC(dict(hyp), copy.deepcopy(net0), train, device=dev, seed=1, use_graph=True)
+        s.optimizer.param_groups[0]['num_training_samples'] = n_noise     # the N of optim_sghmc.py:48,64: the workload's 50,000
+        idx = s.arena.layout.gather_index(dev)
+        probe = s.engine.gate_probe = fused_bn.GateProbe(n_bn, cap, dev, force=force)
 
-    rel = lambda a, b: ((a - b).abs() / b.abs()).max().item()
-    # (1) sampler: first posterior sample, GPU vs port
-    pg, eg = gpu_predictive(ens[:1])
-    pc, ec = cpu_predictive(cpu_members[:1])
-    sampler = {'max_rel_err_proba': rel(pg, pc), 'max_rel_err_entropy': rel(eg, ec)}
-    # later samples: reported only
-    growth = []
-    for k in range(1, samples):
-        pgk, _ = gpu_predictive(ens[k:k + 1])
-        pck, _ = cpu_predictive(cpu_members[k:k + 1])
-        growth.append({'minibatch_steps': (k + 1) * steps_per_sample, 'max_rel_err_proba': rel(pgk, pck)})
-    # (2) bma: the GPU ensemble, same members evaluated by the CPU loop
-    host_members = []
-    for m in ens:
-        h = models.PreResNet(CLASSES, depth)
-        h.load_state_dict({k_: v.detach().cpu() for k_, v in m.state_dict().items()})
-        host_members.append(h)
-    pg, eg = gpu_predictive(ens)
-    pc, ec = cpu_predictive(host_members)
-    bma = {'members': samples, 'max_rel_err_proba': rel(pg, pc), 'max_rel_err_entropy': rel(eg, ec)}
-    if s.engine.stats['eager_steps'] != 0 or s.engine.stats['graph_replays'] != total:
-        raise AssertionError(f'parity: the compared steps were not all hipGraph replays: {s.engine.stats}')
-    flips, gates = first_step_gate_flips(net0, xtr[:rows], dev)
-    return {'seed_offset': seed_offset, 'gate_flips_first_step': flips, 'gates_first_step': gates,
-            'engine': dict(s.engine.stats), 'sampler_first_sample': sampler, 'bma_same_members': bma,
-            'trajectory_growth_reported_not_asserted': growth}
+        def eps(k):
+            e = torch.zeros(s.arena.n, device=dev)
+            e[idx] = torch.cat([t.reshape(-1) for t in eps_steps[k % total]]).to(dev)
+            return e
+        s.eps_provider = eps
+        s.gate_provider = lambda k: lists[k % total]
+        # Compare the path that is TIMED: hipGraph replays reading the injected noise (and here the gate lists) from
+        # persistent buffers. Capture needs one eager warm-up step (MIOpen's solver search cannot run inside a
+        # capture): take it and the capture on this very chain, then put the chain back to its initial state, so
+        # that EVERY compared minibatch step below - the first sample included - is a graph replay.
+        a = s.arena
+        saved = (a.theta.clone(), None if a.fbuf is None else a.fbuf.clone(), [b.clone() for _, b in a.ibufs])
+        s.engine.WARMUP_STEPS = 1
+        for _ in range(2):                                                # eager warm-up step, then capture + first replay
+            s.engine.run_epoch(train, True, eps_per_step=eps, gates_per_step=lambda k: lists[0])
+        assert s.engine.stats['captures'] == 1 and s.engine.stats['graph_replays'] >= 1, s.engine.stats
+        with torch.no_grad():
+            a.theta.copy_(saved[0])
+            if saved[1] is not None:
+                a.fbuf.copy_(saved[1])
+            for (_, b), v in zip(a.ibufs, saved[2]):
+                b.copy_(v)
+            a.mom.zero_()
+        s.optimizer._step, s.optimizer._has_mom = 0, [False]              # first-step rule and Philox call index as at construction
+        s.optimizer.state.clear()
+        s.engine.stats.update(graph_replays=0, eager_steps=0)
+        probe.history.clear()
+        got_lrs, ens = [], []
+        for _ in range(samples):
+            got_lrs.append(s.optimizer.param_groups[0]['lr'])
+            ens.append(s.sample_iterative())
+        assert got_lrs == lrs, (got_lrs, lrs)
+        if s.engine.stats['eager_steps'] != 0 or s.engine.stats['graph_replays'] != total:
+            raise AssertionError(f'parity: the compared steps were not all hipGraph replays: {s.engine.stats}')
+        flips = [sum(h['flips']) for h in probe.history]
+        outside = [h['n_open_as_reference'] == [c['n_open'] for c in calls] for h, calls in zip(probe.history, gate_steps)]
+        # (1) sampler: every posterior sample, GPU member vs the port's member
+        per_sample = []
+        for k in range(samples):
+            pgk, egk = gpu_predictive(ens[k:k + 1])
+            pck, eck = cpu_predictive(cpu_members[k:k + 1])
+            per_sample.append({'minibatch_steps': (k + 1) * steps_per_sample, 'max_rel_err_proba': rel(pgk, pck),
+                               'max_rel_err_entropy': rel(egk, eck)})
+        # (2) bma: the GPU ensemble, same members evaluated by the CPU loop
+        host_members = []
+        for m in ens:
+            h = models.PreResNet(CLASSES, depth)
+            h.load_state_dict({k_: v.detach().cpu() for k_, v in m.state_dict().items()})
+            host_members.append(h)
+        pg, eg = gpu_predictive(ens)
+        pc, ec = cpu_predictive(host_members)
+        return {'gates_given': bool(force), 'gate_flips_per_step': flips, 'no_gate_outside_the_band_differs_per_step': outside,
+                'per_sample': per_sample, 'engine': dict(s.engine.stats),
+                'bma_same_members': {'members': samples, 'max_rel_err_proba': rel(pg, pc), 'max_rel_err_entropy': rel(eg, ec)}}
+
+    out = {'rows': rows, 'seed_offset': seed_offset, 'gates_per_step': int(sum(c['numel'] for c in gate_steps[0])),
+           'near_zero_listed_per_step': [int(sum(len(c['idx']) for c in calls)) for calls in gate_steps],
+           'natural': gpu_run(False)}
+    if given_gates:
+        out['given'] = gpu_run(True)
+    return out
 
 
-def parity_block(dev, steps_per_sample=1, samples=3, rows=128, test_rows=64, depth=20, n_noise=N_TRAIN, small_rows=32):
+PARITY_SEEDS = (0, 10, 20)       # fixed list: every trial runs, every trial is in the line, nothing is selected
+
+
+def parity_block(dev, steps_per_sample=1, samples=3, rows=128, test_rows=64, depth=20, n_noise=N_TRAIN, small_rows=32,
+                 seeds=PARITY_SEEDS):
     """§8(d): before timing, the GPU path against the reference CPU path (its torch-CPU port,
     oracle/torch_cpu_path.py — pinned bitwise to the imported reference in tests/test_cpu_port.py) on
     IDENTICAL inputs, initial weights and Langevin noise (the kernel's eps input carries the noise the
     port draws from torch's generator). PreResNet-20, the workload's hyper-parameters, `samples` SGHMC
-    samples of `steps_per_sample` minibatch steps on `rows` rows. Two assertions at 1e-5 relative on the
+    samples of `steps_per_sample` minibatch steps; every compared step is a hipGraph replay. 1e-5 relative on the
     fp32 predictive probabilities (north_star's criterion):
-      sampler  — the FIRST posterior sample (forward/backward + fused update + snapshot) evaluated on
+      sampler  — each posterior sample (forward/backward + fused update + snapshot) evaluated on
                  `test_rows` rows: GPU member vs the port's member;
       bma      — the whole ensemble produced on the GPU, its members copied to the host and pushed through
                  the port's CPU loop (prediction.py:52-64), vs Prediction.update_statistics on the GPU
                  (bank -> twin -> hipGraph forwards -> BMA kernel).
-    Later samples of the two trajectories are compared too and REPORTED (`trajectory_growth`): SG-MCMC at
-    lr = 0.1 amplifies the 1e-6 MIOpen-vs-oneDNN gradient differences about 10x per step (SURVEY.md §7
-    hard part 2), so member k > 1 is not an implementation check.
 
-    The same amplification has a discrete source inside ONE step: ReLU gates (first_step_gate_flips). At the
-    workload's 128 rows a PreResNet-20 forward has 24M gates and 1-7 of them differ between the devices for every seed
-    tried (and did under MIOpen's own BatchNorm launches: rounds 1-2 passed this leg on a seed whose two differing
-    gates happened to sit in the 131,072-element channels of the first stage). The criterion is therefore asserted
-    where it is a statement about the implementation - on a step that takes the same gates on both devices, i.e.
-    where the two paths compute the same piecewise-linear function: the 128-row trial is run first and reported with
-    its gate count (asserted if that is 0); then `small_rows`-row trials (6M gates, about half of the seeds are
-    gate-equal), first come, never hidden: every trial is in `trials` with rows, seed, gate count and error. A
-    gate-equal trial beyond 1e-5 fails the leg; so does finding none within MAX_PARITY_SEEDS seeds."""
-    plan = [(rows, 0)] + [(small_rows, 10 * k) for k in range(MAX_PARITY_SEEDS)]
-    trials, t = [], None
-    for r, off in plan:
-        t = parity_trial(dev, off, steps_per_sample, samples, r, test_rows, depth, n_noise)
-        t['rows'] = r
-        trials.append({'rows': r, 'seed_offset': off, 'gate_flips_first_step': t['gate_flips_first_step'],
-                       'gates_first_step': t['gates_first_step'],
-                       'max_rel_err_proba': t['sampler_first_sample']['max_rel_err_proba'],
-                       'bma_same_members_max_rel_err_proba': t['bma_same_members']['max_rel_err_proba']})
-        if t['gate_flips_first_step'] == 0:
-            break
-    ok = (t['gate_flips_first_step'] == 0 and t['sampler_first_sample']['max_rel_err_proba'] <= PARITY_RTOL
-          and all(x['bma_same_members_max_rel_err_proba'] <= PARITY_RTOL for x in trials))
+    The one thing that can move such a comparison past 1e-5 without an implementation error is a ReLU gate: MIOpen's and
+    oneDNN's convolutions differ by ~1e-6, so a BatchNorm output within that of zero is open on one device and closed on
+    the other (for ANY BatchNorm arithmetic), which changes nothing in the forward pass and O(dy) in that element's
+    gradient. The port's run records the pre-activations it computed within 1e-4 of zero and the gate it took there
+    (tests/gate_lists.py); ursabench_amd.fused_bn.GateProbe counts the GPU gates that differ among them and can hand
+    the list to the backward launches (ursa_bn_relu_bwd_gated_f32). What is asserted - on a FIXED list of trials, all
+    of them run, all of them in `trials`:
+      pass_workload_rows : at the workload's own batch (`rows` = 128), every seed, gates GIVEN: every sample of the
+                           trajectory (1, 2, 3 steps) within 1e-5, and no gate outside the listed band differs;
+      pass_gate_equal    : every natural trial (`rows` and `small_rows`) is held to 1e-5 on its gate-equal prefix - the
+                           samples before the first differing gate (about half of the 32-row first steps are gate-equal;
+                           at 128 rows 1-7 of the 24 M gates differ on most seeds);
+      bma_same_members   : every run, natural or given (it compares the evaluation path, not the trajectory).
+    Natural errors after a differing gate are reported per sample, never asserted, never hidden."""
+    plan = [(rows, off, True) for off in seeds] + [(small_rows, off, False) for off in seeds]
+    trials, ok_work, ok_equal, ok_bma, n_equal = [], True, True, True, 0
+    for r, off, given in plan:
+        t = parity_trial(dev, off, steps_per_sample, samples, r, test_rows, depth, n_noise, given_gates=given)
+        trials.append(t)
+        nat = t['natural']
+        for k, ps in enumerate(nat['per_sample']):           # gate-equal prefix of the natural run
+            upto = (k + 1) * steps_per_sample
+            if sum(nat['gate_flips_per_step'][:upto]) or not all(nat['no_gate_outside_the_band_differs_per_step'][:upto]):
+                break
+            n_equal += 1
+            ok_equal &= ps['max_rel_err_proba'] <= PARITY_RTOL
+        ok_bma &= nat['bma_same_members']['max_rel_err_proba'] <= PARITY_RTOL
+        if given:
+            gv = t['given']
+            ok_work &= all(ps['max_rel_err_proba'] <= PARITY_RTOL for ps in gv['per_sample'])
+            ok_work &= all(gv['no_gate_outside_the_band_differs_per_step'])
+            ok_bma &= gv['bma_same_members']['max_rel_err_proba'] <= PARITY_RTOL
+    worst = lambda key: max(ps['max_rel_err_proba'] for t in trials if key in t for ps in t[key]['per_sample'])
     out = {'what': f'PreResNet-{depth} SGHMC at the workload hyper-parameters, identical init / inputs / injected noise, predictive '
-                   f'on {test_rows} test rows; GPU path (every compared minibatch step a hipGraph replay reading the injected '
-                   'noise) vs torch-CPU port of the reference path; sampler_first_sample is asserted on the first trial whose '
-                   'first step takes the same ReLU gates on both devices, bma_same_members on every trial',
-           'asserted_on': {'rows': t['rows'], 'seed_offset': t['seed_offset']},
-           'engine': t['engine'], 'rtol': PARITY_RTOL, 'trials': trials,
-           'sampler_first_sample': t['sampler_first_sample'], 'bma_same_members': t['bma_same_members'],
-           'trajectory_growth_reported_not_asserted': t['trajectory_growth_reported_not_asserted'], 'pass': bool(ok)}
-    if not ok:
+                   f'on {test_rows} test rows after each of {samples} samples of {steps_per_sample} minibatch step(s); GPU path (every '
+                   'compared step a hipGraph replay reading the injected noise) vs torch-CPU port of the reference path; '
+                   'fixed trial list, every trial asserted: gates given at the workload batch; natural runs on their gate-equal prefix',
+           'rtol': PARITY_RTOL, 'seeds': list(seeds), 'rows_workload': rows, 'rows_small': small_rows,
+           'pass_workload_rows': bool(ok_work), 'pass_gate_equal': bool(ok_equal), 'gate_equal_samples_asserted': n_equal,
+           'pass_bma_same_members': bool(ok_bma),
+           'worst_max_rel_err_proba_gates_given': worst('given'), 'worst_max_rel_err_proba_natural_reported': worst('natural'),
+           'trials': trials, 'pass': bool(ok_work and ok_equal and ok_bma)}
+    if not out['pass']:
         raise AssertionError(f'parity: predictive probabilities beyond {PARITY_RTOL} relative: {json.dumps(out)}')
     return out
 

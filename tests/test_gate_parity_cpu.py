@@ -36,7 +36,8 @@ def g16_case(g, sd):
         eps.append(torch.cat([t.reshape(-1) for t in e]))
     chk = [float(xtr.double().sum()), float(ytr.sum()), float(xte.double().sum()), float(yte.sum()),
            float(theta0.double().sum())] + eps_sums
-    assert chk == list(g[f's{sd}/checksums']), 'torch CPU generator stream differs from the one the fixture was made with'
+    # float64 sums of 393,216 values: torch's reduction order follows the host's thread count, so compare to 1e-12
+    assert np.allclose(chk, g[f's{sd}/checksums'], rtol=1e-12, atol=1e-9), 'torch CPU generator stream differs from the one the fixture was made with'
     train = DataLoader(TensorDataset(xtr, ytr), batch_size=128)
     test = DataLoader(TensorDataset(xte, yte), batch_size=64)
     return net, train, test, eps, unpack(g, f's{sd}/')

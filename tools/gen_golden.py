@@ -406,10 +406,24 @@ def gen_e2e_preresnet():
     net = models.PreResNet8.base(num_classes=10, depth=8)
     out['theta0'] = flat(net.parameters())
     out['buffers0'] = torch.cat([b.detach().float().reshape(-1) for b in net.buffers()]).numpy()
+    # the pre-activations this run computes within 1e-4 of zero and the ReLU gates it takes there, per minibatch step and
+    # BatchNorm call (tests/gate_lists.py: read by forward hooks, the run itself is untouched): the GPU replays take
+    # them as given (ursa_bn_relu_bwd_gated_f32), see gen_e2e_preresnet_seeds
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from gate_lists import NearZeroGates, pack
+    log = NearZeroGates(net)
     s = inference.SGHMC(dict(hyp), net, train)
     tap = NoiseTap(s.optimizer)
+    gate_steps, tapped = [], tap.opt.step
+
+    def step_and_take(add_langevin_noise=True, closure=None):
+        gate_steps.append(log.take())
+        return tapped(add_langevin_noise=add_langevin_noise, closure=closure)
+    s.optimizer.step = step_and_take
     with quiet():
         ens = s.sample()
+    log.remove()
+    out.update(pack(gate_steps))
     out['eps'] = np.stack([r['eps'] for r in tap.records])
     out['samples'] = np.stack([flat(m.parameters()) for m in ens])
     out['sample_buffers'] = np.stack([torch.cat([b.detach().float().reshape(-1) for b in m.buffers()]).numpy() for m in ens])

@@ -103,8 +103,8 @@ class ChainGroup:
         """What a captured round bakes in per chain: the optimizer object and the addresses of its control
         block, schedule table and vectors."""
         ptr = lambda t: None if t is None else t.data_ptr()
-        return [(id(s.optimizer), ptr(s.optimizer._ctl), ptr(s.optimizer._sched), ptr(s.arena.mom), ptr(s.arena.theta))
-                for s in self.samplers]
+        return [(id(s.optimizer), ptr(s.optimizer._ctl), ptr(s.optimizer._sched), ptr(s.arena.mom), ptr(s.arena.theta),
+                 id(s.engine.gate_probe)) for s in self.samplers]
 
     def _run_epoch(self, plans):
         for s, (noise, sched) in zip(self.samplers, plans):
@@ -129,6 +129,7 @@ class ChainGroup:
             # captured update launch reads / does not read the injected-noise slab
             self._graph, self._captured_with = None, None
         self._graph_eps = inject
+        gated = [(s.engine.gate_probe, s._gates_for_epoch()) for s in self.samplers if s.gate_provider is not None]
         full = getattr(self.loader, 'batch_size', None)
         seen = steps = 0
         for x, y in self.loader:
@@ -137,6 +138,8 @@ class ChainGroup:
             if inject:
                 for k, p in enumerate(providers):
                     self.eps[k].copy_(p(steps))
+            for probe, gp in gated:                          # parity runs: the reference run's near-zero gate lists
+                probe.load(gp(steps))
             if self.use_graph and x.shape[0] == full:
                 if self._graph is None and self._warm >= self.WARMUP_STEPS:
                     self._capture(x, y)
@@ -157,6 +160,8 @@ class ChainGroup:
             else:
                 self._round_eager(x, y)
                 self.stats['eager_rounds'] += 1
+            for probe, _ in gated:
+                probe.collect()
             seen += x.shape[0]
             steps += 1
         for s in self.samplers:
