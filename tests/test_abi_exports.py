@@ -57,6 +57,26 @@ def test_argument_errors_do_not_need_a_gpu():
     assert bwd(None, None, None, None, None, None, None, None, None, None, None, 2, 3, 4, 0x10, None) == -4
     assert ev(None, None, None, None, None, None, None, None, 2, 3, 4, 1e-5, 1, None) == -1
     assert ev(p, None, p, p, p, p, p, p, 2, 3, 4, 1e-5, 1, None) == -1                              # z_out without addend
+    # the gated backward (parity instrument): list pointers, list size, RELU required, 32-bit element offsets
+    gb = lib.ursa_bn_relu_bwd_gated_f32
+    assert gb(p, p, None, p, p, p, p, p, p, p, p, 2, 3, 4, 1, None, None, 5, None) == -1               # list pointers missing
+    assert gb(p, p, None, p, p, p, p, p, p, p, p, 2, 3, 4, 1, p, p, -1, None) == -2                    # negative list size
+    assert gb(p, p, None, p, p, p, p, p, p, p, p, 2, 3, 4, 0, p, p, 1, None) == -4                     # without URSA_BN_RELU
+    assert gb(p, p, None, p, p, p, p, p, p, p, p, 1 << 20, 64, 1 << 10, 1, p, p, 1, None) == -2        # 2^36 elements: offsets do not fit
+    assert gb(None, None, None, None, None, None, None, None, None, None, None, 0, 3, 4, 1, None, None, 0, None) == 0
+
+
+def test_the_shipped_library_reads_no_environment():
+    """Kernel selection by URSA_* environment variables exists only in the -DURSA_DEBUG_KNOBS build
+    (csrc/libursa_hip_knobs.so: tests' A/B cases and tools/): the shipped library does not import getenv at all."""
+    import subprocess
+    from ursabench_amd import _native
+    syms = subprocess.run(['nm', '-D', '--undefined-only', _native.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert 'getenv' not in syms
+    if os.path.exists(_native.KNOBS_LIB_PATH):
+        knobs = subprocess.run(['nm', '-D', '--undefined-only', _native.KNOBS_LIB_PATH], capture_output=True, text=True, check=True).stdout
+        assert 'getenv' in knobs
+        assert _native.load_library(_native.KNOBS_LIB_PATH).ursa_abi_version() == _native.ABI_VERSION
 
 
 def test_wrappers_refuse_cpu_tensors():

@@ -373,14 +373,19 @@ def test_k5_float4_rows(K, S, B, C):
 
 @pytest.mark.parametrize('S,B,C', [(50, 1000, 10), (7, 64, 16), (30, 256, 100), (3, 64, 64)])
 def test_k5_fast_paths_agree_with_the_lane_group_kernel(K, S, B, C, monkeypatch):
-    """The debug switches select the generic lane-group kernel (scalar loads); both must satisfy the same bar and
-    agree with each other to rounding."""
+    """The knobs build (csrc/libursa_hip_knobs.so; the shipped library reads no environment) selects the generic
+    lane-group kernel (scalar loads); both must satisfy the same bar and agree with each other to rounding. The shipped
+    library must ignore the same variables."""
+    from ursabench_amd import _native
     rng = np.random.default_rng(5)
     z = (rng.standard_normal((S, B, C)) * 3).astype(np.float32)
     fast = _k5_check(K, z, True, True, np.random.default_rng(9))
     monkeypatch.setenv('URSA_BMA_NO_ROWLANE', '1')
     monkeypatch.setenv('URSA_BMA_NO_V4', '1')
-    slow = _k5_check(K, z, True, True, np.random.default_rng(9))
+    same = _k5_check(K, z, True, True, np.random.default_rng(9))
+    for a, b in zip(fast, same):
+        assert np.array_equal(a, b)                       # shipped library: the variables change nothing
+    slow = _k5_check(_native.knobs_kernels(), z, True, True, np.random.default_rng(9))
     for a, b in zip(fast, slow):
         np.testing.assert_allclose(a, b, rtol=2e-6, atol=1e-7)
 

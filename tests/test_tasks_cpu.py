@@ -127,3 +127,77 @@ def test_ece_brier_simple_cases():
     assert M.brier(p, t) == pytest.approx(np.mean([0.02, 0.72, 0.08]))
     # bins (0.8,0.8667],(0.8667,0.9333],(0.6,0.6667]: |0.8-1|/3 + |0.9-1|/3 + |0.6-0|/3
     assert M.ece(p, t) == pytest.approx((0.2 + 0.1 + 0.6) / 3)
+
+
+def test_distilled_tasks_vs_reference(golden_dir):
+    """G17: PredictionDistilled / OODDetectionDistilled (two students instead of an ensemble; URSABench/tasks/
+    prediction_distilled.py:11, ood_detection_distilled.py:11) against the reference's own run: accumulators, the
+    one-sample-per-call count, metric keys and values; the reference's error behaviour."""
+    g = np.load(os.path.join(golden_dir, 'tasks_distilled.npz'))
+    B = int(g['batch'])
+    x, y, xo = (torch.tensor(g[k]) for k in ('x', 'y', 'x_out'))
+    l_in = DataLoader(DS['c10'](x, y), batch_size=B)
+    l_out = DataLoader(DS['c10'](xo, torch.zeros(len(xo), dtype=torch.long)), batch_size=B)
+    ms = []
+    for nm in ('student', 'unc'):
+        W, b = g[f'{nm}/W'], g[f'{nm}/b']
+        m = torch.nn.Linear(W.shape[1], W.shape[0])
+        with torch.no_grad():
+            m.weight.copy_(torch.tensor(W))
+            m.bias.copy_(torch.tensor(b))
+        ms.append(m)
+    K = OracleKernels()
+    pred = tasks.PredictionDistilled({'in_distribution_test': l_in}, 10, torch.device('cpu'), 'ALL', kernels=K)
+    pred.update_statistics(ms, output_performance=False)
+    pred.update_statistics(ms, output_performance=False)
+    assert pred.num_samples_collected == int(g['pred_count']) == 2
+    np.testing.assert_allclose(pred.ensemble_proba.numpy(), g['pred_proba'], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(pred.expected_data_uncertainty.numpy(), g['pred_ent'], rtol=1e-6, atol=1e-9)
+    gold, got = json.loads(str(g['pred_metrics'])), pred.get_performance_metrics()
+    assert list(got) == list(gold)
+    for k in gold:
+        assert got[k] == pytest.approx(gold[k], rel=2e-5, abs=1e-7), k
+    pred.reset()
+    assert pred.num_samples_collected == 0 and not pred.ensemble_proba.any() and pred.expected_data_uncertainty.any()
+    with pytest.raises(Exception, match='exactly two'):
+        pred.update_statistics(ms[0], output_performance=False)
+    with pytest.raises(NotImplementedError):
+        pred.update_statistics([ms[0], 3], output_performance=False)
+    ood = tasks.OODDetectionDistilled({'in_distribution_test': l_in, 'out_distribution_test': l_out}, 10, torch.device('cpu'),
+                                      kernels=K)
+    om = ood.update_statistics(ms, output_performance=True)
+    for k, v in (('ood_in_proba', ood.in_distribution_ensemble_proba), ('ood_out_proba', ood.out_distribution_ensemble_proba),
+                 ('ood_in_ent', ood.in_distribution_data_uncertainty), ('ood_out_ent', ood.out_distribution_data_uncertainty)):
+        np.testing.assert_allclose(v.numpy(), g[k], rtol=1e-6, atol=1e-9)
+    gold = json.loads(str(g['ood_metrics']))
+    assert list(om) == list(gold)
+    for k in gold:
+        assert om[k] == pytest.approx(gold[k], rel=1e-6), k
+    # the namespace the harness looks tasks up in holds every name the reference's does (tasks/__init__.py:1-5)
+    for name in ('Prediction', 'OODDetection', 'Decision', 'OODDetectionDistilled', 'PredictionDistilled'):
+        assert hasattr(tasks, name)
+
+
+def test_private_miopen_directories_of_dead_processes_are_swept(tmp_path, monkeypatch):
+    """ursabench_amd.tuning: a directory whose owner no longer runs goes away the next time a process asks for one; a live
+    owner's directory and unmarked directories stay."""
+    import subprocess
+    import sys
+    import tempfile
+    from ursabench_amd import tuning
+    monkeypatch.setattr(tempfile, 'tempdir', str(tmp_path))
+    monkeypatch.delenv('MIOPEN_USER_DB_PATH', raising=False)
+    dead = tmp_path / 'ursa_x_miopen_dead'
+    dead.mkdir()
+    p = subprocess.Popen([sys.executable, '-c', 'pass'])
+    p.wait()
+    (dead / tuning._OWNER).write_text(str(p.pid))
+    alive = tmp_path / 'ursa_x_miopen_alive'
+    alive.mkdir()
+    (alive / tuning._OWNER).write_text(str(os.getpid()))
+    foreign = tmp_path / 'ursa_x_miopen_unmarked'
+    foreign.mkdir()
+    mine = tuning.use_shipped_miopen_db('ursa_t_miopen_')
+    monkeypatch.delenv('MIOPEN_USER_DB_PATH', raising=False)
+    assert not dead.exists() and alive.exists() and foreign.exists() and os.path.isdir(mine)
+    assert open(os.path.join(mine, tuning._OWNER)).read() == str(os.getpid())

@@ -7,7 +7,7 @@ if len(sys.argv) > 1 and sys.argv[1] == 'child':
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
     from ursabench_amd import _native
     from tools.kbench import timeit
-    K = _native.default_kernels()
+    K = _native.knobs_kernels()        # the -DURSA_DEBUG_KNOBS build: the shipped library reads no environment
     out = {}
     for n in (36546980 + (-36546980) % 4, 1 << 26, 1 << 24):
         th, g, m, snap = (torch.randn(n, device='cuda') for _ in range(4))

@@ -262,6 +262,38 @@ def gen_tasks():
     print('G4 tasks', sorted({k.split('/')[0] for k in out}))
 
 
+def gen_tasks_distilled():
+    """G17: the reference's PredictionDistilled / OODDetectionDistilled (tasks/prediction_distilled.py:11,
+    ood_detection_distilled.py:11) on two small students: a 12 -> C linear predictor and a 12 -> 1 linear
+    log-uncertainty model; two update_statistics calls (accumulators persist, every call counts one sample)."""
+    out = {}
+    d, C, N, Nout, B = 12, 10, 37, 23, 16
+    g = torch.Generator().manual_seed(17)
+    x, xo = torch.randn(N, d, generator=g), torch.randn(Nout, d, generator=g) * 3
+    y, yo = torch.randint(0, C, (N,), generator=g), torch.randint(0, C, (Nout,), generator=g)
+    student, unc = member(d, C, 70, 1.1), member(d, 1, 71, 0.4)
+    with torch.no_grad():
+        y = torch.where(torch.rand(N, generator=g) < 0.6, student(x).argmax(1), y)
+    ds = torchvision.datasets.cifar.CIFAR10
+    l_in, l_out = DataLoader(ds(x, y), batch_size=B), DataLoader(ds(xo, yo), batch_size=B)
+    out['x'], out['y'], out['x_out'], out['batch'] = x.numpy(), y.numpy(), xo.numpy(), np.array(B)
+    for nm, m in (('student', student), ('unc', unc)):
+        out[f'{nm}/W'], out[f'{nm}/b'] = m.weight.detach().numpy(), m.bias.detach().numpy()
+    pred = tasks.PredictionDistilled({'in_distribution_test': l_in}, C, torch.device('cpu'), 'ALL')
+    pred.update_statistics([student, unc], output_performance=False)
+    pred.update_statistics([student, unc], output_performance=False)
+    out['pred_proba'], out['pred_ent'] = pred.ensemble_proba.numpy(), pred.expected_data_uncertainty.numpy()
+    out['pred_count'] = np.array(pred.num_samples_collected)
+    out['pred_metrics'] = json.dumps({k: float(v) for k, v in pred.get_performance_metrics().items()})
+    ood = tasks.OODDetectionDistilled({'in_distribution_test': l_in, 'out_distribution_test': l_out}, C, torch.device('cpu'))
+    om = ood.update_statistics([student, unc], output_performance=True)
+    out['ood_in_proba'], out['ood_out_proba'] = ood.in_distribution_ensemble_proba.numpy(), ood.out_distribution_ensemble_proba.numpy()
+    out['ood_in_ent'], out['ood_out_ent'] = ood.in_distribution_data_uncertainty.numpy(), ood.out_distribution_data_uncertainty.numpy()
+    out['ood_metrics'] = json.dumps({k: float(v) for k, v in om.items()})
+    np.savez_compressed(os.path.join(OUT, 'tasks_distilled.npz'), **out)
+    print('G17 tasks_distilled', out['pred_metrics'][:80])
+
+
 # ------------------------------------------------------------------------------------- G5
 def gen_swag():
     out = {}
@@ -744,8 +776,8 @@ def gen_model_keys():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['k1', 'sgd', 'sched', 'csghmc', 'tasks', 'swag', 'swag_e2e', 'e2e', 'e2e_preresnet', 'e2e_preresnet_seeds', 'mcdropout', 'columns', 'cyclic', 'cyclic_update_hyp', 'sgd_sampler', 'hmc_wrapper', 'keys']
-    fns = dict(k1=gen_k1, sgd=gen_sgd, swag_e2e=gen_swag_e2e, e2e_preresnet=gen_e2e_preresnet, e2e_preresnet_seeds=gen_e2e_preresnet_seeds, sched=gen_schedules, csghmc=gen_csghmc, tasks=gen_tasks, swag=gen_swag, e2e=gen_e2e,
+    which = sys.argv[1:] or ['k1', 'sgd', 'sched', 'csghmc', 'tasks', 'tasks_distilled', 'swag', 'swag_e2e', 'e2e', 'e2e_preresnet', 'e2e_preresnet_seeds', 'mcdropout', 'columns', 'cyclic', 'cyclic_update_hyp', 'sgd_sampler', 'hmc_wrapper', 'keys']
+    fns = dict(k1=gen_k1, sgd=gen_sgd, swag_e2e=gen_swag_e2e, e2e_preresnet=gen_e2e_preresnet, e2e_preresnet_seeds=gen_e2e_preresnet_seeds, sched=gen_schedules, csghmc=gen_csghmc, tasks=gen_tasks, tasks_distilled=gen_tasks_distilled, swag=gen_swag, e2e=gen_e2e,
                keys=gen_model_keys, mcdropout=gen_mcdropout, columns=gen_experiment_columns, cyclic=gen_e2e_cyclic, cyclic_update_hyp=gen_cyclic_update_hyp, sgd_sampler=gen_sgd_sampler, hmc_wrapper=gen_hmc_wrapper)
     for w in which:
         fns[w]()

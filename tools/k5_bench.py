@@ -6,7 +6,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ursabench_amd import _native
 from tools.kbench import timeit
-K = _native.default_kernels()
+K = _native.knobs_kernels()        # the -DURSA_DEBUG_KNOBS build: the shipped library reads no environment
 args = [int(a) for a in sys.argv[1:]]
 shapes = [tuple(args[i:i + 3]) for i in range(0, len(args), 3)] or [(50, 10000, 10), (20, 10000, 10), (3, 10000, 10), (3, 128, 10),
                                                                   (30, 10000, 100), (30, 128, 100), (30, 10000, 16), (30, 10000, 64)]

@@ -16,6 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libursa_hip.so')
+KNOBS_LIB_PATH = os.path.join(_HERE, 'csrc', 'libursa_hip_knobs.so')   # -DURSA_DEBUG_KNOBS build: tests / tools only
 
 ABI_VERSION = 4
 
@@ -154,8 +155,10 @@ class HipKernels:
 
     name = 'hip-gfx950'
 
-    def __init__(self):
-        self.lib = load_library()
+    def __init__(self, lib=None):
+        """lib: a library handle from load_library(path) - tests and tools that need the experiment knobs pass
+        csrc/libursa_hip_knobs.so (KNOBS_LIB_PATH); the product uses the shipped library, which reads no environment."""
+        self.lib = load_library() if lib is None else lib
 
     # K1 ------------------------------------------------------------------------------
     def sgmcmc_step(self, theta, grad, mom, *, lr, mu, c_wd, c_noise, n_train, flags, seed=0, step=0,
@@ -363,6 +366,12 @@ class HipKernels:
         with torch.cuda.device(dev):
             rc = self.lib.ursa_bn_relu_bwd_f32(*args, _stream(dev))
         _check(self.lib, rc, 'ursa_bn_relu_bwd_f32')
+
+
+def knobs_kernels():
+    """A HipKernels bound to csrc/libursa_hip_knobs.so - the build whose kernel selection can be steered by URSA_*
+    environment variables (tools/, A/B tests). Never used by the samplers or tasks."""
+    return HipKernels(load_library(KNOBS_LIB_PATH))
 
 
 _default = None

@@ -91,12 +91,20 @@ def save_chain(sampler, path):
 
 def load_chain(sampler, path):
     """Put a freshly constructed sampler (same class, model architecture, loader, hyper-parameters) into the saved state."""
-    ck = torch.load(path, weights_only=False)
+    ck = torch.load(path, weights_only=True)          # tensors, lists, dicts and scalars only: no pickled code runs
     if ck.get('format') != CHAIN_FORMAT:
         raise ValueError(f'unknown chain checkpoint format {ck.get("format")}')
     a, opt = sampler.arena, sampler.optimizer
     if ck['kind'] != type(sampler).__name__ or ck['n'] != a.n or ck['param_names'] != list(a.param_names):
         raise ValueError('chain checkpoint does not match this sampler (class / model layout)')
+    # buffer layout: a silent zip() truncation would resume with partly stale BatchNorm counters / statistics
+    if len(ck['ibufs']) != len(a.ibufs) or any(v.shape != b.shape for (_, b), v in zip(a.ibufs, ck['ibufs'])):
+        raise ValueError(f'chain checkpoint holds {len(ck["ibufs"])} integer buffers, the model has {len(a.ibufs)} (or shapes differ)')
+    if (ck['fbuf'] is None) != (a.fbuf is None) or (a.fbuf is not None and ck['fbuf'].numel() != a.fbuf.numel()):
+        raise ValueError('chain checkpoint and model disagree on the floating-point buffers (BatchNorm running statistics)')
+    if ck.get('swag') is not None:
+        if not hasattr(sampler, 'swag_arena') or len(ck['swag']['swag_ibufs']) != len(sampler.swag_arena.ibufs):
+            raise ValueError('chain checkpoint and sampler disagree on the SWAG model\'s integer buffers')
     with torch.no_grad():
         a.theta.copy_(ck['theta'])
         if ck['mom'] is not None:

@@ -589,8 +589,12 @@ inline int bn_plan(int64_t N, int64_t C, int64_t HW, bool vec_ok, BnPlan* p)
     const int V = (vec_ok && (HW & 3) == 0) ? 4 : 1;
     const int64_t hw = HW / V;
     const int64_t per_ch = N * hw;
+#ifdef URSA_DEBUG_KNOBS                    // geometry experiments (tools/exp/bn_fused_bench.py): libursa_hip_knobs.so only
     static const int target = [] { const char* e = getenv("URSA_BN_TARGET_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : kBnTargetWgs; }();
-    int64_t S = (target + C - 1) / C;      // URSA_BN_TARGET_WGS: geometry experiments (tools/exp/bn_fused_bench.py)
+#else
+    constexpr int target = kBnTargetWgs;
+#endif
+    int64_t S = (target + C - 1) / C;
     if (S > kBnMaxSplit) S = kBnMaxSplit;
     if (S < 1) S = 1;
     int64_t chunk = (per_ch + S - 1) / S;

@@ -33,11 +33,20 @@ constexpr int64_t kMaxElems = 1ll << 40;    // keeps ceil(n/2048) blocks inside 
 // elements (201-335 MB, mostly cache-resident) it costs 12 %; round 1's 512 MiB threshold missed the first case.
 constexpr int64_t kNtBytesDefault = 256ll << 20;
 
-// Debug override of the non-temporal threshold in MiB (tools/exp/nt_threshold.py); read once.
+// Kernel-selection knobs for experiments and A/B tests (tools/k1_ctl_bench.py, tools/k5_bench.py, tools/exp/*): compiled
+// into libursa_hip_knobs.so only (-DURSA_DEBUG_KNOBS, `make libursa_hip_knobs.so`). The shipped library reads no
+// environment: every knob() below is a constant nullptr there and the branches fold away.
+#ifdef URSA_DEBUG_KNOBS
+inline const char* knob(const char* name) { return getenv(name); }
+#else
+inline const char* knob(const char*) { return nullptr; }
+#endif
+
+// Knob: the non-temporal threshold in MiB (tools/exp/nt_threshold.py); read once.
 inline int64_t nt_bytes()
 {
     static const int64_t v = [] {
-        const char* e = getenv("URSA_NT_MIB");
+        const char* e = knob("URSA_NT_MIB");
         return e && e[0] ? (int64_t)atoll(e) << 20 : kNtBytesDefault;
     }();
     return v;
@@ -86,11 +95,11 @@ inline int bma_grid(int64_t rows, int rows_per_block)      // one block per row 
     return (int)(g < 1 ? 1 : g > (1 << 20) ? (1 << 20) : g);
 }
 
-// Debug-only kernel-selection switches (tools/exp/k5_sweep.sh): an environment variable set to anything
-// but "0" / empty disables the named fast path. Never needed for correctness.
+// Knobs that disable a fast path (tools/exp/k5_sweep.sh, tests): set to anything but "0" / empty. Never needed for
+// correctness; absent from the shipped library (knob() above).
 inline bool getenv_flag(const char* name)
 {
-    const char* v = getenv(name);
+    const char* v = knob(name);
     return v && v[0] && !(v[0] == '0' && !v[1]);
 }
 
@@ -264,6 +273,11 @@ __global__ __launch_bounds__(1024) void k_sgmcmc_step_ctl(float* theta, float* g
     float next_lr = 0.f, next_col = 0.f;
     bool walk = false;
     if (advance) {
+        // "Holds its copy" made explicit rather than left to what __syncthreads() happens to lower to: the wait retires
+        // this wave's loads of *ctl (scalar and vector) before it arrives at the barrier, and the memory clobber forbids
+        // the compiler to sink those loads below this point or to re-load a field after it (a re-load after the ticket
+        // could see the NEXT step's scalars). The ticket below is an atomic behind the barrier: it cannot move up.
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();                                 // every wave of this workgroup holds its copy of *ctl
         if (threadIdx.x == 0) {
             const float* sched = ctl->sched;             // (sched, sched_len, sched_base are never written by the device)
@@ -1229,7 +1243,7 @@ int ursa_sgmcmc_step_f32(float* theta, float* grad, float* mom, const float* eps
 inline int ctl_block(int64_t n4, int n_chains)
 {
     static const int forced = [] {
-        const char* e = getenv("URSA_CTL_BLOCK");
+        const char* e = knob("URSA_CTL_BLOCK");
         const int v = e && e[0] ? atoi(e) : 0;
         return (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) ? v : 0;
     }();
@@ -1398,7 +1412,7 @@ int ursa_bma_accumulate_f32(const float* logits, float* proba_sum, float* ent_su
         // 4 waves (16 member slots) from 12 members up: measured best at S = 20 (5.7 vs 6.2 us with 2 waves) and at
         // S = 50 (8.0 vs 9.0 us with 8 waves); small ensembles keep small blocks (tools/k5_bench.py rowlane_wavesN)
         int W = S >= 12 ? 4 : S >= 5 ? 2 : 1;
-        if (const char* w = getenv("URSA_BMA_RL_WAVES")) {        // debug: tools/k5_bench.py sweeps
+        if (const char* w = knob("URSA_BMA_RL_WAVES")) {          // knob: tools/k5_bench.py sweeps
             const int v = atoi(w);
             if (v >= 1 && v <= 8) W = v;
         }

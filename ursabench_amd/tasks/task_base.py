@@ -16,8 +16,15 @@ def _prefer_aten_batchnorm_in_eval(module):
     other way round, so only eval is redirected). `torch.batch_norm` picks its backend from the
     process-global cudnn/MIOpen switch; `torch.native_batch_norm` IS the ATen kernel, so the eval
     forward of OUR twin's BatchNorm layers calls that directly: no global state is touched (RCCL
-    watchdog / ChainGroup threads may be alive) and no private API is used."""
+    watchdog / ChainGroup threads may be alive) and no private API is used.
+
+    Only for networks whose BatchNorm layers run their own `forward`: the twin of a FOREIGN module, or of ours with
+    K6 switched off (URSA_FUSED_BN=0 A/B runs). The networks of ursabench_amd.models call `fused_bn.bn_relu`, whose
+    evaluation path is one K6 launch that never enters `BatchNorm.forward`: they are left untouched."""
     from torch.nn.modules.batchnorm import _BatchNorm
+    from .. import fused_bn
+    if fused_bn.enabled() and type(module).__module__ == 'ursabench_amd.models':
+        return
     for m in module.modules():
         if isinstance(m, _BatchNorm) and not hasattr(m, '_ursa_bn_wrapped'):
             inner = m.forward

@@ -18,12 +18,44 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SHIPPED = os.path.join(_HERE, 'miopen_db')
 
 
+_OWNER = 'ursa_owner.pid'
+
+
+def _sweep_dead_owners():
+    """Every bench rank, experiment / time_script main and smoke() makes a private directory; long sweeps used to pile
+    them up under the temp directory. A directory is removed by the NEXT process that comes through here once its owner
+    (the pid in its marker file) no longer runs - not at the owner's own exit, where MIOpen may still be flushing its
+    databases into it. Directories without a marker (made by something else) are never touched."""
+    tmp = tempfile.gettempdir()
+    try:
+        names = os.listdir(tmp)
+    except OSError:
+        return
+    for name in names:
+        d = os.path.join(tmp, name)
+        if not (name.startswith('ursa_') and 'miopen' in name and os.path.isdir(d)):
+            continue
+        try:
+            pid = int(open(os.path.join(d, _OWNER)).read().strip())
+        except (OSError, ValueError):
+            continue
+        try:
+            os.kill(pid, 0)                       # signal 0: existence check only
+        except ProcessLookupError:
+            shutil.rmtree(d, ignore_errors=True)
+        except OSError:
+            pass                                  # exists but not ours (EPERM): leave it
+
+
 def use_shipped_miopen_db(prefix='ursa_miopen_'):
     """Call BEFORE the first convolution of the process. Respects an MIOPEN_USER_DB_PATH the caller already set;
     URSA_NO_SHIPPED_MIOPEN_DB=1 gives an empty private database instead (what round 2 ran with)."""
     if 'MIOPEN_USER_DB_PATH' in os.environ:
         return os.environ['MIOPEN_USER_DB_PATH']
+    _sweep_dead_owners()
     d = tempfile.mkdtemp(prefix=prefix)
+    with open(os.path.join(d, _OWNER), 'w') as f:
+        f.write(str(os.getpid()))
     if os.environ.get('URSA_NO_SHIPPED_MIOPEN_DB') != '1' and os.path.isdir(SHIPPED):
         for f in os.listdir(SHIPPED):
             if f.endswith('.txt'):
