@@ -66,7 +66,11 @@ def parse(argv=None):
     ap.add_argument('--config', choices=['c2', 'c4', 'c5'], default='c2')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
     ap.add_argument('--chains-per-gpu', type=int, default=1, help='>1: ChainGroup (parallel graph branches); the headline config is 1')
-    ap.add_argument('--multi-chain-probe', type=int, default=4, help='chains of the informational multi-chain run at N=1 (0: skip)')
+    ap.add_argument('--multi-chain-probe', type=int, default=None, help='(older scripts) 0 = --multi-chain-sweep ""')
+    ap.add_argument('--multi-chain-sweep', default='2,4,8,16', help='chains per GPU of the multi_chain_per_gpu sweep at N=1 (empty: skip)')
+    ap.add_argument('--bma-members', type=int, default=30, help='c2: ensemble size of the BMA leg (the reference configs use 30-50): the '
+                    'chain\'s own samples, topped up with further snapshots of the continuing chain; 0: only the timed samples')
+    ap.add_argument('--no-sanity-legs', action='store_true', help='c2: skip the reduced-size C4 / C5 code-path legs')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--force-dist', action='store_true', help='join a process group even when WORLD_SIZE is 1')
@@ -86,6 +90,8 @@ def parse(argv=None):
         a.steps = {'c2': 3, 'c4': 30, 'c5': 20}[a.config]
     if a.warmup is None:
         a.warmup = 1
+    if a.multi_chain_probe == 0:
+        a.multi_chain_sweep = ''
     return a
 
 
@@ -194,6 +200,26 @@ def pmc_traffic(kernel_key, elements):
                 return (int(round(v['hbm_bytes_per_launch_corrected'] * elements / n)),
                         f'profiles/{name} (rocprofv3 --pmc passes of an earlier run of this kernel at this size; not collected in this run)')
     return None, 'none (no committed PMC pass for this kernel and size)'
+
+
+def rocprof_average(kernel_substr, files=('r04_bench_kernel_stats.csv', 'r03_bench_kernel_stats.csv')):
+    """Average duration of a kernel in the committed `rocprofv3 --kernel-trace --stats` summary of THIS command
+    (profiles/rNN_bench_kernel_stats.csv, written by tools/r04_evidence.sh). The profiler cannot run inside the
+    measurement, so this is read from the file and named: a reader recomputes frac_rocprof = bytes / us from it.
+    Returns dict(us, calls, file) or None."""
+    import csv
+    for name in files:
+        path = os.path.join(ROOT, 'profiles', name)
+        if not os.path.exists(path):
+            continue
+        tot = calls = 0
+        for row in csv.DictReader(open(path)):
+            if kernel_substr in row['Name']:
+                tot += float(row['TotalDurationNs'])
+                calls += int(row['Calls'])
+        if calls:
+            return {'us': round(tot / calls / 1e3, 3), 'calls': calls, 'file': f'profiles/{name}'}
+    return None
 
 
 # ---- c2 legs ------------------------------------------------------------------------------------------
@@ -469,10 +495,28 @@ def roofline_block(sampler, large_n, group=None):
     ms = event_time_ms(fn, 2048, stream, graph_batch=256)
     bytes_per_launch = 20 * arena.n * chains
     achieved = bytes_per_launch / (ms * 1e-3) / 1e9
+    # the profiler's reading of the same launch, and a control: a 1-thread kernel (ursa_step_ctl_advance on a scratch
+    # block) timed the same two ways. At 3-4 us per launch the two clocks disagree by the profiler's per-dispatch floor.
+    from ursabench_amd import _native
+    scratch = torch.zeros(_native.CTL_BYTES, dtype=torch.uint8, device=arena.theta.device)
+    ms_ctrl = event_time_ms(lambda: K.step_ctl_advance(scratch), 2048, stream, graph_batch=256)
+    prof = rocprof_average('k_sgmcmc_step_ctl<false, true>' if chains > 1 else 'k_sgmcmc_step_ctl<false, false>')
+    prof_ctrl = rocprof_average('k_step_ctl_advance')
     out = {'bound': 'hbm', 'kernel': 'k_sgmcmc_step_ctl' + (f' ({chains} chains in one launch)' if chains > 1 else ''),
            'chains_per_launch': chains, 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS,
            'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': pmc_traffic('step_ctl', arena.n)[0],
            'traffic_source': pmc_traffic('step_ctl', arena.n)[1], 'bytes_per_launch': bytes_per_launch, 'us_per_launch': round(ms * 1e3, 3),
+           'frac_uses': 'us_per_launch_hip_events (measured live in this run, below); frac_rocprof uses the committed profile of this command',
+           'us_per_launch_hip_events': round(ms * 1e3, 3),
+           'us_per_launch_rocprof': None if prof is None else prof['us'],
+           'frac_rocprof': None if prof is None else round(bytes_per_launch / (prof['us'] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
+           'rocprof_source': None if prof is None else f"{prof['file']}: {prof['calls']} launches of this kernel (inside training-step replays and this leg)",
+           'control_1_thread_kernel': {'kernel': 'k_step_ctl_advance (1 thread, 1 workgroup)', 'us_hip_events': round(ms_ctrl * 1e3, 3),
+                                       'us_rocprof': None if prof_ctrl is None else prof_ctrl['us'],
+                                       'rocprof_source': None if prof_ctrl is None else f"{prof_ctrl['file']}: {prof_ctrl['calls']} launches",
+                                       'reading': 'a kernel that does nothing takes us_hip_events per launch in a 256-launch replay (that is the '
+                                                  'dependent-launch boundary) and reads us_rocprof in the profile: the difference is the '
+                                                  'profiler\'s per-dispatch floor, the same for the update launch'},
            'note': 'workload-sized launch (5.5 MB of state, L2/Infinity-Cache resident, one float4 per lane, 134 workgroups), '
                    'self-advancing its control block (no separate advance launch): latency-bound; us_per_launch is a '
                    '256-launch hipGraph replay / 256 and includes the ~1.5 us kernel boundary; see roofline_large for the '
@@ -674,19 +718,38 @@ def cpu_baseline_block(steps):
     return out
 
 
-def multi_chain_block(k, make_chain, inference):
-    """Informational (NOT the headline config, which is one chain per GPU): K independent chains on this one
-    GPU stepped as K parallel branches of one hipGraph (inference/chain_group.py). One untimed sample per
-    chain, then one timed."""
-    group = inference.ChainGroup([make_chain(100 + c) for c in range(k)])
-    group.sample_iterative()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    group.sample_iterative()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    return {'chains_per_gpu': k, 'value': round(k / dt, 4), 'unit': 'posterior-samples/s (aggregate over the chains)',
-            'ms_per_lockstep_round': round(1e3 * dt / len(group.loader), 3), 'engine': group.stats}
+def multi_chain_block(ks, make_chain, inference, single_chain_value):
+    """SURVEY.md 8f-1 (NOT the headline config, which is one chain per GPU): K independent chains on this one GPU stepped
+    as K parallel branches of one hipGraph joined by ONE multi-chain update launch (inference/chain_group.py), swept over
+    K. Per K: one untimed sample per chain (warm-up steps + capture), then one timed; the K1 `_multi` launch of that very
+    group timed by HIP events (graph-batched) with its HBM fraction. `x_single_chain` = aggregate samples/s over the
+    headline's one-chain figure of this run."""
+    out = []
+    for k in ks:
+        group = inference.ChainGroup([make_chain(100 + c) for c in range(k)])
+        group.sample_iterative()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        group.sample_iterative()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        K = group.kernels
+        for s_ in group.samplers:
+            s_.optimizer.ctl_begin(True)
+        ms = event_time_ms(lambda: K.sgmcmc_step_multi(group.theta, group.grad, group.mom, group.ctl), 1024,
+                           torch.cuda.current_stream(), graph_batch=128)
+        nbytes = 20 * group.samplers[0].arena.n * k
+        out.append({'chains_per_gpu': k, 'value': round(k / dt, 4), 'unit': 'posterior-samples/s (aggregate over the chains)',
+                    'x_single_chain': None if not single_chain_value else round(k / dt / single_chain_value, 3),
+                    'ms_per_lockstep_round': round(1e3 * dt / len(group.loader), 3),
+                    'k1_multi_us_per_launch': round(ms * 1e3, 3), 'k1_multi_bytes_per_launch': nbytes,
+                    'k1_multi_frac': round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), 'engine': dict(group.stats)})
+        del group
+        torch.cuda.empty_cache()
+    best = max(out, key=lambda r: r['value']) if out else None
+    return {'sweep': out, 'best': None if best is None else {'chains_per_gpu': best['chains_per_gpu'], 'value': best['value'],
+                                                              'x_single_chain': best['x_single_chain']},
+            'form': 'K forward/backward branches of one hipGraph + ONE k_sgmcmc_step_ctl<.., multi> launch over [K, n] slabs'}
 
 
 def reference_style_gpu_block(steps, dev):
@@ -904,7 +967,23 @@ def run_c2(a, job, legs, line):
     legs.run('sampling', sampling)
 
     # ---- BMA predictive over the test set: members sharded over ranks, one all-reduce -------------
+    def top_up():
+        """An ensemble of the size the reference's configurations evaluate (30-50 members), not of the 3-20 samples the
+        timed region happened to produce: the chain keeps running (untimed) and is snapshot every `thin` minibatch steps
+        until the rank holds --bma-members members. Real, distinct posterior snapshots of this chain, thinned less than
+        the timed ones (one per epoch); the evaluation's throughput does not depend on the weights' values."""
+        from ursabench_amd.data import DeviceLoader
+        thin = 20
+        short = DeviceLoader(train.dataset.x[:thin * batch], train.dataset.y[:thin * batch], batch)
+        added = 0
+        while len(ensemble) < a.bma_members:
+            sampler.engine.run_epoch(short, True)
+            ensemble.append(sampler._snapshot())
+            added += 1
+        return added
+
     def bma():
+        topped = top_up() if (a.bma_members and not job.cpu and group is None and len(ensemble) < a.bma_members) else 0
         pred = tasks.Prediction({'in_distribution_test': test}, CLASSES, dev, 'ALL', **kw)
         pred._acc.accumulate(ensemble)                            # untimed pass: MIOpen eval-mode search + the twin's graph captures for
         #                                                           every (batch shape, lanes in use) this ensemble needs (local: no collective)
@@ -914,10 +993,17 @@ def run_c2(a, job, legs, line):
         metrics = pred.get_performance_metrics()
         members = pred.num_samples_collected
         line.update({'bma_preds_per_s': round(n_test / dt_bma, 1), 'bma_members': members,
+                     'bma_members_per_rank': len(ensemble),
+                     'bma_members_what': f'{len(ensemble) - topped} samples of the timed / warm-up region'
+                                         + (f' + {topped} further snapshots of the continuing chain, one per 20 minibatch steps (untimed)' if topped else ''),
                      'bma_member_forwards_per_s': round(members * n_test / dt_bma, 1),
                      'bma_nll': round(float(metrics['nll']), 5), 'bma_engine': dict(pred._acc.stats)})
     if ensemble:
         legs.run('bma', bma)
+
+    # ---- what the process group is, measured from inside it (every rank: collectives) ------------------------------
+    from ursabench_amd.distributed import describe_group
+    line['rccl'] = legs.run('rccl', describe_group, dev, 4 * (n_test * CLASSES + n_test + 1))
 
     if rank == 0 and not job.cpu:
         r = legs.run('roofline', roofline_block, sampler, a.large_n, group)
@@ -926,13 +1012,67 @@ def run_c2(a, job, legs, line):
         line['roofline_bma_kernel'] = legs.run('roofline_bma_kernel', bma_kernel_block, max(1, len(ensemble)), N_TEST, CLASSES)
         if world == 1:
             line['roofline_kernels'] = legs.run('roofline_kernels', roofline_kernels_block, dev, a.large_n)
-        if world == 1 and kpg == 1 and a.multi_chain_probe > 1:
-            line['multi_chain_per_gpu'] = legs.run('multi_chain_per_gpu', multi_chain_block, a.multi_chain_probe,
-                                                   make_chain, inference)
+            line['roofline_k6'] = legs.run('roofline_k6', roofline_k6_object, line['roofline_kernels'])
+        ks = [int(k) for k in a.multi_chain_sweep.split(',') if k.strip()]
+        if world == 1 and kpg == 1 and ks:
+            line['multi_chain_per_gpu'] = legs.run('multi_chain_per_gpu', multi_chain_block, ks, make_chain, inference, line.get('value'))
         if world == 1 and a.ref_style_steps > 0:
             line['reference_style_gpu'] = legs.run('reference_style_gpu', reference_style_gpu_block, a.ref_style_steps, dev)
+        if world == 1 and not a.no_sanity_legs:
+            line['sanity_c4_c5'] = legs.run('sanity_c4_c5', sanity_block, a, job)
         if world == 1 and not a.no_cpu_baseline:
             line['cpu_baseline'] = legs.run('cpu_baseline', cpu_baseline_block, a.cpu_steps)
+
+
+def roofline_k6_object(rk):
+    """A second roofline object for the largest HAND-WRITTEN share of a training step (K6: relu(bn(x)) + residual sums;
+    17 % of a step's kernel time against K1's 1 %), from this run's roofline_kernels entries: at the workload's own
+    layers (cache-resident, latency-bound: us per call is the figure) and at one HBM-sized layer (PreResNet-164 at the
+    HMC batch, 268 MB), achieved = ALGORITHMIC minimum bytes (8 B/element forward, 12 backward) / time. rocprof's
+    average for the same kernels in the committed profile of this command beside it."""
+    if not rk:
+        return None
+    big_f, big_b = rk['k6_bn_relu_fwd_1024x64x32x32'], rk['k6_bn_relu_bwd_1024x64x32x32']
+    prof = {k: rocprof_average(k) for k in ('k_bn_stats<4', 'k_bn_fwd_apply<4', 'k_bn_bwd_reduce<4', 'k_bn_bwd_dx<4', 'k_bn_fwd_one<', 'k_bn_bwd_one<', 'k_bn_fwd_res<', 'k_bn_bwd_res<')}
+    return {'bound': 'hbm', 'kernel': 'K6 relu(bn(x)) forward at [1024, 64, 32, 32] (268 MB, beyond the Infinity Cache)',
+            'achieved': big_f['GBps'], 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': big_f['frac'], 'traffic': None,
+            'traffic_source': 'profiles/r03_pmc.json holds the PMC passes of the two-launch form at this size (1.0002-1.0005 x its form bytes)',
+            'bytes_per_launch': big_f['bytes'], 'us_per_launch': big_f['us'], 'form': big_f.get('form'), 'form_bytes': big_f.get('form_bytes'),
+            'backward': {'achieved': big_b['GBps'], 'frac': big_b['frac'], 'bytes_per_launch': big_b['bytes'], 'us_per_launch': big_b['us'],
+                         'form': big_b.get('form'), 'form_bytes': big_b.get('form_bytes')},
+            'workload_layers_us_per_call': {k[len('k6_bn_relu_'):]: {'us': v['us'], 'frac_of_algorithmic_minimum': v['frac'], 'form': v.get('form')}
+                                            for k, v in rk.items() if k.startswith('k6_') and ('128x16x32x32' in k or '128x64x8x8' in k)},
+            'rocprof_average_us_in_the_training_step': {k: v for k, v in prof.items() if v},
+            'share_of_step_kernel_time': 'profiles/r04_bench_kernel_stats.csv (Percentage column, k_bn_* rows)'}
+
+
+def sanity_block(a, job):
+    """NOT A MEASUREMENT. BASELINE configs[3] and [4] run at full size through `--config c4` / `--config c5` (minutes
+    each; builder-run lines under profiles/); the driver only ever runs the default command, so their CODE PATHS are
+    exercised here at reduced size - WideResNet-28-10 SWAG (2-epoch trajectory over 1,280 images, 2 members each with
+    the full bn_update pass over those images, BMA of the 2 members over the 10,000-row test set through K5 at C = 100)
+    and PreResNet-164 HMC (1 chain, full-batch potential over 256 images, L = 2, 2 proposals). Figures are reported so a
+    crash or a 10x regression shows, and are labelled as what they are."""
+    import copy
+    out = {'NOT_A_MEASUREMENT': 'reduced-size code-path check of the c4 / c5 legs under the default command; '
+                                'full-size lines: profiles/r04_c4_bench_line.json, profiles/r04_c5_bench_line.json'}
+    for cfg, fn, over in (('c4', run_c4, dict(steps=2, warmup=0, c4_train=1280, c4_epochs=2, c4_weak=False)),
+                          ('c5', run_c5, dict(steps=2, warmup=0, c5_batch=256, c5_chains=1, c5_L=2))):
+        a2 = copy.copy(a)
+        for k, v in over.items():
+            setattr(a2, k, v)
+        sub_legs, sub = Legs(), {'config': {}}
+        t0 = time.perf_counter()
+        fn(a2, job, sub_legs, sub)
+        out[cfg] = {'seconds': round(time.perf_counter() - t0, 1), 'value': sub.get('value'), 'unit': sub.get('unit'),
+                    'overrides': over, 'errors': sub_legs.errors,
+                    **{k: sub[k] for k in ('bma_preds_per_s', 'bma_members', 'bma_nll', 'trajectory_seconds', 'leapfrog_steps_per_s',
+                                           'acceptance_rate_rank0') if k in sub},
+                    'roofline': sub.get('roofline')}
+        torch.cuda.empty_cache()
+        if sub_legs.errors:
+            raise RuntimeError(f'sanity {cfg}: {json.dumps(sub_legs.errors)[:1200]}')
+    return out
 
 
 def run_c4(a, job, legs, line):

@@ -39,6 +39,7 @@ def test_dry_run_single_process():
     assert line['value'] > 0 and line['ms_per_step'] > 0 and line['bma_members'] == 2
     assert line['value'] == pytest.approx(2 / (line['ms_per_step'] * 2 / 1e3), rel=1e-3)
     assert line['config']['workload'].startswith('PreResNet-20')
+    assert line['rccl']['world'] == 1 and line['rccl']['backend'] is None and line['rccl']['all_reduce_us'] is None
 
 
 def test_dry_run_world_size_2_gloo():
@@ -46,6 +47,11 @@ def test_dry_run_world_size_2_gloo():
     assert rc == 0 and line['errors'] == {}
     assert line['n_gpus'] == 2 and line['config']['chains'] == 2
     assert line['bma_members'] == 4                       # 2 members per rank, summed by the all-reduce
+    # the line proves by itself what the process group was: backend, ranks that answered, one device record per rank
+    r = line['rccl']
+    assert r['backend'] == 'gloo' and r['world'] == 2 and r['ranks_seen'] == [0, 1] and len(r['devices']) == 2
+    assert {d['rank'] for d in r['devices']} == {0, 1} and len({d['pid'] for d in r['devices']}) == 2
+    assert r['all_reduce_bytes'] == 4 * (96 * 10 + 96 + 1) and r['all_reduce_us'] > 0
     # whole-job aggregate: world x K samples over the max-over-ranks time
     assert line['value'] == pytest.approx(2 * 2 / (line['ms_per_step'] * 2 / 1e3), rel=1e-3)
 

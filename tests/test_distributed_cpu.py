@@ -186,3 +186,23 @@ def test_shard_and_seed_helpers():
     from ursabench_amd.distributed import chain_seed, shard
     assert shard(range(30), 7, 8) == [7, 15, 23] and sum(len(shard(range(30), r, 8)) for r in range(8)) == 30
     assert [chain_seed(0, r) for r in range(3)] == [0, 1, 2]
+
+
+def test_c3_partition_check_job_world_size_2_gloo():
+    """tools/c3_partition_check.py (the job the GPU suite starts over RCCL on every visible GPU) at world size 2 on CPU:
+    the all-reduced predictive equals the one-process sum of the ranks' local accumulators, the count is chains x
+    samples, the chains differ, both ranks answered."""
+    import json
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    root = os.path.dirname(HERE)
+    p = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr',
+                        '127.0.0.1', '--master-port', str(port), os.path.join(root, 'tools', 'c3_partition_check.py'), '--cpu'],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, PYTHONPATH=root))
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+    assert p.returncode == 0 and len(lines) == 1, (p.stdout[-1500:], p.stderr[-1500:])
+    line = json.loads(lines[0])
+    assert line['pass'] and line['pass_on_every_rank'] and line['world'] == 2 and all(line['ok'].values()), line
+    assert line['rccl']['ranks_seen'] == [0, 1] and line['rccl']['backend'] == 'gloo'

@@ -474,6 +474,34 @@ def test_rccl_process_group_with_graph_capture_world_size_1():
     assert total == pytest.approx(2 * 300, rel=1e-5)         # every member's probabilities sum to 1 per row
 
 
+def test_c3_partition_over_rccl_on_every_visible_gpu():
+    """BASELINE configs[2] in miniature over REAL RCCL: tools/c3_partition_check.py as a torch.distributed.run job with
+    one rank per visible GPU (at most 4: the box admits 6 GPU processes), started as a fresh child process so that
+    nothing in it has touched a GPU before its own ranks do. Each rank checks that the RCCL all-reduce of the predictive
+    equals the one-process sum of every rank's local accumulators, that N ranks answered on N distinct devices, and
+    that the chains differ. Skips on a 1-GPU box (world size 1 over RCCL is test_rccl_process_group_..._world_size_1)."""
+    import socket
+    import subprocess
+    import sys
+    n = min(torch.cuda.device_count(), 4)
+    if n < 2:
+        pytest.skip(f'{torch.cuda.device_count()} GPU visible: the N > 1 RCCL job needs at least 2')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, PYTHONPATH=root, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    p = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr',
+                        '127.0.0.1', '--master-port', str(port), os.path.join(root, 'tools', 'c3_partition_check.py')],
+                       capture_output=True, text=True, timeout=900, env=env)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+    assert p.returncode == 0 and len(lines) == 1, (p.stdout[-2000:], p.stderr[-2000:])
+    line = json.loads(lines[0])
+    assert line['pass_on_every_rank'] and line['world'] == n and line['backend'] == 'nccl', line
+    assert line['rccl']['ranks_seen'] == list(range(n)) and line['rccl']['distinct_devices'] == n, line['rccl']
+    assert line['engine']['graph_replays'] > 0
+
+
 @pytest.mark.parametrize('use_graph', [False, True])
 def test_end_to_end_preresnet8_vs_reference_on_gpu(golden_dir, use_graph):
     """BASELINE configs[1]'s network family (PreResNet, BatchNorm) and sampler (SGHMC): the reference's CPU run

@@ -54,3 +54,53 @@ def share_swag_moments(sampler, src=0, group=None):
     dist.broadcast(count, src, group=group)
     sampler.num_models_collected = count.cpu()
     sampler.adopt_moments()
+
+
+def describe_group(device, all_reduce_bytes, repeats=20, group=None):
+    """What the process group actually is, measured from inside it (every rank must call this: it runs collectives):
+    backend, world size, the ranks that answered an all-reduce, the device each rank computes on (index, name, PCI bus
+    id where the runtime gives one - N ranks must name N different devices), and the duration of the predictive
+    all-reduce at its real size (`all_reduce_bytes` of fp32, HIP events on the collective's stream; host clock on CPU
+    tensors). Without a process group: world 1, no collective. bench.py puts the result in its line as `rccl`, so the
+    first multi-GPU run of the job proves by itself that RCCL saw N ranks on N GPUs."""
+    import time
+    device = torch.device(device)
+    me = {'rank': int(os.environ.get('RANK', 0)), 'local_rank': int(os.environ.get('LOCAL_RANK', 0)), 'device': str(device), 'pid': os.getpid()}
+    if device.type == 'cuda':
+        p = torch.cuda.get_device_properties(device)
+        me.update(name=p.name, pci_bus_id=getattr(p, 'pci_bus_id', None), pci_device_id=getattr(p, 'pci_device_id', None),
+                  uuid=str(getattr(p, 'uuid', '')) or None)
+    if not (dist.is_available() and dist.is_initialized()):
+        return {'backend': None, 'world': 1, 'ranks_seen': [0], 'devices': [me], 'all_reduce_bytes': 0, 'all_reduce_us': None,
+                'note': 'single process: no process group, no collective on the path'}
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    seen = torch.zeros(world, device=device)
+    seen[rank] = rank + 1.0
+    dist.all_reduce(seen, group=group)
+    every = [None] * world
+    dist.all_gather_object(every, me, group=group)
+    buf = torch.ones(max(1, int(all_reduce_bytes) // 4), device=device)
+    for _ in range(3):
+        dist.all_reduce(buf, group=group)
+        buf.fill_(1.0)
+    if device.type == 'cuda':
+        torch.cuda.synchronize(device)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(repeats):
+            dist.all_reduce(buf, group=group)
+        b.record()
+        b.synchronize()
+        us = a.elapsed_time(b) * 1e3 / repeats
+    else:
+        t0 = time.perf_counter()
+        for _ in range(repeats):
+            dist.all_reduce(buf, group=group)
+        us = (time.perf_counter() - t0) * 1e6 / repeats
+    t = torch.tensor([us], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return {'backend': dist.get_backend(group), 'world': world,
+            'ranks_seen': [r for r in range(world) if float(seen[r]) == r + 1.0], 'devices': every,
+            'distinct_devices': len({(d.get('pci_bus_id'), d.get('uuid'), d.get('device')) for d in every}),
+            'all_reduce_bytes': int(buf.numel() * 4), 'all_reduce_us': round(float(t.item()), 2),
+            'all_reduce_what': f'sum over {world} ranks of the predictive buffer [N*C + N + count] fp32, max over ranks of the mean of {repeats}'}

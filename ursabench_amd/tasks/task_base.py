@@ -308,14 +308,15 @@ class EnsembleAccumulator:
         RCCL/xGMI (gloo on CPU), then ONE device-to-host copy. This is the path's only collective and the
         only place the host waits for the device; it is entered from update_statistics alone (never from
         a constructor or reset()), so every rank must call update_statistics the same number of times —
-        with an empty member list if it holds none."""
+        with an empty member list if it holds none. `group=False`: this rank's own sums, no collective (a task
+        built with process_group=False inside a job: tools/c3_partition_check.py compares the two)."""
         parts = [self.proba.reshape(-1)]
         if self.ent is not None:
             parts.append(self.ent)
         if self.risk is not None:
             parts.append(self.risk.reshape(-1))
         buf = torch.cat(parts + [torch.tensor([float(count)], device=self.device)])
-        if dist.is_available() and dist.is_initialized():       # also at world size 1: the collective is then a no-op
+        if group is not False and dist.is_available() and dist.is_initialized():   # also at world size 1: a no-op collective
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
         buf = buf.cpu()
         count = int(round(float(buf[-1])))
