@@ -269,12 +269,21 @@ int ursa_sumsq_f32(const float* x, int64_t n, float* out, float* ws, ursa_stream
  * Deterministic (no atomics); fp32 throughout. Error vs exact arithmetic: a few ulp on y / dx
  * (tests compare with float64 BatchNorm at 2e-6 relative to the activation scale).
  * Traffic: forward 12 B/element (x twice, y once), backward 20 B/element, evaluation 8 B/element;
- * residual form: forward 20, backward 24, evaluation 16.
+ * residual form: forward 20, backward 24, evaluation 16. One-pass and held forms (URSA_BN_HELD): 8 / 12 and 16 / 16.
  */
 #define URSA_BN_RELU        0x1u
-#define URSA_BN_TWO_LAUNCH  0x2u   /* keep the two-launch form where the one-pass form would apply (A/B, tests) */
-#define URSA_BN_ALLFLAGS    0x3u
-#define URSA_BN_WS_FLOATS(C) ((int64_t)(C) * 64 * 4)
+#define URSA_BN_TWO_LAUNCH  0x2u   /* keep the two-launch form where the one-pass / held form would apply (A/B, tests) */
+#define URSA_BN_HELD        0x4u   /* the caller vouches that ws's sync words (below) are ZERO: the library may then run the
+                                      held form - ONE launch, every input read once - on activations of >= 24 MiB whose
+                                      channels do not fit one workgroup (per-channel workgroups hold their chunk in registers,
+                                      exchange double partial sums through ws and wait for each other; bounded wait; the sync
+                                      words are zero again when the launch has drained, so a zeroed ws can be reused call
+                                      after call). Same floats as the two-launch form. Without the flag ws needs no
+                                      initialisation and the held form is never taken. */
+#define URSA_BN_ALLFLAGS    0x7u
+/* partial sums: C x 64 x {double, double}; then the sync words: ticket, err, 2 spare, one arrival counter per channel */
+#define URSA_BN_WS_FLOATS(C) ((int64_t)(C) * 64 * 4 + (int64_t)(C) + 64)
+#define URSA_BN_WS_SYNC_OFFSET_FLOATS(C) ((int64_t)(C) * 64 * 4)
 
 int ursa_bn_relu_fwd_f32(const float* x, const float* addend /* or NULL */, float* z_out /* iff addend */,
                          float* y, const float* gamma, const float* beta,

@@ -521,3 +521,105 @@ def test_gated_backward_argument_errors(K):
         K.bn_relu_backward(x, x, torch.empty_like(x), v, v, v, v, v.clone(), v.clone(), ws, relu=True, gates=(gi, go[:1]))
     with pytest.raises(ValueError):
         K.bn_relu_backward(x, x, torch.empty_like(x), v, v, v, v, v.clone(), v.clone(), ws, relu=True, gates=(gi.long(), go))
+
+
+HELD_SHAPES = [(128, 160, 32, 32),      # WideResNet-28-10 stage 1: 84 MB, S = 8
+               (256, 64, 32, 32),       # 67 MB, S = 16
+               (512, 16, 32, 32),       # few channels: 16 x 32 workgroups
+               (96, 96, 34, 30)]        # ragged: H*W = 1020 (float4 path, chunk tail), S = 6
+
+
+def _sync_words(ws, C):
+    return ws[C * 256:].view(torch.int32)
+
+
+@pytest.mark.parametrize('shape', HELD_SHAPES)
+@pytest.mark.parametrize('relu', [True, False])
+def test_held_form_equals_two_launch_form(K, shape, relu):
+    """URSA_BN_HELD (activations >= 24 MiB whose channels do not fit one workgroup): ONE launch per direction - the
+    channel's workgroups hold their chunks in registers, exchange double partial sums through ws and wait for each other -
+    must produce the two-launch form's floats (plain and residual forms), leave its sync words zero so that the SAME
+    zeroed ws serves call after call, and never run into its bounded wait."""
+    from ursabench_amd import _native
+    g = torch.Generator().manual_seed(sum(shape) + 3 * relu)
+    C = shape[1]
+    a, b, dy, dz = (torch.randn(shape, generator=g).cuda() for _ in range(4))
+    w, bb = (torch.rand(C, generator=g) + 0.5).cuda(), torch.randn(C, generator=g).cuda()
+    assert a.numel() * 4 >= _native.BN_HELD_MIN_BYTES
+    ws = torch.zeros(_native.bn_ws_floats(C), device='cuda')              # zeroed ONCE, reused by every held call below
+    outs = []
+    for held in (True, False):
+        for resid in (False, True):
+            z, y, dx = torch.full_like(a, float('nan')), torch.full_like(a, float('nan')), torch.full_like(a, float('nan'))
+            sm, si, dw, db = (torch.full((C,), float('nan'), device='cuda') for _ in range(4))
+            rm, rv = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
+            for _ in range(2 if held else 1):                               # twice: the launch re-arms its own sync words
+                rm.zero_(), rv.fill_(1.0)
+                K.bn_relu_forward(a, y, w, bb, rm, rv, sm, si, ws, eps=1e-5, momentum=0.1, relu=relu, held=held,
+                                  **(dict(addend=b, z_out=z) if resid else {}))
+                K.bn_relu_backward(z if resid else a, dy, dx, w, bb, sm, si, dw, db, ws, relu=relu, held=held,
+                                   dz=dz if resid else None)
+                if held:
+                    torch.cuda.synchronize()
+                    assert not _sync_words(ws, C).any(), 'sync words not re-armed (or the bounded wait ran out: word 1)'
+            outs.append((resid, [y, sm, si, rm, rv, dx, dw, db] + ([z] if resid else [])))
+    for (r1, o1), (r2, o2) in ((outs[0], outs[2]), (outs[1], outs[3])):
+        assert r1 == r2
+        for t1, t2, name in zip(o1, o2, ('y', 'mean', 'invstd', 'running_mean', 'running_var', 'dx', 'dgamma', 'dbeta', 'z')):
+            assert not torch.isnan(t1).any(), name
+            if name in ('dgamma', 'dbeta', 'mean', 'invstd', 'running_mean', 'running_var'):
+                assert int((t1 != t2).sum()) <= 1 and torch.allclose(t1, t2, rtol=2e-7, atol=0), name
+            elif name in ('dx', 'y'):
+                ok = (o1[1] == o2[1]) & (o1[2] == o2[2]) & (o1[6] == o2[6]) & (o1[7] == o2[7])
+                assert torch.equal(t1[:, ok], t2[:, ok]), name
+            else:
+                assert torch.equal(t1, t2), name
+
+
+def test_held_form_on_parallel_streams_and_through_the_module_path():
+    """(a) Four held launches in flight at once on four streams (what a ChainGroup's branches do): all drain, all
+    correct - a launch only ever waits for workgroups of its own that are already running. (b) fused_bn picks the held
+    form by itself for a large activation (zeroed scratch) and the layer's output / gradients equal the two-launch run."""
+    from ursabench_amd import _native, fused_bn
+    K = _native.default_kernels()
+    shape, C = (128, 160, 32, 32), 160
+    g = torch.Generator().manual_seed(5)
+    xs = [torch.randn(shape, generator=g).cuda() for _ in range(4)]
+    w, bb = (torch.rand(C, generator=g) + 0.5).cuda(), torch.randn(C, generator=g).cuda()
+    ref = []
+    for x in xs:
+        y, sm, si = torch.empty_like(x), torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
+        K.bn_relu_forward(x, y, w, bb, None, None, sm, si, torch.empty(_native.bn_ws_floats(C), device='cuda'), eps=1e-5,
+                          momentum=0.0, two_launch=True)
+        ref.append(y)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    wss = [torch.zeros(_native.bn_ws_floats(C), device='cuda') for _ in range(4)]
+    got = [torch.empty_like(x) for x in xs]
+    stats = [(torch.empty(C, device='cuda'), torch.empty(C, device='cuda')) for _ in range(4)]
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for k, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                K.bn_relu_forward(xs[k], got[k], w, bb, None, None, stats[k][0], stats[k][1], wss[k], eps=1e-5, momentum=0.0,
+                                  held=True)
+    torch.cuda.synchronize()
+    for k in range(4):
+        assert not _sync_words(wss[k], C).any()
+        assert torch.equal(got[k], ref[k])
+    # (b) module path
+    bn = nn.BatchNorm2d(C).cuda().train()
+    x = xs[0].clone().requires_grad_(True)
+    dy = torch.randn(shape, generator=g).cuda()
+    res = {}
+    for mode in (True, False):
+        old = fused_bn.held(mode)
+        try:
+            bn.reset_running_stats()
+            y = fused_bn.bn_relu(bn, x)
+            gx, gw, gb = torch.autograd.grad(y, (x, bn.weight, bn.bias), dy)
+            res[mode] = (y.detach(), gx, gw, gb, bn.running_mean.clone(), bn.running_var.clone())
+        finally:
+            fused_bn.held(old)
+    for t1, t2 in zip(res[True], res[False]):
+        assert torch.allclose(t1, t2, rtol=2e-7, atol=0) and float((t1 != t2).float().mean()) < 1e-3

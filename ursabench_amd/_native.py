@@ -25,12 +25,15 @@ STEP_NOISE, STEP_FIRST, STEP_ZERO_GRAD, STEP_WD, STEP_SGD, STEP_ADVANCE = 0x1, 0
 BMA_SMOOTHED = 0x1
 LEAP_KICK, LEAP_DRIFT = 0x1, 0x2
 REDUCE_WS_FLOATS = 2048
-BN_RELU, BN_TWO_LAUNCH = 0x1, 0x2
+BN_RELU, BN_TWO_LAUNCH, BN_HELD = 0x1, 0x2, 0x4
 
 
 def bn_ws_floats(channels):
-    """URSA_BN_WS_FLOATS(C): scratch of one BatchNorm call."""
-    return int(channels) * 64 * 4
+    """URSA_BN_WS_FLOATS(C): scratch of one BatchNorm call (partial sums, then the held form's sync words)."""
+    return int(channels) * 64 * 4 + int(channels) + 64
+
+
+BN_HELD_MIN_BYTES = 24 << 20      # activations from this size on may take the held form (ursa_bn.hip kHeldMinFloat4)
 BMA_MAX_CLASSES = 1024
 
 _vp, _i64, _i32, _u64, _u32, _f = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_uint64,
@@ -306,10 +309,11 @@ class HipKernels:
         return N, C, x.numel() // max(N * C, 1)
 
     def bn_relu_forward(self, x, y, gamma, beta, running_mean, running_var, save_mean, save_invstd, ws, *, eps,
-                        momentum, relu=True, addend=None, z_out=None, two_launch=False):
+                        momentum, relu=True, addend=None, z_out=None, two_launch=False, held=False):
         """Training-mode BatchNorm (+ ReLU) of a contiguous [N, C, *] tensor: batch statistics, running statistics
         updated in place (skipped when both are None), mean / invstd saved for the backward. With `addend` the
-        normalised tensor is z = x + addend, also stored to `z_out` (the residual sum folded into the statistics pass)."""
+        normalised tensor is z = x + addend, also stored to `z_out` (the residual sum folded into the statistics pass).
+        held=True: `ws` is ZEROED (at least its sync words) - the library may then take the one-launch held form."""
         if (addend is None) != (z_out is None):
             raise ValueError('addend and z_out go together')
         N, C, HW = self._bn_dims(x)
@@ -323,7 +327,7 @@ class HipKernels:
                 _ptr(running_mean, 'running_mean', C, dev, optional=True),
                 _ptr(running_var, 'running_var', C, dev, optional=True), _ptr(save_mean, 'save_mean', C, dev),
                 _ptr(save_invstd, 'save_invstd', C, dev), _ptr(ws, 'ws', None, dev), N, C, HW, eps, momentum,
-                (BN_RELU if relu else 0) | (BN_TWO_LAUNCH if two_launch else 0), _stream(dev))
+                (BN_RELU if relu else 0) | (BN_TWO_LAUNCH if two_launch else 0) | (BN_HELD if held else 0), _stream(dev))
         _check(self.lib, rc, 'ursa_bn_relu_fwd_f32')
 
     def bn_relu_eval(self, x, y, gamma, beta, running_mean, running_var, *, eps, relu=True, addend=None, z_out=None):
@@ -340,7 +344,7 @@ class HipKernels:
         _check(self.lib, rc, 'ursa_bn_relu_eval_f32')
 
     def bn_relu_backward(self, x, dy, dx, gamma, beta, save_mean, save_invstd, dgamma, dbeta, ws, *, relu=True, dz=None,
-                         two_launch=False, gates=None):
+                         two_launch=False, gates=None, held=False):
         """`x` is the tensor the forward normalised (z_out in the residual form); with `dz` the result is dx + dz.
         `gates=(idx int32 [n], open uint8 [n])`: the parity instrument ursa_bn_relu_bwd_gated_f32 - the ReLU gates of the
         listed element offsets (ascending; INT32_MAX = padding) are taken from `open` instead of recomputed."""
@@ -351,7 +355,8 @@ class HipKernels:
         args = (_ptr(x, 'x'), _ptr(dy, 'dy', n, dev), _ptr(dz, 'dz', n, dev, optional=True), _ptr(dx, 'dx', n, dev),
                 _ptr(gamma, 'gamma', C, dev), _ptr(beta, 'beta', C, dev), _ptr(save_mean, 'save_mean', C, dev),
                 _ptr(save_invstd, 'save_invstd', C, dev), _ptr(dgamma, 'dgamma', C, dev), _ptr(dbeta, 'dbeta', C, dev),
-                _ptr(ws, 'ws', None, dev), N, C, HW, (BN_RELU if relu else 0) | (BN_TWO_LAUNCH if two_launch else 0))
+                _ptr(ws, 'ws', None, dev), N, C, HW,
+                (BN_RELU if relu else 0) | (BN_TWO_LAUNCH if two_launch else 0) | (BN_HELD if held and gates is None else 0))
         if gates is not None:
             gi, go = gates
             for t, dt, nm in ((gi, torch.int32, 'gate idx'), (go, torch.uint8, 'gate open')):

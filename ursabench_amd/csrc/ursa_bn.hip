@@ -570,6 +570,275 @@ __global__ __launch_bounds__(kOneBlock) void k_bn_bwd_one(const float* __restric
     }
 }
 
+
+// ---- held forms: a channel too large for one workgroup, read ONCE -------------------------------------------------------
+// The two-launch form reads its inputs twice; beyond the 256 MiB Infinity Cache that is 1.5x (forward) / 1.67x (backward)
+// the algorithmic bytes from HBM. Here the channel's S workgroups each load their chunk into REGISTERS, publish their
+// double partial sums, wait until all S partials of the channel are there, merge them (every workgroup by itself, fixed
+// lane order: identical scalars, no broadcast) and finish from registers: one launch, every byte read once.
+//   * Work is handed out by ticket (one atomic per workgroup), channel-major: ticket t -> channel t / S, chunk t % S. A
+//     waiting workgroup only ever waits for tickets of its own channel, and tickets are taken in order by workgroups that
+//     are RUNNING - so the launch cannot deadlock as long as S workgroups of it can be resident at once (S <= 64 of the
+//     chip's >= 1,024 slots; with K such launches sharing the chip from parallel graph branches at least one of them
+//     holds >= slots / K >= S of them and drains). The wait is bounded all the same: after ~3 s a workgroup raises
+//     sync->err and goes on with what it has, so a logic error ends in wrong numbers, never in a hung GPU.
+//   * Hand-off of the 16-byte partials: 8-byte agent-scope atomic stores, the storing lane's vmcnt(0), then its agent-scope
+//     add on the channel's arrival counter; the consumer polls that counter with agent-scope loads (s_sleep between
+//     polls), passes a workgroup barrier and reads the partials with 8-byte agent-scope atomic loads (MI355X_MICROARCH.md,
+//     inter-workgroup visibility: atomics on both sides, signalled by the storing lane after its wait).
+//   * The sync words (ticket, arrival counters) must be zero at launch and are zero again when the launch has drained: the
+//     workgroup holding the last ticket re-arms the ticket, the last workgroup to leave a channel's wait re-arms its counter.
+// Same arithmetic as the two-launch form (double sums rounded once), hence the same floats.
+struct BnSync {
+    uint32_t ticket;
+    uint32_t err;            // sticky: a bounded wait ran out (tests read it; never set in a correct run)
+    uint32_t pad[2];
+    uint32_t arrived[1];     // [C]
+};
+
+constexpr int kHeldFwdBlock = 256, kHeldFwdEpt = 16;     // 16 float4 of x per thread
+constexpr int kHeldBwdBlock = 512, kHeldBwdEpt = 8;      // 8 float4 of x + 8 of dy per thread
+constexpr uint32_t kHeldSpinLimit = 1u << 22;            // x ~0.85 us of s_sleep
+
+__device__ __forceinline__ void bn_publish(double2* slot, double a, double b, uint32_t* arrived)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(&slot->x), __builtin_bit_cast(unsigned long long, a),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(&slot->y), __builtin_bit_cast(unsigned long long, b),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void bn_wait_channel(uint32_t* arrived, uint32_t S, uint32_t* err)
+{
+    uint32_t spins = 0;
+    while (__hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < S) {
+        __builtin_amdgcn_s_sleep(32);
+        if (++spins > kHeldSpinLimit) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+}
+
+// merge by wave 0 of the calling workgroup (S <= 64): same lane order as bn_merge, partials read coherently
+__device__ __forceinline__ void bn_merge_held(const double2* slots, int S, double& a, double& b)
+{
+    a = 0.0; b = 0.0;
+    if ((int)threadIdx.x < S) {
+        const unsigned long long* q = reinterpret_cast<const unsigned long long*>(slots + threadIdx.x);
+        a = __builtin_bit_cast(double, __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        b = __builtin_bit_cast(double, __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    a = bn_wave_sum(a);
+    b = bn_wave_sum(b);
+}
+
+template <int BLOCK>
+__device__ __forceinline__ void bn_block_sum2_n(double& a, double& b, double* sh /* 2 * BLOCK/64 */)
+{
+    a = bn_wave_sum(a);
+    b = bn_wave_sum(b);
+    if ((threadIdx.x & 63) == 0) { sh[2 * (threadIdx.x >> 6)] = a; sh[2 * (threadIdx.x >> 6) + 1] = b; }
+    __syncthreads();
+    a = b = 0.0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; ++w) { a += sh[2 * w]; b += sh[2 * w + 1]; }
+}
+
+// departure from a channel's wait: the last of its S workgroups to leave re-arms the counter
+__device__ __forceinline__ void bn_leave_channel(uint32_t* arrived, uint32_t S)
+{
+    if (__hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2u * S - 1u)
+        __hip_atomic_store(arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// (per-component builtins: the compiler merges them into one global_load/store_dwordx4 ... nt, as in ursa_kernels.hip)
+template <bool NT> __device__ __forceinline__ float4 bn_ld(const float4* p)
+{
+    if (!NT) return *p;
+    float4 r;
+    r.x = __builtin_nontemporal_load(&p->x); r.y = __builtin_nontemporal_load(&p->y);
+    r.z = __builtin_nontemporal_load(&p->z); r.w = __builtin_nontemporal_load(&p->w);
+    return r;
+}
+template <bool NT> __device__ __forceinline__ void bn_st(float4* p, const float4& v)
+{
+    if (!NT) { *p = v; return; }
+    __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y);
+    __builtin_nontemporal_store(v.z, &p->z); __builtin_nontemporal_store(v.w, &p->w);
+}
+
+template <bool RELU, bool ADD, int EPT, bool NT>
+__global__ __launch_bounds__(kHeldFwdBlock) void k_bn_fwd_held(const float* __restrict__ x, const float* __restrict__ addend,
+                                                              float* __restrict__ z, float* __restrict__ y,
+                                                              double2* partial, BnSync* sync,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                              float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                              float eps, float momentum, BnGeom g, int S)
+{
+    __shared__ double sh[2 * kHeldFwdBlock / 64];
+    __shared__ float shf[2];
+    __shared__ uint32_t sh_t;
+    if (threadIdx.x == 0) {
+        const uint32_t t = __hip_atomic_fetch_add(&sync->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == gridDim.x - 1) __hip_atomic_store(&sync->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // all tickets are out
+        sh_t = t;
+    }
+    __syncthreads();
+    const int c = (int)(sh_t / (uint32_t)S), sp = (int)(sh_t % (uint32_t)S);
+    const float4* __restrict__ xv = reinterpret_cast<const float4*>(x);
+    const float4* __restrict__ av = reinterpret_cast<const float4*>(addend);
+    float4* __restrict__ zv = reinterpret_cast<float4*>(z);
+    float4* __restrict__ yv = reinterpret_cast<float4*>(y);
+    const int lo = sp * g.chunk;
+    const int hi = lo + g.chunk < (int)g.per_ch ? lo + g.chunk : (int)g.per_ch;
+    float4 v[EPT];
+    int o[EPT];
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) {
+        const int i = lo + threadIdx.x + u * kHeldFwdBlock;
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        o[u] = -1;
+        if (i < hi) {
+            o[u] = bn_off32(g, c, i);
+            v[u] = bn_ld<NT>(xv + o[u]);
+            if (ADD) v[u] = vadd(v[u], bn_ld<NT>(av + o[u]));
+        }
+    }
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) {
+        if (ADD && o[u] >= 0) bn_st<NT>(zv + o[u], v[u]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const double d = (double)comp(v[u], k); s1 += d; s2 = fma(d, d, s2); }
+    }
+    bn_block_sum2_n<kHeldFwdBlock>(s1, s2, sh);
+    uint32_t* arrived = &sync->arrived[c];
+    if (threadIdx.x == 0) {
+        bn_publish(partial + (int64_t)c * S + sp, s1, s2, arrived);
+        bn_wait_channel(arrived, (uint32_t)S, &sync->err);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        double a, b;
+        bn_merge_held(partial + (int64_t)c * S, S, a, b);
+        if (threadIdx.x == 0) {
+            const double n = (double)g.per_ch * 4.0;
+            const double mean = a / n;
+            double var = b / n - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float meanf = (float)mean;
+            const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+            const float alpha = invstd * gamma[c];
+            shf[0] = alpha;
+            shf[1] = fmaf(-meanf, alpha, beta[c]);
+            if (sp == 0) {
+                save_mean[c] = meanf;
+                save_invstd[c] = invstd;
+                if (running_mean) {
+                    running_mean[c] = momentum * meanf + (1.0f - momentum) * running_mean[c];
+                    running_var[c] = momentum * (float)(var * (n / (n - 1.0))) + (1.0f - momentum) * running_var[c];
+                }
+            }
+            bn_leave_channel(arrived, (uint32_t)S);
+        }
+    }
+    __syncthreads();
+    const float scale = shf[0], shift = shf[1];
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) {
+        if (o[u] >= 0) {
+            float4 r;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float t = fmaf(comp(v[u], k), scale, shift); setc(r, k, RELU ? bn_relu_fwd(t) : t); }
+            bn_st<NT>(yv + o[u], r);
+        }
+    }
+}
+
+template <bool RELU, bool RES, int EPT, bool NT>
+__global__ __launch_bounds__(kHeldBwdBlock) void k_bn_bwd_held(const float* __restrict__ x, const float* __restrict__ dy,
+                                                              const float* __restrict__ dz, float* __restrict__ dx,
+                                                              double2* partial, BnSync* sync,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, BnGeom g, int S)
+{
+    __shared__ double sh[2 * kHeldBwdBlock / 64];
+    __shared__ float shf[2];
+    __shared__ uint32_t sh_t;
+    if (threadIdx.x == 0) {
+        const uint32_t t = __hip_atomic_fetch_add(&sync->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == gridDim.x - 1) __hip_atomic_store(&sync->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sh_t = t;
+    }
+    __syncthreads();
+    const int c = (int)(sh_t / (uint32_t)S), sp = (int)(sh_t % (uint32_t)S);
+    const float4* __restrict__ xv = reinterpret_cast<const float4*>(x);
+    const float4* __restrict__ dv = reinterpret_cast<const float4*>(dy);
+    const float4* __restrict__ rv = reinterpret_cast<const float4*>(dz);
+    float4* __restrict__ ov = reinterpret_cast<float4*>(dx);
+    const float mean = save_mean[c], invstd = save_invstd[c], w = gamma[c];
+    const float scale = invstd * w;
+    const float shift = fmaf(-mean, scale, beta[c]);
+    const double meand = (double)mean;
+    const int lo = sp * g.chunk;
+    const int hi = lo + g.chunk < (int)g.per_ch ? lo + g.chunk : (int)g.per_ch;
+    float4 a[EPT], b[EPT];
+    int o[EPT];
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) {
+        const int i = lo + threadIdx.x + u * kHeldBwdBlock;
+        a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        b[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        o[u] = -1;
+        if (i < hi) { o[u] = bn_off32(g, c, i); a[u] = bn_ld<NT>(xv + o[u]); b[u] = bn_ld<NT>(dv + o[u]); }
+    }
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float xe = comp(a[u], k);
+            float ge = comp(b[u], k);                // zero beyond the chunk: adds nothing
+            if (RELU && !(fmaf(xe, scale, shift) > 0.f)) ge = 0.f;
+            setc(b[u], k, ge);
+            s1 += (double)ge;
+            s2 = fma((double)ge, (double)xe - meand, s2);
+        }
+    }
+    bn_block_sum2_n<kHeldBwdBlock>(s1, s2, sh);
+    uint32_t* arrived = &sync->arrived[c];
+    if (threadIdx.x == 0) {
+        bn_publish(partial + (int64_t)c * S + sp, s1, s2, arrived);
+        bn_wait_channel(arrived, (uint32_t)S, &sync->err);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        double sa, sb;
+        bn_merge_held(partial + (int64_t)c * S, S, sa, sb);
+        if (threadIdx.x == 0) {
+            const double n = (double)g.per_ch * 4.0, iv = (double)invstd;
+            shf[0] = (float)(sa / n);
+            shf[1] = (float)(sb * iv * iv / n);
+            if (sp == 0) { dbeta[c] = (float)sa; dgamma[c] = (float)(sb * iv); }
+            bn_leave_channel(arrived, (uint32_t)S);
+        }
+    }
+    __syncthreads();
+    const float gm = shf[0], kk = shf[1];
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) {
+        if (o[u] >= 0) {
+            float4 r;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) setc(r, k, (((comp(b[u], k) - gm) - (comp(a[u], k) - mean) * kk) * invstd) * w);
+            if (RES) r = vadd(bn_ld<NT>(rv + o[u]), r);
+            bn_st<NT>(ov + o[u], r);
+        }
+    }
+}
+
 // ---- host side ----------------------------------------------------------------------------------------------------
 struct BnPlan {
     BnGeom g;
@@ -614,6 +883,31 @@ inline int bn_plan(int64_t N, int64_t C, int64_t HW, bool vec_ok, BnPlan* p)
 
 inline int bn_launch_status() { return (int)hipGetLastError(); }
 
+// Held form (one launch, inputs read once): float4 accesses, 32-bit float4 offsets, the channel cut into 2 <= S <= 64
+// register-sized chunks, enough workgroups to fill the chip, and an activation large enough that the second read of the
+// two-launch form costs more than the wait (measured: tools/exp/bn_fused_bench.py). The caller vouches for zeroed sync
+// words with URSA_BN_HELD.
+constexpr int64_t kHeldMinFloat4 = (24ll << 20) / 16;     // 24 MiB of activation
+struct BnHeld { int S, chunk, ept; };
+inline bool bn_held_plan(const BnPlan& p, uint32_t flags, int block, int max_ept, BnHeld* h)
+{
+    if (!(flags & URSA_BN_HELD) || (flags & URSA_BN_TWO_LAUNCH) || p.V != 4) return false;
+    const int64_t per_ch = p.g.per_ch;
+    if (per_ch * p.g.C >= (1ll << 31) || per_ch * p.g.C < kHeldMinFloat4) return false;
+    const int64_t cap = (int64_t)block * max_ept;
+    int64_t S = (per_ch + cap - 1) / cap;
+    if (S < 2 || S > kBnMaxSplit) return false;
+    int64_t chunk = (per_ch + S - 1) / S;
+    chunk = (chunk + block - 1) / block * block;
+    S = (per_ch + chunk - 1) / chunk;
+    if (S < 2 || S * p.g.C < 512 || S * p.g.C >= (1ll << 31)) return false;
+    const int need = (int)(chunk / block);
+    h->S = (int)S;
+    h->chunk = (int)chunk;
+    h->ept = need <= max_ept / 4 ? max_ept / 4 : need <= max_ept / 2 ? max_ept / 2 : max_ept;
+    return true;
+}
+
 // One-pass form: float4 accesses, the channel fits one workgroup's registers, 32-bit float4 offsets suffice, and there
 // are enough channels (= workgroups) to spread over the CUs. Measured (tools/exp/bn_fused_bench.py): [128,64,8,8] forward
 // 6.7 -> 5.8 us, backward 5.4 -> 3.8; [128,320,16,16] 23 -> 19 / 34 -> 26; with only 32 channels ([128,32,16,16]) the
@@ -646,6 +940,27 @@ int ursa_bn_relu_fwd_f32(const float* x, const float* addend, float* z_out, floa
     const dim3 grid(p.S, p.g.C), block(kBnBlock);
     double2* part = reinterpret_cast<double2*>(ws);
     const bool relu = flags & URSA_BN_RELU;
+    BnHeld hd;
+    if (!bn_one_pass(p, flags) && bn_held_plan(p, flags, kHeldFwdBlock, kHeldFwdEpt, &hd)) {
+        BnGeom gh = p.g;
+        gh.chunk = hd.chunk;
+        BnSync* sync = reinterpret_cast<BnSync*>(ws + (int64_t)C * kBnMaxSplit * 4);
+        const dim3 gg((unsigned)(hd.S * p.g.C)), bb(kHeldFwdBlock);
+        // beyond the 256 MiB Infinity Cache the streams go past it (as K1-K4 do)
+        const bool nt = p.g.per_ch * p.g.C * 16 * (addend ? 4 : 2) > (256ll << 20);
+#define URSA_BN_HELD_E(R, A, E) do { \
+    if (nt) hipLaunchKernelGGL((k_bn_fwd_held<R, A, E, true>), gg, bb, 0, st, x, addend, z_out, y, part, sync, gamma, beta, \
+                               running_mean, running_var, save_mean, save_invstd, eps, momentum, gh, hd.S); \
+    else hipLaunchKernelGGL((k_bn_fwd_held<R, A, E, false>), gg, bb, 0, st, x, addend, z_out, y, part, sync, gamma, beta, \
+                            running_mean, running_var, save_mean, save_invstd, eps, momentum, gh, hd.S); } while (0)
+#define URSA_BN_HELD_F(R, A) do { if (hd.ept == kHeldFwdEpt / 4) URSA_BN_HELD_E(R, A, kHeldFwdEpt / 4); \
+                                  else if (hd.ept == kHeldFwdEpt / 2) URSA_BN_HELD_E(R, A, kHeldFwdEpt / 2); else URSA_BN_HELD_E(R, A, kHeldFwdEpt); } while (0)
+        if (relu) { if (addend) URSA_BN_HELD_F(true, true); else URSA_BN_HELD_F(true, false); }
+        else      { if (addend) URSA_BN_HELD_F(false, true); else URSA_BN_HELD_F(false, false); }
+#undef URSA_BN_HELD_F
+#undef URSA_BN_HELD_E
+        return bn_launch_status();
+    }
     if (bn_one_pass(p, flags)) {
         const dim3 g1(p.g.C), b1(kOneBlock);
 #define URSA_BN_ONE_E(R, A, E) hipLaunchKernelGGL((k_bn_fwd_one<R, A, E>), g1, b1, 0, st, x, addend, z_out, y, gamma, beta, running_mean, \
@@ -728,6 +1043,26 @@ static int bn_bwd_impl(const float* x, const float* dy, const float* dz, float* 
                             save_invstd, part, p.S, dgamma, dbeta, p.g, gt); } while (0)
         if (p.V == 4) URSA_BN_BWD_G(4); else URSA_BN_BWD_G(1);
 #undef URSA_BN_BWD_G
+        return bn_launch_status();
+    }
+    BnHeld hd;
+    if (!bn_one_pass(p, flags) && bn_held_plan(p, flags, kHeldBwdBlock, kHeldBwdEpt, &hd)) {
+        BnGeom gh = p.g;
+        gh.chunk = hd.chunk;
+        BnSync* sync = reinterpret_cast<BnSync*>(ws + (int64_t)C * kBnMaxSplit * 4);
+        const dim3 gg((unsigned)(hd.S * p.g.C)), bb(kHeldBwdBlock);
+        const bool nt = p.g.per_ch * p.g.C * 16 * (dz ? 4 : 3) > (256ll << 20);
+#define URSA_BN_HELD_E(R, A, E) do { \
+    if (nt) hipLaunchKernelGGL((k_bn_bwd_held<R, A, E, true>), gg, bb, 0, st, x, dy, dz, dx, part, sync, gamma, beta, save_mean, \
+                               save_invstd, dgamma, dbeta, gh, hd.S); \
+    else hipLaunchKernelGGL((k_bn_bwd_held<R, A, E, false>), gg, bb, 0, st, x, dy, dz, dx, part, sync, gamma, beta, save_mean, \
+                            save_invstd, dgamma, dbeta, gh, hd.S); } while (0)
+#define URSA_BN_HELD_B(R, A) do { if (hd.ept == kHeldBwdEpt / 4) URSA_BN_HELD_E(R, A, kHeldBwdEpt / 4); \
+                                  else if (hd.ept == kHeldBwdEpt / 2) URSA_BN_HELD_E(R, A, kHeldBwdEpt / 2); else URSA_BN_HELD_E(R, A, kHeldBwdEpt); } while (0)
+        if (relu) { if (dz) URSA_BN_HELD_B(true, true); else URSA_BN_HELD_B(true, false); }
+        else      { if (dz) URSA_BN_HELD_B(false, true); else URSA_BN_HELD_B(false, false); }
+#undef URSA_BN_HELD_B
+#undef URSA_BN_HELD_E
         return bn_launch_status();
     }
     if (bn_one_pass(p, flags)) {

@@ -26,7 +26,26 @@ from torch.autograd.function import once_differentiable
 from . import _native
 
 _on = os.environ.get('URSA_FUSED_BN', '1') != '0'
-_two_launch = os.environ.get('URSA_BN_TWO_LAUNCH', '0') == '1'     # A/B: never take the one-pass form
+_two_launch = os.environ.get('URSA_BN_TWO_LAUNCH', '0') == '1'     # A/B: never take the one-pass / held form
+_held = os.environ.get('URSA_BN_HELD', '1') != '0'                 # activations >= 24 MiB: ONE launch, inputs read once
+
+
+def held(flag=None):
+    """Query / set whether large activations may take K6's held form (one launch per direction; the channel's workgroups
+    hold their chunks in registers and wait for each other's partial sums). Off: the two-launch form. ChainGroup turns
+    it off for more chains than the chip can keep S workgroups resident for (csrc/ursa_bn.hip)."""
+    global _held
+    old = _held
+    if flag is not None:
+        _held = bool(flag)
+    return old
+
+
+def _scratch(x, C):
+    """(ws, held): the call's scratch; zeroed - which lets the library take the held form - when the activation is large."""
+    if _held and not _two_launch and x.numel() * 4 >= _native.BN_HELD_MIN_BYTES:
+        return x.new_zeros(_native.bn_ws_floats(C)), True
+    return x.new_empty(_native.bn_ws_floats(C)), False
 
 
 def enabled(flag=None):
@@ -147,9 +166,9 @@ class _BNReLUTrain(torch.autograd.Function):
         C = x.shape[1]
         y = torch.empty_like(x)
         stats = x.new_empty(2, C)                       # save_mean, save_invstd
-        ws = x.new_empty(_native.bn_ws_floats(C))
+        ws, hd = _scratch(x, C)
         K.bn_relu_forward(x, y, weight, bias, running_mean, running_var, stats[0], stats[1], ws, eps=eps,
-                          momentum=momentum, relu=relu, two_launch=_two_launch)
+                          momentum=momentum, relu=relu, two_launch=_two_launch, held=hd)
         ctx.save_for_backward(x, weight, bias, stats)
         ctx.relu, ctx.gates = relu, gates
         return y
@@ -163,9 +182,9 @@ class _BNReLUTrain(torch.autograd.Function):
         dy = dy.contiguous()
         dx = torch.empty_like(x)
         dwb = x.new_empty(2, C)
-        ws = x.new_empty(_native.bn_ws_floats(C))
+        ws, hd = _scratch(x, C)
         K.bn_relu_backward(x, dy, dx, weight, bias, stats[0], stats[1], dwb[0], dwb[1], ws, relu=ctx.relu,
-                           two_launch=_two_launch, gates=ctx.gates)
+                           two_launch=_two_launch, gates=ctx.gates, held=hd)
         return dx, dwb[0], dwb[1], None, None, None, None, None, None
 
 
@@ -179,9 +198,9 @@ class _AddBNReLUTrain(torch.autograd.Function):
         C = a.shape[1]
         z, y = torch.empty_like(a), torch.empty_like(a)
         stats = a.new_empty(2, C)
-        ws = a.new_empty(_native.bn_ws_floats(C))
+        ws, hd = _scratch(a, C)
         K.bn_relu_forward(a, y, weight, bias, running_mean, running_var, stats[0], stats[1], ws, eps=eps,
-                          momentum=momentum, relu=relu, addend=b, z_out=z, two_launch=_two_launch)
+                          momentum=momentum, relu=relu, addend=b, z_out=z, two_launch=_two_launch, held=hd)
         ctx.save_for_backward(z, weight, bias, stats)
         ctx.relu, ctx.gates = relu, gates
         return z, y
@@ -198,9 +217,9 @@ class _AddBNReLUTrain(torch.autograd.Function):
         dz = None if dz is None else dz.contiguous()
         dx = torch.empty_like(z)
         dwb = z.new_empty(2, C)
-        ws = z.new_empty(_native.bn_ws_floats(C))
+        ws, hd = _scratch(z, C)
         K.bn_relu_backward(z, dy, dx, weight, bias, stats[0], stats[1], dwb[0], dwb[1], ws, relu=ctx.relu, dz=dz,
-                           two_launch=_two_launch, gates=ctx.gates)
+                           two_launch=_two_launch, gates=ctx.gates, held=hd)
         return dx, dx, dwb[0], dwb[1], None, None, None, None, None, None
 
 
