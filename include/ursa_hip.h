@@ -273,16 +273,17 @@ int ursa_sumsq_f32(const float* x, int64_t n, float* out, float* ws, ursa_stream
  */
 #define URSA_BN_RELU        0x1u
 #define URSA_BN_TWO_LAUNCH  0x2u   /* keep the two-launch form where the one-pass / held form would apply (A/B, tests) */
-#define URSA_BN_HELD        0x4u   /* the caller vouches that ws's sync words (below) are ZERO: the library may then run the
-                                      held form - ONE launch, every input read once - on activations of >= 24 MiB whose
+#define URSA_BN_HELD        0x4u   /* the caller vouches that ws (all of it) is ZERO: the library may then run the
+                                      held form - ONE launch, every input read once - on activations of >= 24 MiB (backward) / >= 128 MiB (forward) whose
                                       channels do not fit one workgroup (per-channel workgroups hold their chunk in registers,
-                                      exchange double partial sums through ws and wait for each other; bounded wait; the sync
-                                      words are zero again when the launch has drained, so a zeroed ws can be reused call
-                                      after call). Same floats as the two-launch form. Without the flag ws needs no
-                                      initialisation and the held form is never taken. */
+                                      exchange double partial sums through ws and wait for each other; bounded wait; ws is
+                                      zero again when the launch has drained, so a zeroed ws that only held-form calls touch
+                                      can be reused call after call). Same floats as the two-launch form. Without the flag ws
+                                      needs no initialisation and the held form is never taken. */
 #define URSA_BN_ALLFLAGS    0x7u
-/* partial sums: C x 64 x {double, double}; then the sync words: ticket, err, 2 spare, one arrival counter per channel */
-#define URSA_BN_WS_FLOATS(C) ((int64_t)(C) * 64 * 4 + (int64_t)(C) + 64)
+/* partial sums: C x 64 x {double, double}; then the held form's counters, one 128-byte line each: ticket, {done, err},
+ * one per channel */
+#define URSA_BN_WS_FLOATS(C) ((int64_t)(C) * 64 * 4 + ((int64_t)(C) + 2) * 32)
 #define URSA_BN_WS_SYNC_OFFSET_FLOATS(C) ((int64_t)(C) * 64 * 4)
 
 int ursa_bn_relu_fwd_f32(const float* x, const float* addend /* or NULL */, float* z_out /* iff addend */,

@@ -30,7 +30,7 @@ BN_RELU, BN_TWO_LAUNCH, BN_HELD = 0x1, 0x2, 0x4
 
 def bn_ws_floats(channels):
     """URSA_BN_WS_FLOATS(C): scratch of one BatchNorm call (partial sums, then the held form's sync words)."""
-    return int(channels) * 64 * 4 + int(channels) + 64
+    return int(channels) * 64 * 4 + (int(channels) + 2) * 32
 
 
 BN_HELD_MIN_BYTES = 24 << 20      # activations from this size on may take the held form (ursa_bn.hip kHeldMinFloat4)
@@ -147,6 +147,10 @@ def _ptr(t, name, n=None, device=None, optional=False):
     if device is not None and t.device != device:
         raise ValueError(f'{name} is on {t.device}, expected {device}')
     return t.data_ptr()
+
+
+def _held_flags(held):
+    return BN_HELD if held else 0
 
 
 def _stream(device):
@@ -327,7 +331,7 @@ class HipKernels:
                 _ptr(running_mean, 'running_mean', C, dev, optional=True),
                 _ptr(running_var, 'running_var', C, dev, optional=True), _ptr(save_mean, 'save_mean', C, dev),
                 _ptr(save_invstd, 'save_invstd', C, dev), _ptr(ws, 'ws', None, dev), N, C, HW, eps, momentum,
-                (BN_RELU if relu else 0) | (BN_TWO_LAUNCH if two_launch else 0) | (BN_HELD if held else 0), _stream(dev))
+                (BN_RELU if relu else 0) | (BN_TWO_LAUNCH if two_launch else 0) | _held_flags(held), _stream(dev))
         _check(self.lib, rc, 'ursa_bn_relu_fwd_f32')
 
     def bn_relu_eval(self, x, y, gamma, beta, running_mean, running_var, *, eps, relu=True, addend=None, z_out=None):
@@ -356,7 +360,7 @@ class HipKernels:
                 _ptr(gamma, 'gamma', C, dev), _ptr(beta, 'beta', C, dev), _ptr(save_mean, 'save_mean', C, dev),
                 _ptr(save_invstd, 'save_invstd', C, dev), _ptr(dgamma, 'dgamma', C, dev), _ptr(dbeta, 'dbeta', C, dev),
                 _ptr(ws, 'ws', None, dev), N, C, HW,
-                (BN_RELU if relu else 0) | (BN_TWO_LAUNCH if two_launch else 0) | (BN_HELD if held and gates is None else 0))
+                (BN_RELU if relu else 0) | (BN_TWO_LAUNCH if two_launch else 0) | (_held_flags(held) if gates is None else 0))
         if gates is not None:
             gi, go = gates
             for t, dt, nm in ((gi, torch.int32, 'gate idx'), (go, torch.uint8, 'gate open')):

@@ -574,62 +574,102 @@ __global__ __launch_bounds__(kOneBlock) void k_bn_bwd_one(const float* __restric
 // ---- held forms: a channel too large for one workgroup, read ONCE -------------------------------------------------------
 // The two-launch form reads its inputs twice; beyond the 256 MiB Infinity Cache that is 1.5x (forward) / 1.67x (backward)
 // the algorithmic bytes from HBM. Here the channel's S workgroups each load their chunk into REGISTERS, publish their
-// double partial sums, wait until all S partials of the channel are there, merge them (every workgroup by itself, fixed
-// lane order: identical scalars, no broadcast) and finish from registers: one launch, every byte read once.
+// double partial sums, gather all S partials of the channel (every workgroup by itself, fixed lane order: identical
+// scalars, no broadcast) and finish from registers: one launch, every byte read once.
 //   * Work is handed out by ticket (one atomic per workgroup), channel-major: ticket t -> channel t / S, chunk t % S. A
-//     waiting workgroup only ever waits for tickets of its own channel, and tickets are taken in order by workgroups that
-//     are RUNNING - so the launch cannot deadlock as long as S workgroups of it can be resident at once (S <= 64 of the
-//     chip's >= 1,024 slots; with K such launches sharing the chip from parallel graph branches at least one of them
-//     holds >= slots / K >= S of them and drains). The wait is bounded all the same: after ~3 s a workgroup raises
-//     sync->err and goes on with what it has, so a logic error ends in wrong numbers, never in a hung GPU.
-//   * Hand-off of the 16-byte partials: 8-byte agent-scope atomic stores, the storing lane's vmcnt(0), then its agent-scope
-//     add on the channel's arrival counter; the consumer polls that counter with agent-scope loads (s_sleep between
-//     polls), passes a workgroup barrier and reads the partials with 8-byte agent-scope atomic loads (MI355X_MICROARCH.md,
-//     inter-workgroup visibility: atomics on both sides, signalled by the storing lane after its wait).
-//   * The sync words (ticket, arrival counters) must be zero at launch and are zero again when the launch has drained: the
-//     workgroup holding the last ticket re-arms the ticket, the last workgroup to leave a channel's wait re-arms its counter.
+//     workgroup only ever waits for partials of its own channel, and tickets are drawn in order by workgroups that are
+//     RUNNING - so the launch cannot deadlock as long as S (<= 64) workgroups of it can be resident at once (the chip holds
+//     >= 512 of them; with K such launches sharing the chip from parallel graph branches the one holding the most slots
+//     has >= 512 / K and drains first: safe up to K = 8). A ticket queue per XCD (a channel's workgroups on one L2) was
+//     tried: no faster, and it needs 8 x 63 + 64 resident workgroups - the backward form, 512 resident, ran into its
+//     bounded wait. The wait is bounded all the same: after ~3 s a workgroup raises the err word and goes on with what it
+//     has, so a logic error ends in wrong numbers, never in a hung GPU.
+//   * Hand-off of the partials: each is two 8-byte words stored with agent-scope atomic stores as bits(value) XOR a NaN
+//     payload no sum can produce, so that ZERO means "not there yet"; wave 0 of every workgroup polls the channel's S
+//     slots (lane i polls slot i, agent-scope 8-byte loads, s_sleep between polls) until none is zero - the poll IS the
+//     read, there is no flag, no ordering between the two words is needed and nothing else is fetched.
+//   * ws (slots and counters) must be ZERO at launch and is zero again when the launch has drained: the last workgroup to
+//     have gathered a channel clears its slots, the one that clears the last channel re-arms the ticket queues.
 // Same arithmetic as the two-launch form (double sums rounded once), hence the same floats.
+// tools/exp/bn_held_timeline.hip: where a workgroup's ~25 us go (the chunk sits in registers from first load to last store).
+constexpr int kSyncStride = 32;          // uint32 per 128-byte line: every counter on a line of its own (atomics and polls to
+                                         // ONE line serialise at ~11.5 ns each whichever word they hit)
 struct BnSync {
     uint32_t ticket;
-    uint32_t err;            // sticky: a bounded wait ran out (tests read it; never set in a correct run)
-    uint32_t pad[2];
-    uint32_t arrived[1];     // [C]
+    uint32_t pad0[kSyncStride - 1];
+    uint32_t done;                              // channels fully gathered
+    uint32_t err;                               // sticky: a bounded wait ran out / a workgroup found no work (never in a correct run)
+    uint32_t pad[kSyncStride - 2];
+    uint32_t left[1][kSyncStride];              // [C]: workgroups that have gathered channel c
 };
+constexpr unsigned long long kSlotXor = 0xFFF8DEADBEEF0001ull;   // a NaN payload with low mantissa bits set: no sum of floats has it
 
 constexpr int kHeldFwdBlock = 256, kHeldFwdEpt = 16;     // 16 float4 of x per thread
 constexpr int kHeldBwdBlock = 512, kHeldBwdEpt = 8;      // 8 float4 of x + 8 of dy per thread
-constexpr uint32_t kHeldSpinLimit = 1u << 22;            // x ~0.85 us of s_sleep
+constexpr uint32_t kHeldSpinLimit = 1u << 21;            // x ~1.7 us of s_sleep
 
-__device__ __forceinline__ void bn_publish(double2* slot, double a, double b, uint32_t* arrived)
+typedef unsigned long long bn_u64;
+
+// thread 0: draw a work item. Returns false (and raises err) if every queue is empty: only when grid != C * S.
+__device__ __forceinline__ bool bn_take_item(BnSync* sy, int C, int S, int& c, int& sp)
 {
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(&slot->x), __builtin_bit_cast(unsigned long long, a),
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(&slot->y), __builtin_bit_cast(unsigned long long, b),
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t t = __hip_atomic_fetch_add(&sy->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t < (uint32_t)C * (uint32_t)S) { c = (int)(t / (uint32_t)S); sp = (int)(t % (uint32_t)S); return true; }
+    __hip_atomic_store(&sy->err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return false;
 }
 
-__device__ __forceinline__ void bn_wait_channel(uint32_t* arrived, uint32_t S, uint32_t* err)
+__device__ __forceinline__ void bn_publish(bn_u64* slot, double a, double b)
 {
+    __hip_atomic_store(slot, __builtin_bit_cast(bn_u64, a) ^ kSlotXor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(slot + 1, __builtin_bit_cast(bn_u64, b) ^ kSlotXor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// wave 0: lane i < S polls slot i of the channel until both words are there; returns the channel's sums in every lane
+__device__ __forceinline__ void bn_gather(const bn_u64* slots, int S, uint32_t* err, double& a, double& b)
+{
+    bn_u64 wa = 1, wb = 1;                       // lanes >= S: "there", contribute zeros below
+    const bool mine = (int)threadIdx.x < S;
+    if (mine) wa = wb = 0;
     uint32_t spins = 0;
-    while (__hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < S) {
-        __builtin_amdgcn_s_sleep(32);
-        if (++spins > kHeldSpinLimit) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    for (;;) {
+        if (mine && (wa == 0 || wb == 0)) {
+            wa = __hip_atomic_load(slots + 2 * threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            wb = __hip_atomic_load(slots + 2 * threadIdx.x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (__builtin_amdgcn_ballot_w64(wa == 0 || wb == 0) == 0) break;
+        if (spins < 24) __builtin_amdgcn_s_sleep(6); else __builtin_amdgcn_s_sleep(64);   // the channel's workgroups start together: short waits first
+        if (++spins > kHeldSpinLimit) { if (threadIdx.x == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
     }
-}
-
-// merge by wave 0 of the calling workgroup (S <= 64): same lane order as bn_merge, partials read coherently
-__device__ __forceinline__ void bn_merge_held(const double2* slots, int S, double& a, double& b)
-{
-    a = 0.0; b = 0.0;
-    if ((int)threadIdx.x < S) {
-        const unsigned long long* q = reinterpret_cast<const unsigned long long*>(slots + threadIdx.x);
-        a = __builtin_bit_cast(double, __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        b = __builtin_bit_cast(double, __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    }
+    a = mine ? __builtin_bit_cast(double, wa ^ kSlotXor) : 0.0;
+    b = mine ? __builtin_bit_cast(double, wb ^ kSlotXor) : 0.0;
     a = bn_wave_sum(a);
     b = bn_wave_sum(b);
+}
+
+// wave 0, after its gather: count this workgroup out of channel c; the last one out clears the channel's slots and counter,
+// and the one that clears the last channel re-arms the ticket queues. `ret` = the returned count (issued early, used late).
+__device__ __forceinline__ uint32_t bn_leave_issue(BnSync* sy, int c)
+{
+    uint32_t r = 0;
+    if (threadIdx.x == 0) r = __hip_atomic_fetch_add(&sy->left[c][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return r;
+}
+__device__ __forceinline__ void bn_leave_finish(BnSync* sy, bn_u64* slots, int c, int C, int S, uint32_t ret)
+{
+    const bool last = __builtin_amdgcn_readfirstlane((int)ret) == S - 1;        // wave-uniform (lane 0's value)
+    if (!last) return;
+    if ((int)threadIdx.x < S) {
+        __hip_atomic_store(slots + 2 * threadIdx.x, (bn_u64)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(slots + 2 * threadIdx.x + 1, (bn_u64)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&sy->left[c][0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__hip_atomic_fetch_add(&sy->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)C - 1u) {
+            __hip_atomic_store(&sy->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&sy->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 template <int BLOCK>
@@ -642,13 +682,6 @@ __device__ __forceinline__ void bn_block_sum2_n(double& a, double& b, double* sh
     a = b = 0.0;
 #pragma unroll
     for (int w = 0; w < BLOCK / 64; ++w) { a += sh[2 * w]; b += sh[2 * w + 1]; }
-}
-
-// departure from a channel's wait: the last of its S workgroups to leave re-arms the counter
-__device__ __forceinline__ void bn_leave_channel(uint32_t* arrived, uint32_t S)
-{
-    if (__hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2u * S - 1u)
-        __hip_atomic_store(arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // (per-component builtins: the compiler merges them into one global_load/store_dwordx4 ... nt, as in ursa_kernels.hip)
@@ -670,7 +703,7 @@ template <bool NT> __device__ __forceinline__ void bn_st(float4* p, const float4
 template <bool RELU, bool ADD, int EPT, bool NT>
 __global__ __launch_bounds__(kHeldFwdBlock) void k_bn_fwd_held(const float* __restrict__ x, const float* __restrict__ addend,
                                                               float* __restrict__ z, float* __restrict__ y,
-                                                              double2* partial, BnSync* sync,
+                                                              bn_u64* slots_base, BnSync* sync,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               float* __restrict__ running_mean, float* __restrict__ running_var,
                                                               float* __restrict__ save_mean, float* __restrict__ save_invstd,
@@ -678,50 +711,47 @@ __global__ __launch_bounds__(kHeldFwdBlock) void k_bn_fwd_held(const float* __re
 {
     __shared__ double sh[2 * kHeldFwdBlock / 64];
     __shared__ float shf[2];
-    __shared__ uint32_t sh_t;
+    __shared__ int sh_item[2];
     if (threadIdx.x == 0) {
-        const uint32_t t = __hip_atomic_fetch_add(&sync->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t == gridDim.x - 1) __hip_atomic_store(&sync->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // all tickets are out
-        sh_t = t;
+        int c0 = -1, sp0 = 0;
+        bn_take_item(sync, g.C, S, c0, sp0);
+        sh_item[0] = c0; sh_item[1] = sp0;
     }
     __syncthreads();
-    const int c = (int)(sh_t / (uint32_t)S), sp = (int)(sh_t % (uint32_t)S);
+    const int c = sh_item[0], sp = sh_item[1];
+    if (c < 0) return;                                   // (grid != C * S: flagged in err)
     const float4* __restrict__ xv = reinterpret_cast<const float4*>(x);
     const float4* __restrict__ av = reinterpret_cast<const float4*>(addend);
     float4* __restrict__ zv = reinterpret_cast<float4*>(z);
     float4* __restrict__ yv = reinterpret_cast<float4*>(y);
     const int lo = sp * g.chunk;
     const int hi = lo + g.chunk < (int)g.per_ch ? lo + g.chunk : (int)g.per_ch;
-    float4 v[EPT];
-    int o[EPT];
+    float4 v[EPT];                       // (offsets are recomputed for the stores rather than kept live)
 #pragma unroll
     for (int u = 0; u < EPT; ++u) {
         const int i = lo + threadIdx.x + u * kHeldFwdBlock;
         v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        o[u] = -1;
         if (i < hi) {
-            o[u] = bn_off32(g, c, i);
-            v[u] = bn_ld<NT>(xv + o[u]);
-            if (ADD) v[u] = vadd(v[u], bn_ld<NT>(av + o[u]));
+            const int o = bn_off32(g, c, i);
+            v[u] = bn_ld<NT>(xv + o);
+            if (ADD) v[u] = vadd(v[u], bn_ld<NT>(av + o));
         }
     }
     double s1 = 0.0, s2 = 0.0;
 #pragma unroll
     for (int u = 0; u < EPT; ++u) {
-        if (ADD && o[u] >= 0) bn_st<NT>(zv + o[u], v[u]);
+        if (ADD) { const int i = lo + threadIdx.x + u * kHeldFwdBlock; if (i < hi) bn_st<NT>(zv + bn_off32(g, c, i), v[u]); }
 #pragma unroll
         for (int k = 0; k < 4; ++k) { const double d = (double)comp(v[u], k); s1 += d; s2 = fma(d, d, s2); }
     }
     bn_block_sum2_n<kHeldFwdBlock>(s1, s2, sh);
-    uint32_t* arrived = &sync->arrived[c];
-    if (threadIdx.x == 0) {
-        bn_publish(partial + (int64_t)c * S + sp, s1, s2, arrived);
-        bn_wait_channel(arrived, (uint32_t)S, &sync->err);
-    }
-    __syncthreads();
+    bn_u64* slots = slots_base + (int64_t)c * kBnMaxSplit * 2;
+    if (threadIdx.x == 0) bn_publish(slots + 2 * sp, s1, s2);
+    uint32_t left = 0;
     if (threadIdx.x < 64) {
         double a, b;
-        bn_merge_held(partial + (int64_t)c * S, S, a, b);
+        bn_gather(slots, S, &sync->err, a, b);
+        left = bn_leave_issue(sync, c);
         if (threadIdx.x == 0) {
             const double n = (double)g.per_ch * 4.0;
             const double mean = a / n;
@@ -740,40 +770,42 @@ __global__ __launch_bounds__(kHeldFwdBlock) void k_bn_fwd_held(const float* __re
                     running_var[c] = momentum * (float)(var * (n / (n - 1.0))) + (1.0f - momentum) * running_var[c];
                 }
             }
-            bn_leave_channel(arrived, (uint32_t)S);
         }
     }
     __syncthreads();
     const float scale = shf[0], shift = shf[1];
 #pragma unroll
     for (int u = 0; u < EPT; ++u) {
-        if (o[u] >= 0) {
+        const int i = lo + threadIdx.x + u * kHeldFwdBlock;
+        if (i < hi) {
             float4 r;
 #pragma unroll
             for (int k = 0; k < 4; ++k) { const float t = fmaf(comp(v[u], k), scale, shift); setc(r, k, RELU ? bn_relu_fwd(t) : t); }
-            bn_st<NT>(yv + o[u], r);
+            bn_st<NT>(yv + bn_off32(g, c, i), r);
         }
     }
+    if (threadIdx.x < 64) bn_leave_finish(sync, slots, c, g.C, S, left);
 }
 
 template <bool RELU, bool RES, int EPT, bool NT>
 __global__ __launch_bounds__(kHeldBwdBlock) void k_bn_bwd_held(const float* __restrict__ x, const float* __restrict__ dy,
                                                               const float* __restrict__ dz, float* __restrict__ dx,
-                                                              double2* partial, BnSync* sync,
+                                                              bn_u64* slots_base, BnSync* sync,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta, BnGeom g, int S)
 {
     __shared__ double sh[2 * kHeldBwdBlock / 64];
     __shared__ float shf[2];
-    __shared__ uint32_t sh_t;
+    __shared__ int sh_item[2];
     if (threadIdx.x == 0) {
-        const uint32_t t = __hip_atomic_fetch_add(&sync->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t == gridDim.x - 1) __hip_atomic_store(&sync->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sh_t = t;
+        int c0 = -1, sp0 = 0;
+        bn_take_item(sync, g.C, S, c0, sp0);
+        sh_item[0] = c0; sh_item[1] = sp0;
     }
     __syncthreads();
-    const int c = (int)(sh_t / (uint32_t)S), sp = (int)(sh_t % (uint32_t)S);
+    const int c = sh_item[0], sp = sh_item[1];
+    if (c < 0) return;
     const float4* __restrict__ xv = reinterpret_cast<const float4*>(x);
     const float4* __restrict__ dv = reinterpret_cast<const float4*>(dy);
     const float4* __restrict__ rv = reinterpret_cast<const float4*>(dz);
@@ -785,14 +817,12 @@ __global__ __launch_bounds__(kHeldBwdBlock) void k_bn_bwd_held(const float* __re
     const int lo = sp * g.chunk;
     const int hi = lo + g.chunk < (int)g.per_ch ? lo + g.chunk : (int)g.per_ch;
     float4 a[EPT], b[EPT];
-    int o[EPT];
 #pragma unroll
     for (int u = 0; u < EPT; ++u) {
         const int i = lo + threadIdx.x + u * kHeldBwdBlock;
         a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         b[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        o[u] = -1;
-        if (i < hi) { o[u] = bn_off32(g, c, i); a[u] = bn_ld<NT>(xv + o[u]); b[u] = bn_ld<NT>(dv + o[u]); }
+        if (i < hi) { const int o = bn_off32(g, c, i); a[u] = bn_ld<NT>(xv + o); b[u] = bn_ld<NT>(dv + o); }
     }
     double s1 = 0.0, s2 = 0.0;
 #pragma unroll
@@ -808,35 +838,35 @@ __global__ __launch_bounds__(kHeldBwdBlock) void k_bn_bwd_held(const float* __re
         }
     }
     bn_block_sum2_n<kHeldBwdBlock>(s1, s2, sh);
-    uint32_t* arrived = &sync->arrived[c];
-    if (threadIdx.x == 0) {
-        bn_publish(partial + (int64_t)c * S + sp, s1, s2, arrived);
-        bn_wait_channel(arrived, (uint32_t)S, &sync->err);
-    }
-    __syncthreads();
+    bn_u64* slots = slots_base + (int64_t)c * kBnMaxSplit * 2;
+    if (threadIdx.x == 0) bn_publish(slots + 2 * sp, s1, s2);
+    uint32_t left = 0;
     if (threadIdx.x < 64) {
         double sa, sb;
-        bn_merge_held(partial + (int64_t)c * S, S, sa, sb);
+        bn_gather(slots, S, &sync->err, sa, sb);
+        left = bn_leave_issue(sync, c);
         if (threadIdx.x == 0) {
             const double n = (double)g.per_ch * 4.0, iv = (double)invstd;
             shf[0] = (float)(sa / n);
             shf[1] = (float)(sb * iv * iv / n);
             if (sp == 0) { dbeta[c] = (float)sa; dgamma[c] = (float)(sb * iv); }
-            bn_leave_channel(arrived, (uint32_t)S);
         }
     }
     __syncthreads();
     const float gm = shf[0], kk = shf[1];
 #pragma unroll
     for (int u = 0; u < EPT; ++u) {
-        if (o[u] >= 0) {
+        const int i = lo + threadIdx.x + u * kHeldBwdBlock;
+        if (i < hi) {
+            const int o = bn_off32(g, c, i);
             float4 r;
 #pragma unroll
             for (int k = 0; k < 4; ++k) setc(r, k, (((comp(b[u], k) - gm) - (comp(a[u], k) - mean) * kk) * invstd) * w);
-            if (RES) r = vadd(bn_ld<NT>(rv + o[u]), r);
-            bn_st<NT>(ov + o[u], r);
+            if (RES) r = vadd(bn_ld<NT>(rv + o), r);
+            bn_st<NT>(ov + o, r);
         }
     }
+    if (threadIdx.x < 64) bn_leave_finish(sync, slots, c, g.C, S, left);
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------
@@ -887,13 +917,20 @@ inline int bn_launch_status() { return (int)hipGetLastError(); }
 // register-sized chunks, enough workgroups to fill the chip, and an activation large enough that the second read of the
 // two-launch form costs more than the wait (measured: tools/exp/bn_fused_bench.py). The caller vouches for zeroed sync
 // words with URSA_BN_HELD.
-constexpr int64_t kHeldMinFloat4 = (24ll << 20) / 16;     // 24 MiB of activation
+// Measured, us per call inside a hipGraph, held / two-launch (tools/exp/bn_held_ab.py, profiles/r04_bn_held_ab.json):
+//   [1024,64,32,32] 268 MB  forward 135 / 152   backward 171 / 246        [1024,128,16,16] 134 MB   59 / 60    96 / 115
+//   [128,160,32,32]  84 MB           41 / 41             50 /  65        [1024,256,8,8]    67 MB   32 / 33    40 /  52
+//   [1024,16,32,32]  67 MB           37 / 33             48 /  51        [256,64,32,32]    67 MB   36 / 32    45 /  52
+// The backward saves 8 of 20 B/element and wins from 24 MiB on; the forward saves 4 of 12 and pays the same wait: it wins
+// only where the second read would come from HBM (activation + output beyond the 256 MiB Infinity Cache).
+constexpr int64_t kHeldMinFloat4Bwd = (24ll << 20) / 16;      // 24 MiB of activation
+constexpr int64_t kHeldMinFloat4Fwd = (128ll << 20) / 16;     // 128 MiB
 struct BnHeld { int S, chunk, ept; };
-inline bool bn_held_plan(const BnPlan& p, uint32_t flags, int block, int max_ept, BnHeld* h)
+inline bool bn_held_plan(const BnPlan& p, uint32_t flags, int block, int max_ept, int64_t min_float4, BnHeld* h)
 {
     if (!(flags & URSA_BN_HELD) || (flags & URSA_BN_TWO_LAUNCH) || p.V != 4) return false;
     const int64_t per_ch = p.g.per_ch;
-    if (per_ch * p.g.C >= (1ll << 31) || per_ch * p.g.C < kHeldMinFloat4) return false;
+    if (per_ch * p.g.C >= (1ll << 31) || per_ch * p.g.C < min_float4) return false;
     const int64_t cap = (int64_t)block * max_ept;
     int64_t S = (per_ch + cap - 1) / cap;
     if (S < 2 || S > kBnMaxSplit) return false;
@@ -941,17 +978,18 @@ int ursa_bn_relu_fwd_f32(const float* x, const float* addend, float* z_out, floa
     double2* part = reinterpret_cast<double2*>(ws);
     const bool relu = flags & URSA_BN_RELU;
     BnHeld hd;
-    if (!bn_one_pass(p, flags) && bn_held_plan(p, flags, kHeldFwdBlock, kHeldFwdEpt, &hd)) {
+    if (!bn_one_pass(p, flags) && bn_held_plan(p, flags, kHeldFwdBlock, kHeldFwdEpt, kHeldMinFloat4Fwd, &hd)) {
         BnGeom gh = p.g;
         gh.chunk = hd.chunk;
         BnSync* sync = reinterpret_cast<BnSync*>(ws + (int64_t)C * kBnMaxSplit * 4);
+        bn_u64* slots = reinterpret_cast<bn_u64*>(ws);
         const dim3 gg((unsigned)(hd.S * p.g.C)), bb(kHeldFwdBlock);
         // beyond the 256 MiB Infinity Cache the streams go past it (as K1-K4 do)
         const bool nt = p.g.per_ch * p.g.C * 16 * (addend ? 4 : 2) > (256ll << 20);
 #define URSA_BN_HELD_E(R, A, E) do { \
-    if (nt) hipLaunchKernelGGL((k_bn_fwd_held<R, A, E, true>), gg, bb, 0, st, x, addend, z_out, y, part, sync, gamma, beta, \
+    if (nt) hipLaunchKernelGGL((k_bn_fwd_held<R, A, E, true>), gg, bb, 0, st, x, addend, z_out, y, slots, sync, gamma, beta, \
                                running_mean, running_var, save_mean, save_invstd, eps, momentum, gh, hd.S); \
-    else hipLaunchKernelGGL((k_bn_fwd_held<R, A, E, false>), gg, bb, 0, st, x, addend, z_out, y, part, sync, gamma, beta, \
+    else hipLaunchKernelGGL((k_bn_fwd_held<R, A, E, false>), gg, bb, 0, st, x, addend, z_out, y, slots, sync, gamma, beta, \
                             running_mean, running_var, save_mean, save_invstd, eps, momentum, gh, hd.S); } while (0)
 #define URSA_BN_HELD_F(R, A) do { if (hd.ept == kHeldFwdEpt / 4) URSA_BN_HELD_E(R, A, kHeldFwdEpt / 4); \
                                   else if (hd.ept == kHeldFwdEpt / 2) URSA_BN_HELD_E(R, A, kHeldFwdEpt / 2); else URSA_BN_HELD_E(R, A, kHeldFwdEpt); } while (0)
@@ -1046,16 +1084,17 @@ static int bn_bwd_impl(const float* x, const float* dy, const float* dz, float* 
         return bn_launch_status();
     }
     BnHeld hd;
-    if (!bn_one_pass(p, flags) && bn_held_plan(p, flags, kHeldBwdBlock, kHeldBwdEpt, &hd)) {
+    if (!bn_one_pass(p, flags) && bn_held_plan(p, flags, kHeldBwdBlock, kHeldBwdEpt, kHeldMinFloat4Bwd, &hd)) {
         BnGeom gh = p.g;
         gh.chunk = hd.chunk;
         BnSync* sync = reinterpret_cast<BnSync*>(ws + (int64_t)C * kBnMaxSplit * 4);
+        bn_u64* slots = reinterpret_cast<bn_u64*>(ws);
         const dim3 gg((unsigned)(hd.S * p.g.C)), bb(kHeldBwdBlock);
         const bool nt = p.g.per_ch * p.g.C * 16 * (dz ? 4 : 3) > (256ll << 20);
 #define URSA_BN_HELD_E(R, A, E) do { \
-    if (nt) hipLaunchKernelGGL((k_bn_bwd_held<R, A, E, true>), gg, bb, 0, st, x, dy, dz, dx, part, sync, gamma, beta, save_mean, \
+    if (nt) hipLaunchKernelGGL((k_bn_bwd_held<R, A, E, true>), gg, bb, 0, st, x, dy, dz, dx, slots, sync, gamma, beta, save_mean, \
                                save_invstd, dgamma, dbeta, gh, hd.S); \
-    else hipLaunchKernelGGL((k_bn_bwd_held<R, A, E, false>), gg, bb, 0, st, x, dy, dz, dx, part, sync, gamma, beta, save_mean, \
+    else hipLaunchKernelGGL((k_bn_bwd_held<R, A, E, false>), gg, bb, 0, st, x, dy, dz, dx, slots, sync, gamma, beta, save_mean, \
                             save_invstd, dgamma, dbeta, gh, hd.S); } while (0)
 #define URSA_BN_HELD_B(R, A) do { if (hd.ept == kHeldBwdEpt / 4) URSA_BN_HELD_E(R, A, kHeldBwdEpt / 4); \
                                   else if (hd.ept == kHeldBwdEpt / 2) URSA_BN_HELD_E(R, A, kHeldBwdEpt / 2); else URSA_BN_HELD_E(R, A, kHeldBwdEpt); } while (0)

@@ -71,8 +71,20 @@ class ChainGroup:
         for s, keep in zip(self.samplers, keeps):
             s.engine.finish(keep)
 
+    def _forward_backward(self, s, x, y):
+        """K6's held form (activations >= 24 MiB) needs <= 8 of its launches in flight at once to be deadlock-free
+        (csrc/ursa_bn.hip): larger groups keep the two-launch form."""
+        if len(self.samplers) <= 8:
+            return s.engine.forward_backward(x, y)
+        from .. import fused_bn
+        old = fused_bn.held(False)
+        try:
+            return s.engine.forward_backward(x, y)
+        finally:
+            fused_bn.held(old)
+
     def _round_eager(self, x, y):
-        keeps = [s.engine.forward_backward(x, y) for s in self.samplers]
+        keeps = [self._forward_backward(s, x, y) for s in self.samplers]
         with torch.no_grad():
             self._update(keeps)
 
@@ -89,7 +101,7 @@ class ChainGroup:
             for s, st in zip(self.samplers, side):          # fork: one forward/backward branch per chain
                 st.wait_stream(cap)
                 with torch.cuda.stream(st):
-                    keeps.append(s.engine.forward_backward(*self._static))
+                    keeps.append(self._forward_backward(s, *self._static))
             for st in side:                                  # join
                 cap.wait_stream(st)
             with torch.no_grad():
