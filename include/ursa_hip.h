@@ -273,18 +273,18 @@ int ursa_sumsq_f32(const float* x, int64_t n, float* out, float* ws, ursa_stream
  */
 #define URSA_BN_RELU        0x1u
 #define URSA_BN_TWO_LAUNCH  0x2u   /* keep the two-launch form where the one-pass / held form would apply (A/B, tests) */
-#define URSA_BN_HELD        0x4u   /* the caller vouches that ws (all of it) is ZERO: the library may then run the
+#define URSA_BN_HELD        0x4u   /* the caller vouches that ws from URSA_BN_WS_HELD_OFFSET_FLOATS(C) on is ZERO: the library may then run the
                                       held form - ONE launch, every input read once - on activations of >= 24 MiB (backward) / >= 128 MiB (forward) whose
                                       channels do not fit one workgroup (per-channel workgroups hold their chunk in registers,
-                                      exchange double partial sums through ws and wait for each other; bounded wait; ws is
-                                      zero again when the launch has drained, so a zeroed ws that only held-form calls touch
-                                      can be reused call after call). Same floats as the two-launch form. Without the flag ws
-                                      needs no initialisation and the held form is never taken. */
+                                      exchange double partial sums through ws and wait for each other; bounded wait; that part
+                                      of ws is zero again when the launch has drained and no other form writes there, so a ws
+                                      zeroed once can be reused call after call). Same floats as the two-launch form. Without
+                                      the flag ws needs no initialisation and the held form is never taken. */
 #define URSA_BN_ALLFLAGS    0x7u
-/* partial sums: C x 64 x {double, double}; then the held form's counters, one 128-byte line each: ticket, {done, err},
- * one per channel */
-#define URSA_BN_WS_FLOATS(C) ((int64_t)(C) * 64 * 4 + ((int64_t)(C) + 2) * 32)
-#define URSA_BN_WS_SYNC_OFFSET_FLOATS(C) ((int64_t)(C) * 64 * 4)
+/* [two-launch form: partial sums, C x 64 x {double, double}] [held form: its partial-sum slots, the same size; then its
+ * counters, one 128-byte line each: ticket, {done, err}, one per channel] */
+#define URSA_BN_WS_FLOATS(C) ((int64_t)(C) * 64 * 8 + ((int64_t)(C) + 2) * 32)
+#define URSA_BN_WS_HELD_OFFSET_FLOATS(C) ((int64_t)(C) * 64 * 4)
 
 int ursa_bn_relu_fwd_f32(const float* x, const float* addend /* or NULL */, float* z_out /* iff addend */,
                          float* y, const float* gamma, const float* beta,
@@ -302,6 +302,26 @@ int ursa_bn_relu_bwd_f32(const float* x /* the normalised input: z_out if the fo
                          const float* beta, const float* save_mean, const float* save_invstd,
                          float* dgamma, float* dbeta, float* ws, int64_t N, int64_t C, int64_t HW,
                          uint32_t flags, ursa_stream_t stream);
+
+/* The same forward / backward that ALSO store their output channels-last (NHWC, [N, HW, C]) as a second tensor: y_nhwc /
+ * dx_nhwc hold the same floats as y / dx (dx + dz in the residual form). Why: MIOpen's fastest weight-gradient kernel for the
+ * benchmark networks works on NHWC operands and transposes NCHW ones itself (15-20 % of a training step's kernel time);
+ * both operands of every 3x3 weight gradient are K6 outputs, so K6 hands them over ready-made (ursabench_amd/fused_conv.py;
+ * replaces nothing in the reference, whose stock ops leave the layout to the backend). Needs HW % 4 == 0, C % 4 == 0
+ * and 16-byte aligned pointers (URSA_EVALUE otherwise: the caller falls back to the plain entry points); always the two
+ * launches of the two-launch form (no one-pass / held form); the gated backward has no twin. The second launch works on four
+ * channels at a time: its four waves merge the four channels' partial sums side by side (same lane order as the plain
+ * form: same floats), a thread loads one float4 from each of the four channel rows, transposes the 4x4 block in registers
+ * and stores four NCHW float4 as before plus four NHWC float4 (channels 4k..4k+3 of four consecutive positions). */
+int ursa_bn_relu_fwd_nhwc_f32(const float* x, const float* addend /* or NULL */, float* z_out /* iff addend */, float* y,
+                              float* y_nhwc, const float* gamma, const float* beta, float* running_mean /* or NULL */,
+                              float* running_var /* or NULL */, float* save_mean, float* save_invstd, float* ws,
+                              int64_t N, int64_t C, int64_t HW, float eps, float momentum, uint32_t flags,
+                              ursa_stream_t stream);
+int ursa_bn_relu_bwd_nhwc_f32(const float* x, const float* dy, const float* dz /* or NULL */, float* dx, float* dx_nhwc,
+                              const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
+                              float* dgamma, float* dbeta, float* ws, int64_t N, int64_t C, int64_t HW, uint32_t flags,
+                              ursa_stream_t stream);
 
 /* The same backward with the ReLU gates of LISTED elements given instead of recomputed: a parity instrument, not a
  * production launch (binary search per element; always the two-launch kernels; URSA_BN_RELU required).

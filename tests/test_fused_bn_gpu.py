@@ -523,15 +523,17 @@ def test_gated_backward_argument_errors(K):
         K.bn_relu_backward(x, x, torch.empty_like(x), v, v, v, v, v.clone(), v.clone(), ws, relu=True, gates=(gi.long(), go))
 
 
-HELD_SHAPES = [(128, 160, 32, 32),      # WideResNet-28-10 stage 1: 84 MB, S = 8
+HELD_SHAPES = [(512, 64, 32, 32),       # 134 MB: forward AND backward take the held form (forward: from 128 MiB on)
+               (128, 160, 32, 32),      # WideResNet-28-10 stage 1: 84 MB, S = 8 (backward held, forward two-launch)
                (256, 64, 32, 32),       # 67 MB, S = 16
                (512, 16, 32, 32),       # few channels: 16 x 32 workgroups
                (96, 96, 34, 30)]        # ragged: H*W = 1020 (float4 path, chunk tail), S = 6
 
 
 def _sync_words(ws, C):
-    """All of ws as the held form must leave it: partial-sum slots and counters zero."""
-    return ws.view(torch.int32)
+    """The held form's part of ws (URSA_BN_WS_HELD_OFFSET_FLOATS(C) on) as it must leave it: slots and counters zero.
+    (The two-launch form's partials in front of it are scratch; a forward below 128 MiB takes that form.)"""
+    return ws[C * 256:].view(torch.int32)
 
 
 @pytest.mark.parametrize('shape', HELD_SHAPES)
@@ -583,7 +585,7 @@ def test_held_form_on_parallel_streams_and_through_the_module_path():
     form by itself for a large activation (zeroed scratch) and the layer's output / gradients equal the two-launch run."""
     from ursabench_amd import _native, fused_bn
     K = _native.default_kernels()
-    shape, C = (128, 160, 32, 32), 160
+    shape, C = (512, 64, 32, 32), 64            # 134 MB: the forward takes the held form
     g = torch.Generator().manual_seed(5)
     xs = [torch.randn(shape, generator=g).cuda() for _ in range(4)]
     w, bb = (torch.rand(C, generator=g) + 0.5).cuda(), torch.randn(C, generator=g).cuda()

@@ -112,12 +112,12 @@ int main(int argc, char** argv)
     const int grid = hd.S * (int)C;
     long long* st;
     hipMalloc((void**)&st, (int64_t)grid * 8 * 8);
-    BnSync* sync = reinterpret_cast<BnSync*>(ws + C * kBnMaxSplit * 4);
+    BnSync* sync = reinterpret_cast<BnSync*>(ws + C * kBnMaxSplit * 8);
     const int sg = argc > 1 ? atoi(argv[1]) : 0;
     for (int rep = 0; rep < 3; ++rep) {
-        if (argc > 2 && atoi(argv[2]) == 20) hipLaunchKernelGGL(k_tl<20>, dim3(grid), dim3(kHeldFwdBlock), 0, 0, x, y, reinterpret_cast<bn_u64*>(ws), sync, gam, bet, gh, hd.S, st, sg);
-        else if (argc > 2 && atoi(argv[2]) == 80) hipLaunchKernelGGL(k_tl<80>, dim3(grid), dim3(kHeldFwdBlock), 0, 0, x, y, reinterpret_cast<bn_u64*>(ws), sync, gam, bet, gh, hd.S, st, sg);
-        else hipLaunchKernelGGL(k_tl<40>, dim3(grid), dim3(kHeldFwdBlock), 0, 0, x, y, reinterpret_cast<bn_u64*>(ws), sync, gam, bet, gh, hd.S, st, sg);
+        if (argc > 2 && atoi(argv[2]) == 20) hipLaunchKernelGGL(k_tl<20>, dim3(grid), dim3(kHeldFwdBlock), 0, 0, x, y, reinterpret_cast<bn_u64*>(ws + C * kBnMaxSplit * 4), sync, gam, bet, gh, hd.S, st, sg);
+        else if (argc > 2 && atoi(argv[2]) == 80) hipLaunchKernelGGL(k_tl<80>, dim3(grid), dim3(kHeldFwdBlock), 0, 0, x, y, reinterpret_cast<bn_u64*>(ws + C * kBnMaxSplit * 4), sync, gam, bet, gh, hd.S, st, sg);
+        else hipLaunchKernelGGL(k_tl<40>, dim3(grid), dim3(kHeldFwdBlock), 0, 0, x, y, reinterpret_cast<bn_u64*>(ws + C * kBnMaxSplit * 4), sync, gam, bet, gh, hd.S, st, sg);
     }
     hipDeviceSynchronize();
     std::vector<long long> hs((int64_t)grid * 8);

@@ -30,7 +30,7 @@ BN_RELU, BN_TWO_LAUNCH, BN_HELD = 0x1, 0x2, 0x4
 
 def bn_ws_floats(channels):
     """URSA_BN_WS_FLOATS(C): scratch of one BatchNorm call (partial sums, then the held form's sync words)."""
-    return int(channels) * 64 * 4 + (int(channels) + 2) * 32
+    return int(channels) * 64 * 8 + (int(channels) + 2) * 32
 
 
 BN_HELD_MIN_BYTES = 24 << 20      # activations from this size on may take the held form (ursa_bn.hip kHeldMinFloat4)
@@ -59,6 +59,8 @@ SIGNATURES = {
     'ursa_bn_relu_fwd_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f, _f, _u32, _vp]),
     'ursa_bn_relu_eval_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f, _u32, _vp]),
     'ursa_bn_relu_bwd_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _u32, _vp]),
+    'ursa_bn_relu_fwd_nhwc_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f, _f, _u32, _vp]),
+    'ursa_bn_relu_bwd_nhwc_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _u32, _vp]),
     'ursa_bn_relu_bwd_gated_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _u32,
                                                   _vp, _vp, _i64, _vp]),
 }
@@ -146,6 +148,24 @@ def _ptr(t, name, n=None, device=None, optional=False):
         raise ValueError(f'{name} has {t.numel()} elements, expected {n}')
     if device is not None and t.device != device:
         raise ValueError(f'{name} is on {t.device}, expected {device}')
+    return t.data_ptr()
+
+
+def nhwc_twin_supported(x):
+    """Whether K6 can store a channels-last twin of an output shaped like `x` (ursa_bn_relu_*_nhwc_f32's conditions)."""
+    return (x.dim() == 4 and x.is_contiguous() and x.shape[1] % 4 == 0
+            and (x.shape[2] * x.shape[3]) % 4 == 0 and x.data_ptr() % 16 == 0)
+
+
+def nhwc_twin(x):
+    """An uninitialised tensor with x's logical shape and channels-last strides (physically [N, H, W, C])."""
+    return torch.empty_like(x, memory_format=torch.channels_last)
+
+
+def _twin_ptr(t, like):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.shape == like.shape
+            and t.device == like.device and t.is_contiguous(memory_format=torch.channels_last)):
+        raise ValueError('the NHWC twin must be a float32 channels-last tensor of the output\'s shape on its device')
     return t.data_ptr()
 
 
@@ -313,7 +333,7 @@ class HipKernels:
         return N, C, x.numel() // max(N * C, 1)
 
     def bn_relu_forward(self, x, y, gamma, beta, running_mean, running_var, save_mean, save_invstd, ws, *, eps,
-                        momentum, relu=True, addend=None, z_out=None, two_launch=False, held=False):
+                        momentum, relu=True, addend=None, z_out=None, two_launch=False, held=False, y_nhwc=None):
         """Training-mode BatchNorm (+ ReLU) of a contiguous [N, C, *] tensor: batch statistics, running statistics
         updated in place (skipped when both are None), mean / invstd saved for the backward. With `addend` the
         normalised tensor is z = x + addend, also stored to `z_out` (the residual sum folded into the statistics pass).
@@ -324,14 +344,18 @@ class HipKernels:
         dev, n = x.device, x.numel()
         if ws.numel() < bn_ws_floats(C):
             raise ValueError(f'ws must hold {bn_ws_floats(C)} floats')
-        with torch.cuda.device(dev):
-            rc = self.lib.ursa_bn_relu_fwd_f32(
-                _ptr(x, 'x'), _ptr(addend, 'addend', n, dev, optional=True), _ptr(z_out, 'z_out', n, dev, optional=True),
-                _ptr(y, 'y', n, dev), _ptr(gamma, 'gamma', C, dev), _ptr(beta, 'beta', C, dev),
+        head = (_ptr(x, 'x'), _ptr(addend, 'addend', n, dev, optional=True), _ptr(z_out, 'z_out', n, dev, optional=True),
+                _ptr(y, 'y', n, dev))
+        tail = (_ptr(gamma, 'gamma', C, dev), _ptr(beta, 'beta', C, dev),
                 _ptr(running_mean, 'running_mean', C, dev, optional=True),
                 _ptr(running_var, 'running_var', C, dev, optional=True), _ptr(save_mean, 'save_mean', C, dev),
                 _ptr(save_invstd, 'save_invstd', C, dev), _ptr(ws, 'ws', None, dev), N, C, HW, eps, momentum,
-                (BN_RELU if relu else 0) | (BN_TWO_LAUNCH if two_launch else 0) | _held_flags(held), _stream(dev))
+                (BN_RELU if relu else 0) | (BN_TWO_LAUNCH if two_launch else 0) | _held_flags(held and y_nhwc is None), _stream(dev))
+        with torch.cuda.device(dev):
+            if y_nhwc is not None:              # second output: the same floats channels-last (nhwc_twin() allocates it)
+                rc = self.lib.ursa_bn_relu_fwd_nhwc_f32(*head, _twin_ptr(y_nhwc, x), *tail)
+            else:
+                rc = self.lib.ursa_bn_relu_fwd_f32(*head, *tail)
         _check(self.lib, rc, 'ursa_bn_relu_fwd_f32')
 
     def bn_relu_eval(self, x, y, gamma, beta, running_mean, running_var, *, eps, relu=True, addend=None, z_out=None):
@@ -348,7 +372,7 @@ class HipKernels:
         _check(self.lib, rc, 'ursa_bn_relu_eval_f32')
 
     def bn_relu_backward(self, x, dy, dx, gamma, beta, save_mean, save_invstd, dgamma, dbeta, ws, *, relu=True, dz=None,
-                         two_launch=False, gates=None, held=False):
+                         two_launch=False, gates=None, held=False, dx_nhwc=None):
         """`x` is the tensor the forward normalised (z_out in the residual form); with `dz` the result is dx + dz.
         `gates=(idx int32 [n], open uint8 [n])`: the parity instrument ursa_bn_relu_bwd_gated_f32 - the ReLU gates of the
         listed element offsets (ascending; INT32_MAX = padding) are taken from `open` instead of recomputed."""
@@ -356,6 +380,18 @@ class HipKernels:
         dev, n = x.device, x.numel()
         if ws.numel() < bn_ws_floats(C):
             raise ValueError(f'ws must hold {bn_ws_floats(C)} floats')
+        if dx_nhwc is not None:
+            if gates is not None:
+                raise ValueError('the gated backward has no NHWC twin')
+            with torch.cuda.device(dev):
+                rc = self.lib.ursa_bn_relu_bwd_nhwc_f32(
+                    _ptr(x, 'x'), _ptr(dy, 'dy', n, dev), _ptr(dz, 'dz', n, dev, optional=True), _ptr(dx, 'dx', n, dev),
+                    _twin_ptr(dx_nhwc, x), _ptr(gamma, 'gamma', C, dev), _ptr(beta, 'beta', C, dev),
+                    _ptr(save_mean, 'save_mean', C, dev), _ptr(save_invstd, 'save_invstd', C, dev), _ptr(dgamma, 'dgamma', C, dev),
+                    _ptr(dbeta, 'dbeta', C, dev), _ptr(ws, 'ws', None, dev), N, C, HW,
+                    (BN_RELU if relu else 0) | (BN_TWO_LAUNCH if two_launch else 0), _stream(dev))
+            _check(self.lib, rc, 'ursa_bn_relu_bwd_nhwc_f32')
+            return
         args = (_ptr(x, 'x'), _ptr(dy, 'dy', n, dev), _ptr(dz, 'dz', n, dev, optional=True), _ptr(dx, 'dx', n, dev),
                 _ptr(gamma, 'gamma', C, dev), _ptr(beta, 'beta', C, dev), _ptr(save_mean, 'save_mean', C, dev),
                 _ptr(save_invstd, 'save_invstd', C, dev), _ptr(dgamma, 'dgamma', C, dev), _ptr(dbeta, 'dbeta', C, dev),

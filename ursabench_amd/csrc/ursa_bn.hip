@@ -869,6 +869,150 @@ __global__ __launch_bounds__(kHeldBwdBlock) void k_bn_bwd_held(const float* __re
     if (threadIdx.x < 64) bn_leave_finish(sync, slots, c, g.C, S, left);
 }
 
+// ---- NHWC twins: the second launch of the two-launch form also stores its output channels-last ----------------------------
+// MIOpen's fastest weight-gradient kernel for these networks (igemm_wrw_gtcx35_nhwc) wants NHWC operands and, handed NCHW
+// tensors, transposes both of them itself: 15 % of a PreResNet-20 training step's kernel time (20 % with its zero-fills),
+// 16 % of a PreResNet-164 HMC step. Both operands of every 3x3 weight gradient are K6 outputs - the convolution's input
+// is a forward y, its output gradient a backward dx - so K6 can hand them over in NHWC as a second store
+// (ursabench_amd/fused_conv.py takes the weight gradient on those twins; forward and backward-data stay on the NCHW
+// Winograd kernels).
+// The second launches in a FOUR-CHANNEL form: a workgroup owns channels 4cg..4cg+3 and 256 float4 columns of them; its four
+// waves merge the four channels' partials side by side (wave w: channel 4cg + w - the same sums in the same lane order as
+// bn_merge, so the same floats, and no longer than the one-channel merge of the plain kernels); a thread loads one float4
+// from each of the four rows, transposes the 4x4 block in registers and stores four NCHW float4 as before plus four
+// NHWC float4 (channels 4cg..4cg+3 of positions 4j..4j+3: 16 contiguous bytes each).
+constexpr int kTwinMaxC = 65535 * 4;
+
+template <bool RELU>
+__global__ __launch_bounds__(kBnBlock) void k_bn_fwd_apply_4(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ yt,
+                                                            const double2* __restrict__ partial, int S,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                            float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                            float eps, float momentum, BnGeom g)
+{
+    __shared__ float sh[8];
+    const float4* __restrict__ xv = reinterpret_cast<const float4*>(x);
+    float4* __restrict__ yv = reinterpret_cast<float4*>(y);
+    float4* __restrict__ tv = reinterpret_cast<float4*>(yt);
+    const int c0 = 4 * blockIdx.y, C = g.C, hw = g.hw;
+    const int64_t i = (int64_t)blockIdx.x * kBnBlock + threadIdx.x;            // float4 column of the channel rows: (n, j)
+    const bool active = i < g.per_ch;
+    int64_t n = 0, j = 0;
+    float4 v[4];
+    if (active) {
+        if (g.hw_shift >= 0) n = i >> g.hw_shift; else n = i / hw;
+        j = i - n * hw;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = xv[(n * C + c0 + r) * hw + j];                 // in flight under the merge
+    }
+    {
+        const int c = c0 + (threadIdx.x >> 6), lane = threadIdx.x & 63;                   // wave w merges channel c0 + w
+        double a = 0.0, b = 0.0;
+        if (lane < S) { const double2 p = partial[(int64_t)c * S + lane]; a = p.x; b = p.y; }
+        a = bn_wave_sum(a);
+        b = bn_wave_sum(b);
+        if (lane == 0) {
+            const double cnt = (double)g.per_ch * 4.0;
+            const double mean = a / cnt;
+            double var = b / cnt - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float meanf = (float)mean;
+            const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+            const float alpha = invstd * gamma[c];
+            sh[2 * (threadIdx.x >> 6)] = alpha;
+            sh[2 * (threadIdx.x >> 6) + 1] = fmaf(-meanf, alpha, beta[c]);
+            if (blockIdx.x == 0) {
+                save_mean[c] = meanf;
+                save_invstd[c] = invstd;
+                if (running_mean) {
+                    running_mean[c] = momentum * meanf + (1.0f - momentum) * running_mean[c];
+                    running_var[c] = momentum * (float)(var * (cnt / (cnt - 1.0))) + (1.0f - momentum) * running_var[c];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float scale = sh[2 * r], shift = sh[2 * r + 1];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const float t = fmaf(comp(v[r], k), scale, shift); setc(v[r], k, RELU ? bn_relu_fwd(t) : t); }
+        yv[(n * C + c0 + r) * hw + j] = v[r];
+    }
+    const int64_t tb = (n * hw + j) * 4 * (C / 4) + blockIdx.y;        // float4 index of (n, position 4j, channels c0..c0+3)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        tv[tb + (int64_t)q * (C / 4)] = make_float4(comp(v[0], q), comp(v[1], q), comp(v[2], q), comp(v[3], q));
+}
+
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(kBnBlock) void k_bn_bwd_dx_4(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ dz,
+                                                         float* __restrict__ dx, float* __restrict__ dxt, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, const float* __restrict__ save_mean,
+                                                         const float* __restrict__ save_invstd, const double2* __restrict__ partial, int S,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, BnGeom g)
+{
+    __shared__ float sh[8];
+    const float4* __restrict__ xv = reinterpret_cast<const float4*>(x);
+    const float4* __restrict__ dv = reinterpret_cast<const float4*>(dy);
+    const float4* __restrict__ rv = reinterpret_cast<const float4*>(dz);
+    float4* __restrict__ ov = reinterpret_cast<float4*>(dx);
+    float4* __restrict__ tv = reinterpret_cast<float4*>(dxt);
+    const int c0 = 4 * blockIdx.y, C = g.C, hw = g.hw;
+    const int64_t i = (int64_t)blockIdx.x * kBnBlock + threadIdx.x;
+    const bool active = i < g.per_ch;
+    int64_t n = 0, j = 0;
+    float4 a[4], b[4], rz[4];
+    if (active) {
+        if (g.hw_shift >= 0) n = i >> g.hw_shift; else n = i / hw;
+        j = i - n * hw;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t o = (n * C + c0 + r) * hw + j;
+            a[r] = xv[o]; b[r] = dv[o];
+            if (RES) rz[r] = rv[o];
+        }
+    }
+    {
+        const int c = c0 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+        double sa = 0.0, sb = 0.0;
+        if (lane < S) { const double2 p = partial[(int64_t)c * S + lane]; sa = p.x; sb = p.y; }
+        sa = bn_wave_sum(sa);
+        sb = bn_wave_sum(sb);
+        if (lane == 0) {
+            const double cnt = (double)g.per_ch * 4.0, iv = (double)save_invstd[c];
+            sh[2 * (threadIdx.x >> 6)] = (float)(sa / cnt);
+            sh[2 * (threadIdx.x >> 6) + 1] = (float)(sb * iv * iv / cnt);
+            if (blockIdx.x == 0) { dbeta[c] = (float)sa; dgamma[c] = (float)(sb * iv); }
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int c = c0 + r;
+        const float mean = save_mean[c], invstd = save_invstd[c], w = gamma[c];
+        const float scale = invstd * w;
+        const float shift = fmaf(-mean, scale, beta[c]);
+        const float gm = sh[2 * r], kk = sh[2 * r + 1];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float xe = comp(a[r], k);
+            float ge = comp(b[r], k);
+            if (RELU && !(fmaf(xe, scale, shift) > 0.f)) ge = 0.f;
+            setc(b[r], k, (((ge - gm) - (xe - mean) * kk) * invstd) * w);
+        }
+        if (RES) b[r] = vadd(rz[r], b[r]);
+        ov[(n * C + c0 + r) * hw + j] = b[r];
+    }
+    const int64_t tb = (n * hw + j) * 4 * (C / 4) + blockIdx.y;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        tv[tb + (int64_t)q * (C / 4)] = make_float4(comp(b[0], q), comp(b[1], q), comp(b[2], q), comp(b[3], q));
+}
+
 // ---- host side ----------------------------------------------------------------------------------------------------
 struct BnPlan {
     BnGeom g;
@@ -912,6 +1056,12 @@ inline int bn_plan(int64_t N, int64_t C, int64_t HW, bool vec_ok, BnPlan* p)
 }
 
 inline int bn_launch_status() { return (int)hipGetLastError(); }
+
+// NHWC twin (see k_bn_fwd_apply_4): float4 accesses, channels a multiple of 4, 16-byte aligned twin, a grid that fits.
+inline bool bn_twin_ok(const BnPlan& p, const void* twin)
+{
+    return p.V == 4 && (p.g.C & 3) == 0 && bn_aligned16(twin) && (p.g.per_ch + kBnBlock - 1) / kBnBlock < (1ll << 31);
+}
 
 // Held form (one launch, inputs read once): float4 accesses, 32-bit float4 offsets, the channel cut into 2 <= S <= 64
 // register-sized chunks, enough workgroups to fill the chip, and an activation large enough that the second read of the
@@ -959,9 +1109,10 @@ inline bool bn_one_pass(const BnPlan& p, uint32_t flags)
 
 extern "C" {
 
-int ursa_bn_relu_fwd_f32(const float* x, const float* addend, float* z_out, float* y, const float* gamma, const float* beta,
-                         float* running_mean, float* running_var, float* save_mean, float* save_invstd, float* ws,
-                         int64_t N, int64_t C, int64_t HW, float eps, float momentum, uint32_t flags, ursa_stream_t stream)
+static int bn_fwd_impl(const float* x, const float* addend, float* z_out, float* y, float* y_nhwc,
+                       const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, float* save_mean, float* save_invstd, float* ws,
+                       int64_t N, int64_t C, int64_t HW, float eps, float momentum, uint32_t flags, ursa_stream_t stream)
 {
     if (flags & ~URSA_BN_ALLFLAGS) return URSA_EFLAGS;
     if (N == 0 || C == 0 || HW == 0) return (N < 0 || C < 0 || HW < 0) ? URSA_ESIZE : URSA_OK;
@@ -977,12 +1128,26 @@ int ursa_bn_relu_fwd_f32(const float* x, const float* addend, float* z_out, floa
     const dim3 grid(p.S, p.g.C), block(kBnBlock);
     double2* part = reinterpret_cast<double2*>(ws);
     const bool relu = flags & URSA_BN_RELU;
+    if (y_nhwc) {
+        // NHWC-twin form: the plain statistics launch, then the four-channel launch that stores y twice
+        if (!bn_twin_ok(p, y_nhwc)) return URSA_EVALUE;
+        if (addend) hipLaunchKernelGGL((k_bn_stats<4, true>), grid, block, 0, st, x, addend, z_out, part, p.g);
+        else hipLaunchKernelGGL((k_bn_stats<4, false>), grid, block, 0, st, x, addend, z_out, part, p.g);
+        const dim3 g4((unsigned)((p.g.per_ch + kBnBlock - 1) / kBnBlock), (unsigned)(p.g.C / 4));
+        const float* in2t = addend ? z_out : x;
+        if (relu) hipLaunchKernelGGL((k_bn_fwd_apply_4<true>), g4, block, 0, st, in2t, y, y_nhwc, part, p.S, gamma, beta, running_mean, running_var,
+                                     save_mean, save_invstd, eps, momentum, p.g);
+        else hipLaunchKernelGGL((k_bn_fwd_apply_4<false>), g4, block, 0, st, in2t, y, y_nhwc, part, p.S, gamma, beta, running_mean, running_var,
+                                save_mean, save_invstd, eps, momentum, p.g);
+        return bn_launch_status();
+    }
     BnHeld hd;
     if (!bn_one_pass(p, flags) && bn_held_plan(p, flags, kHeldFwdBlock, kHeldFwdEpt, kHeldMinFloat4Fwd, &hd)) {
         BnGeom gh = p.g;
         gh.chunk = hd.chunk;
-        BnSync* sync = reinterpret_cast<BnSync*>(ws + (int64_t)C * kBnMaxSplit * 4);
-        bn_u64* slots = reinterpret_cast<bn_u64*>(ws);
+        // the held form's own part of ws (slots, then counters): the two-launch form's partials never touch it
+        bn_u64* slots = reinterpret_cast<bn_u64*>(ws + (int64_t)C * kBnMaxSplit * 4);
+        BnSync* sync = reinterpret_cast<BnSync*>(ws + (int64_t)C * kBnMaxSplit * 8);
         const dim3 gg((unsigned)(hd.S * p.g.C)), bb(kHeldFwdBlock);
         // beyond the 256 MiB Infinity Cache the streams go past it (as K1-K4 do)
         const bool nt = p.g.per_ch * p.g.C * 16 * (addend ? 4 : 2) > (256ll << 20);
@@ -1030,6 +1195,24 @@ int ursa_bn_relu_fwd_f32(const float* x, const float* addend, float* z_out, floa
     return bn_launch_status();
 }
 
+int ursa_bn_relu_fwd_f32(const float* x, const float* addend, float* z_out, float* y, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, float* save_mean, float* save_invstd, float* ws,
+                         int64_t N, int64_t C, int64_t HW, float eps, float momentum, uint32_t flags, ursa_stream_t stream)
+{
+    return bn_fwd_impl(x, addend, z_out, y, nullptr, gamma, beta, running_mean, running_var, save_mean, save_invstd, ws, N, C, HW,
+                       eps, momentum, flags, stream);
+}
+
+int ursa_bn_relu_fwd_nhwc_f32(const float* x, const float* addend, float* z_out, float* y, float* y_nhwc,
+                              const float* gamma, const float* beta, float* running_mean, float* running_var, float* save_mean,
+                              float* save_invstd, float* ws, int64_t N, int64_t C, int64_t HW, float eps, float momentum,
+                              uint32_t flags, ursa_stream_t stream)
+{
+    if (!y_nhwc) return URSA_ENULL;
+    return bn_fwd_impl(x, addend, z_out, y, y_nhwc, gamma, beta, running_mean, running_var, save_mean, save_invstd, ws, N, C, HW,
+                       eps, momentum, flags, stream);
+}
+
 int ursa_bn_relu_eval_f32(const float* x, const float* addend, float* z_out, float* y, const float* gamma, const float* beta,
                           const float* running_mean, const float* running_var, int64_t N, int64_t C, int64_t HW, float eps,
                           uint32_t flags, ursa_stream_t stream)
@@ -1055,7 +1238,8 @@ int ursa_bn_relu_eval_f32(const float* x, const float* addend, float* z_out, flo
     return bn_launch_status();
 }
 
-static int bn_bwd_impl(const float* x, const float* dy, const float* dz, float* dx, const float* gamma, const float* beta,
+static int bn_bwd_impl(const float* x, const float* dy, const float* dz, float* dx, float* dx_nhwc,
+                       const float* gamma, const float* beta,
                        const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, float* ws,
                        int64_t N, int64_t C, int64_t HW, uint32_t flags, const BnGates* gates, ursa_stream_t stream)
 {
@@ -1070,6 +1254,20 @@ static int bn_bwd_impl(const float* x, const float* dy, const float* dz, float* 
     const dim3 grid(p.S, p.g.C), block(kBnBlock);
     double2* part = reinterpret_cast<double2*>(ws);
     const bool relu = flags & URSA_BN_RELU;
+    if (dx_nhwc) {
+        // NHWC-twin form: the plain reduction launch, then the four-channel launch that stores dx twice
+        if (gates || !bn_twin_ok(p, dx_nhwc)) return URSA_EVALUE;
+        const dim3 g4((unsigned)((p.g.per_ch + kBnBlock - 1) / kBnBlock), (unsigned)(p.g.C / 4));
+#define URSA_BN_BWD_T(R) do { \
+    hipLaunchKernelGGL((k_bn_bwd_reduce<4, R>), grid, block, 0, st, x, dy, gamma, beta, save_mean, save_invstd, part, p.g, BnGates{}); \
+    if (dz) hipLaunchKernelGGL((k_bn_bwd_dx_4<R, true>), g4, block, 0, st, x, dy, dz, dx, dx_nhwc, gamma, beta, save_mean, save_invstd, part, p.S, \
+                               dgamma, dbeta, p.g); \
+    else hipLaunchKernelGGL((k_bn_bwd_dx_4<R, false>), g4, block, 0, st, x, dy, dz, dx, dx_nhwc, gamma, beta, save_mean, save_invstd, part, p.S, \
+                            dgamma, dbeta, p.g); } while (0)
+        if (relu) URSA_BN_BWD_T(true); else URSA_BN_BWD_T(false);
+#undef URSA_BN_BWD_T
+        return bn_launch_status();
+    }
     if (gates) {                                                  // parity instrument: always the two-launch kernels
         if (!relu) return URSA_EFLAGS;
         const BnGates gt = *gates;
@@ -1087,8 +1285,9 @@ static int bn_bwd_impl(const float* x, const float* dy, const float* dz, float* 
     if (!bn_one_pass(p, flags) && bn_held_plan(p, flags, kHeldBwdBlock, kHeldBwdEpt, kHeldMinFloat4Bwd, &hd)) {
         BnGeom gh = p.g;
         gh.chunk = hd.chunk;
-        BnSync* sync = reinterpret_cast<BnSync*>(ws + (int64_t)C * kBnMaxSplit * 4);
-        bn_u64* slots = reinterpret_cast<bn_u64*>(ws);
+        // the held form's own part of ws (slots, then counters): the two-launch form's partials never touch it
+        bn_u64* slots = reinterpret_cast<bn_u64*>(ws + (int64_t)C * kBnMaxSplit * 4);
+        BnSync* sync = reinterpret_cast<BnSync*>(ws + (int64_t)C * kBnMaxSplit * 8);
         const dim3 gg((unsigned)(hd.S * p.g.C)), bb(kHeldBwdBlock);
         const bool nt = p.g.per_ch * p.g.C * 16 * (dz ? 4 : 3) > (256ll << 20);
 #define URSA_BN_HELD_E(R, A, E) do { \
@@ -1132,7 +1331,17 @@ int ursa_bn_relu_bwd_f32(const float* x, const float* dy, const float* dz, float
                          const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, float* ws,
                          int64_t N, int64_t C, int64_t HW, uint32_t flags, ursa_stream_t stream)
 {
-    return bn_bwd_impl(x, dy, dz, dx, gamma, beta, save_mean, save_invstd, dgamma, dbeta, ws, N, C, HW, flags, nullptr, stream);
+    return bn_bwd_impl(x, dy, dz, dx, nullptr, gamma, beta, save_mean, save_invstd, dgamma, dbeta, ws, N, C, HW, flags, nullptr, stream);
+}
+
+int ursa_bn_relu_bwd_nhwc_f32(const float* x, const float* dy, const float* dz, float* dx, float* dx_nhwc,
+                              const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
+                              float* dgamma, float* dbeta, float* ws, int64_t N, int64_t C, int64_t HW, uint32_t flags,
+                              ursa_stream_t stream)
+{
+    if (!dx_nhwc) return URSA_ENULL;
+    return bn_bwd_impl(x, dy, dz, dx, dx_nhwc, gamma, beta, save_mean, save_invstd, dgamma, dbeta, ws, N, C, HW, flags, nullptr,
+                       stream);
 }
 
 int ursa_bn_relu_bwd_gated_f32(const float* x, const float* dy, const float* dz, float* dx, const float* gamma,
@@ -1145,7 +1354,7 @@ int ursa_bn_relu_bwd_gated_f32(const float* x, const float* dy, const float* dz,
     if (!bn_aligned4(gate_idx)) return URSA_EALIGN;
     if (N > 0 && C > 0 && HW > 0 && N * C > (int64_t)0x7ffffffe / HW) return URSA_ESIZE;      // 32-bit element offsets
     const BnGates gt{gate_idx, gate_open, (int)n_gates};
-    return bn_bwd_impl(x, dy, dz, dx, gamma, beta, save_mean, save_invstd, dgamma, dbeta, ws, N, C, HW, flags, &gt, stream);
+    return bn_bwd_impl(x, dy, dz, dx, nullptr, gamma, beta, save_mean, save_invstd, dgamma, dbeta, ws, N, C, HW, flags, &gt, stream);
 }
 
 }  // extern "C"

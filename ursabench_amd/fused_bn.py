@@ -41,6 +41,27 @@ def held(flag=None):
     return old
 
 
+TWIN_Y, TWIN_DX = 1, 2       # `twins` of bn_relu / add_bn_relu: which outputs the launches also store channels-last
+_twins_on = os.environ.get('URSA_NHWC_WGRAD', '0') == '1'     # opt-in: measured -2 % on BASELINE configs[1] as built
+
+
+def nhwc_twins(flag=None):
+    """Query / set whether K6 stores NHWC twins for the weight gradients of fused_conv.conv2d (A/B runs)."""
+    global _twins_on
+    old = _twins_on
+    if flag is not None:
+        _twins_on = bool(flag)
+    return old
+
+
+TWIN_MIN_HW = 256     # maps from 16x16 on. Measured per 3x3 weight gradient at batch 128 (profiles/r03_wrw_nhwc_probe.json): 15 / 11 / 5 us
+#                       saved at 32x32 / 16x16 / 8x8; at 8x8 the layer's K6 launches are the one-pass form (one launch, no twin)
+
+
+def _twin_mask(x, twins):
+    return twins if (twins and _twins_on and _native.nhwc_twin_supported(x) and x.shape[2] * x.shape[3] >= TWIN_MIN_HW) else 0
+
+
 def _scratch(x, C):
     """(ws, held): the call's scratch; zeroed - which lets the library take the held form - when the activation is large."""
     if _held and not _two_launch and x.numel() * 4 >= _native.BN_HELD_MIN_BYTES:
@@ -161,16 +182,19 @@ class probing:
 
 class _BNReLUTrain(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, relu, gates=None):
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, relu, gates=None, twins=0):
         K = _native.default_kernels()
         C = x.shape[1]
         y = torch.empty_like(x)
         stats = x.new_empty(2, C)                       # save_mean, save_invstd
         ws, hd = _scratch(x, C)
+        yt = _native.nhwc_twin(x) if (twins & TWIN_Y) else None
         K.bn_relu_forward(x, y, weight, bias, running_mean, running_var, stats[0], stats[1], ws, eps=eps,
-                          momentum=momentum, relu=relu, two_launch=_two_launch, held=hd)
+                          momentum=momentum, relu=relu, two_launch=_two_launch, held=hd, y_nhwc=yt)
         ctx.save_for_backward(x, weight, bias, stats)
-        ctx.relu, ctx.gates = relu, gates
+        ctx.relu, ctx.gates, ctx.twin_dx = relu, gates, bool(twins & TWIN_DX) and gates is None
+        if yt is not None:
+            y._ursa_nhwc = yt                           # read by fused_conv.conv2d (the convolution that consumes y)
         return y
 
     @staticmethod
@@ -183,26 +207,32 @@ class _BNReLUTrain(torch.autograd.Function):
         dx = torch.empty_like(x)
         dwb = x.new_empty(2, C)
         ws, hd = _scratch(x, C)
+        dxt = _native.nhwc_twin(x) if ctx.twin_dx else None
         K.bn_relu_backward(x, dy, dx, weight, bias, stats[0], stats[1], dwb[0], dwb[1], ws, relu=ctx.relu,
-                           two_launch=_two_launch, gates=ctx.gates, held=hd)
-        return dx, dwb[0], dwb[1], None, None, None, None, None, None
+                           two_launch=_two_launch, gates=ctx.gates, held=hd, dx_nhwc=dxt)
+        if dxt is not None:
+            dx._ursa_nhwc = dxt                         # read by the backward of the convolution that produced x
+        return dx, dwb[0], dwb[1], None, None, None, None, None, None, None
 
 
 class _AddBNReLUTrain(torch.autograd.Function):
     """(z, y) = (a + b, relu(bn(a + b))). backward: d(a) = d(b) = dz + bn_relu_backward(dy) in the same two launches."""
 
     @staticmethod
-    def forward(ctx, a, b, weight, bias, running_mean, running_var, eps, momentum, relu, gates=None):
+    def forward(ctx, a, b, weight, bias, running_mean, running_var, eps, momentum, relu, gates=None, twins=0):
         ctx.set_materialize_grads(False)                 # an unused output's gradient arrives as None, not as zeros
         K = _native.default_kernels()
         C = a.shape[1]
         z, y = torch.empty_like(a), torch.empty_like(a)
         stats = a.new_empty(2, C)
         ws, hd = _scratch(a, C)
+        yt = _native.nhwc_twin(a) if (twins & TWIN_Y) else None
         K.bn_relu_forward(a, y, weight, bias, running_mean, running_var, stats[0], stats[1], ws, eps=eps,
-                          momentum=momentum, relu=relu, addend=b, z_out=z, two_launch=_two_launch, held=hd)
+                          momentum=momentum, relu=relu, addend=b, z_out=z, two_launch=_two_launch, held=hd, y_nhwc=yt)
         ctx.save_for_backward(z, weight, bias, stats)
-        ctx.relu, ctx.gates = relu, gates
+        ctx.relu, ctx.gates, ctx.twin_dx = relu, gates, bool(twins & TWIN_DX) and gates is None
+        if yt is not None:
+            y._ursa_nhwc = yt
         return z, y
 
     @staticmethod
@@ -212,15 +242,18 @@ class _AddBNReLUTrain(torch.autograd.Function):
         K = _native.default_kernels()
         C = z.shape[1]
         if dy is None:                                   # y unused: only the sum's own gradient flows
-            return dz, dz, None, None, None, None, None, None, None, None
+            return dz, dz, None, None, None, None, None, None, None, None, None
         dy = dy.contiguous()
         dz = None if dz is None else dz.contiguous()
         dx = torch.empty_like(z)
         dwb = z.new_empty(2, C)
         ws, hd = _scratch(z, C)
+        dxt = _native.nhwc_twin(z) if ctx.twin_dx else None
         K.bn_relu_backward(z, dy, dx, weight, bias, stats[0], stats[1], dwb[0], dwb[1], ws, relu=ctx.relu, dz=dz,
-                           two_launch=_two_launch, gates=ctx.gates, held=hd)
-        return dx, dx, dwb[0], dwb[1], None, None, None, None, None, None
+                           two_launch=_two_launch, gates=ctx.gates, held=hd, dx_nhwc=dxt)
+        if dxt is not None:
+            dx._ursa_nhwc = dxt
+        return dx, dx, dwb[0], dwb[1], None, None, None, None, None, None, None
 
 
 def _fusable(bn, x):
@@ -243,8 +276,10 @@ def _stock(bn, x, relu):
     return y
 
 
-def bn_relu(bn, x, relu=True):
-    """relu(bn(x)) (or bn(x) with relu=False) with the module semantics of nn.BatchNorm2d."""
+def bn_relu(bn, x, relu=True, twins=0):
+    """relu(bn(x)) (or bn(x) with relu=False) with the module semantics of nn.BatchNorm2d. `twins` (TWIN_Y | TWIN_DX): in
+    training mode on the fused path, also store y / the input's gradient channels-last for the weight gradient of the
+    3x3 convolution that consumes y / produced x (fused_conv.conv2d picks them up from the tensors themselves)."""
     if not _fusable(bn, x):
         return _stock(bn, x, relu)
     use_batch_stats = bn.training or bn.running_mean is None
@@ -264,21 +299,22 @@ def bn_relu(bn, x, relu=True):
     if track and bn.num_batches_tracked is not None:    # None inside util.deferred_bn_counters
         bn.num_batches_tracked.add_(1)
     rm, rv = (bn.running_mean, bn.running_var) if track else (None, None)
+    tw = _twin_mask(x, twins) if torch.is_grad_enabled() else 0
     if _probe is not None and relu:
         k = _probe.slot()
-        y = _BNReLUTrain.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum if track else 0.0, relu, _probe.gates(k))
+        y = _BNReLUTrain.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum if track else 0.0, relu, _probe.gates(k), tw)
         _probe.observe(k, y)
         return y
-    return _BNReLUTrain.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum if track else 0.0, relu)
+    return _BNReLUTrain.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum if track else 0.0, relu, None, tw)
 
 
-def add_bn_relu(bn, x, relu=True):
+def add_bn_relu(bn, x, relu=True, twins=0):
     """`x` is a tensor, or a pending residual sum `(a, b)` standing for a + b (what a pre-activation block returns here
     instead of adding). Returns `(z, relu(bn(z)))` with z the summed tensor: the next block needs z for its own
     shortcut. A plain tensor, host tensors and everything `bn_relu` sends to the stock path: z = a + b with torch's add,
     then `bn_relu` - op for op the reference's `out += residual` followed by the next block's bn / relu."""
     if not isinstance(x, tuple):
-        return x, bn_relu(bn, x, relu)
+        return x, bn_relu(bn, x, relu, twins)
     a, b = x
     same = (b.shape == a.shape and b.dtype == a.dtype and b.device == a.device and b.is_contiguous()
             and a.data_ptr() != b.data_ptr())
@@ -305,10 +341,11 @@ def add_bn_relu(bn, x, relu=True):
     if track and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
     rm, rv = (bn.running_mean, bn.running_var) if track else (None, None)
+    tw = _twin_mask(a, twins) if torch.is_grad_enabled() else 0
     if _probe is not None and relu:
         k = _probe.slot()
         z, y = _AddBNReLUTrain.apply(a, b, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum if track else 0.0, relu,
-                                     _probe.gates(k))
+                                     _probe.gates(k), tw)
         _probe.observe(k, y)
         return z, y
-    return _AddBNReLUTrain.apply(a, b, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum if track else 0.0, relu)
+    return _AddBNReLUTrain.apply(a, b, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum if track else 0.0, relu, None, tw)
