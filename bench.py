@@ -628,14 +628,23 @@ def roofline_kernels_block(dev, large_n):
         w, b = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev)
         rm, rv, sm, si, dg, db = (torch.zeros(C, device=dev) for _ in range(6))
         rv.fill_(1.0)
-        wsb = torch.empty(_native.bn_ws_floats(C), device=dev)
+        wsb = torch.zeros(_native.bn_ws_floats(C), device=dev)     # zeroed once: the held form may be taken (csrc/ursa_bn.hip)
         e = x.numel()
         one = C >= 48 and e // C <= 32768                       # csrc/ursa_bn.hip bn_one_pass
-        form = dict(form='one-pass (1 launch)' if one else 'two-launch')
-        entry(f'k6_bn_relu_fwd_{label}', 8 * e, lambda: K.bn_relu_forward(x, y, w, b, rm, rv, sm, si, wsb, eps=1e-5, momentum=0.1),
-              cache_resident=resident, shape=list(shape), form_bytes=(8 if one else 12) * e, **form)
-        entry(f'k6_bn_relu_bwd_{label}', 12 * e, lambda: K.bn_relu_backward(x, dy, dx, w, b, sm, si, dg, db, wsb),
-              cache_resident=resident, shape=list(shape), form_bytes=(12 if one else 20) * e, **form)
+        big = e * 4 >= _native.BN_HELD_MIN_BYTES and not one
+        held_f, held_b = big and e * 4 >= (128 << 20), big      # forward from 128 MiB, backward from 24 MiB (kHeldMinFloat4*)
+        form_f = 'one-pass (1 launch)' if one else 'held (1 launch, inputs read once)' if held_f else 'two-launch'
+        form_b = 'one-pass (1 launch)' if one else 'held (1 launch, inputs read once)' if held_b else 'two-launch'
+        entry(f'k6_bn_relu_fwd_{label}', 8 * e, lambda: K.bn_relu_forward(x, y, w, b, rm, rv, sm, si, wsb, eps=1e-5, momentum=0.1, held=big),
+              cache_resident=resident, shape=list(shape), form_bytes=(8 if one or held_f else 12) * e, form=form_f)
+        entry(f'k6_bn_relu_bwd_{label}', 12 * e, lambda: K.bn_relu_backward(x, dy, dx, w, b, sm, si, dg, db, wsb, held=big),
+              cache_resident=resident, shape=list(shape), form_bytes=(12 if one or held_b else 20) * e, form=form_b)
+        if big:                                                 # the two-launch form of the same layer beside it
+            entry(f'k6_bn_relu_fwd_two_launch_{label}', 8 * e, lambda: K.bn_relu_forward(x, y, w, b, rm, rv, sm, si, wsb, eps=1e-5, momentum=0.1, two_launch=True),
+                  cache_resident=resident, shape=list(shape), form_bytes=12 * e, form='two-launch')
+            entry(f'k6_bn_relu_bwd_two_launch_{label}', 12 * e, lambda: K.bn_relu_backward(x, dy, dx, w, b, sm, si, dg, db, wsb, two_launch=True),
+                  cache_resident=resident, shape=list(shape), form_bytes=20 * e, form='two-launch')
+            wsb[C * 256:].zero_()
         entry(f'k6_bn_relu_eval_{label}', 8 * e, lambda: K.bn_relu_eval(x, y, w, b, rm, rv, eps=1e-5),
               cache_resident=resident, shape=list(shape), form_bytes=8 * e, form='1 launch')
         del x, dy, y, dx
@@ -1028,13 +1037,18 @@ def roofline_k6_object(rk):
     """A second roofline object for the largest HAND-WRITTEN share of a training step (K6: relu(bn(x)) + residual sums;
     17 % of a step's kernel time against K1's 1 %), from this run's roofline_kernels entries: at the workload's own
     layers (cache-resident, latency-bound: us per call is the figure) and at one HBM-sized layer (PreResNet-164 at the
-    HMC batch, 268 MB), achieved = ALGORITHMIC minimum bytes (8 B/element forward, 12 backward) / time. rocprof's
-    average for the same kernels in the committed profile of this command beside it."""
+    HMC batch, 268 MB: the held form - one launch, inputs read once - with the two-launch form of the same layer beside
+    it), achieved = ALGORITHMIC minimum bytes (8 B/element forward, 12 backward) / time. rocprof's average for the same
+    kernels in the committed profile of this command beside it."""
     if not rk:
         return None
     big_f, big_b = rk['k6_bn_relu_fwd_1024x64x32x32'], rk['k6_bn_relu_bwd_1024x64x32x32']
-    prof = {k: rocprof_average(k) for k in ('k_bn_stats<4', 'k_bn_fwd_apply<4', 'k_bn_bwd_reduce<4', 'k_bn_bwd_dx<4', 'k_bn_fwd_one<', 'k_bn_bwd_one<', 'k_bn_fwd_res<', 'k_bn_bwd_res<')}
+    prof = {k: rocprof_average(k) for k in ('k_bn_stats<4', 'k_bn_fwd_apply<4', 'k_bn_bwd_reduce<4', 'k_bn_bwd_dx<4', 'k_bn_fwd_one<', 'k_bn_bwd_one<',
+                                            'k_bn_fwd_held<', 'k_bn_bwd_held<')}
+    two = {d: rk.get(f'k6_bn_relu_{d}_two_launch_1024x64x32x32') for d in ('fwd', 'bwd')}
     return {'bound': 'hbm', 'kernel': 'K6 relu(bn(x)) forward at [1024, 64, 32, 32] (268 MB, beyond the Infinity Cache)',
+            'two_launch_form_of_the_same_layer': {d: None if v is None else {'us_per_launch': v['us'], 'frac': v['frac'], 'form_bytes': v['form_bytes']}
+                                                  for d, v in two.items()},
             'achieved': big_f['GBps'], 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': big_f['frac'], 'traffic': None,
             'traffic_source': 'profiles/r03_pmc.json holds the PMC passes of the two-launch form at this size (1.0002-1.0005 x its form bytes)',
             'bytes_per_launch': big_f['bytes'], 'us_per_launch': big_f['us'], 'form': big_f.get('form'), 'form_bytes': big_f.get('form_bytes'),

@@ -99,8 +99,9 @@ def test_shipped_miopen_db_is_copied_privately(monkeypatch, tmp_path):
     monkeypatch.delenv('MIOPEN_USER_DB_PATH', raising=False)
     monkeypatch.delenv('URSA_NO_SHIPPED_MIOPEN_DB', raising=False)
     d = tuning.use_shipped_miopen_db()
-    assert os.environ['MIOPEN_USER_DB_PATH'] == d and os.listdir(d) == ['gfx950.udb.txt'] and d != str(shipped)
+    # (besides the databases: the owner marker by which a later process recognises a dead owner's directory)
+    assert os.environ['MIOPEN_USER_DB_PATH'] == d and sorted(os.listdir(d)) == ['gfx950.udb.txt', tuning._OWNER] and d != str(shipped)
     assert tuning.use_shipped_miopen_db() == d                         # already set: respected
     monkeypatch.delenv('MIOPEN_USER_DB_PATH')
     monkeypatch.setenv('URSA_NO_SHIPPED_MIOPEN_DB', '1')
-    assert os.listdir(tuning.use_shipped_miopen_db()) == []
+    assert os.listdir(tuning.use_shipped_miopen_db()) == [tuning._OWNER]

@@ -13,8 +13,11 @@ shapes = [tuple(args[i:i + 3]) for i in range(0, len(args), 3)] or [(50, 10000, 
 res = []
 VARIANTS = [('fast', {}), ('lane_group_scalar', {'URSA_BMA_NO_ROWLANE': '1', 'URSA_BMA_NO_V4': '1'})]
 VARIANTS += [(f'rowlane_waves{w}', {'URSA_BMA_RL_WAVES': str(w)}) for w in (1, 2, 4, 8)]
+VARIANTS += [('prefetch', {'URSA_BMA_PREFETCH': '1'}), ('no_prefetch', {'URSA_BMA_PREFETCH': '0'})]
+if os.environ.get('K5_ONLY'):
+    VARIANTS = [v for v in VARIANTS if v[0] in os.environ['K5_ONLY'].split(',')]
 for variant, env in VARIANTS:
-    for k in ('URSA_BMA_NO_ROWLANE', 'URSA_BMA_NO_V4', 'URSA_BMA_RL_WAVES', 'URSA_BMA_NO_G4'):
+    for k in ('URSA_BMA_NO_ROWLANE', 'URSA_BMA_NO_V4', 'URSA_BMA_RL_WAVES', 'URSA_BMA_NO_G4', 'URSA_BMA_PREFETCH'):
         os.environ.pop(k, None)
     os.environ.update(env)
     for (S, B, C) in shapes:

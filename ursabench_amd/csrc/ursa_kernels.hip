@@ -103,6 +103,14 @@ inline bool getenv_flag(const char* name)
     return v && v[0] && !(v[0] == '0' && !v[1]);
 }
 
+// Knob (A/B, tools/k5_bench.py): URSA_BMA_PREFETCH=0/1 overrides whether the C > 64 float4 kernel software-pipelines its loads.
+constexpr bool kBmaPrefetchDefault = false;
+inline bool bma_prefetch()
+{
+    const char* v = knob("URSA_BMA_PREFETCH");
+    return v && v[0] ? v[0] != '0' : kBmaPrefetchDefault;
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline bool aligned4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
 
@@ -665,15 +673,11 @@ __device__ __forceinline__ int bma_class(int lane, int e) { return V4 ? 4 * (lan
 // its arithmetic fuses explicitly: e = exp(x - max) through v_exp_f32 with a compensated exponent (1-2 ulp),
 // p = e / sum (one IEEE reciprocal per row instead of the reference's second exp), q = fma(p, 1-g, g/C),
 // entropy accumulated as sum q log2 q on v_log_f32 (ln 2 applied once per row at the end).
-template <int G, int EPL, bool RISK, bool V4, int U>
-__device__ __forceinline__ void lg_members(const float* __restrict__ z0, int64_t member_stride, int lane, int C,
-                                           float omg, float goc, bool want_ent,
-                                           const float* __restrict__ cost, float (&acc_p)[EPL],
-                                           float (&acc_r)[RISK ? EPL : 1], float& acc_e2)
+// Loads carry NO class masks: a lane whose classes lie beyond C reads (clamped address) logits that really exist,
+// which cannot change the row maximum; the mask enters once, as the -inf bias of the exponent fma in lg_compute.
+template <int G, int EPL, bool V4, int U>
+__device__ __forceinline__ void lg_load(const float* __restrict__ z0, int64_t member_stride, int lane, int C, float (&xs)[U][EPL])
 {
-    // Loads carry NO class masks: a lane whose classes lie beyond C reads (clamped address) logits that really exist,
-    // which cannot change the row maximum; the mask enters once, as the -inf bias of the exponent fma below.
-    float xs[U][EPL];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const float* z = z0 + u * member_stride;
@@ -692,6 +696,13 @@ __device__ __forceinline__ void lg_members(const float* __restrict__ z0, int64_t
             }
         }
     }
+}
+
+template <int G, int EPL, bool RISK, bool V4, int U>
+__device__ __forceinline__ void lg_compute(float (&xs)[U][EPL], int lane, int C, float omg, float goc, bool want_ent,
+                                           const float* __restrict__ cost, float (&acc_p)[EPL],
+                                           float (&acc_r)[RISK ? EPL : 1], float& acc_e2)
+{
     constexpr float kLog2e = 1.44269502162933349609375f;
     // every class slot beyond C adds exactly q = gamma/C to the entropy sum: taken out analytically, per row and member
     const float ent_fake = (float)(G * EPL - C) * (goc * __builtin_amdgcn_logf(goc));
@@ -749,7 +760,18 @@ __device__ __forceinline__ void lg_members(const float* __restrict__ z0, int64_t
     }
 }
 
-template <int G, int EPL, bool RISK, bool V4>
+template <int G, int EPL, bool RISK, bool V4, int U>
+__device__ __forceinline__ void lg_members(const float* __restrict__ z0, int64_t member_stride, int lane, int C,
+                                           float omg, float goc, bool want_ent,
+                                           const float* __restrict__ cost, float (&acc_p)[EPL],
+                                           float (&acc_r)[RISK ? EPL : 1], float& acc_e2)
+{
+    float xs[U][EPL];
+    lg_load<G, EPL, V4, U>(z0, member_stride, lane, C, xs);
+    lg_compute<G, EPL, RISK, V4, U>(xs, lane, C, omg, goc, want_ent, cost, acc_p, acc_r, acc_e2);
+}
+
+template <int G, int EPL, bool RISK, bool V4, bool PF = false>
 __global__ __launch_bounds__(kBlock) void k_bma_accumulate(const float* __restrict__ logits,
                                                            float* __restrict__ proba_sum,
                                                            float* __restrict__ ent_sum,
@@ -797,10 +819,27 @@ __global__ __launch_bounds__(kBlock) void k_bma_accumulate(const float* __restri
         constexpr int U = EPL <= 2 ? 8 : EPL <= 4 ? 4 : EPL <= 8 ? URSA_BMA_U_EPL8 : URSA_BMA_U_EPL16;   // members in flight per lane
         const float* zrow = logits + (row_ok ? b : 0) * (int64_t)C;          // rows past B recompute row 0 (never stored)
         int s0 = s_lo;
+        if (PF) {
+            // software pipeline: the next chunk's loads are issued before this chunk's arithmetic (two register buffers)
+            float xa[U][EPL], xb[U][EPL];
+            if (s0 + U <= s_hi) lg_load<G, EPL, V4, U>(zrow + s0 * BC, BC, lane, C, xa);
 #pragma unroll 1
-        for (; s0 + U <= s_hi; s0 += U)
-            lg_members<G, EPL, RISK, V4, U>(zrow + s0 * BC, BC, lane, C, omg, goc, ent_sum != nullptr, cost,
-                                            acc_p, acc_r, acc_e2);
+            for (; s0 + 2 * U <= s_hi; s0 += 2 * U) {
+                lg_load<G, EPL, V4, U>(zrow + (s0 + U) * BC, BC, lane, C, xb);
+                lg_compute<G, EPL, RISK, V4, U>(xa, lane, C, omg, goc, ent_sum != nullptr, cost, acc_p, acc_r, acc_e2);
+                if (s0 + 3 * U <= s_hi) lg_load<G, EPL, V4, U>(zrow + (s0 + 2 * U) * BC, BC, lane, C, xa);
+                lg_compute<G, EPL, RISK, V4, U>(xb, lane, C, omg, goc, ent_sum != nullptr, cost, acc_p, acc_r, acc_e2);
+            }
+            if (s0 + U <= s_hi) {            // one full chunk left: it is in xa already
+                lg_compute<G, EPL, RISK, V4, U>(xa, lane, C, omg, goc, ent_sum != nullptr, cost, acc_p, acc_r, acc_e2);
+                s0 += U;
+            }
+        } else {
+#pragma unroll 1
+            for (; s0 + U <= s_hi; s0 += U)
+                lg_members<G, EPL, RISK, V4, U>(zrow + s0 * BC, BC, lane, C, omg, goc, ent_sum != nullptr, cost,
+                                                acc_p, acc_r, acc_e2);
+        }
         if (U > 1)
 #pragma unroll 1
             for (; s0 < s_hi; ++s0)
@@ -1444,6 +1483,10 @@ int ursa_bma_accumulate_f32(const float* logits, float* proba_sum, float* ent_su
     do {                                                                                                        \
         if (risk_sum)                                                                                           \
             hipLaunchKernelGGL((k_bma_accumulate<G, EPL, true, V4>), dim3(bma_grid(B, 64 / G)), dim3(kBlock), 0, st, \
+                               logits, proba_sum, ent_sum, risk_sum, cost, (int)S, B, (int)C, one_minus_gamma,  \
+                               gamma_over_c, flags);                                                            \
+        else if (V4 && EPL >= 8 && bma_prefetch())                                                              \
+            hipLaunchKernelGGL((k_bma_accumulate<G, EPL, false, V4, true>), dim3(bma_grid(B, 64 / G)), dim3(kBlock), 0, st, \
                                logits, proba_sum, ent_sum, risk_sum, cost, (int)S, B, (int)C, one_minus_gamma,  \
                                gamma_over_c, flags);                                                            \
         else                                                                                                    \
