@@ -11,9 +11,11 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from ursabench_amd import _native  # noqa: E402
 
-K = _native.default_kernels()
+K = _native.knobs_kernels() if os.environ.get('URSA_BN_HELD_MIN_MIB') else _native.default_kernels()
 SHAPES = [(1024, 64, 32, 32), (1024, 16, 32, 32), (1024, 128, 16, 16), (1024, 256, 8, 8), (128, 160, 32, 32), (256, 64, 32, 32)]
-REPS = 20
+if os.environ.get('URSA_BN_HELD_MIN_MIB'):          # experiment: the held form at the workload's own (cache-resident) layers
+    SHAPES = [(128, 16, 32, 32), (128, 32, 16, 16), (128, 64, 16, 16)]
+REPS = 50 if os.environ.get('URSA_BN_HELD_MIN_MIB') else 20
 
 
 def timed(fn):

@@ -119,6 +119,18 @@ for shape, one in K6_SHAPES:
     chunk = -(-(-(-per // Se)) // 256) * 256
     Se = -(-per // chunk)
     manifest.append(dict(pattern='k_bn_eval', label=f'K6 evaluation {tag}', algorithmic_bytes_per_launch=8 * e, blocks=Se * C, wg=256))
+    if not one and e * 4 >= (128 << 20):
+        # the held form of the same layer (one launch per direction, chunks held in registers): its HBM traffic must be the
+        # ALGORITHMIC bytes - x read once (forward), x and dy read once (backward)
+        wsz = torch.zeros(_native.bn_ws_floats(C), device='cuda')
+        for _ in range(10):
+            K.bn_relu_forward(x, y, w, b, rm, rv, sm, si, wsz, eps=1e-5, momentum=0.1, held=True)
+            K.bn_relu_backward(x, dy, dx, w, b, sm, si, dg, db, wsz, held=True)
+        per = e // C // 4
+        manifest.append(dict(pattern='k_bn_fwd_held', label=f'K6 forward, held form (1 launch) {tag}', algorithmic_bytes_per_launch=8 * e,
+                             blocks=-(-per // 4096) * C, wg=256))
+        manifest.append(dict(pattern='k_bn_bwd_held', label=f'K6 backward, held form (1 launch) {tag}', algorithmic_bytes_per_launch=12 * e,
+                             blocks=-(-per // 4096) * C, wg=512))
     del x, dy, y, dx
 torch.cuda.synchronize()
 json.dump(manifest, open(sys.argv[1], 'w'), indent=1)

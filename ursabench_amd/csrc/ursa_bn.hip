@@ -1080,14 +1080,22 @@ inline bool bn_held_plan(const BnPlan& p, uint32_t flags, int block, int max_ept
 {
     if (!(flags & URSA_BN_HELD) || (flags & URSA_BN_TWO_LAUNCH) || p.V != 4) return false;
     const int64_t per_ch = p.g.per_ch;
+#ifdef URSA_DEBUG_KNOBS                    // experiments (tools/exp/bn_held_ab.py): the size from which the held form is taken, in MiB
+    static const int64_t forced = [] { const char* e = getenv("URSA_BN_HELD_MIN_MIB"); return e && e[0] ? ((int64_t)atoll(e) << 20) / 16 : (int64_t)-1; }();
+    if (forced >= 0) min_float4 = forced;
+#endif
     if (per_ch * p.g.C >= (1ll << 31) || per_ch * p.g.C < min_float4) return false;
+    // the LARGEST register chunk: fewer, larger pieces per channel = fewer workgroups to wait for. (Measured the other way
+    // round - the smallest chunk that still gives <= 64 pieces, for more workgroups - [1024,128,16,16] 59 -> 123 us forward,
+    // 96 -> 129 backward; and at the workload's own cache-resident layers the held form takes twice the two launches'
+    // time, [128,16,32,32] 14 vs 7 us: the thresholds above stay.)
     const int64_t cap = (int64_t)block * max_ept;
     int64_t S = (per_ch + cap - 1) / cap;
     if (S < 2 || S > kBnMaxSplit) return false;
     int64_t chunk = (per_ch + S - 1) / S;
     chunk = (chunk + block - 1) / block * block;
     S = (per_ch + chunk - 1) / chunk;
-    if (S < 2 || S * p.g.C < 512 || S * p.g.C >= (1ll << 31)) return false;
+    if (S < 2 || S * p.g.C < 256 || S * p.g.C >= (1ll << 31)) return false;
     const int need = (int)(chunk / block);
     h->S = (int)S;
     h->chunk = (int)chunk;
