@@ -189,7 +189,7 @@ def pmc_traffic(kernel_key, elements):
     passes, tools/pmc_run.sh). PMC needs the profiler, so this is NOT measured in this run: it is the committed
     measurement under profiles/ for a launch of this kernel at this size (within 0.1 %: arena padding; scaled by
     the element ratio). Returns (bytes or None, source string) — the source travels in the line as `traffic_source`."""
-    for name in ('r03_pmc.json', 'r02_pmc.json', 'r01_k1_pmc.json'):
+    for name in ('r04_pmc.json', 'r03_pmc.json', 'r02_pmc.json', 'r01_k1_pmc.json'):
         path = os.path.join(ROOT, 'profiles', name)
         if not os.path.exists(path):
             continue
@@ -220,6 +220,18 @@ def rocprof_average(kernel_substr, files=('r04_bench_kernel_stats.csv', 'r03_ben
         if calls:
             return {'us': round(tot / calls / 1e3, 3), 'calls': calls, 'file': f'profiles/{name}'}
     return None
+
+
+def pmc_bytes(kernel_substr, name='r04_pmc.json'):
+    """HBM bytes per launch of a kernel from the committed PMC passes (like pmc_traffic, keyed by kernel name only: the
+    entries of the K6 launches at [1024, 64, 32, 32]). (bytes or None, source)."""
+    path = os.path.join(ROOT, 'profiles', name)
+    if os.path.exists(path):
+        for k, v in json.load(open(path))['kernels'].items():
+            if kernel_substr in k and 'hbm_bytes_per_launch_corrected' in v:
+                return int(v['hbm_bytes_per_launch_corrected']), (f'profiles/{name}: {v.get("label", k)} (rocprofv3 --pmc passes of this kernel at '
+                                                                    'this size, 2 x FETCH_SIZE + WRITE_SIZE; not collected in this run)')
+    return None, 'none (no committed PMC pass for this kernel)'
 
 
 # ---- c2 legs ------------------------------------------------------------------------------------------
@@ -1049,10 +1061,11 @@ def roofline_k6_object(rk):
     return {'bound': 'hbm', 'kernel': 'K6 relu(bn(x)) forward at [1024, 64, 32, 32] (268 MB, beyond the Infinity Cache)',
             'two_launch_form_of_the_same_layer': {d: None if v is None else {'us_per_launch': v['us'], 'frac': v['frac'], 'form_bytes': v['form_bytes']}
                                                   for d, v in two.items()},
-            'achieved': big_f['GBps'], 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': big_f['frac'], 'traffic': None,
-            'traffic_source': 'profiles/r03_pmc.json holds the PMC passes of the two-launch form at this size (1.0002-1.0005 x its form bytes)',
+            'achieved': big_f['GBps'], 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': big_f['frac'],
+            'traffic': pmc_bytes('k_bn_fwd_held')[0], 'traffic_source': pmc_bytes('k_bn_fwd_held')[1],
             'bytes_per_launch': big_f['bytes'], 'us_per_launch': big_f['us'], 'form': big_f.get('form'), 'form_bytes': big_f.get('form_bytes'),
             'backward': {'achieved': big_b['GBps'], 'frac': big_b['frac'], 'bytes_per_launch': big_b['bytes'], 'us_per_launch': big_b['us'],
+                         'traffic': pmc_bytes('k_bn_bwd_held')[0],
                          'form': big_b.get('form'), 'form_bytes': big_b.get('form_bytes')},
             'workload_layers_us_per_call': {k[len('k6_bn_relu_'):]: {'us': v['us'], 'frac_of_algorithmic_minimum': v['frac'], 'form': v.get('form')}
                                             for k, v in rk.items() if k.startswith('k6_') and ('128x16x32x32' in k or '128x64x8x8' in k)},

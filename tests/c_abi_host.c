@@ -22,6 +22,8 @@ int oracle_bn_relu_fwd_f32(const float*, float*, const float*, const float*, flo
                            int64_t, int64_t, float, float, int);
 int oracle_bn_relu_bwd_f32(const float*, const float*, float*, const float*, const float*, const float*, const float*,
                            float*, float*, int64_t, int64_t, int64_t, int);
+int oracle_bn_relu_bwd_gated_f32(const float*, const float*, float*, const float*, const float*, const float*, const float*,
+                                 float*, float*, int64_t, int64_t, int64_t, int, const int32_t*, const uint8_t*, int64_t);
 
 #define CHECK(x) do { int rc_ = (x); if (rc_) { printf("FAIL %s -> %d (%s)\n", #x, rc_, ursa_strerror(rc_)); return 1; } } while (0)
 
@@ -146,14 +148,49 @@ int main(void)
         if (memcmp(hy, oy, tot * 4)) { printf("FAIL K6 forward differs from the oracle\n"); return 1; }
         if (memcmp(gdg, odg, 24) || memcmp(gdb, odb, 24)) { printf("FAIL K6 dgamma / dbeta differ from the oracle\n"); return 1; }
         if (memcmp(hdx, odx, tot * 4)) { printf("FAIL K6 dx differs from the oracle\n"); return 1; }
+        /* ABI 4: the gated backward (the parity instrument) against its oracle twin: three listed gates flipped */
+        {
+            int32_t hidx[4] = {5, 40, 700, 0x7fffffff};                    /* ascending; INT32_MAX = padding */
+            uint8_t hop[4];
+            for (int k = 0; k < 3; ++k) hop[k] = !(oy[hidx[k]] > 0.0f);    /* the opposite of the gate the forward took */
+            hop[3] = 1;
+            oracle_bn_relu_bwd_gated_f32(hx, hdy, odx, hg, hb, osm, osi, odg, odb, N, C, HW, 1, hidx, hop, 4);
+            int32_t* didx; uint8_t* dop;
+            CHECK(hipMalloc((void**)&didx, sizeof hidx)); CHECK(hipMalloc((void**)&dop, sizeof hop));
+            CHECK(hipMemcpy(didx, hidx, sizeof hidx, hipMemcpyHostToDevice)); CHECK(hipMemcpy(dop, hop, sizeof hop, hipMemcpyHostToDevice));
+            CHECK(ursa_bn_relu_bwd_gated_f32(dx_, ddy, NULL, ddx, dg_, db_, dsm, dsi, ddg, ddb, dws, N, C, HW, URSA_BN_RELU, didx, dop, 4, st));
+            CHECK(hipStreamSynchronize(st));
+            CHECK(hipMemcpy(hdx, ddx, tot * 4, hipMemcpyDeviceToHost));
+            CHECK(hipMemcpy(gdg, ddg, 24, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(gdb, ddb, 24, hipMemcpyDeviceToHost));
+            if (memcmp(gdg, odg, 24) || memcmp(gdb, odb, 24) || memcmp(hdx, odx, tot * 4)) { printf("FAIL K6 gated backward differs from the oracle\n"); return 1; }
+        }
+        /* ABI 4: the channels-last twin of the forward ([N, HW, C] beside [N, C, HW]; C = 8 here: a multiple of 4) */
+        {
+            const int64_t C8 = 8, tot8 = N * C8 * HW;
+            float *h8 = malloc(tot8 * 4), *y8 = malloc(tot8 * 4), *t8 = malloc(tot8 * 4), g8[8], b8[8];
+            for (int64_t i = 0; i < tot8; ++i) h8[i] = frand(&sd);
+            for (int c = 0; c < 8; ++c) { g8[c] = 1.0f; b8[c] = 0.1f * c; }
+            float *dx8, *dy8, *dt8, *dg8, *db8, *dm8, *di8, *dw8;
+            CHECK(hipMalloc((void**)&dx8, tot8 * 4)); CHECK(hipMalloc((void**)&dy8, tot8 * 4)); CHECK(hipMalloc((void**)&dt8, tot8 * 4));
+            CHECK(hipMalloc((void**)&dg8, 32)); CHECK(hipMalloc((void**)&db8, 32)); CHECK(hipMalloc((void**)&dm8, 32)); CHECK(hipMalloc((void**)&di8, 32));
+            CHECK(hipMalloc((void**)&dw8, URSA_BN_WS_FLOATS(C8) * 4));
+            CHECK(hipMemcpy(dx8, h8, tot8 * 4, hipMemcpyHostToDevice)); CHECK(hipMemcpy(dg8, g8, 32, hipMemcpyHostToDevice)); CHECK(hipMemcpy(db8, b8, 32, hipMemcpyHostToDevice));
+            CHECK(ursa_bn_relu_fwd_nhwc_f32(dx8, NULL, NULL, dy8, dt8, dg8, db8, NULL, NULL, dm8, di8, dw8, N, C8, HW, 1e-5f, 0.0f, URSA_BN_RELU, st));
+            CHECK(hipStreamSynchronize(st));
+            CHECK(hipMemcpy(y8, dy8, tot8 * 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(t8, dt8, tot8 * 4, hipMemcpyDeviceToHost));
+            for (int64_t nn = 0; nn < N; ++nn) for (int64_t c = 0; c < C8; ++c) for (int64_t p = 0; p < HW; ++p)
+                if (memcmp(&y8[(nn * C8 + c) * HW + p], &t8[(nn * HW + p) * C8 + c], 4)) { printf("FAIL K6 NHWC twin differs from y\n"); return 1; }
+            if (ursa_bn_relu_fwd_nhwc_f32(dx_, NULL, NULL, dy_, dt8, dg_, db_, NULL, NULL, dsm, dsi, dws, N, C, HW, 1e-5f, 0.0f, URSA_BN_RELU, st) != URSA_EVALUE) {
+                printf("FAIL K6 twin with C %% 4 != 0 must be refused\n"); return 1; }
+        }
         if (ursa_bn_relu_fwd_f32(dx_, NULL, NULL, dy_, dg_, db_, NULL, NULL, dsm, dsi, dws, 1, C, 1, 1e-5f, 0.0f, 0, st) != URSA_EVALUE) { printf("FAIL K6 evalue\n"); return 1; }
-        if (ursa_bn_relu_fwd_f32(dx_, NULL, NULL, dy_, dg_, db_, NULL, NULL, dsm, dsi, dws, N, C, HW, 1e-5f, 0.0f, 0x8u, st) != URSA_EFLAGS) { printf("FAIL K6 eflags\n"); return 1; }
+        if (ursa_bn_relu_fwd_f32(dx_, NULL, NULL, dy_, dg_, db_, NULL, NULL, dsm, dsi, dws, N, C, HW, 1e-5f, 0.0f, 0x10u, st) != URSA_EFLAGS) { printf("FAIL K6 eflags\n"); return 1; }
     }
     /* argument errors come back as codes, not crashes */
     if (ursa_sgmcmc_step_f32(NULL, NULL, NULL, NULL, NULL, 8, 0, 0, 0, 0, 1, 0, 0, 0, st) != URSA_ENULL) { printf("FAIL enull\n"); return 1; }
     if (ursa_bma_accumulate_f32(dz, dp, de, NULL, NULL, S, B, 5000, omg, goc, 0, st) != URSA_EVALUE) { printf("FAIL evalue\n"); return 1; }
     if (ursa_sgmcmc_step_multi_f32(dth, dgr, dmo, NULL, NULL, 64, 2, 62, NULL, st) != URSA_ESIZE) { printf("FAIL esize (stride < n)\n"); return 1; }
     printf("C-ABI host OK: K1 bit-equal to the oracle over 3 steps (n=%lld), 2 chains in one self-advancing launch bit-equal, "
-           "generator self-test clean, K5 max relative error %.2e, K6 forward + backward bit-equal\n", (long long)n, worst);
+           "generator self-test clean, K5 max relative error %.2e, K6 forward + backward + gated backward bit-equal, NHWC twin == y\n", (long long)n, worst);
     return 0;
 }
