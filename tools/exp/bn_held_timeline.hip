@@ -107,7 +107,7 @@ int main(int argc, char** argv)
     BnPlan p;
     bn_plan(N, C, HW, true, &p);
     BnHeld hd;
-    if (!bn_held_plan(p, URSA_BN_HELD, kHeldFwdBlock, kHeldFwdEpt, kHeldMinFloat4Fwd, &hd)) { printf("not eligible\n"); return 1; }
+    if (!bn_held_plan(p, URSA_BN_HELD, kHeldFwdBlock, kHeldFwdEpt, 0, kHeldMinFloat4Fwd, &hd)) { printf("not eligible\n"); return 1; }
     BnGeom gh = p.g; gh.chunk = hd.chunk;
     const int grid = hd.S * (int)C;
     long long* st;

@@ -590,8 +590,13 @@ __global__ __launch_bounds__(kOneBlock) void k_bn_bwd_one(const float* __restric
 //     read, there is no flag, no ordering between the two words is needed and nothing else is fetched.
 //   * ws (slots and counters) must be ZERO at launch and is zero again when the launch has drained: the last workgroup to
 //     have gathered a channel clears its slots, the one that clears the last channel re-arms the ticket queues.
+//   * What bounds the form is (bytes resident on the chip) / (time a chunk stays resident): ~28 us per workgroup
+//     (tools/exp/bn_held_timeline.hip: ticket 3.4, load + reduce 10.1, gather 8.5, scalars 1.6, apply 4.2) with 64 MB in
+//     the registers of the whole chip. So the chunk ALSO lives in LDS where that is free: LX further float4 per thread
+//     arrive by LDS-DMA (global_load_lds_dwordx4: no register on the way), 9 per thread forward (36 KB per workgroup, 4 per
+//     CU), 4 + 4 backward (64 KB, 2 per CU): + 56 % / + 50 % bytes per workgroup, 268 MB forward 136 -> 123 us, backward
+//     176 -> 159 us. Not in the residual forward (its addend would need the registers the chunk lives in).
 // Same arithmetic as the two-launch form (double sums rounded once), hence the same floats.
-// tools/exp/bn_held_timeline.hip: where a workgroup's ~25 us go (the chunk sits in registers from first load to last store).
 constexpr int kSyncStride = 32;          // uint32 per 128-byte line: every counter on a line of its own (atomics and polls to
                                          // ONE line serialise at ~11.5 ns each whichever word they hit)
 struct BnSync {
@@ -604,8 +609,8 @@ struct BnSync {
 };
 constexpr unsigned long long kSlotXor = 0xFFF8DEADBEEF0001ull;   // a NaN payload with low mantissa bits set: no sum of floats has it
 
-constexpr int kHeldFwdBlock = 256, kHeldFwdEpt = 16;     // 16 float4 of x per thread
-constexpr int kHeldBwdBlock = 512, kHeldBwdEpt = 8;      // 8 float4 of x + 8 of dy per thread
+constexpr int kHeldFwdBlock = 256, kHeldFwdEpt = 16, kHeldFwdLx = 9;     // 16 float4 of x per thread in registers + 9 in LDS (36 KB: 4 workgroups per CU)
+constexpr int kHeldBwdBlock = 512, kHeldBwdEpt = 8, kHeldBwdLx = 4;      // 8 + 8 float4 of x and dy per thread in registers + 4 + 4 in LDS (64 KB: 2 per CU)
 constexpr uint32_t kHeldSpinLimit = 1u << 21;            // x ~1.7 us of s_sleep
 
 typedef unsigned long long bn_u64;
@@ -700,8 +705,19 @@ template <bool NT> __device__ __forceinline__ void bn_st(float4* p, const float4
     __builtin_nontemporal_store(v.z, &p->z); __builtin_nontemporal_store(v.w, &p->w);
 }
 
-template <bool RELU, bool ADD, int EPT, bool NT>
-__global__ __launch_bounds__(kHeldFwdBlock) void k_bn_fwd_held(const float* __restrict__ x, const float* __restrict__ addend,
+// LDS-DMA (global_load_lds_dwordx4): a load that lands in LDS without passing through registers - lane l of the wave writes
+// 16 bytes at (wave-uniform base) + 16 l. The held forms use it to hold MORE of the channel per workgroup than the register
+// file alone allows (what bounds them is bytes resident x 1 / residency time, §held forms): LX further float4 per thread.
+typedef __attribute__((address_space(1))) const void* bn_gptr;
+typedef __attribute__((address_space(3))) void* bn_lptr;
+template <bool NT> __device__ __forceinline__ void bn_ld_lds(const float4* src, float4* wave_base_in_lds)
+{
+    __builtin_amdgcn_global_load_lds((bn_gptr)src, (bn_lptr)wave_base_in_lds, 16, 0, NT ? 2 : 0);
+}
+
+template <bool RELU, bool ADD, int EPT, int LX, bool NT>
+__global__ __launch_bounds__(kHeldFwdBlock, 4) void k_bn_fwd_held(      // 4 waves per SIMD = 4 workgroups per CU: <= 128 VGPRs
+                                                                     const float* __restrict__ x, const float* __restrict__ addend,
                                                               float* __restrict__ z, float* __restrict__ y,
                                                               bn_u64* slots_base, BnSync* sync,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -709,9 +725,11 @@ __global__ __launch_bounds__(kHeldFwdBlock) void k_bn_fwd_held(const float* __re
                                                               float* __restrict__ save_mean, float* __restrict__ save_invstd,
                                                               float eps, float momentum, BnGeom g, int S)
 {
+    static_assert(!(ADD && LX > 0), "the residual form holds nothing in LDS (its addend would need the registers the chunk lives in)");
     __shared__ double sh[2 * kHeldFwdBlock / 64];
     __shared__ float shf[2];
     __shared__ int sh_item[2];
+    __shared__ float4 hold[LX > 0 ? LX * kHeldFwdBlock : 1];
     if (threadIdx.x == 0) {
         int c0 = -1, sp0 = 0;
         bn_take_item(sync, g.C, S, c0, sp0);
@@ -726,6 +744,12 @@ __global__ __launch_bounds__(kHeldFwdBlock) void k_bn_fwd_held(const float* __re
     float4* __restrict__ yv = reinterpret_cast<float4*>(y);
     const int lo = sp * g.chunk;
     const int hi = lo + g.chunk < (int)g.per_ch ? lo + g.chunk : (int)g.per_ch;
+    // thread t owns float4 lo + t + u * 256 of the chunk: u < EPT in registers, EPT <= u < EPT + LX in LDS (DMA first: no registers)
+#pragma unroll
+    for (int u = 0; u < LX; ++u) {
+        const int i = lo + threadIdx.x + (EPT + u) * kHeldFwdBlock;
+        if (i < hi) bn_ld_lds<NT>(xv + bn_off32(g, c, i), &hold[u * kHeldFwdBlock + (threadIdx.x & ~63)]);
+    }
     float4 v[EPT];                       // (offsets are recomputed for the stores rather than kept live)
 #pragma unroll
     for (int u = 0; u < EPT; ++u) {
@@ -743,6 +767,18 @@ __global__ __launch_bounds__(kHeldFwdBlock) void k_bn_fwd_held(const float* __re
         if (ADD) { const int i = lo + threadIdx.x + u * kHeldFwdBlock; if (i < hi) bn_st<NT>(zv + bn_off32(g, c, i), v[u]); }
 #pragma unroll
         for (int k = 0; k < 4; ++k) { const double d = (double)comp(v[u], k); s1 += d; s2 = fma(d, d, s2); }
+    }
+    if (LX > 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's own DMA has landed (it only reads its own lanes' slots)
+#pragma unroll
+        for (int u = 0; u < LX; ++u) {
+            const int i = lo + threadIdx.x + (EPT + u) * kHeldFwdBlock;
+            if (i < hi) {
+                const float4 w = hold[u * kHeldFwdBlock + threadIdx.x];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const double d = (double)comp(w, k); s1 += d; s2 = fma(d, d, s2); }
+            }
+        }
     }
     bn_block_sum2_n<kHeldFwdBlock>(s1, s2, sh);
     bn_u64* slots = slots_base + (int64_t)c * kBnMaxSplit * 2;
@@ -784,10 +820,21 @@ __global__ __launch_bounds__(kHeldFwdBlock) void k_bn_fwd_held(const float* __re
             bn_st<NT>(yv + bn_off32(g, c, i), r);
         }
     }
+#pragma unroll
+    for (int u = 0; u < LX; ++u) {
+        const int i = lo + threadIdx.x + (EPT + u) * kHeldFwdBlock;
+        if (i < hi) {
+            const float4 w = hold[u * kHeldFwdBlock + threadIdx.x];
+            float4 r;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float t = fmaf(comp(w, k), scale, shift); setc(r, k, RELU ? bn_relu_fwd(t) : t); }
+            bn_st<NT>(yv + bn_off32(g, c, i), r);
+        }
+    }
     if (threadIdx.x < 64) bn_leave_finish(sync, slots, c, g.C, S, left);
 }
 
-template <bool RELU, bool RES, int EPT, bool NT>
+template <bool RELU, bool RES, int EPT, int LX, bool NT>
 __global__ __launch_bounds__(kHeldBwdBlock) void k_bn_bwd_held(const float* __restrict__ x, const float* __restrict__ dy,
                                                               const float* __restrict__ dz, float* __restrict__ dx,
                                                               bn_u64* slots_base, BnSync* sync,
@@ -798,6 +845,7 @@ __global__ __launch_bounds__(kHeldBwdBlock) void k_bn_bwd_held(const float* __re
     __shared__ double sh[2 * kHeldBwdBlock / 64];
     __shared__ float shf[2];
     __shared__ int sh_item[2];
+    __shared__ float4 holdx[LX > 0 ? LX * kHeldBwdBlock : 1], holdd[LX > 0 ? LX * kHeldBwdBlock : 1];
     if (threadIdx.x == 0) {
         int c0 = -1, sp0 = 0;
         bn_take_item(sync, g.C, S, c0, sp0);
@@ -816,6 +864,15 @@ __global__ __launch_bounds__(kHeldBwdBlock) void k_bn_bwd_held(const float* __re
     const double meand = (double)mean;
     const int lo = sp * g.chunk;
     const int hi = lo + g.chunk < (int)g.per_ch ? lo + g.chunk : (int)g.per_ch;
+#pragma unroll
+    for (int u = 0; u < LX; ++u) {                   // the LDS-held part of the chunk: x and dy by DMA, no registers
+        const int i = lo + threadIdx.x + (EPT + u) * kHeldBwdBlock;
+        if (i < hi) {
+            const int o = bn_off32(g, c, i);
+            bn_ld_lds<NT>(xv + o, &holdx[u * kHeldBwdBlock + (threadIdx.x & ~63)]);
+            bn_ld_lds<NT>(dv + o, &holdd[u * kHeldBwdBlock + (threadIdx.x & ~63)]);
+        }
+    }
     float4 a[EPT], b[EPT];
 #pragma unroll
     for (int u = 0; u < EPT; ++u) {
@@ -835,6 +892,27 @@ __global__ __launch_bounds__(kHeldBwdBlock) void k_bn_bwd_held(const float* __re
             setc(b[u], k, ge);
             s1 += (double)ge;
             s2 = fma((double)ge, (double)xe - meand, s2);
+        }
+    }
+    if (LX > 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < LX; ++u) {
+            const int i = lo + threadIdx.x + (EPT + u) * kHeldBwdBlock;
+            if (i < hi) {
+                const float4 xa = holdx[u * kHeldBwdBlock + threadIdx.x];
+                float4 gb = holdd[u * kHeldBwdBlock + threadIdx.x];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float xe = comp(xa, k);
+                    float ge = comp(gb, k);
+                    if (RELU && !(fmaf(xe, scale, shift) > 0.f)) ge = 0.f;
+                    setc(gb, k, ge);
+                    s1 += (double)ge;
+                    s2 = fma((double)ge, (double)xe - meand, s2);
+                }
+                holdd[u * kHeldBwdBlock + threadIdx.x] = gb;          // the gated gradient, as b[] holds it for the register part
+            }
         }
     }
     bn_block_sum2_n<kHeldBwdBlock>(s1, s2, sh);
@@ -862,6 +940,19 @@ __global__ __launch_bounds__(kHeldBwdBlock) void k_bn_bwd_held(const float* __re
             float4 r;
 #pragma unroll
             for (int k = 0; k < 4; ++k) setc(r, k, (((comp(b[u], k) - gm) - (comp(a[u], k) - mean) * kk) * invstd) * w);
+            if (RES) r = vadd(bn_ld<NT>(rv + o), r);
+            bn_st<NT>(ov + o, r);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < LX; ++u) {
+        const int i = lo + threadIdx.x + (EPT + u) * kHeldBwdBlock;
+        if (i < hi) {
+            const int o = bn_off32(g, c, i);
+            const float4 xa = holdx[u * kHeldBwdBlock + threadIdx.x], gb = holdd[u * kHeldBwdBlock + threadIdx.x];
+            float4 r;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) setc(r, k, (((comp(gb, k) - gm) - (comp(xa, k) - mean) * kk) * invstd) * w);
             if (RES) r = vadd(bn_ld<NT>(rv + o), r);
             bn_st<NT>(ov + o, r);
         }
@@ -1067,40 +1158,49 @@ inline bool bn_twin_ok(const BnPlan& p, const void* twin)
 // register-sized chunks, enough workgroups to fill the chip, and an activation large enough that the second read of the
 // two-launch form costs more than the wait (measured: tools/exp/bn_fused_bench.py). The caller vouches for zeroed sync
 // words with URSA_BN_HELD.
-// Measured, us per call inside a hipGraph, held / two-launch (tools/exp/bn_held_ab.py, profiles/r04_bn_held_ab.json):
-//   [1024,64,32,32] 268 MB  forward 135 / 152   backward 171 / 246        [1024,128,16,16] 134 MB   59 / 60    96 / 115
-//   [128,160,32,32]  84 MB           41 / 41             50 /  65        [1024,256,8,8]    67 MB   32 / 33    40 /  52
-//   [1024,16,32,32]  67 MB           37 / 33             48 /  51        [256,64,32,32]    67 MB   36 / 32    45 /  52
+// Measured, us per call inside a hipGraph, held / two-launch (tools/exp/bn_held_ab.py, profiles/r04_bn_held_ab.json; with
+// the LDS-held extension; registers only: 135 / 171 at 268 MB):
+//   [1024,64,32,32] 268 MB  forward 123 / 152   backward 159 / 253        [1024,128,16,16] 134 MB   62 / 60    83 / 114
+//   [128,160,32,32]  84 MB           41 / 41             48 /  65        [1024,256,8,8]    67 MB   33 / 33    41 /  52
+//   [1024,16,32,32]  67 MB           33 / 33             45 /  52        [256,64,32,32]    67 MB   33 / 32    43 /  51
 // The backward saves 8 of 20 B/element and wins from 24 MiB on; the forward saves 4 of 12 and pays the same wait: it wins
 // only where the second read would come from HBM (activation + output beyond the 256 MiB Infinity Cache).
 constexpr int64_t kHeldMinFloat4Bwd = (24ll << 20) / 16;      // 24 MiB of activation
 constexpr int64_t kHeldMinFloat4Fwd = (128ll << 20) / 16;     // 128 MiB
-struct BnHeld { int S, chunk, ept; };
-inline bool bn_held_plan(const BnPlan& p, uint32_t flags, int block, int max_ept, int64_t min_float4, BnHeld* h)
+struct BnHeld { int S, chunk, ept, lx; };
+inline bool bn_held_plan(const BnPlan& p, uint32_t flags, int block, int max_ept, int max_lx, int64_t min_float4, BnHeld* h)
 {
     if (!(flags & URSA_BN_HELD) || (flags & URSA_BN_TWO_LAUNCH) || p.V != 4) return false;
     const int64_t per_ch = p.g.per_ch;
-#ifdef URSA_DEBUG_KNOBS                    // experiments (tools/exp/bn_held_ab.py): the size from which the held form is taken, in MiB
+#ifdef URSA_DEBUG_KNOBS                    // experiments (tools/exp/bn_held_ab.py): the size from which the held form is taken, in MiB;
     static const int64_t forced = [] { const char* e = getenv("URSA_BN_HELD_MIN_MIB"); return e && e[0] ? ((int64_t)atoll(e) << 20) / 16 : (int64_t)-1; }();
     if (forced >= 0) min_float4 = forced;
+    static const bool no_lds = [] { const char* e = getenv("URSA_BN_HELD_NO_LDS"); return e && e[0] && e[0] != '0'; }();   // registers only
+    if (no_lds) max_lx = 0;
 #endif
     if (per_ch * p.g.C >= (1ll << 31) || per_ch * p.g.C < min_float4) return false;
-    // the LARGEST register chunk: fewer, larger pieces per channel = fewer workgroups to wait for. (Measured the other way
-    // round - the smallest chunk that still gives <= 64 pieces, for more workgroups - [1024,128,16,16] 59 -> 123 us forward,
-    // 96 -> 129 backward; and at the workload's own cache-resident layers the held form takes twice the two launches'
-    // time, [128,16,32,32] 14 vs 7 us: the thresholds above stay.)
-    const int64_t cap = (int64_t)block * max_ept;
-    int64_t S = (per_ch + cap - 1) / cap;
-    if (S < 2 || S > kBnMaxSplit) return false;
-    int64_t chunk = (per_ch + S - 1) / S;
-    chunk = (chunk + block - 1) / block * block;
-    S = (per_ch + chunk - 1) / chunk;
-    if (S < 2 || S * p.g.C < 256 || S * p.g.C >= (1ll << 31)) return false;
-    const int need = (int)(chunk / block);
-    h->S = (int)S;
-    h->chunk = (int)chunk;
-    h->ept = need <= max_ept / 4 ? max_ept / 4 : need <= max_ept / 2 ? max_ept / 2 : max_ept;
-    return true;
+    // the LARGEST chunk: fewer, larger pieces per channel = fewer workgroups to wait for and more bytes resident. (Measured
+    // the other way round - the smallest chunk that still gives <= 64 pieces, for more workgroups - [1024,128,16,16] 59 ->
+    // 123 us forward, 96 -> 129 backward; and at the workload's own cache-resident layers the held form takes twice the two
+    // launches' time, [128,16,32,32] 14 vs 7 us: the thresholds above stay.) First with the LDS-held extension (max_lx more
+    // float4 per thread), then with registers alone.
+    for (int lx = max_lx; lx >= 0; lx -= (max_lx > 0 ? max_lx : 1)) {
+        const int64_t cap = (int64_t)block * (max_ept + lx);
+        int64_t S = (per_ch + cap - 1) / cap;
+        if (S < 2 || S > kBnMaxSplit) { if (lx == 0) return false; continue; }
+        int64_t chunk = (per_ch + S - 1) / S;
+        chunk = (chunk + block - 1) / block * block;
+        S = (per_ch + chunk - 1) / chunk;
+        if (S < 2 || S * p.g.C < 256 || S * p.g.C >= (1ll << 31)) { if (lx == 0) return false; continue; }
+        const int need = (int)(chunk / block);
+        if (lx > 0 && need <= max_ept) continue;               // fits the registers: the register-only kernels
+        h->S = (int)S;
+        h->chunk = (int)chunk;
+        h->lx = lx;
+        h->ept = lx > 0 ? max_ept : need <= max_ept / 4 ? max_ept / 4 : need <= max_ept / 2 ? max_ept / 2 : max_ept;
+        return true;
+    }
+    return false;
 }
 
 // One-pass form: float4 accesses, the channel fits one workgroup's registers, 32-bit float4 offsets suffice, and there
@@ -1150,7 +1250,7 @@ static int bn_fwd_impl(const float* x, const float* addend, float* z_out, float*
         return bn_launch_status();
     }
     BnHeld hd;
-    if (!bn_one_pass(p, flags) && bn_held_plan(p, flags, kHeldFwdBlock, kHeldFwdEpt, kHeldMinFloat4Fwd, &hd)) {
+    if (!bn_one_pass(p, flags) && bn_held_plan(p, flags, kHeldFwdBlock, kHeldFwdEpt, addend ? 0 : kHeldFwdLx, kHeldMinFloat4Fwd, &hd)) {
         BnGeom gh = p.g;
         gh.chunk = hd.chunk;
         // the held form's own part of ws (slots, then counters): the two-launch form's partials never touch it
@@ -1159,15 +1259,16 @@ static int bn_fwd_impl(const float* x, const float* addend, float* z_out, float*
         const dim3 gg((unsigned)(hd.S * p.g.C)), bb(kHeldFwdBlock);
         // beyond the 256 MiB Infinity Cache the streams go past it (as K1-K4 do)
         const bool nt = p.g.per_ch * p.g.C * 16 * (addend ? 4 : 2) > (256ll << 20);
-#define URSA_BN_HELD_E(R, A, E) do { \
-    if (nt) hipLaunchKernelGGL((k_bn_fwd_held<R, A, E, true>), gg, bb, 0, st, x, addend, z_out, y, slots, sync, gamma, beta, \
+#define URSA_BN_HELD_E(R, A, E, L) do { \
+    if (nt) hipLaunchKernelGGL((k_bn_fwd_held<R, A, E, L, true>), gg, bb, 0, st, x, addend, z_out, y, slots, sync, gamma, beta, \
                                running_mean, running_var, save_mean, save_invstd, eps, momentum, gh, hd.S); \
-    else hipLaunchKernelGGL((k_bn_fwd_held<R, A, E, false>), gg, bb, 0, st, x, addend, z_out, y, slots, sync, gamma, beta, \
+    else hipLaunchKernelGGL((k_bn_fwd_held<R, A, E, L, false>), gg, bb, 0, st, x, addend, z_out, y, slots, sync, gamma, beta, \
                             running_mean, running_var, save_mean, save_invstd, eps, momentum, gh, hd.S); } while (0)
-#define URSA_BN_HELD_F(R, A) do { if (hd.ept == kHeldFwdEpt / 4) URSA_BN_HELD_E(R, A, kHeldFwdEpt / 4); \
-                                  else if (hd.ept == kHeldFwdEpt / 2) URSA_BN_HELD_E(R, A, kHeldFwdEpt / 2); else URSA_BN_HELD_E(R, A, kHeldFwdEpt); } while (0)
-        if (relu) { if (addend) URSA_BN_HELD_F(true, true); else URSA_BN_HELD_F(true, false); }
-        else      { if (addend) URSA_BN_HELD_F(false, true); else URSA_BN_HELD_F(false, false); }
+#define URSA_BN_HELD_F(R, A) do { if (hd.ept == kHeldFwdEpt / 4) URSA_BN_HELD_E(R, A, kHeldFwdEpt / 4, 0); \
+                                  else if (hd.ept == kHeldFwdEpt / 2) URSA_BN_HELD_E(R, A, kHeldFwdEpt / 2, 0); else URSA_BN_HELD_E(R, A, kHeldFwdEpt, 0); } while (0)
+        if (hd.lx > 0) { if (relu) URSA_BN_HELD_E(true, false, kHeldFwdEpt, kHeldFwdLx); else URSA_BN_HELD_E(false, false, kHeldFwdEpt, kHeldFwdLx); }
+        else if (relu) { if (addend) URSA_BN_HELD_F(true, true); else URSA_BN_HELD_F(true, false); }
+        else           { if (addend) URSA_BN_HELD_F(false, true); else URSA_BN_HELD_F(false, false); }
 #undef URSA_BN_HELD_F
 #undef URSA_BN_HELD_E
         return bn_launch_status();
@@ -1290,7 +1391,7 @@ static int bn_bwd_impl(const float* x, const float* dy, const float* dz, float* 
         return bn_launch_status();
     }
     BnHeld hd;
-    if (!bn_one_pass(p, flags) && bn_held_plan(p, flags, kHeldBwdBlock, kHeldBwdEpt, kHeldMinFloat4Bwd, &hd)) {
+    if (!bn_one_pass(p, flags) && bn_held_plan(p, flags, kHeldBwdBlock, kHeldBwdEpt, kHeldBwdLx, kHeldMinFloat4Bwd, &hd)) {
         BnGeom gh = p.g;
         gh.chunk = hd.chunk;
         // the held form's own part of ws (slots, then counters): the two-launch form's partials never touch it
@@ -1298,13 +1399,14 @@ static int bn_bwd_impl(const float* x, const float* dy, const float* dz, float* 
         BnSync* sync = reinterpret_cast<BnSync*>(ws + (int64_t)C * kBnMaxSplit * 8);
         const dim3 gg((unsigned)(hd.S * p.g.C)), bb(kHeldBwdBlock);
         const bool nt = p.g.per_ch * p.g.C * 16 * (dz ? 4 : 3) > (256ll << 20);
-#define URSA_BN_HELD_E(R, A, E) do { \
-    if (nt) hipLaunchKernelGGL((k_bn_bwd_held<R, A, E, true>), gg, bb, 0, st, x, dy, dz, dx, slots, sync, gamma, beta, save_mean, \
+#define URSA_BN_HELD_E(R, A, E, L) do { \
+    if (nt) hipLaunchKernelGGL((k_bn_bwd_held<R, A, E, L, true>), gg, bb, 0, st, x, dy, dz, dx, slots, sync, gamma, beta, save_mean, \
                                save_invstd, dgamma, dbeta, gh, hd.S); \
-    else hipLaunchKernelGGL((k_bn_bwd_held<R, A, E, false>), gg, bb, 0, st, x, dy, dz, dx, slots, sync, gamma, beta, save_mean, \
+    else hipLaunchKernelGGL((k_bn_bwd_held<R, A, E, L, false>), gg, bb, 0, st, x, dy, dz, dx, slots, sync, gamma, beta, save_mean, \
                             save_invstd, dgamma, dbeta, gh, hd.S); } while (0)
-#define URSA_BN_HELD_B(R, A) do { if (hd.ept == kHeldBwdEpt / 4) URSA_BN_HELD_E(R, A, kHeldBwdEpt / 4); \
-                                  else if (hd.ept == kHeldBwdEpt / 2) URSA_BN_HELD_E(R, A, kHeldBwdEpt / 2); else URSA_BN_HELD_E(R, A, kHeldBwdEpt); } while (0)
+#define URSA_BN_HELD_B(R, A) do { if (hd.lx > 0) URSA_BN_HELD_E(R, A, kHeldBwdEpt, kHeldBwdLx); \
+                                  else if (hd.ept == kHeldBwdEpt / 4) URSA_BN_HELD_E(R, A, kHeldBwdEpt / 4, 0); \
+                                  else if (hd.ept == kHeldBwdEpt / 2) URSA_BN_HELD_E(R, A, kHeldBwdEpt / 2, 0); else URSA_BN_HELD_E(R, A, kHeldBwdEpt, 0); } while (0)
         if (relu) { if (dz) URSA_BN_HELD_B(true, true); else URSA_BN_HELD_B(true, false); }
         else      { if (dz) URSA_BN_HELD_B(false, true); else URSA_BN_HELD_B(false, false); }
 #undef URSA_BN_HELD_B
