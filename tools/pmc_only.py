@@ -127,10 +127,15 @@ for shape, one in K6_SHAPES:
             K.bn_relu_forward(x, y, w, b, rm, rv, sm, si, wsz, eps=1e-5, momentum=0.1, held=True)
             K.bn_relu_backward(x, dy, dx, w, b, sm, si, dg, db, wsz, held=True)
         per = e // C // 4
+
+        def held_blocks(block, slots):            # csrc/ursa_bn.hip bn_held_plan: registers + LDS-held float4 per thread
+            S = -(-per // (block * slots))
+            chunk = -(-(-(-per // S)) // block) * block
+            return -(-per // chunk) * C
         manifest.append(dict(pattern='k_bn_fwd_held', label=f'K6 forward, held form (1 launch) {tag}', algorithmic_bytes_per_launch=8 * e,
-                             blocks=-(-per // 4096) * C, wg=256))
+                             blocks=held_blocks(256, 16 + 9), wg=256))
         manifest.append(dict(pattern='k_bn_bwd_held', label=f'K6 backward, held form (1 launch) {tag}', algorithmic_bytes_per_launch=12 * e,
-                             blocks=-(-per // 4096) * C, wg=512))
+                             blocks=held_blocks(512, 8 + 4), wg=512))
     del x, dy, y, dx
 torch.cuda.synchronize()
 json.dump(manifest, open(sys.argv[1], 'w'), indent=1)
