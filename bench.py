@@ -610,6 +610,10 @@ def roofline_kernels_block(dev, large_n):
     pr, en = torch.zeros(B, C, device=dev), torch.zeros(B, device=dev)
     entry('k5_bma_30x10000x100', 4 * S * B * C + 2 * 4 * B * (C + 1),
           lambda: K.bma_accumulate(z, pr, en, one_minus_gamma=1 - 1e-4, gamma_over_c=1e-4 / C, smoothed=False), shape=[S, B, C])
+    # ... and what a launch that ONLY reads the same 120 MB achieves (K4's sum-of-squares reduction over the logits slab):
+    # the practical ceiling K5's fraction has to be read against at this size
+    acc, ws = torch.zeros(1, device=dev), torch.zeros(_native.REDUCE_WS_FLOATS, device=dev)
+    entry('read_only_reduction_same_bytes_as_k5_30x10000x100', 4 * S * B * C, lambda: K.sumsq(z.view(-1), acc, ws), elements=S * B * C)
     del z, pr, en
     # the floor of ANY launch at K1's workload size: a plain device copy of one PreResNet-20 arena vector (1.09 MB), timed
     # the same way (128-launch hipGraph replays) — what the 3.9 us of `roofline` has to be read against

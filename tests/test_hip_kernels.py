@@ -295,7 +295,11 @@ def test_k5_vs_reference_golden(K, golden_dir, tag):
 
 
 @pytest.mark.parametrize('S,B,C', [(1, 1, 1), (2, 5, 2), (3, 100, 3), (4, 1000, 10), (2, 333, 17), (3, 257, 64),
-                                   (30, 512, 100), (2, 65, 129), (2, 40, 1000), (1, 3, 1024), (5, 10000, 10)])
+                                   (30, 512, 100), (2, 65, 129), (2, 40, 1000), (1, 3, 1024), (5, 10000, 10),
+                                   # the member-range forms of the float4 lane-group kernel (bma_form in ursa_kernels.hip):
+                                   # 2 ranges (many row groups, 8 classes per lane), 1 range (16 per lane), 8 ranges (few
+                                   # rows, ragged ranges), 4 ranges with fewer members than ranges
+                                   (5, 8200, 100), (4, 8200, 132), (17, 100, 100), (3, 9000, 100), (30, 1001, 36)])
 def test_k5_vs_oracle_shapes(K, S, B, C):
     rng = np.random.default_rng(S * 1000 + C)
     z = (rng.standard_normal((S, B, C)) * 4).astype(np.float32)

@@ -105,6 +105,25 @@ inline bool getenv_flag(const char* name)
 
 // Knob (A/B, tools/k5_bench.py): URSA_BMA_PREFETCH=0/1 overrides whether the C > 64 float4 kernel software-pipelines its loads.
 constexpr bool kBmaPrefetchDefault = false;
+// Form of the float4 lane-group kernel (k_bma_accumulate, no cost matrix): waves per block = the number of contiguous
+// ranges the S members of a row group are split into, and whether wave 0 fetches the row's accumulators at the top of a
+// round instead of in its epilogue. Knobs (tools/exp/k5_waves_ab.py): URSA_BMA_WAVES=1|2|4|8, URSA_BMA_EARLY=0|1.
+struct BmaForm { int waves; bool early; };
+inline BmaForm bma_form(int64_t row_groups, int S, int epl)
+{
+    // Measured (tools/exp/k5_waves_ab.py, profiles/r04_k5_waves_ab.json): the early fetch gains everywhere (2-20 %); test-set
+    // sized calls with 8 / 16 classes per lane run best with 2 / 1 member ranges per row group (fewer, longer-lived waves:
+    // 25.9 -> 24.5 us at (30, 10^4, 100), 63.5 -> 56.6 at C = 256), a few rows with 8 (6.7 -> 5.4 us at B = 128).
+    BmaForm f{4, true};
+    if (row_groups >= 2048 && S >= 4 && epl >= 8) f.waves = epl >= 16 ? 1 : 2;
+    else if (row_groups < 256 && S >= 16) f.waves = 8;
+    if (const char* v = knob("URSA_BMA_WAVES")) {
+        const int w = atoi(v);
+        if (w == 1 || w == 2 || w == 4 || w == 8) f.waves = w;
+    }
+    if (const char* v = knob("URSA_BMA_EARLY")) f.early = v[0] && v[0] != '0';
+    return f;
+}
 inline bool bma_prefetch()
 {
     const char* v = knob("URSA_BMA_PREFETCH");
@@ -725,14 +744,15 @@ __device__ __forceinline__ void lg_compute(float (&xs)[U][EPL], int lane, int C,
             sum += xs[u][e];
         }
         const float inv = 1.0f / group_sum<G>(sum);
+        const float inv_omg = inv * omg;
         float ent2 = 0.f;
         float qv[RISK ? EPL : 1];
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
-            const float p = xs[u][e] * inv;
-            const float q = __builtin_fmaf(p, omg, goc);    // goc > 0 (the launcher floors it): q > 0, log finite
+            // p = e / sum enters both uses through one fma each: q = (1-g) p + g/C and acc += p
+            const float q = __builtin_fmaf(xs[u][e], inv_omg, goc);   // goc > 0 (the launcher floors it): q > 0, log finite
             ent2 = __builtin_fmaf(q, __builtin_amdgcn_logf(q), ent2);
-            acc_p[e] += p;                                   // raw p always; smoothing of the SUM is applied once per row
+            acc_p[e] = __builtin_fmaf(xs[u][e], inv, acc_p[e]);       // raw p always; smoothing of the SUM is applied once per row
             if (RISK) qv[e] = q;                             // (slots beyond C: junk, never stored / never read)
         }
         if (want_ent) acc_e2 += group_sum<G>(ent2) - ent_fake;
@@ -771,8 +791,8 @@ __device__ __forceinline__ void lg_members(const float* __restrict__ z0, int64_t
     lg_compute<G, EPL, RISK, V4, U>(xs, lane, C, omg, goc, want_ent, cost, acc_p, acc_r, acc_e2);
 }
 
-template <int G, int EPL, bool RISK, bool V4, bool PF = false>
-__global__ __launch_bounds__(kBlock) void k_bma_accumulate(const float* __restrict__ logits,
+template <int G, int EPL, bool RISK, bool V4, bool PF = false, int W = kBlock / 64, bool EARLY = false>
+__global__ __launch_bounds__(64 * W) void k_bma_accumulate(const float* __restrict__ logits,
                                                            float* __restrict__ proba_sum,
                                                            float* __restrict__ ent_sum,
                                                            float* __restrict__ risk_sum,
@@ -786,9 +806,9 @@ __global__ __launch_bounds__(kBlock) void k_bma_accumulate(const float* __restri
     // RISK (Decision's expected-cost accumulator) is a template flag so Prediction/OOD do not carry its
     // registers: <16 lanes, 8 classes per lane> needs 122 VGPRs with it (4 waves/SIMD), half without.
     constexpr int kRows = 64 / G;
-    constexpr int kWaves = kBlock / 64;
+    constexpr int kWaves = W;
     constexpr int kVals = (RISK ? 2 : 1) * EPL + 1;          // proba[EPL], (risk[EPL]), entropy
-    __shared__ float part[kWaves - 1][kVals][64];
+    __shared__ float part[kWaves > 1 ? kWaves - 1 : 1][kVals][64];
     const int wave = threadIdx.x >> 6, wl = threadIdx.x & 63;
     const int lane = wl % G, grp = wl / G;
     const bool smoothed = flags & URSA_BMA_SMOOTHED;
@@ -809,6 +829,17 @@ __global__ __launch_bounds__(kBlock) void k_bma_accumulate(const float* __restri
 #pragma unroll
         for (int e = 0; e < (RISK ? EPL : 1); ++e) acc_r[e] = 0.f;
 
+        // EARLY: wave 0 fetches the row's accumulators now, so that the read-modify-write at the end of the round does not
+        // start with a cold load while every other block of the launch is in its own epilogue too
+        float old_p[EARLY ? EPL : 1], old_e = 0.f;
+        if (EARLY && wave == 0 && row_ok) {
+#pragma unroll
+            for (int e = 0; e < (EARLY ? EPL : 1); ++e) {
+                const int c = bma_class<G, V4>(lane, e);
+                old_p[e] = proba_sum[b * C + (c < C ? c : C - 1)];
+            }
+            if (ent_sum) old_e = ent_sum[b];
+        }
         // full chunks of U members, then the remainder one at a time: no per-member liveness masks anywhere
 #ifndef URSA_BMA_U_EPL8
 #define URSA_BMA_U_EPL8 2
@@ -816,7 +847,14 @@ __global__ __launch_bounds__(kBlock) void k_bma_accumulate(const float* __restri
 #ifndef URSA_BMA_U_EPL16
 #define URSA_BMA_U_EPL16 1
 #endif
-        constexpr int U = EPL <= 2 ? 8 : EPL <= 4 ? 4 : EPL <= 8 ? URSA_BMA_U_EPL8 : URSA_BMA_U_EPL16;   // members in flight per lane
+#ifndef URSA_BMA_U_EPL8_W2
+#define URSA_BMA_U_EPL8_W2 1
+#endif
+#ifndef URSA_BMA_U_EPL4
+#define URSA_BMA_U_EPL4 4
+#endif
+        // members whose loads are in flight per lane
+        constexpr int U = EPL <= 2 ? 8 : EPL <= 4 ? URSA_BMA_U_EPL4 : EPL <= 8 ? (W <= 2 ? URSA_BMA_U_EPL8_W2 : URSA_BMA_U_EPL8) : URSA_BMA_U_EPL16;
         const float* zrow = logits + (row_ok ? b : 0) * (int64_t)C;          // rows past B recompute row 0 (never stored)
         int s0 = s_lo;
         if (PF) {
@@ -866,7 +904,7 @@ __global__ __launch_bounds__(kBlock) void k_bma_accumulate(const float* __restri
             for (int e = 0; e < EPL; ++e) {
                 const int c = bma_class<G, V4>(lane, e);
                 if (c < C) {
-                    float p = proba_sum[b * C + c] + acc_p[e];
+                    float p = (EARLY ? old_p[EARLY ? e : 0] : proba_sum[b * C + c]) + acc_p[e];
 #pragma unroll
                     for (int w = 0; w < kWaves - 1; ++w) p += part[w][e][wl];
                     proba_sum[b * C + c] = p;
@@ -879,7 +917,7 @@ __global__ __launch_bounds__(kBlock) void k_bma_accumulate(const float* __restri
                 }
             }
             if (ent_sum && lane == 0) {
-                float en = ent_sum[b] + acc_e;
+                float en = (EARLY ? old_e : ent_sum[b]) + acc_e;
 #pragma unroll
                 for (int w = 0; w < kWaves - 1; ++w) en += part[w][kVals - 1][wl];
                 ent_sum[b] = en;
@@ -1479,6 +1517,10 @@ int ursa_bma_accumulate_f32(const float* logits, float* proba_sum, float* ent_su
 #undef URSA_RL
         return launch_status();
     }
+#define URSA_LAUNCH_WE(G, EPL, V4, W, EARLY)                                                                    \
+    hipLaunchKernelGGL((k_bma_accumulate<G, EPL, false, V4, false, W, EARLY>), dim3(bma_grid(B, 64 / G)), dim3(64 * W), 0, st, \
+                       logits, proba_sum, ent_sum, risk_sum, cost, (int)S, B, (int)C, one_minus_gamma,          \
+                       gamma_over_c, flags)
 #define URSA_LAUNCH_V(G, EPL, V4)                                                                               \
     do {                                                                                                        \
         if (risk_sum)                                                                                           \
@@ -1489,6 +1531,19 @@ int ursa_bma_accumulate_f32(const float* logits, float* proba_sum, float* ent_su
             hipLaunchKernelGGL((k_bma_accumulate<G, EPL, false, V4, true>), dim3(bma_grid(B, 64 / G)), dim3(kBlock), 0, st, \
                                logits, proba_sum, ent_sum, risk_sum, cost, (int)S, B, (int)C, one_minus_gamma,  \
                                gamma_over_c, flags);                                                            \
+        else if (V4) {                                                                                          \
+            const BmaForm f = bma_form((B + 64 / G - 1) / (64 / G), (int)S, EPL);                               \
+            switch (f.waves * 2 + (f.early ? 1 : 0)) {                                                          \
+            case 2: URSA_LAUNCH_WE(G, EPL, V4, 1, false); break;                                                \
+            case 3: URSA_LAUNCH_WE(G, EPL, V4, 1, true); break;                                                 \
+            case 4: URSA_LAUNCH_WE(G, EPL, V4, 2, false); break;                                                \
+            case 5: URSA_LAUNCH_WE(G, EPL, V4, 2, true); break;                                                 \
+            case 9: URSA_LAUNCH_WE(G, EPL, V4, 4, true); break;                                                 \
+            case 16: URSA_LAUNCH_WE(G, EPL, V4, 8, false); break;                                               \
+            case 17: URSA_LAUNCH_WE(G, EPL, V4, 8, true); break;                                                \
+            default: URSA_LAUNCH_WE(G, EPL, V4, 4, false); break;                                               \
+            }                                                                                                   \
+        }                                                                                                       \
         else                                                                                                    \
             hipLaunchKernelGGL((k_bma_accumulate<G, EPL, false, V4>), dim3(bma_grid(B, 64 / G)), dim3(kBlock), 0, st, \
                                logits, proba_sum, ent_sum, risk_sum, cost, (int)S, B, (int)C, one_minus_gamma,  \
@@ -1514,6 +1569,7 @@ int ursa_bma_accumulate_f32(const float* logits, float* proba_sum, float* ent_su
     else if (C <= 512) URSA_LAUNCH(64, 8);
     else URSA_LAUNCH(64, 16);
 #undef URSA_LAUNCH_V
+#undef URSA_LAUNCH_WE
 #undef URSA_LAUNCH
     return launch_status();
 }
