@@ -191,6 +191,7 @@ def test_loader_batches_are_merged_into_evaluation_batches(monkeypatch):
     train, test = img_loader(32, 16), img_loader(37, 8, seed=7)              # loader batches: 8, 8, 8, 8, 5
     _, ens = bn_chain(8, 3, train)
     monkeypatch.setattr(EnsembleAccumulator, 'EVAL_ROWS', 20)               # -> 16, 16, 5
+    monkeypatch.setattr(EnsembleAccumulator, 'SMALL_PARAMS', 0)             # (no small-network tier: see below)
     pred = tasks.Prediction({'in_distribution_test': test}, 10, torch.device('cpu'), 'ALL', kernels=OracleKernels(), acc_kw=TWIN)
     sizes = [[len(x) for _, x in batches] for _, _, batches in pred._acc._chunks(3)]
     assert sizes == [[16, 16, 5]]
@@ -202,6 +203,16 @@ def test_loader_batches_are_merged_into_evaluation_batches(monkeypatch):
     monkeypatch.setattr(EnsembleAccumulator, 'EVAL_ROWS', 1024)             # everything in one forward
     one = tasks.Prediction({'in_distribution_test': test}, 10, torch.device('cpu'), 'ALL', kernels=OracleKernels(), acc_kw=TWIN)
     assert [[len(x) for _, x in b] for _, _, b in one._acc._chunks(3)] == [[37]]
+    # small networks (<= SMALL_PARAMS parameters) merge up to EVAL_ROWS_SMALL rows
+    monkeypatch.setattr(EnsembleAccumulator, 'EVAL_ROWS', 8)
+    monkeypatch.setattr(EnsembleAccumulator, 'SMALL_PARAMS', 10 ** 9)
+    monkeypatch.setattr(EnsembleAccumulator, 'EVAL_ROWS_SMALL', 20)
+    small = tasks.Prediction({'in_distribution_test': test}, 10, torch.device('cpu'), 'ALL', kernels=OracleKernels(), acc_kw=TWIN)
+    small.update_statistics(ens, output_performance=False)
+    assert small._acc.stats['twin_forwards'] == 3 * 3                        # 16 + 16 + 5 rows again
+    assert torch.allclose(small.ensemble_proba, pred.ensemble_proba, rtol=1e-6, atol=1e-9)
+    monkeypatch.setattr(EnsembleAccumulator, 'SMALL_PARAMS', 0)
+    monkeypatch.setattr(EnsembleAccumulator, 'EVAL_ROWS', 1024)
     # networks above MERGE_MAX_PARAMS keep one forward per loader batch (a 128-row WideResNet-28-10 forward already fills the GPU)
     monkeypatch.setattr(EnsembleAccumulator, 'MERGE_MAX_PARAMS', 10)
     big = tasks.Prediction({'in_distribution_test': test}, 10, torch.device('cpu'), 'ALL', kernels=OracleKernels(), acc_kw=TWIN)

@@ -190,6 +190,9 @@ class EnsembleAccumulator:
 
     EVAL_ROWS = 1024           # rows per member forward: consecutive loader batches are merged up to this many ...
     MERGE_MAX_PARAMS = 4_000_000   # ... for networks up to this many parameters
+    EVAL_ROWS_SMALL = 4096     # ... and up to this many for networks of at most SMALL_PARAMS parameters (PreResNet-20: 660 k ->
+    SMALL_PARAMS = 500_000     # 698 k member-forwards/s at 20 members, tools/exp/bma_probe.py; deeper / wider networks keep
+                               # 1,024: their activations per row are what bounds the captured forward's memory)
 
     def _chunks(self, S, eval_rows=None):
         """The loader's batches grouped into chunks of consecutive rows: (first row, rows, [(offset, x on device), ...]).
@@ -262,6 +265,8 @@ class EnsembleAccumulator:
                 by_twin.setdefault(id(twin), (twin, []))[1].append(s)
         biggest = max(self._param_count(m) for m in members)
         eval_rows = self.EVAL_ROWS if biggest <= self.MERGE_MAX_PARAMS else 0
+        if eval_rows and biggest <= self.SMALL_PARAMS:
+            eval_rows = self.EVAL_ROWS_SMALL
         for start, rows, batches in self._chunks(S, eval_rows):
             slab = self._slabs.get((S, rows))
             if slab is None:
