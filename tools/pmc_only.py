@@ -82,7 +82,9 @@ if not K6_ONLY:
         for _ in range(10):
             K.bma_accumulate(z, p, e, one_minus_gamma=0.9999, gamma_over_c=1e-4 / C, smoothed=False)
         grid = (B + 15) // 16 if C <= 16 else (B + 3) // 4
-        wg = 64 * (4 if S >= 12 else 2 if S >= 5 else 1) if C <= 16 else 256
+        # (C > 16: the lane-group kernel; bma_form in ursa_kernels.hip gives a test-set sized call with 8 classes per lane
+        #  two member ranges per row group = 2 waves per block)
+        wg = 64 * (4 if S >= 12 else 2 if S >= 5 else 1) if C <= 16 else (128 if (B + 3) // 4 >= 2048 and S >= 4 and 64 < C <= 128 else 256)
         note('k_bma_', f'K5 S={S} B={B} C={C}', 4 * S * B * C + 8 * B * (C + 1), shape=[S, B, C], blocks=grid, wg=wg)
     del z, p, e
 # K6 relu(bn(x)): the two-launch form on a 268 MB activation (PreResNet-164's first stage at the HMC batch: beyond the
