@@ -648,7 +648,7 @@ def roofline_kernels_block(dev, large_n):
         e = x.numel()
         one = C >= 48 and e // C <= 32768                       # csrc/ursa_bn.hip bn_one_pass
         big = e * 4 >= _native.BN_HELD_MIN_BYTES and not one
-        held_f, held_b = big and e * 4 >= (128 << 20), big      # forward from 128 MiB, backward from 24 MiB (kHeldMinFloat4*)
+        held_f, held_b = big and e * 4 >= _native.BN_HELD_MIN_BYTES_FWD, big      # forward from 48 MiB, backward from 24 MiB (kHeldMinFloat4*)
         form_f = 'one-pass (1 launch)' if one else 'held (1 launch, inputs read once)' if held_f else 'two-launch'
         form_b = 'one-pass (1 launch)' if one else 'held (1 launch, inputs read once)' if held_b else 'two-launch'
         entry(f'k6_bn_relu_fwd_{label}', 8 * e, lambda: K.bn_relu_forward(x, y, w, b, rm, rv, sm, si, wsb, eps=1e-5, momentum=0.1, held=big),

@@ -274,7 +274,7 @@ int ursa_sumsq_f32(const float* x, int64_t n, float* out, float* ws, ursa_stream
 #define URSA_BN_RELU        0x1u
 #define URSA_BN_TWO_LAUNCH  0x2u   /* keep the two-launch form where the one-pass / held form would apply (A/B, tests) */
 #define URSA_BN_HELD        0x4u   /* the caller vouches that ws from URSA_BN_WS_HELD_OFFSET_FLOATS(C) on is ZERO: the library may then run the
-                                      held form - ONE launch, every input read once - on activations of >= 24 MiB (backward) / >= 128 MiB (forward) whose
+                                      held form - ONE launch, every input read once - on activations of >= 24 MiB (backward) / >= 48 MiB (forward; 32 MiB with an addend) whose
                                       channels do not fit one workgroup (per-channel workgroups hold their chunk in registers,
                                       exchange double partial sums through ws and wait for each other; bounded wait; that part
                                       of ws is zero again when the launch has drained and no other form writes there, so a ws

@@ -523,16 +523,17 @@ def test_gated_backward_argument_errors(K):
         K.bn_relu_backward(x, x, torch.empty_like(x), v, v, v, v, v.clone(), v.clone(), ws, relu=True, gates=(gi.long(), go))
 
 
-HELD_SHAPES = [(512, 64, 32, 32),       # 134 MB: forward AND backward take the held form (forward: from 128 MiB on)
-               (128, 160, 32, 32),      # WideResNet-28-10 stage 1: 84 MB, S = 8 (backward held, forward two-launch)
-               (256, 64, 32, 32),       # 67 MB, S = 16
-               (512, 16, 32, 32),       # few channels: 16 x 32 workgroups
-               (96, 96, 34, 30)]        # ragged: H*W = 1020 (float4 path, chunk tail), S = 6
+HELD_SHAPES = [(512, 64, 32, 32),       # 134 MB: forward AND backward take the held form (forward: from 48 MiB on)
+               (128, 160, 32, 32),      # WideResNet-28-10 stage 1: 84 MB: both directions held; forward in two pieces of 32 float4 per thread
+               (256, 64, 32, 32),       # 67 MB: forward in 4 pieces with the LDS part in use
+               (512, 16, 32, 32),       # few channels, 34 MB: backward held (16 x 11 workgroups), forward two-launch
+               (1024, 256, 8, 8),       # 67 MB, 256 KB per channel: forward in two pieces of 16 float4 per thread
+               (96, 96, 34, 30)]        # ragged: H*W = 1020 (float4 path, chunk tail)
 
 
 def _sync_words(ws, C):
     """The held form's part of ws (URSA_BN_WS_HELD_OFFSET_FLOATS(C) on) as it must leave it: slots and counters zero.
-    (The two-launch form's partials in front of it are scratch; a forward below 128 MiB takes that form.)"""
+    (The two-launch form's partials in front of it are scratch; a forward below 48 MiB takes that form.)"""
     return ws[C * 256:].view(torch.int32)
 
 

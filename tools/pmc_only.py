@@ -121,7 +121,7 @@ for shape, one in K6_SHAPES:
     chunk = -(-(-(-per // Se)) // 256) * 256
     Se = -(-per // chunk)
     manifest.append(dict(pattern='k_bn_eval', label=f'K6 evaluation {tag}', algorithmic_bytes_per_launch=8 * e, blocks=Se * C, wg=256))
-    if not one and e * 4 >= (128 << 20):
+    if not one and e * 4 >= _native.BN_HELD_MIN_BYTES_FWD:
         # the held form of the same layer (one launch per direction, chunks held in registers): its HBM traffic must be the
         # ALGORITHMIC bytes - x read once (forward), x and dy read once (backward)
         wsz = torch.zeros(_native.bn_ws_floats(C), device='cuda')
@@ -131,11 +131,11 @@ for shape, one in K6_SHAPES:
         per = e // C // 4
 
         def held_blocks(block, slots):            # csrc/ursa_bn.hip bn_held_plan: registers + LDS-held float4 per thread
-            S = -(-per // (block * slots))
+            S = -(-per // (block * slots))        # (the largest shape; the forward's round-fill rule does not bite at these sizes)
             chunk = -(-(-(-per // S)) // block) * block
             return -(-per // chunk) * C
         manifest.append(dict(pattern='k_bn_fwd_held', label=f'K6 forward, held form (1 launch) {tag}', algorithmic_bytes_per_launch=8 * e,
-                             blocks=held_blocks(256, 16 + 9), wg=256))
+                             blocks=held_blocks(512, 32 + 9), wg=512))
         manifest.append(dict(pattern='k_bn_bwd_held', label=f'K6 backward, held form (1 launch) {tag}', algorithmic_bytes_per_launch=12 * e,
                              blocks=held_blocks(512, 8 + 4), wg=512))
     del x, dy, y, dx

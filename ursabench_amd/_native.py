@@ -33,7 +33,8 @@ def bn_ws_floats(channels):
     return int(channels) * 64 * 8 + (int(channels) + 2) * 32
 
 
-BN_HELD_MIN_BYTES = 24 << 20      # activations from this size on may take the held form (ursa_bn.hip kHeldMinFloat4)
+BN_HELD_MIN_BYTES = 24 << 20      # activations from this size on may take the held form (ursa_bn.hip kHeldMinFloat4Bwd) ...
+BN_HELD_MIN_BYTES_FWD = 48 << 20  # ... the forward from this size on (kHeldMinFloat4Fwd)
 BMA_MAX_CLASSES = 1024
 
 _vp, _i64, _i32, _u64, _u32, _f = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_uint64,

@@ -578,11 +578,11 @@ __global__ __launch_bounds__(kOneBlock) void k_bn_bwd_one(const float* __restric
 // scalars, no broadcast) and finish from registers: one launch, every byte read once.
 //   * Work is handed out by ticket (one atomic per workgroup), channel-major: ticket t -> channel t / S, chunk t % S. A
 //     workgroup only ever waits for partials of its own channel, and tickets are drawn in order by workgroups that are
-//     RUNNING - so the launch cannot deadlock as long as S (<= 64) workgroups of it can be resident at once (the chip holds
-//     >= 512 of them; with K such launches sharing the chip from parallel graph branches the one holding the most slots
-//     has >= 512 / K and drains first: safe up to K = 8). A ticket queue per XCD (a channel's workgroups on one L2) was
-//     tried: no faster, and it needs 8 x 63 + 64 resident workgroups - the backward form, 512 resident, ran into its
-//     bounded wait. The wait is bounded all the same: after ~3 s a workgroup raises the err word and goes on with what it
+//     RUNNING - so the launch cannot deadlock as long as S workgroups of it can be resident at once; with K such launches
+//     sharing the chip from parallel graph branches none starves while sum (S_k - 1) stays below the resident workgroups:
+//     safe up to K = 8 with S <= 64 backward (512 resident) and S <= 32 forward (256 resident), kHeld*MaxSplit below. A
+//     ticket queue per XCD (a channel's workgroups on one L2) was tried: no faster, and it needs 8 x 63 + 64 resident
+//     workgroups - the backward form, 512 resident, ran into its bounded wait. The wait is bounded all the same: after ~3 s a workgroup raises the err word and goes on with what it
 //     has, so a logic error ends in wrong numbers, never in a hung GPU.
 //   * Hand-off of the partials: each is two 8-byte words stored with agent-scope atomic stores as bits(value) XOR a NaN
 //     payload no sum can produce, so that ZERO means "not there yet"; wave 0 of every workgroup polls the channel's S
@@ -590,12 +590,11 @@ __global__ __launch_bounds__(kOneBlock) void k_bn_bwd_one(const float* __restric
 //     read, there is no flag, no ordering between the two words is needed and nothing else is fetched.
 //   * ws (slots and counters) must be ZERO at launch and is zero again when the launch has drained: the last workgroup to
 //     have gathered a channel clears its slots, the one that clears the last channel re-arms the ticket queues.
-//   * What bounds the form is (bytes resident on the chip) / (time a chunk stays resident): ~28 us per workgroup
-//     (tools/exp/bn_held_timeline.hip: ticket 3.4, load + reduce 10.1, gather 8.5, scalars 1.6, apply 4.2) with 64 MB in
-//     the registers of the whole chip. So the chunk ALSO lives in LDS where that is free: LX further float4 per thread
-//     arrive by LDS-DMA (global_load_lds_dwordx4: no register on the way), 9 per thread forward (36 KB per workgroup, 4 per
-//     CU), 4 + 4 backward (64 KB, 2 per CU): + 56 % / + 50 % bytes per workgroup, 268 MB forward 136 -> 123 us, backward
-//     176 -> 159 us. Not in the residual forward (its addend would need the registers the chunk lives in).
+//   * A workgroup of the 256-thread form spends ~28 us per chunk (tools/exp/bn_held_timeline.hip: ticket 3.4, load +
+//     reduce 10.1, gather 8.5, scalars 1.6, apply 4.2), half of it waiting. The chunk ALSO lives in LDS: LX further float4 per thread
+//     arrive by LDS-DMA (global_load_lds_dwordx4: no register on the way), 9 per thread forward, 4 + 4 backward (64 KB, 2 per
+//     CU): with 256-thread workgroups 268 MB forward 136 -> 123 us, backward 176 -> 159 us. Not in the residual forward.
+//     (The forward's workgroup shape was re-measured after that and is now 512 threads, one workgroup per CU: below.)
 // Same arithmetic as the two-launch form (double sums rounded once), hence the same floats.
 constexpr int kSyncStride = 32;          // uint32 per 128-byte line: every counter on a line of its own (atomics and polls to
                                          // ONE line serialise at ~11.5 ns each whichever word they hit)
@@ -609,8 +608,33 @@ struct BnSync {
 };
 constexpr unsigned long long kSlotXor = 0xFFF8DEADBEEF0001ull;   // a NaN payload with low mantissa bits set: no sum of floats has it
 
-constexpr int kHeldFwdBlock = 256, kHeldFwdEpt = 16, kHeldFwdLx = 9;     // 16 float4 of x per thread in registers + 9 in LDS (36 KB: 4 workgroups per CU)
-constexpr int kHeldBwdBlock = 512, kHeldBwdEpt = 8, kHeldBwdLx = 4;      // 8 + 8 float4 of x and dy per thread in registers + 4 + 4 in LDS (64 KB: 2 per CU)
+// Workgroup shapes (compile-time A/B: tools/exp/bn_held_fwd_ab.sh, profiles/r04_bn_held_shapes_ab.json). Forward: 512 threads,
+// up to 32 float4 of x per thread in registers + 9 in LDS (72 KB), no register cap (<= 256 VGPRs, no spills): ONE workgroup
+// per CU. With 256 threads, 16 + 9 float4 and four workgroups per CU (<= 128 VGPRs: 8 spilled) the same CU held more
+// bytes and the 268 MB layer took 126 us instead of 108-113: fewer, larger pieces per channel to wait for and no scratch
+// traffic count for more than bytes resident. Backward: 512 threads, 8 + 8 float4 of x and dy in registers + 4 + 4 in LDS
+// (64 KB), two workgroups per CU - every larger or smaller shape tried was slower (160 us at 268 MB; 165-176 with 12-16
+// float4 in registers or 2-9 in LDS, 225 with 1024 threads, 263 with 256).
+#ifndef URSA_HELD_FWD_BLOCK
+#define URSA_HELD_FWD_BLOCK 512
+#endif
+#ifndef URSA_HELD_FWD_EPT
+#define URSA_HELD_FWD_EPT 32
+#endif
+#ifndef URSA_HELD_FWD_LX
+#define URSA_HELD_FWD_LX 9
+#endif
+#ifndef URSA_HELD_BWD_BLOCK
+#define URSA_HELD_BWD_BLOCK 512
+#endif
+#ifndef URSA_HELD_BWD_EPT
+#define URSA_HELD_BWD_EPT 8
+#endif
+#ifndef URSA_HELD_BWD_LX
+#define URSA_HELD_BWD_LX 4
+#endif
+constexpr int kHeldFwdBlock = URSA_HELD_FWD_BLOCK, kHeldFwdEpt = URSA_HELD_FWD_EPT, kHeldFwdLx = URSA_HELD_FWD_LX;
+constexpr int kHeldBwdBlock = URSA_HELD_BWD_BLOCK, kHeldBwdEpt = URSA_HELD_BWD_EPT, kHeldBwdLx = URSA_HELD_BWD_LX;
 constexpr uint32_t kHeldSpinLimit = 1u << 21;            // x ~1.7 us of s_sleep
 
 typedef unsigned long long bn_u64;
@@ -716,7 +740,11 @@ template <bool NT> __device__ __forceinline__ void bn_ld_lds(const float4* src, 
 }
 
 template <bool RELU, bool ADD, int EPT, int LX, bool NT>
-__global__ __launch_bounds__(kHeldFwdBlock, 4) void k_bn_fwd_held(      // 4 waves per SIMD = 4 workgroups per CU: <= 128 VGPRs
+#ifdef URSA_HELD_FWD_MIN_WAVES            // (A/B only: round 4's first shape was 256 threads with 4 waves per SIMD = <= 128 VGPRs)
+__global__ __launch_bounds__(kHeldFwdBlock, URSA_HELD_FWD_MIN_WAVES) void k_bn_fwd_held(
+#else
+__global__ __launch_bounds__(kHeldFwdBlock) void k_bn_fwd_held(         // no register cap: one workgroup per CU (see the shapes above)
+#endif
                                                                      const float* __restrict__ x, const float* __restrict__ addend,
                                                               float* __restrict__ z, float* __restrict__ y,
                                                               bn_u64* slots_base, BnSync* sync,
@@ -1158,17 +1186,26 @@ inline bool bn_twin_ok(const BnPlan& p, const void* twin)
 // register-sized chunks, enough workgroups to fill the chip, and an activation large enough that the second read of the
 // two-launch form costs more than the wait (measured: tools/exp/bn_fused_bench.py). The caller vouches for zeroed sync
 // words with URSA_BN_HELD.
-// Measured, us per call inside a hipGraph, held / two-launch (tools/exp/bn_held_ab.py, profiles/r04_bn_held_ab.json; with
-// the LDS-held extension; registers only: 135 / 171 at 268 MB):
-//   [1024,64,32,32] 268 MB  forward 123 / 152   backward 159 / 253        [1024,128,16,16] 134 MB   62 / 60    83 / 114
-//   [128,160,32,32]  84 MB           41 / 41             48 /  65        [1024,256,8,8]    67 MB   33 / 33    41 /  52
-//   [1024,16,32,32]  67 MB           33 / 33             45 /  52        [256,64,32,32]    67 MB   33 / 32    43 /  51
-// The backward saves 8 of 20 B/element and wins from 24 MiB on; the forward saves 4 of 12 and pays the same wait: it wins
-// only where the second read would come from HBM (activation + output beyond the 256 MiB Infinity Cache).
+// Measured, us per call inside a hipGraph, held / two-launch (tools/exp/bn_held_fwd_ab.py, profiles/r04_bn_held_shapes_ab.json;
+// plain and residual forms):
+//   [1024,64,32,32] 268 MB  forward 108 / 152 (205 / 251)   backward 156 / 253        [1024,128,16,16] 134 MB  51 / 60   84 / 114
+//   [128,160,32,32]  84 MB           34 /  41 ( 74 /  73)             48 /  65        [256,64,32,32]    67 MB  25 / 32   43 /  51
+//   [128,96,32,32]   50 MB           25 /  27 ( 37 /  41)             33 / (41)       [512,16,32,32]    34 MB  17 / 16   24 / (27)
+// The backward saves 8 of 20 B/element and wins from 24 MiB on; the forward saves 4 of 12: from 48 MiB on (below that it is
+// a tie or, with few channels, a loss); the residual forward 4 of 20 (the two-launch form's second pass over z): from
+// 32 MiB on (34 MB: 23-26 vs 27-31 us).
 constexpr int64_t kHeldMinFloat4Bwd = (24ll << 20) / 16;      // 24 MiB of activation
-constexpr int64_t kHeldMinFloat4Fwd = (128ll << 20) / 16;     // 128 MiB
+constexpr int64_t kHeldMinFloat4Fwd = (48ll << 20) / 16;      // 48 MiB
+constexpr int64_t kHeldMinFloat4FwdAdd = (32ll << 20) / 16;   // the residual forward (20 B/element two-launch, 16 held): 32 MiB
 struct BnHeld { int S, chunk, ept, lx; };
-inline bool bn_held_plan(const BnPlan& p, uint32_t flags, int block, int max_ept, int max_lx, int64_t min_float4, BnHeld* h)
+struct BnHeldShape { int ept, lx; };       // a compiled kernel shape: float4 per thread in registers / in LDS
+// `shapes`: the compiled shapes, largest capacity first. The LARGEST chunk that still splits the channel in two: fewer,
+// larger pieces per channel = fewer workgroups to wait for. (Measured the other way round - the smallest chunk that still
+// gives <= 64 pieces, for more workgroups - [1024,128,16,16] 59 -> 123 us forward, 96 -> 129 backward.) The kernel that runs
+// is the smallest compiled shape that holds the chunk.
+template <int NSHAPES>
+inline bool bn_held_plan(const BnPlan& p, uint32_t flags, int block, const BnHeldShape (&shapes)[NSHAPES], bool lds_ok,
+                         int max_split, int resident, int64_t min_float4, BnHeld* h)
 {
     if (!(flags & URSA_BN_HELD) || (flags & URSA_BN_TWO_LAUNCH) || p.V != 4) return false;
     const int64_t per_ch = p.g.per_ch;
@@ -1176,32 +1213,51 @@ inline bool bn_held_plan(const BnPlan& p, uint32_t flags, int block, int max_ept
     static const int64_t forced = [] { const char* e = getenv("URSA_BN_HELD_MIN_MIB"); return e && e[0] ? ((int64_t)atoll(e) << 20) / 16 : (int64_t)-1; }();
     if (forced >= 0) min_float4 = forced;
     static const bool no_lds = [] { const char* e = getenv("URSA_BN_HELD_NO_LDS"); return e && e[0] && e[0] != '0'; }();   // registers only
-    if (no_lds) max_lx = 0;
+    if (no_lds) lds_ok = false;
 #endif
     if (per_ch * p.g.C >= (1ll << 31) || per_ch * p.g.C < min_float4) return false;
-    // the LARGEST chunk: fewer, larger pieces per channel = fewer workgroups to wait for and more bytes resident. (Measured
-    // the other way round - the smallest chunk that still gives <= 64 pieces, for more workgroups - [1024,128,16,16] 59 ->
-    // 123 us forward, 96 -> 129 backward; and at the workload's own cache-resident layers the held form takes twice the two
-    // launches' time, [128,16,32,32] 14 vs 7 us: the thresholds above stay.) First with the LDS-held extension (max_lx more
-    // float4 per thread), then with registers alone.
-    for (int lx = max_lx; lx >= 0; lx -= (max_lx > 0 ? max_lx : 1)) {
-        const int64_t cap = (int64_t)block * (max_ept + lx);
+    // Per shape: pieces S, chunk, and how full the launch's last round of `resident` workgroups is. The first (largest)
+    // shape whose rounds are >= 80 % full is taken - [128,160,32,32] in two pieces per channel is 320 workgroups on 256 CUs,
+    // 1.25 rounds: three pieces (480) run the residual form in 72 us instead of 79 - else the fullest.
+    int pick = -1;
+    double pick_fill = 0.0;
+    int64_t pick_S = 0, pick_chunk = 0;
+    for (int k = 0; k < NSHAPES; ++k) {
+        if (shapes[k].lx > 0 && !lds_ok) continue;
+        const int64_t cap = (int64_t)block * (shapes[k].ept + shapes[k].lx);
         int64_t S = (per_ch + cap - 1) / cap;
-        if (S < 2 || S > kBnMaxSplit) { if (lx == 0) return false; continue; }
+        if (S < 2) continue;                                    // the channel fits one such piece: a smaller shape
+        if (S > max_split) break;                               // (smaller shapes only give more pieces)
         int64_t chunk = (per_ch + S - 1) / S;
         chunk = (chunk + block - 1) / block * block;
         S = (per_ch + chunk - 1) / chunk;
-        if (S < 2 || S * p.g.C < 256 || S * p.g.C >= (1ll << 31)) { if (lx == 0) return false; continue; }
-        const int need = (int)(chunk / block);
-        if (lx > 0 && need <= max_ept) continue;               // fits the registers: the register-only kernels
-        h->S = (int)S;
-        h->chunk = (int)chunk;
-        h->lx = lx;
-        h->ept = lx > 0 ? max_ept : need <= max_ept / 4 ? max_ept / 4 : need <= max_ept / 2 ? max_ept / 2 : max_ept;
-        return true;
+        const int64_t wgs = S * p.g.C;
+        if (S < 2 || S > max_split || wgs < 256 || wgs >= (1ll << 31)) continue;
+        const double fill = resident > 0 ? (double)wgs / (double)((wgs + resident - 1) / resident * resident) : 1.0;
+        if (pick < 0 || fill > pick_fill) { pick = k; pick_fill = fill; pick_S = S; pick_chunk = chunk; }
+        if (fill >= 0.8) break;
     }
-    return false;
+    if (pick < 0) return false;
+    const int need = (int)(pick_chunk / block);
+    int best = pick;                                            // the smallest compiled shape that holds `need` float4 per thread
+    for (int m = 0; m < NSHAPES; ++m) {
+        if (shapes[m].lx > 0 && !lds_ok) continue;
+        const int cm = shapes[m].ept + shapes[m].lx, cb = shapes[best].ept + shapes[best].lx;
+        if (cm >= need && (cm < cb || (cm == cb && shapes[m].lx < shapes[best].lx))) best = m;
+    }
+    h->S = (int)pick_S;
+    h->chunk = (int)pick_chunk;
+    h->ept = shapes[best].ept;
+    h->lx = shapes[best].lx;
+    return true;
 }
+constexpr BnHeldShape kHeldFwdShapes[] = {{kHeldFwdEpt, kHeldFwdLx}, {kHeldFwdEpt, 0}, {kHeldFwdEpt / 2, kHeldFwdLx}, {kHeldFwdEpt / 2, 0}};
+constexpr BnHeldShape kHeldBwdShapes[] = {{kHeldBwdEpt, kHeldBwdLx}, {kHeldBwdEpt, 0}};
+// Most pieces per channel. A launch cannot starve while S of its workgroups fit the chip beside the other held launches in
+// flight: with K launches sharing R resident workgroups, all of them starve only if sum (S_k - 1) >= R. The backward has
+// R = 512 (two workgroups per CU) and S <= 64; the forward, one workgroup per CU, R = 256 and therefore S <= 32: either way
+// K <= 8 launches (8 x 63 / 2 = 252 and 8 x 31 = 248 CUs' worth, and any mix in between, < 256) - the bound ChainGroup keeps.
+constexpr int kHeldFwdMaxSplit = 32, kHeldBwdMaxSplit = kBnMaxSplit;
 
 // One-pass form: float4 accesses, the channel fits one workgroup's registers, 32-bit float4 offsets suffice, and there
 // are enough channels (= workgroups) to spread over the CUs. Measured (tools/exp/bn_fused_bench.py): [128,64,8,8] forward
@@ -1250,7 +1306,7 @@ static int bn_fwd_impl(const float* x, const float* addend, float* z_out, float*
         return bn_launch_status();
     }
     BnHeld hd;
-    if (!bn_one_pass(p, flags) && bn_held_plan(p, flags, kHeldFwdBlock, kHeldFwdEpt, addend ? 0 : kHeldFwdLx, kHeldMinFloat4Fwd, &hd)) {
+    if (!bn_one_pass(p, flags) && bn_held_plan(p, flags, kHeldFwdBlock, kHeldFwdShapes, /*lds_ok=*/addend == nullptr, kHeldFwdMaxSplit, /*resident=*/256, addend ? kHeldMinFloat4FwdAdd : kHeldMinFloat4Fwd, &hd)) {
         BnGeom gh = p.g;
         gh.chunk = hd.chunk;
         // the held form's own part of ws (slots, then counters): the two-launch form's partials never touch it
@@ -1264,11 +1320,12 @@ static int bn_fwd_impl(const float* x, const float* addend, float* z_out, float*
                                running_mean, running_var, save_mean, save_invstd, eps, momentum, gh, hd.S); \
     else hipLaunchKernelGGL((k_bn_fwd_held<R, A, E, L, false>), gg, bb, 0, st, x, addend, z_out, y, slots, sync, gamma, beta, \
                             running_mean, running_var, save_mean, save_invstd, eps, momentum, gh, hd.S); } while (0)
-#define URSA_BN_HELD_F(R, A) do { if (hd.ept == kHeldFwdEpt / 4) URSA_BN_HELD_E(R, A, kHeldFwdEpt / 4, 0); \
-                                  else if (hd.ept == kHeldFwdEpt / 2) URSA_BN_HELD_E(R, A, kHeldFwdEpt / 2, 0); else URSA_BN_HELD_E(R, A, kHeldFwdEpt, 0); } while (0)
-        if (hd.lx > 0) { if (relu) URSA_BN_HELD_E(true, false, kHeldFwdEpt, kHeldFwdLx); else URSA_BN_HELD_E(false, false, kHeldFwdEpt, kHeldFwdLx); }
+#define URSA_BN_HELD_F(R, A) do { if (hd.ept == kHeldFwdEpt / 2) URSA_BN_HELD_E(R, A, kHeldFwdEpt / 2, 0); else URSA_BN_HELD_E(R, A, kHeldFwdEpt, 0); } while (0)
+#define URSA_BN_HELD_L(R) do { if (hd.ept == kHeldFwdEpt / 2) URSA_BN_HELD_E(R, false, kHeldFwdEpt / 2, kHeldFwdLx); else URSA_BN_HELD_E(R, false, kHeldFwdEpt, kHeldFwdLx); } while (0)
+        if (hd.lx > 0) { if (relu) URSA_BN_HELD_L(true); else URSA_BN_HELD_L(false); }
         else if (relu) { if (addend) URSA_BN_HELD_F(true, true); else URSA_BN_HELD_F(true, false); }
         else           { if (addend) URSA_BN_HELD_F(false, true); else URSA_BN_HELD_F(false, false); }
+#undef URSA_BN_HELD_L
 #undef URSA_BN_HELD_F
 #undef URSA_BN_HELD_E
         return bn_launch_status();
@@ -1391,7 +1448,7 @@ static int bn_bwd_impl(const float* x, const float* dy, const float* dz, float* 
         return bn_launch_status();
     }
     BnHeld hd;
-    if (!bn_one_pass(p, flags) && bn_held_plan(p, flags, kHeldBwdBlock, kHeldBwdEpt, kHeldBwdLx, kHeldMinFloat4Bwd, &hd)) {
+    if (!bn_one_pass(p, flags) && bn_held_plan(p, flags, kHeldBwdBlock, kHeldBwdShapes, /*lds_ok=*/true, kHeldBwdMaxSplit, /*resident=*/0 /* the largest shape, as measured */, kHeldMinFloat4Bwd, &hd)) {
         BnGeom gh = p.g;
         gh.chunk = hd.chunk;
         // the held form's own part of ws (slots, then counters): the two-launch form's partials never touch it
@@ -1404,9 +1461,7 @@ static int bn_bwd_impl(const float* x, const float* dy, const float* dz, float* 
                                save_invstd, dgamma, dbeta, gh, hd.S); \
     else hipLaunchKernelGGL((k_bn_bwd_held<R, A, E, L, false>), gg, bb, 0, st, x, dy, dz, dx, slots, sync, gamma, beta, save_mean, \
                             save_invstd, dgamma, dbeta, gh, hd.S); } while (0)
-#define URSA_BN_HELD_B(R, A) do { if (hd.lx > 0) URSA_BN_HELD_E(R, A, kHeldBwdEpt, kHeldBwdLx); \
-                                  else if (hd.ept == kHeldBwdEpt / 4) URSA_BN_HELD_E(R, A, kHeldBwdEpt / 4, 0); \
-                                  else if (hd.ept == kHeldBwdEpt / 2) URSA_BN_HELD_E(R, A, kHeldBwdEpt / 2, 0); else URSA_BN_HELD_E(R, A, kHeldBwdEpt, 0); } while (0)
+#define URSA_BN_HELD_B(R, A) do { if (hd.lx > 0) URSA_BN_HELD_E(R, A, kHeldBwdEpt, kHeldBwdLx); else URSA_BN_HELD_E(R, A, kHeldBwdEpt, 0); } while (0)
         if (relu) { if (dz) URSA_BN_HELD_B(true, true); else URSA_BN_HELD_B(true, false); }
         else      { if (dz) URSA_BN_HELD_B(false, true); else URSA_BN_HELD_B(false, false); }
 #undef URSA_BN_HELD_B

@@ -27,7 +27,7 @@ from . import _native
 
 _on = os.environ.get('URSA_FUSED_BN', '1') != '0'
 _two_launch = os.environ.get('URSA_BN_TWO_LAUNCH', '0') == '1'     # A/B: never take the one-pass / held form
-_held = os.environ.get('URSA_BN_HELD', '1') != '0'                 # activations >= 24 MiB: ONE launch, inputs read once
+_held = os.environ.get('URSA_BN_HELD', '1') != '0'                 # large activations (backward >= 24 MiB, forward >= 48 / 32 MiB): ONE launch, inputs read once
 
 
 def held(flag=None):
