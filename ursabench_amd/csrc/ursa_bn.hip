@@ -107,6 +107,24 @@ __device__ __forceinline__ void bn_block_sum2(F& a, F& b, F* sh)
 
 __device__ inline float bn_relu_fwd(float v) { return v < 0.f ? 0.f : v; }   // NaN stays NaN
 
+// Streaming accesses for tensors beyond the Infinity Cache (NT = true): nontemporal loads / stores
+// (per-component builtins: the compiler merges them into one global_load/store_dwordx4 ... nt, as in ursa_kernels.hip)
+template <bool NT> __device__ __forceinline__ float4 bn_ld(const float4* p)
+{
+    if (!NT) return *p;
+    float4 r;
+    r.x = __builtin_nontemporal_load(&p->x); r.y = __builtin_nontemporal_load(&p->y);
+    r.z = __builtin_nontemporal_load(&p->z); r.w = __builtin_nontemporal_load(&p->w);
+    return r;
+}
+template <bool NT> __device__ __forceinline__ void bn_st(float4* p, const float4& v)
+{
+    if (!NT) { *p = v; return; }
+    __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y);
+    __builtin_nontemporal_store(v.z, &p->z); __builtin_nontemporal_store(v.w, &p->w);
+}
+
+
 // ---- forward, launch 1: partial statistics (ADD: of z = x + addend, the residual sum, which is written out) --------
 template <int V, bool ADD>
 __global__ __launch_bounds__(kBnBlock) void k_bn_stats(const float* __restrict__ x, const float* __restrict__ addend,
@@ -217,9 +235,14 @@ __global__ __launch_bounds__(kBnBlock) void k_bn_fwd_apply(const float* __restri
     }
 }
 
+template <bool NT> __device__ __forceinline__ float ev_ld(const float* p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+template <bool NT> __device__ __forceinline__ float4 ev_ld(const float4* p) { return bn_ld<NT>(p); }
+template <bool NT> __device__ __forceinline__ void ev_st(float* p, const float& v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
+template <bool NT> __device__ __forceinline__ void ev_st(float4* p, const float4& v) { bn_st<NT>(p, v); }
+
 // ---- evaluation mode: y = relu(gamma * (x - running_mean) / sqrt(running_var + eps) + beta), one launch;
 //      ADD: of z = x + addend, which is written out too -----------------------------------------------------------
-template <int V, bool RELU, bool ADD>
+template <int V, bool RELU, bool ADD, bool NT = false>
 __global__ __launch_bounds__(kBnBlock) void k_bn_eval(const float* __restrict__ x, const float* __restrict__ addend,
                                                       float* __restrict__ z, float* __restrict__ y,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -242,13 +265,13 @@ __global__ __launch_bounds__(kBnBlock) void k_bn_eval(const float* __restrict__ 
         T v[4], w[4];
         int64_t o[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { o[u] = bn_off(g, c, i + u * kBnBlock); v[u] = xv[o[u]]; if (ADD) w[u] = av[o[u]]; }
+        for (int u = 0; u < 4; ++u) { o[u] = bn_off(g, c, i + u * kBnBlock); v[u] = ev_ld<NT>(xv + o[u]); if (ADD) w[u] = ev_ld<NT>(av + o[u]); }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if (ADD) { v[u] = vadd(v[u], w[u]); zv[o[u]] = v[u]; }
+            if (ADD) { v[u] = vadd(v[u], w[u]); ev_st<NT>(zv + o[u], v[u]); }
 #pragma unroll
             for (int k = 0; k < V; ++k) { const float t = fmaf(comp(v[u], k), scale, shift); setc(v[u], k, RELU ? bn_relu_fwd(t) : t); }
-            yv[o[u]] = v[u];
+            ev_st<NT>(yv + o[u], v[u]);
         }
     }
     for (; i < hi; i += kBnBlock) {
@@ -713,22 +736,6 @@ __device__ __forceinline__ void bn_block_sum2_n(double& a, double& b, double* sh
     for (int w = 0; w < BLOCK / 64; ++w) { a += sh[2 * w]; b += sh[2 * w + 1]; }
 }
 
-// (per-component builtins: the compiler merges them into one global_load/store_dwordx4 ... nt, as in ursa_kernels.hip)
-template <bool NT> __device__ __forceinline__ float4 bn_ld(const float4* p)
-{
-    if (!NT) return *p;
-    float4 r;
-    r.x = __builtin_nontemporal_load(&p->x); r.y = __builtin_nontemporal_load(&p->y);
-    r.z = __builtin_nontemporal_load(&p->z); r.w = __builtin_nontemporal_load(&p->w);
-    return r;
-}
-template <bool NT> __device__ __forceinline__ void bn_st(float4* p, const float4& v)
-{
-    if (!NT) { *p = v; return; }
-    __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y);
-    __builtin_nontemporal_store(v.z, &p->z); __builtin_nontemporal_store(v.w, &p->w);
-}
-
 // LDS-DMA (global_load_lds_dwordx4): a load that lands in LDS without passing through registers - lane l of the wave writes
 // 16 bytes at (wave-uniform base) + 16 l. The held forms use it to hold MORE of the channel per workgroup than the register
 // file alone allows (what bounds them is bytes resident x 1 / residency time, §held forms): LX further float4 per thread.
@@ -1139,6 +1146,15 @@ struct BnPlan {
     int V;
 };
 
+inline bool bn_eval_no_nt()           // knob (A/B): URSA_BN_EVAL_NO_NT=1 keeps the evaluation launch's accesses temporal
+{
+#ifdef URSA_DEBUG_KNOBS
+    static const bool v = [] { const char* e = getenv("URSA_BN_EVAL_NO_NT"); return e && e[0] && e[0] != '0'; }();
+    return v;
+#else
+    return false;
+#endif
+}
 inline bool bn_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline bool bn_aligned4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
 
@@ -1394,8 +1410,11 @@ int ursa_bn_relu_eval_f32(const float* x, const float* addend, float* z_out, flo
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(p.S, p.g.C), block(kBnBlock);
     const bool relu = flags & URSA_BN_RELU;
-#define URSA_BN_EVAL(V, R, A) \
-    hipLaunchKernelGGL((k_bn_eval<V, R, A>), grid, block, 0, st, x, addend, z_out, y, gamma, beta, running_mean, running_var, eps, p.g)
+    // beyond the 256 MiB Infinity Cache the streams go past it (as K1-K4 and the held forms do)
+    const bool nt = p.V == 4 && N * C * HW * 4 * (addend ? 4 : 2) > (256ll << 20) && !bn_eval_no_nt();
+#define URSA_BN_EVAL(V, R, A) do { \
+    if (nt) hipLaunchKernelGGL((k_bn_eval<V, R, A, true>), grid, block, 0, st, x, addend, z_out, y, gamma, beta, running_mean, running_var, eps, p.g); \
+    else hipLaunchKernelGGL((k_bn_eval<V, R, A, false>), grid, block, 0, st, x, addend, z_out, y, gamma, beta, running_mean, running_var, eps, p.g); } while (0)
 #define URSA_BN_EVAL2(V, R) do { if (addend) URSA_BN_EVAL(V, R, true); else URSA_BN_EVAL(V, R, false); } while (0)
     if (p.V == 4) { if (relu) URSA_BN_EVAL2(4, true); else URSA_BN_EVAL2(4, false); }
     else          { if (relu) URSA_BN_EVAL2(1, true); else URSA_BN_EVAL2(1, false); }
