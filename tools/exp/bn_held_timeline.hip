@@ -1,6 +1,6 @@
 // Experiment: where a workgroup of K6's held forward spends its time (the chunk sits in registers from the first load to
 // the last store). Includes csrc/ursa_bn.hip itself (its kernels live in an anonymous namespace) and re-times a copy of
-// k_bn_fwd_held<true,false,16,true> with wall_clock64 stamps between the phases; argv: [stagger groups] [stagger sleep 20|40|80]
+// k_bn_fwd_held<true,false,EPT,0,true> (registers only; TL_BLOCK_THREADS x TL_EPT) with wall_clock64 stamps between the phases; argv: [stagger groups] [stagger sleep 20|40|80]
 // (delaying the first residency's channels to de-phase loads and stores: measured, no gain).
 // Measured at [1024,64,32,32] (r04): ticket 3.3 us, load + reduce 9.4, publish 2.0, wait 8.4, merge 2.6, apply 3.9 = 29.5 us per
 // workgroup, 4 residencies of 1,024 workgroups -> 139 us; the chunk is held in registers all that time.
@@ -10,14 +10,21 @@
 #include <vector>
 #include <algorithm>
 
+#ifndef TL_BLOCK_THREADS
+#define TL_BLOCK_THREADS 512       // the shipped forward shape's workgroup (round 4's first shape: -DTL_BLOCK_THREADS=256 -DTL_EPT=16)
+#endif
+#ifndef TL_EPT
+#define TL_EPT 32
+#endif
 namespace {
-constexpr int EPT = 16;
+constexpr int TL_BLOCK = TL_BLOCK_THREADS;
+constexpr int EPT = TL_EPT;
 template <int stagger_sleep>
-__global__ __launch_bounds__(kHeldFwdBlock) void k_tl(const float* __restrict__ x, float* __restrict__ y, bn_u64* slots_base, BnSync* sync,
+__global__ __launch_bounds__(TL_BLOCK) void k_tl(const float* __restrict__ x, float* __restrict__ y, bn_u64* slots_base, BnSync* sync,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta, BnGeom g, int S,
                                                      long long* stamps /* [grid][8] */, int stagger_groups)
 {
-    __shared__ double sh[2 * kHeldFwdBlock / 64];
+    __shared__ double sh[2 * TL_BLOCK / 64];
     __shared__ float shf[2];
     __shared__ int sh_item[2];
     long long t0 = wall_clock64();
@@ -39,7 +46,7 @@ __global__ __launch_bounds__(kHeldFwdBlock) void k_tl(const float* __restrict__ 
     float4 v[EPT];
 #pragma unroll
     for (int u = 0; u < EPT; ++u) {
-        const int i = lo + threadIdx.x + u * kHeldFwdBlock;
+        const int i = lo + threadIdx.x + u * TL_BLOCK;
         v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i < hi) v[u] = bn_ld<true>(xv + bn_off32(g, c, i));
     }
@@ -48,7 +55,7 @@ __global__ __launch_bounds__(kHeldFwdBlock) void k_tl(const float* __restrict__ 
     for (int u = 0; u < EPT; ++u)
 #pragma unroll
         for (int k = 0; k < 4; ++k) { const double d = (double)comp(v[u], k); s1 += d; s2 = fma(d, d, s2); }
-    bn_block_sum2_n<kHeldFwdBlock>(s1, s2, sh);
+    bn_block_sum2_n<TL_BLOCK>(s1, s2, sh);
     long long t2 = wall_clock64();
     bn_u64* slots = slots_base + (int64_t)c * kBnMaxSplit * 2;
     if (threadIdx.x == 0) bn_publish(slots + 2 * sp, s1, s2);
@@ -74,7 +81,7 @@ __global__ __launch_bounds__(kHeldFwdBlock) void k_tl(const float* __restrict__ 
     const float scale = shf[0], shift = shf[1];
 #pragma unroll
     for (int u = 0; u < EPT; ++u) {
-        const int i = lo + threadIdx.x + u * kHeldFwdBlock;
+        const int i = lo + threadIdx.x + u * TL_BLOCK;
         if (i < hi) {
             float4 r;
 #pragma unroll
@@ -107,7 +114,8 @@ int main(int argc, char** argv)
     BnPlan p;
     bn_plan(N, C, HW, true, &p);
     BnHeld hd;
-    if (!bn_held_plan(p, URSA_BN_HELD, kHeldFwdBlock, kHeldFwdEpt, 0, kHeldMinFloat4Fwd, &hd)) { printf("not eligible\n"); return 1; }
+    const BnHeldShape shapes[] = {{EPT, 0}};
+    if (!bn_held_plan(p, URSA_BN_HELD, TL_BLOCK, shapes, false, kBnMaxSplit, 0, 0, &hd)) { printf("not eligible\n"); return 1; }
     BnGeom gh = p.g; gh.chunk = hd.chunk;
     const int grid = hd.S * (int)C;
     long long* st;
@@ -115,9 +123,9 @@ int main(int argc, char** argv)
     BnSync* sync = reinterpret_cast<BnSync*>(ws + C * kBnMaxSplit * 8);
     const int sg = argc > 1 ? atoi(argv[1]) : 0;
     for (int rep = 0; rep < 3; ++rep) {
-        if (argc > 2 && atoi(argv[2]) == 20) hipLaunchKernelGGL(k_tl<20>, dim3(grid), dim3(kHeldFwdBlock), 0, 0, x, y, reinterpret_cast<bn_u64*>(ws + C * kBnMaxSplit * 4), sync, gam, bet, gh, hd.S, st, sg);
-        else if (argc > 2 && atoi(argv[2]) == 80) hipLaunchKernelGGL(k_tl<80>, dim3(grid), dim3(kHeldFwdBlock), 0, 0, x, y, reinterpret_cast<bn_u64*>(ws + C * kBnMaxSplit * 4), sync, gam, bet, gh, hd.S, st, sg);
-        else hipLaunchKernelGGL(k_tl<40>, dim3(grid), dim3(kHeldFwdBlock), 0, 0, x, y, reinterpret_cast<bn_u64*>(ws + C * kBnMaxSplit * 4), sync, gam, bet, gh, hd.S, st, sg);
+        if (argc > 2 && atoi(argv[2]) == 20) hipLaunchKernelGGL(k_tl<20>, dim3(grid), dim3(TL_BLOCK), 0, 0, x, y, reinterpret_cast<bn_u64*>(ws + C * kBnMaxSplit * 4), sync, gam, bet, gh, hd.S, st, sg);
+        else if (argc > 2 && atoi(argv[2]) == 80) hipLaunchKernelGGL(k_tl<80>, dim3(grid), dim3(TL_BLOCK), 0, 0, x, y, reinterpret_cast<bn_u64*>(ws + C * kBnMaxSplit * 4), sync, gam, bet, gh, hd.S, st, sg);
+        else hipLaunchKernelGGL(k_tl<40>, dim3(grid), dim3(TL_BLOCK), 0, 0, x, y, reinterpret_cast<bn_u64*>(ws + C * kBnMaxSplit * 4), sync, gam, bet, gh, hd.S, st, sg);
     }
     hipDeviceSynchronize();
     std::vector<long long> hs((int64_t)grid * 8);
@@ -127,7 +135,7 @@ int main(int argc, char** argv)
     double sum[6] = {0};
     for (int t = 0; t < grid; ++t) for (int k = 0; k < 6; ++k) sum[k] += (double)(hs[t * 8 + k + 1] - hs[t * 8 + k]);
     const char* names[6] = {"ticket", "load+reduce", "publish", "gather (wait + read)", "scalars + barrier", "apply + store issue + leave"};
-    printf("S=%d chunk=%d grid=%d  kernel span %lld cycles (wall_clock64: 100 MHz => %.1f us)\n", hd.S, hd.chunk, grid, last - first, (last - first) / 100.0);
+    printf("%d threads per workgroup, %d float4 per thread in registers: S=%d chunk=%d grid=%d  kernel span %lld cycles (wall_clock64: 100 MHz => %.1f us)\n", TL_BLOCK, EPT, hd.S, hd.chunk, grid, last - first, (last - first) / 100.0);
     for (int k = 0; k < 6; ++k) printf("  %-18s mean %.2f us\n", names[k], sum[k] / grid / 100.0);
     // start-time histogram: how many workgroups start in each 10 us slice
     int hist[64] = {0};

@@ -19,7 +19,7 @@ a)  # kernel micro-benchmarks and diagnostics
   python3 tools/exp/k3_spread.py > $out/k3_spread.log 2>&1; echo "k3_spread rc=$?"; cp gpurun_out/k3_spread.json $out/r04_k3_spread.json
   python3 tools/exp/bn_fused_bench.py > $out/r04_bn_fused_bench.json 2> $out/bn_fused_bench.err; echo "bn_fused_bench rc=$?"
   python3 tools/exp/bn_held_ab.py > $out/r04_bn_held_ab.json 2> $out/bn_held_ab.err; echo "bn_held_ab rc=$?"
-  (/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -w -o /tmp/bn_tl tools/exp/bn_held_timeline.hip 2>/dev/null && timeout -k 5 60 /tmp/bn_tl > $out/r04_bn_held_timeline.txt); echo "bn_held_timeline rc=$?"
+  (/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -w -o /tmp/bn_tl tools/exp/bn_held_timeline.hip 2>/dev/null && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -w -DTL_BLOCK_THREADS=256 -DTL_EPT=16 -o /tmp/bn_tl256 tools/exp/bn_held_timeline.hip 2>/dev/null && timeout -k 5 60 /tmp/bn_tl > $out/r04_bn_held_timeline.txt && timeout -k 5 60 /tmp/bn_tl256 >> $out/r04_bn_held_timeline.txt); echo "bn_held_timeline rc=$?"
   python3 tools/exp/grouped_conv_ab.py > $out/r04_grouped_conv_ab.json 2> $out/grouped_conv_ab.err; echo "grouped_conv_ab rc=$?"
   K5_ONLY=prefetch,no_prefetch python3 tools/k5_bench.py 30 10000 100 30 10000 64 30 10000 128 30 10000 256 > $out/r04_k5_prefetch_ab.txt 2>&1; echo "k5 prefetch A/B rc=$?"
   # the gate-conditioned parity report (G16, eight seeds, K6 vs stock launches paired): written by the GPU test itself

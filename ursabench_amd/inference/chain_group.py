@@ -72,8 +72,8 @@ class ChainGroup:
             s.engine.finish(keep)
 
     def _forward_backward(self, s, x, y):
-        """K6's held form (activations >= 24 MiB) needs <= 8 of its launches in flight at once to be deadlock-free
-        (csrc/ursa_bn.hip): larger groups keep the two-launch form."""
+        """K6's held form (large activations: >= 24 MiB backward, >= 48 / 32 MiB forward) needs <= 8 of its launches in
+        flight at once to be deadlock-free (csrc/ursa_bn.hip, kHeld*MaxSplit): larger groups keep the two-launch form."""
         if len(self.samplers) <= 8:
             return s.engine.forward_backward(x, y)
         from .. import fused_bn
