@@ -302,8 +302,10 @@ def test_fused_layers_replay_inside_a_hipgraph():
     m.load_state_dict(state)
     g.replay()
     torch.cuda.synchronize()
-    for a, b in zip(grads, eager):      # MIOpen's split-K weight gradients add with atomics: not bit-reproducible
-        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6 * float(b.abs().max()))
+    for a, b in zip(grads, eager):      # MIOpen's split-K weight gradients add with atomics: not bit-reproducible, and an
+        # element that nearly cancels carries the rounding of its largest terms - judged on the tensor's own scale
+        # (a 1e-6 bound failed once in ~10 runs of the suite on one element of the first convolution's gradient)
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5 * float(b.abs().max()))
 
 
 @pytest.mark.parametrize('shape', [(128, 16, 32, 32), (128, 64, 8, 8), (33, 6, 5, 3), (16, 160, 16, 16)])
