@@ -582,6 +582,57 @@ def test_held_form_equals_two_launch_form(K, shape, relu):
                 assert torch.equal(t1, t2), name
 
 
+def test_eight_held_launches_in_flight_at_their_largest_splits():
+    """The bound csrc/ursa_bn.hip states (kHeld*MaxSplit): K <= 8 held launches may share the chip because
+    sum (S_k - 1) stays below the workgroups resident - exercised at the LARGEST splits: four forward launches of 32 pieces
+    per channel and four backward launches of 64, on eight streams at once, three rounds. A starved launch would run into
+    its bounded wait: error word set, sync words dirty, wrong numbers."""
+    from ursabench_amd import _native
+    K = _native.default_kernels()
+    C = 8
+    fshape, bshape = (2624, C, 32, 32), (1536, C, 32, 32)      # 671,744 / 393,216 float4 per channel: 32 / 64 pieces
+    g = torch.Generator().manual_seed(11)
+    w, bb = (torch.rand(C, generator=g) + 0.5).cuda(), torch.randn(C, generator=g).cuda()
+    xs = [torch.randn(fshape, generator=g).cuda() for _ in range(4)]
+    bx = [(torch.randn(bshape, generator=g).cuda(), torch.randn(bshape, generator=g).cuda()) for _ in range(4)]
+    new = lambda: torch.empty(C, device='cuda')
+    ref_y, ref_dx, stats = [], [], []
+    for x in xs:
+        y, sm, si = torch.empty_like(x), new(), new()
+        K.bn_relu_forward(x, y, w, bb, None, None, sm, si, torch.empty(_native.bn_ws_floats(C), device='cuda'), eps=1e-5, momentum=0.0,
+                          two_launch=True)
+        ref_y.append(y)
+    for x, dy in bx:
+        y, sm, si, dx = torch.empty_like(x), new(), new(), torch.empty_like(x)
+        wsb = torch.empty(_native.bn_ws_floats(C), device='cuda')
+        K.bn_relu_forward(x, y, w, bb, None, None, sm, si, wsb, eps=1e-5, momentum=0.0, two_launch=True)
+        K.bn_relu_backward(x, dy, dx, w, bb, sm, si, new(), new(), wsb, two_launch=True)
+        ref_dx.append(dx)
+        stats.append((sm, si))
+        del y
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(8)]
+    wss = [torch.zeros(_native.bn_ws_floats(C), device='cuda') for _ in range(8)]
+    got_y = [torch.empty_like(x) for x in xs]
+    got_dx = [torch.empty_like(x) for x, _ in bx]
+    fstats = [(new(), new()) for _ in range(4)]
+    dgb = [(new(), new()) for _ in range(4)]
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for k in range(4):
+            with torch.cuda.stream(streams[k]):
+                K.bn_relu_forward(xs[k], got_y[k], w, bb, None, None, fstats[k][0], fstats[k][1], wss[k], eps=1e-5, momentum=0.0, held=True)
+            with torch.cuda.stream(streams[4 + k]):
+                K.bn_relu_backward(bx[k][0], bx[k][1], got_dx[k], w, bb, stats[k][0], stats[k][1], dgb[k][0], dgb[k][1], wss[4 + k], held=True)
+    torch.cuda.synchronize()
+    for k in range(8):
+        assert not _sync_words(wss[k], C).any(), f'launch {k}: bounded wait ran out or sync words not re-armed'
+        assert not wss[k][:C * 256].any(), f'launch {k}: the two-launch partials were written - the held form did not run'
+    for k in range(4):
+        assert torch.equal(got_y[k], ref_y[k])
+        assert torch.equal(got_dx[k], ref_dx[k])
+
+
 def test_held_form_on_parallel_streams_and_through_the_module_path():
     """(a) Four held launches in flight at once on four streams (what a ChainGroup's branches do): all drain, all
     correct - a launch only ever waits for workgroups of its own that are already running. (b) fused_bn picks the held
