@@ -278,7 +278,10 @@ int ursa_sumsq_f32(const float* x, int64_t n, float* out, float* ws, ursa_stream
                                       channels do not fit one workgroup (per-channel workgroups hold their chunk in registers,
                                       exchange double partial sums through ws and wait for each other; bounded wait; that part
                                       of ws is zero again when the launch has drained and no other form writes there, so a ws
-                                      zeroed once can be reused call after call). Same floats as the two-launch form. Without
+                                      zeroed once can be reused call after call). Same floats as the two-launch form. ONE such launch
+                                      in flight per device at a time: launches that may overlap with other BatchNorm launches on the
+                                      device (parallel streams / graph branches) must not carry the flag (they can starve each other
+                                      into the bounded wait: error word in ws, wrong numbers). Without
                                       the flag ws needs no initialisation and the held form is never taken. */
 #define URSA_BN_ALLFLAGS    0x7u
 /* [two-launch form: partial sums, C x 64 x {double, double}] [held form: its partial-sum slots, the same size; then its

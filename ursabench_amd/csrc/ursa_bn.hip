@@ -601,11 +601,15 @@ __global__ __launch_bounds__(kOneBlock) void k_bn_bwd_one(const float* __restric
 // scalars, no broadcast) and finish from registers: one launch, every byte read once.
 //   * Work is handed out by ticket (one atomic per workgroup), channel-major: ticket t -> channel t / S, chunk t % S. A
 //     workgroup only ever waits for partials of its own channel, and tickets are drawn in order by workgroups that are
-//     RUNNING - so the launch cannot deadlock as long as S workgroups of it can be resident at once; with K such launches
-//     sharing the chip from parallel graph branches none starves while sum (S_k - 1) stays below the resident workgroups:
-//     safe up to K = 8 with S <= 64 backward (512 resident) and S <= 32 forward (256 resident), kHeld*MaxSplit below. A
-//     ticket queue per XCD (a channel's workgroups on one L2) was tried: no faster, and it needs 8 x 63 + 64 resident
-//     workgroups - the backward form, 512 resident, ran into its bounded wait. The wait is bounded all the same: after ~3 s a workgroup raises the err word and goes on with what it
+//     RUNNING - so ONE launch cannot deadlock as long as S workgroups of it can be resident at once WHEREVER the hardware
+//     puts them: workgroups go to the 8 XCDs round-robin by index while tickets are drawn in start order, so all S pieces
+//     of a channel can land on the slowest XCD, which holds 32 forward / 64 backward workgroups - hence S <= 32 / 64
+//     (kHeld*MaxSplit below). SEVERAL held launches in flight at once can starve one another (each keeps some pieces
+//     resident and waits for the rest): safe only while sum (S_k - 1) stays below those 32 / 64, and measured to fail
+//     otherwise (tools/exp/bn_held_concurrency.py: two to eight launches at the largest splits ran into the bounded wait in
+//     8-23 of 40 trials). The contract is therefore ONE held launch in flight per device; callers that overlap BatchNorm
+//     launches (ChainGroup's branches, bn_update_many's member streams) do not pass URSA_BN_HELD. A ticket queue per XCD (a
+//     channel's workgroups on one L2) was tried: no faster, and it needs 8 x 63 + 64 resident workgroups. The wait is bounded all the same: after ~3 s a workgroup raises the err word and goes on with what it
 //     has, so a logic error ends in wrong numbers, never in a hung GPU.
 //   * Hand-off of the partials: each is two 8-byte words stored with agent-scope atomic stores as bits(value) XOR a NaN
 //     payload no sum can produce, so that ZERO means "not there yet"; wave 0 of every workgroup polls the channel's S
@@ -1269,10 +1273,8 @@ inline bool bn_held_plan(const BnPlan& p, uint32_t flags, int block, const BnHel
 }
 constexpr BnHeldShape kHeldFwdShapes[] = {{kHeldFwdEpt, kHeldFwdLx}, {kHeldFwdEpt, 0}, {kHeldFwdEpt / 2, kHeldFwdLx}, {kHeldFwdEpt / 2, 0}};
 constexpr BnHeldShape kHeldBwdShapes[] = {{kHeldBwdEpt, kHeldBwdLx}, {kHeldBwdEpt, 0}};
-// Most pieces per channel. A launch cannot starve while S of its workgroups fit the chip beside the other held launches in
-// flight: with K launches sharing R resident workgroups, all of them starve only if sum (S_k - 1) >= R. The backward has
-// R = 512 (two workgroups per CU) and S <= 64; the forward, one workgroup per CU, R = 256 and therefore S <= 32: either way
-// K <= 8 launches (8 x 63 / 2 = 252 and 8 x 31 = 248 CUs' worth, and any mix in between, < 256) - the bound ChainGroup keeps.
+// Most pieces per channel = the workgroups ONE XCD holds (32 CUs: one forward workgroup per CU, two backward ones): all
+// pieces of a channel may land on one XCD (see "held forms" above).
 constexpr int kHeldFwdMaxSplit = 32, kHeldBwdMaxSplit = kBnMaxSplit;
 
 // One-pass form: float4 accesses, the channel fits one workgroup's registers, 32-bit float4 offsets suffice, and there

@@ -32,13 +32,27 @@ _held = os.environ.get('URSA_BN_HELD', '1') != '0'                 # large activ
 
 def held(flag=None):
     """Query / set whether large activations may take K6's held form (one launch per direction; the channel's workgroups
-    hold their chunks in registers and wait for each other's partial sums). Off: the two-launch form. ChainGroup turns
-    it off for more chains than the chip can keep S workgroups resident for (csrc/ursa_bn.hip)."""
+    hold their chunks in registers and wait for each other's partial sums). Off: the two-launch form. The held form is for
+    ONE such launch in flight per device (csrc/ursa_bn.hip, "held forms": a second one can starve both): code that runs
+    training-mode forwards / backwards on several streams at once wraps them in `several_streams()`."""
     global _held
     old = _held
     if flag is not None:
         _held = bool(flag)
     return old
+
+
+class several_streams:
+    """Context: BatchNorm launches issued inside may overlap with others on the device (ChainGroup's parallel graph
+    branches, bn_update_many's member streams) - the held form is not taken."""
+
+    def __enter__(self):
+        self.old = held(False)
+        return self
+
+    def __exit__(self, *exc):
+        held(self.old)
+        return False
 
 
 TWIN_Y, TWIN_DX = 1, 2       # `twins` of bn_relu / add_bn_relu: which outputs the launches also store channels-last

@@ -72,16 +72,13 @@ class ChainGroup:
             s.engine.finish(keep)
 
     def _forward_backward(self, s, x, y):
-        """K6's held form (large activations: >= 24 MiB backward, >= 48 / 32 MiB forward) needs <= 8 of its launches in
-        flight at once to be deadlock-free (csrc/ursa_bn.hip, kHeld*MaxSplit): larger groups keep the two-launch form."""
-        if len(self.samplers) <= 8:
+        """The chains' forward / backward passes overlap on the device (parallel graph branches): K6's held form, which
+        is for one such launch in flight at a time (csrc/ursa_bn.hip), is not taken inside a group of several chains."""
+        if len(self.samplers) == 1:
             return s.engine.forward_backward(x, y)
         from .. import fused_bn
-        old = fused_bn.held(False)
-        try:
+        with fused_bn.several_streams():
             return s.engine.forward_backward(x, y)
-        finally:
-            fused_bn.held(old)
 
     def _round_eager(self, x, y):
         keeps = [self._forward_backward(s, x, y) for s in self.samplers]

@@ -8,6 +8,8 @@ import torch
 from torch.nn import CrossEntropyLoss
 from torch.nn.modules.batchnorm import _BatchNorm
 
+from . import fused_bn
+
 _random_seed = None
 
 
@@ -169,7 +171,8 @@ def bn_update_many(loader, models, subset=None, device=None, streams=None, **kwa
                         # read on the side stream: tell the caching allocator, or the block is handed to a later
                         # gather / copy on `cur` while this forward may still be reading it
                         x.record_stream(streams[k])
-                        with torch.cuda.stream(streams[k]):
+                        # (the members' forwards overlap on the device: K6's held form is for one launch at a time)
+                        with torch.cuda.stream(streams[k]), fused_bn.several_streams():
                             model(x, **kwargs)
                     else:
                         model(x, **kwargs)
