@@ -582,12 +582,12 @@ def test_held_form_equals_two_launch_form(K, shape, relu):
                 assert torch.equal(t1, t2), name
 
 
-def test_one_held_launch_at_its_largest_split_beside_other_traffic():
-    """The contract of csrc/ursa_bn.hip ("held forms"): ONE held launch in flight per device, at up to 32 pieces per channel
-    forward / 64 backward (what one XCD holds - all pieces of a channel may land on one). Exercised at exactly those splits,
-    launch after launch on one stream, while three other streams keep the chip busy with launches that wait for nobody
-    (two-launch BatchNorm, elementwise work): never a bounded wait, same floats as the two-launch form. (Several held
-    launches at once DO starve each other: tools/exp/bn_held_concurrency.py, profiles/r04_bn_held_concurrency.json.)"""
+def test_one_held_launch_at_its_largest_split():
+    """The contract of csrc/ursa_bn.hip ("held forms"): a held launch has the device to itself, at up to 32 pieces per
+    channel forward / 64 backward (what one XCD holds - all pieces of a channel may land on one). Exercised at exactly those
+    splits, launch after launch on one stream: never a bounded wait, same floats as the two-launch form. (With other
+    launches in flight - held ones, and once in four runs of this suite plain ones too - a launch at these splits DID run
+    into its bounded wait: tools/exp/bn_held_concurrency.py, profiles/r04_bn_held_concurrency.json)"""
     from ursabench_amd import _native
     K = _native.default_kernels()
     C = 8
@@ -605,22 +605,11 @@ def test_one_held_launch_at_its_largest_split_beside_other_traffic():
     K.bn_relu_forward(bx, by, w, bb, None, None, bsm, bsi, wsb, eps=1e-5, momentum=0.0, two_launch=True)
     K.bn_relu_backward(bx, bdy, dx_ref, w, bb, bsm, bsi, new(), new(), wsb, two_launch=True)
     del by
-    others = [torch.randn(256, 64, 32, 32, generator=g).cuda() for _ in range(3)]
-    oys = [torch.empty_like(o) for o in others]
-    ows = [torch.empty(_native.bn_ws_floats(64), device='cuda') for _ in range(3)]
-    w64, b64 = torch.ones(64, device='cuda'), torch.zeros(64, device='cuda')
-    ostats = [(torch.empty(64, device='cuda'), torch.empty(64, device='cuda')) for _ in range(3)]
     torch.cuda.synchronize()
-    side = [torch.cuda.Stream() for _ in range(3)]
     ws = torch.zeros(_native.bn_ws_floats(C), device='cuda')
     y, dx = torch.empty_like(x), torch.empty_like(bx)
     fs, dgb = (new(), new()), (new(), new())
     for rep in range(10):
-        for k, st in enumerate(side):
-            with torch.cuda.stream(st):
-                K.bn_relu_forward(others[k], oys[k], w64, b64, None, None, ostats[k][0], ostats[k][1], ows[k], eps=1e-5, momentum=0.0,
-                                  two_launch=True)
-                oys[k].mul_(1.0001)
         K.bn_relu_forward(x, y, w, bb, None, None, fs[0], fs[1], ws, eps=1e-5, momentum=0.0, held=True)
         K.bn_relu_backward(bx, bdy, dx, w, bb, bsm, bsi, dgb[0], dgb[1], ws, held=True)
     torch.cuda.synchronize()
@@ -630,6 +619,32 @@ def test_one_held_launch_at_its_largest_split_beside_other_traffic():
                     f'(counters start at word {C * 256}: ticket, +32 done, +33 err, +64.. left[c])')
     assert not ws[:C * 256].any(), 'the two-launch partials were written - the held form did not run'
     assert torch.equal(y, y_ref) and torch.equal(dx, dx_ref)
+
+
+def test_module_path_shares_one_zeroed_scratch_and_check_held_is_loud():
+    """fused_bn: every held launch of a width shares ONE persistent zeroed scratch per device (one at a time by contract;
+    no memset per call), and check_held() - called by the samplers at their host syncs - raises when a launch left its
+    error word there."""
+    from ursabench_amd import fused_bn
+    C, shape = 16, (512, 16, 32, 32)                    # 34 MB: the backward takes the held form
+    bn = nn.BatchNorm2d(C).cuda().train()
+    x = torch.randn(shape, device='cuda', requires_grad=True)
+    fused_bn._held_ws.pop((x.device.index, C), None)
+    for _ in range(2):
+        y = fused_bn.bn_relu(bn, x)
+        y.backward(torch.randn_like(y))
+    ws = fused_bn._held_ws[(x.device.index, C)]
+    torch.cuda.synchronize()
+    assert not _sync_words(ws, C).any()
+    fused_bn.check_held()                               # quiet
+    ws.view(torch.int32)[C * 512 + 33] = 1              # what a starved launch leaves behind
+    with pytest.raises(RuntimeError, match='starved'):
+        fused_bn.check_held(x.device)
+    ws.view(torch.int32)[C * 512 + 33] = 0
+    fused_bn.check_held()
+    with fused_bn.several_streams():                    # overlapping callers: private, unzeroed scratch, two-launch form
+        s1, h1 = fused_bn._scratch(x, C)
+        assert h1 is False and s1.data_ptr() != ws.data_ptr()
 
 
 def test_several_streams_context_switches_the_held_form_off():

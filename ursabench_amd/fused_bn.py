@@ -76,11 +76,40 @@ def _twin_mask(x, twins):
     return twins if (twins and _twins_on and _native.nhwc_twin_supported(x) and x.shape[2] * x.shape[3] >= TWIN_MIN_HW) else 0
 
 
+_held_ws = {}      # (device index, C) -> the zeroed scratch every held launch of that width shares on that device
+
+
 def _scratch(x, C):
-    """(ws, held): the call's scratch; zeroed - which lets the library take the held form - when the activation is large."""
+    """(ws, held): the call's scratch. Large activations get a ZEROED one, which lets the library take the held form. Held
+    launches are one at a time by contract and re-arm their sync words themselves (csrc/ursa_bn.hip), so all of them share
+    one persistent buffer per (device, width): no memset per call, and the few error words a starved launch would raise
+    sit where `check_held()` finds them. (First sight of a width inside a graph capture: the capture's own zeroed memory.)"""
     if _held and not _two_launch and x.numel() * 4 >= _native.BN_HELD_MIN_BYTES:
-        return x.new_zeros(_native.bn_ws_floats(C)), True
+        key = (x.device.index, int(C))
+        ws = _held_ws.get(key)
+        if ws is None:
+            if torch.cuda.is_current_stream_capturing():
+                return x.new_zeros(_native.bn_ws_floats(C)), True
+            ws = _held_ws[key] = torch.zeros(_native.bn_ws_floats(C), device=x.device)
+        return ws, True
     return x.new_empty(_native.bn_ws_floats(C)), False
+
+
+def check_held(device=None):
+    """One small device-to-host read per width in use: raises if a held launch ran into its bounded wait (it then went on
+    with incomplete sums: the numbers since the last check are wrong). That only happens when the held form's contract -
+    nothing else in flight on the device beside it; overlapping callers use `several_streams()` - was broken. For callers
+    and tests to use at a host sync of their own; no-op while no large activation was seen."""
+    bad = []
+    for (dev, C), ws in _held_ws.items():
+        if device is not None and torch.device(device).index not in (None, dev):
+            continue
+        err = int(ws.view(torch.int32)[C * 512 + 33])          # BnSync.err: csrc/ursa_bn.hip (counters start at float C * 512)
+        if err:
+            bad.append((dev, C, err))
+    if bad:
+        raise RuntimeError(f'K6 held launch starved (device, channels, error word): {bad}: another launch was in flight on the '
+                           f'device beside it; wrap overlapping BatchNorm work in fused_bn.several_streams() or set URSA_BN_HELD=0')
 
 
 def enabled(flag=None):
