@@ -1,8 +1,73 @@
-"""CPU: host-side switches of ursabench_amd/fused_bn.py (no kernels are launched here)."""
+"""Host side of fused_bn (no GPU): on host tensors `bn_relu` / `add_bn_relu` ARE the reference's ops — the module's
+forward, the in-place ReLU, torch's add — so the CPU replays of the reference's runs stay op for op; the pending-sum
+plumbing of the networks computes what `out += residual` followed by the next block computes."""
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
-from ursabench_amd import fused_bn, util
+from ursabench_amd import fused_bn, models, util
+
+
+def test_host_tensors_take_the_stock_ops():
+    torch.manual_seed(0)
+    a, b = torch.randn(4, 6, 5, 5), torch.randn(4, 6, 5, 5)
+    m1, m2 = nn.BatchNorm2d(6), nn.BatchNorm2d(6)
+    assert torch.equal(fused_bn.bn_relu(m1, a), F.relu(m2(a)))
+    assert torch.equal(m1.running_var, m2.running_var) and int(m1.num_batches_tracked) == 1
+    z, y = fused_bn.add_bn_relu(m1, (a, b))
+    assert torch.equal(z, a + b) and torch.equal(y, F.relu(m2(a + b)))
+    z, y = fused_bn.add_bn_relu(m1, a)                     # a plain tensor passes through
+    assert z is a
+    assert torch.equal(fused_bn.bn_relu(m1, a, relu=False), m2(a))
+    m2.load_state_dict(m1.state_dict())
+    m1.eval(), m2.eval()
+    assert torch.equal(fused_bn.add_bn_relu(m1, (a, b))[1], F.relu(m2(a + b)))
+    old = fused_bn.enabled(False)
+    try:
+        assert fused_bn.enabled() is False
+    finally:
+        fused_bn.enabled(old)
+    assert fused_bn.enabled() is old
+
+
+def _reference_style_forward(net, x):
+    """PreResNet.forward written the reference's way (preresnet.py:76-90,139-151): add at the end of each block."""
+    x = net.conv1(x)
+    for layer in (net.layer1, net.layer2, net.layer3):
+        for blk in layer:
+            out = F.relu(blk.bn1(x))
+            out = blk.conv1(out)
+            out = blk.conv2(F.relu(blk.bn2(out)))
+            x = out + (x if blk.downsample is None else blk.downsample(x))
+    x = F.relu(net.bn(x))
+    return net.fc(net.avgpool(x).flatten(1))
+
+
+def test_pending_sums_compute_the_reference_forward_and_gradients():
+    torch.manual_seed(1)
+    net = models.PreResNet(10, 8)
+    twin = models.PreResNet(10, 8)
+    twin.load_state_dict(net.state_dict())
+    x = torch.randn(6, 3, 32, 32)
+    y1 = net(x)
+    y2 = _reference_style_forward(twin, x)
+    assert torch.equal(y1, y2)
+    y1.square().sum().backward()
+    y2.square().sum().backward()
+    for (k, p), q in zip(net.named_parameters(), twin.parameters()):
+        assert torch.equal(p.grad, q.grad), k
+    for (k, b), c in zip(net.named_buffers(), twin.buffers()):
+        assert torch.equal(b, c), k
+
+
+def test_wide_and_bottleneck_blocks_return_pending_sums():
+    torch.manual_seed(2)
+    w = models.WideResNet(10, 10, 1)
+    out = w.layer1(w.conv1(torch.randn(2, 3, 32, 32)))
+    assert isinstance(out, tuple) and len(out) == 2 and out[0].shape == out[1].shape
+    assert w(torch.randn(2, 3, 32, 32)).shape == (2, 10)
+    p = models.PreResNet(100, 47)                          # 9n + 2: bottleneck blocks
+    assert p(torch.randn(2, 3, 32, 32)).shape == (2, 100)
 
 
 def test_several_streams_context_nests_and_restores():
@@ -31,7 +96,7 @@ def test_several_streams_context_nests_and_restores():
         fused_bn.held(old)
 
 
-def test_host_tensors_take_the_stock_ops_and_bn_update_many_is_unchanged_on_cpu():
+def test_bn_update_many_gives_every_model_bn_updates_statistics_on_cpu():
     """fused_bn never touches the native library for host tensors; bn_update_many without streams (the CPU path) gives
     every model the statistics bn_update gives it alone."""
     torch.manual_seed(0)
