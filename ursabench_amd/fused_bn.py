@@ -83,7 +83,10 @@ def _scratch(x, C):
     """(ws, held): the call's scratch. Large activations get a ZEROED one, which lets the library take the held form. Held
     launches are one at a time by contract and re-arm their sync words themselves (csrc/ursa_bn.hip), so all of them share
     one persistent buffer per (device, width): no memset per call, and the few error words a starved launch would raise
-    sit where `check_held()` finds them. (First sight of a width inside a graph capture: the capture's own zeroed memory.)"""
+    sit where `check_held()` finds them. (First sight of a width inside a graph capture: the capture's own zeroed memory.)
+    Consequence of the sharing: large-activation BatchNorm launches of one process must not overlap on a device AT ALL -
+    whichever form the library picks, their partial sums land in the same buffer - unless issued under `several_streams()`,
+    which hands every call a private scratch again."""
     if _held and not _two_launch and x.numel() * 4 >= _native.BN_HELD_MIN_BYTES:
         key = (x.device.index, int(C))
         ws = _held_ws.get(key)
