@@ -70,7 +70,12 @@ def parse(argv=None):
     ap.add_argument('--multi-chain-sweep', default='2,4,8,16', help='chains per GPU of the multi_chain_per_gpu sweep at N=1 (empty: skip)')
     ap.add_argument('--bma-members', type=int, default=30, help='c2: ensemble size of the BMA leg (the reference configs use 30-50): the '
                     'chain\'s own samples, topped up with further snapshots of the continuing chain; 0: only the timed samples')
-    ap.add_argument('--no-sanity-legs', action='store_true', help='c2: skip the reduced-size C4 / C5 code-path legs')
+    ap.add_argument('--sanity-legs', action='store_true', help='c2: also walk the C4 / C5 code paths at reduced size (not a measurement; off by '
+                    'default: their untuned shapes send MIOpen into a solver search inside the run)')
+    ap.add_argument('--no-sanity-legs', action='store_true', help='(older scripts) the default now')
+    ap.add_argument('--detail-out', default=None, help='file for the FULL record of the run (every leg, every trial, every kernel); default '
+                    'gpurun_out/bench_detail_<config>.json. stdout carries ONE compact JSON line (< 8 KB) that names this file')
+    ap.add_argument('--full-line', action='store_true', help='print the full record on stdout instead of the compact line (tools/ only)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--force-dist', action='store_true', help='join a process group even when WORLD_SIZE is 1')
@@ -1043,7 +1048,7 @@ def run_c2(a, job, legs, line):
             line['multi_chain_per_gpu'] = legs.run('multi_chain_per_gpu', multi_chain_block, ks, make_chain, inference, line.get('value'))
         if world == 1 and a.ref_style_steps > 0:
             line['reference_style_gpu'] = legs.run('reference_style_gpu', reference_style_gpu_block, a.ref_style_steps, dev)
-        if world == 1 and not a.no_sanity_legs:
+        if world == 1 and a.sanity_legs and not a.no_sanity_legs:
             line['sanity_c4_c5'] = legs.run('sanity_c4_c5', sanity_block, a, job)
         if world == 1 and not a.no_cpu_baseline:
             line['cpu_baseline'] = legs.run('cpu_baseline', cpu_baseline_block, a.cpu_steps)
@@ -1266,8 +1271,117 @@ def run_c5(a, job, legs, line):
         legs.run('roofline', roofline)
 
 
+COMPACT_LIMIT = 8000            # bytes of the ONE stdout line (the driver keeps a tail of stdout and parses the last line: round 4's
+#                                 27.7 KB line did not fit and went unparsed); everything else goes to the detail file
+
+
+def _pick(d, keys):
+    return None if not isinstance(d, dict) else {k: d[k] for k in keys if k in d}
+
+
+def compact_line(line, detail_path):
+    """The ONE line printed on stdout: the contract keys, the `roofline` and `cpu_baseline` objects, pass flags and worst
+    figures of the parity legs, and the name of the file that holds the full record (every leg's own object: parity
+    trials, roofline_kernels, roofline_k6, the K sweep ...). Bounded: what does not fit is dropped, never the contract keys."""
+    out = {k: line.get(k) for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                                    'vs_baseline', 'dtype', 'data')}
+    cfg = line.get('config') or {}
+    out['config'] = _pick(cfg, ('workload', 'device', 'abi', 'n_train', 'n_test', 'batch', 'hyper', 'chains', 'chains_per_gpu', 'hip_graph',
+                                'minibatch_steps_per_sample', 'params', 'members', 'members_on_rank0', 'full_batch', 'chains_on_rank0',
+                                'ranks_without_a_chain', 'bn_relu'))
+    for k in ('minibatch_steps_per_s', 'bma_preds_per_s', 'bma_members', 'bma_member_forwards_per_s', 'bma_nll', 'bma_seconds',
+              'trajectory_seconds', 'leapfrog_steps_per_s', 'acceptance_rate_rank0', 'accepted_rank0', 'engine'):
+        if k in line:
+            out[k] = line[k]
+    r = line.get('roofline')
+    if r:
+        out['roofline'] = _pick(r, ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'bytes_per_launch', 'us_per_launch',
+                                    'us_per_launch_rocprof', 'frac_rocprof', 'rocprof_source', 'chains_per_launch'))
+    if line.get('roofline_large'):
+        out['roofline_large'] = _pick(line['roofline_large'], ('kernel', 'elements', 'frac', 'achieved', 'us_per_launch', 'bytes_per_launch', 'traffic'))
+    k6 = line.get('roofline_k6')
+    if k6:
+        out['roofline_k6'] = {'workload_layers_us_per_call': {k: v.get('us') for k, v in (k6.get('workload_layers_us_per_call') or {}).items()},
+                              'large_layer': _pick(k6, ('kernel', 'form', 'frac', 'us_per_launch', 'traffic')),
+                              'large_layer_backward': _pick(k6.get('backward'), ('form', 'frac', 'us_per_launch', 'traffic'))}
+    rk = line.get('roofline_kernels')
+    if rk:
+        out['roofline_kernels_frac'] = {k: v.get('frac') for k, v in rk.items() if not v.get('note')}     # HBM-sized entries only
+    if line.get('roofline_bma_kernel'):
+        out['roofline_bma_kernel'] = _pick(line['roofline_bma_kernel'], ('shape', 'us_per_launch', 'frac'))
+    c = line.get('cpu_baseline')
+    if c:
+        out['cpu_baseline'] = _pick(c, ('value', 'unit', 'cores', 'kind', 'sample', 'cpu_model', 'logical_cpus', 'value_1_thread', 'ms_per_minibatch_step'))
+        if c.get('bma'):
+            out['cpu_baseline']['bma'] = _pick(c['bma'], ('value', 'unit', 'members', 'cores'))
+    par = line.get('parity')
+    if par:
+        out['parity'] = _pick(par, ('rtol', 'seeds', 'rows_workload', 'rows_small', 'pass', 'pass_workload_rows', 'pass_gate_equal',
+                                    'gate_equal_samples_asserted', 'pass_bma_same_members', 'worst_max_rel_err_proba_gates_given',
+                                    'worst_max_rel_err_proba_natural_reported', 'pass_k6_not_worse_than_stock', 'natural_first_step_k6_vs_stock'))
+        geg = par.get('given_equal_gradients')
+        if geg:
+            out['parity']['given_equal_gradients'] = _pick(geg, ('minibatch_steps', 'steps_bit_identical_theta_and_momentum', 'pass'))
+    mc = line.get('multi_chain_per_gpu')
+    if mc:
+        out['multi_chain_per_gpu'] = {'best': mc.get('best'), 'samples_per_s_by_chains': {str(r_['chains_per_gpu']): r_['value'] for r_ in mc.get('sweep', [])}}
+    if line.get('reference_style_gpu'):
+        out['reference_style_gpu'] = _pick(line['reference_style_gpu'], ('value', 'unit', 'ms_per_minibatch_step'))
+    rc = line.get('rccl')
+    if rc:
+        out['rccl'] = _pick(rc, ('backend', 'world', 'ranks_seen', 'distinct_devices', 'all_reduce_bytes', 'all_reduce_us'))
+    out['errors'] = {k: str(v)[-300:] for k, v in (line.get('errors') or {}).items()}
+    out['detail'] = detail_path
+    # the bound is part of the contract: shed the optional objects, largest first, until the line fits
+    for k in ('roofline_kernels_frac', 'multi_chain_per_gpu', 'roofline_k6', 'reference_style_gpu', 'roofline_bma_kernel', 'engine', 'parity',
+              'rccl', 'roofline_large'):
+        if len(json.dumps(out)) < COMPACT_LIMIT:
+            break
+        out.pop(k, None)
+        out.setdefault('dropped_for_size', []).append(k)
+    if len(json.dumps(out)) >= COMPACT_LIMIT:
+        out['errors'] = {k: v[-80:] for k, v in list(out['errors'].items())[:8]}
+    return out
+
+
+def write_detail(a, line):
+    """The full record -> a file (default gpurun_out/bench_detail_<config>.json under the repo; the temp dir if that
+    cannot be written). Returns the path that goes into the compact line."""
+    path = a.detail_out or os.path.join(ROOT, 'gpurun_out', f'bench_detail_{a.config}.json')
+    for cand in (path, os.path.join(tempfile.gettempdir(), f'ursa_bench_detail_{a.config}_{os.getpid()}.json')):
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(cand)), exist_ok=True)
+            with open(cand, 'w') as f:
+                json.dump(line, f, indent=1)
+            return os.path.relpath(cand, ROOT) if os.path.abspath(cand).startswith(ROOT + os.sep) else cand
+        except OSError as e:
+            sys.stderr.write(f'[bench] could not write {cand}: {e}\n')
+    return None
+
+
+def self_launch(a, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: THIS process never touches the GPU (importing torch
+    does not); it starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>` as a
+    child - one rank per GPU over RCCL - relays the child's output (rank 0 prints the one line) and returns its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={a.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: RCCL across processes needs it on this driver
+    env.pop('MIOPEN_USER_DB_PATH', None)                    # every rank makes its own private copy (tuning.py)
+    env.pop('MIOPEN_CUSTOM_CACHE_DIR', None)
+    sys.stderr.write(f'[bench] --gpus {a.gpus} without a launcher: starting {" ".join(cmd)}\n')
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main(argv=None):
     a = parse(argv)
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return self_launch(a, argv)
     job = Job(a)
     legs = Legs(a.inject_failure)
     workload = {'c2': 'PreResNet-20 / CIFAR-10-shaped synthetic, SGHMC (BASELINE configs[1] at 1 chain, 1 GPU; configs[2] when n_gpus > 1)',
@@ -1280,7 +1394,10 @@ def main(argv=None):
         errors = job.gather_errors(legs.errors)
         if job.rank == 0:
             line['errors'] = errors
-            print(json.dumps(line), flush=True)
+            if a.full_line:
+                print(json.dumps(line), flush=True)
+            else:
+                print(json.dumps(compact_line(line, write_detail(a, line))), flush=True)
         job.close()
     return 1 if legs.errors else 0
 

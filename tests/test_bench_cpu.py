@@ -15,9 +15,16 @@ KEYS = {'metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', '
         'vs_baseline', 'dtype', 'data', 'config', 'errors'}
 
 
-def run_bench(args, world=1):
+def run_bench(args, world=1, launcher=True, tmp=None):
+    """Runs bench.py (under torch.distributed.run for world > 1 unless launcher=False: bench.py then starts it itself) and
+    returns (exit code, the ONE compact stdout line). The line must be the LAST stdout line, parse by itself and stay under
+    8,000 bytes (the driver keeps a tail of stdout; round 4's 27.7 KB line went unparsed); the full record sits
+    in the file the line names (`detail(line)`)."""
     env = dict(os.environ, PYTHONPATH=ROOT)
-    if world == 1:
+    env.pop('WORLD_SIZE', None), env.pop('RANK', None), env.pop('LOCAL_RANK', None)
+    import tempfile
+    args = args + ['--detail-out', os.path.join(tmp or tempfile.mkdtemp(prefix='ursa_bench_test_'), 'detail.json')]
+    if world == 1 or not launcher:
         cmd = [sys.executable, os.path.join(ROOT, 'bench.py')] + args
     else:
         with socket.socket() as s:
@@ -28,7 +35,15 @@ def run_bench(args, world=1):
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1, (p.stdout[-2000:], p.stderr[-2000:])
-    return p.returncode, json.loads(lines[0])
+    last = p.stdout.rstrip('\n').splitlines()[-1]
+    assert last == lines[0] and len(last.encode()) < 8000, len(last)
+    return p.returncode, json.loads(last)
+
+
+def detail(line):
+    path = line['detail']
+    with open(path if os.path.isabs(path) else os.path.join(ROOT, path)) as f:
+        return json.load(f)
 
 
 def test_dry_run_single_process():
@@ -49,8 +64,11 @@ def test_dry_run_world_size_2_gloo():
     assert line['bma_members'] == 4                       # 2 members per rank, summed by the all-reduce
     # the line proves by itself what the process group was: backend, ranks that answered, one device record per rank
     r = line['rccl']
-    assert r['backend'] == 'gloo' and r['world'] == 2 and r['ranks_seen'] == [0, 1] and len(r['devices']) == 2
-    assert {d['rank'] for d in r['devices']} == {0, 1} and len({d['pid'] for d in r['devices']}) == 2
+    assert r['backend'] == 'gloo' and r['world'] == 2 and r['ranks_seen'] == [0, 1]
+    full = detail(line)
+    assert KEYS <= set(full) and full['value'] == line['value'] and full['rccl']['ranks_seen'] == [0, 1]
+    devs = full['rccl']['devices']
+    assert len(devs) == 2 and {d['rank'] for d in devs} == {0, 1} and len({d['pid'] for d in devs}) == 2
     assert r['all_reduce_bytes'] == 4 * (96 * 10 + 96 + 1) and r['all_reduce_us'] > 0
     # whole-job aggregate: world x K samples over the max-over-ranks time
     assert line['value'] == pytest.approx(2 * 2 / (line['ms_per_step'] * 2 / 1e3), rel=1e-3)
@@ -106,3 +124,31 @@ def test_dry_run_c5_world_size_4_gloo(chains):
 def test_a_leg_failing_on_another_rank_reaches_the_line():
     rc, line = run_bench(['--dry-run-cpu', '--gpus', '2', '--steps', '1', '--warmup', '0', '--inject-failure', 'bma@1:after'], world=2)
     assert rc != 0 and 'rank1:bma' in line['errors'] and 'injected failure' in line['errors']['rank1:bma']
+
+
+def test_gpus_2_without_a_launcher_starts_one_itself():
+    """the driver's N > 1 command may be plain `python bench.py --gpus N`. The parent must not touch the GPU; it
+    starts torch.distributed.run as a child and relays rank 0's line and the exit code."""
+    rc, line = run_bench(['--dry-run-cpu', '--gpus', '2', '--steps', '1', '--warmup', '0'], world=2, launcher=False)
+    assert rc == 0 and line['errors'] == {}
+    assert line['n_gpus'] == 2 and line['rccl']['world'] == 2 and line['rccl']['ranks_seen'] == [0, 1] and line['bma_members'] == 2
+    rc, line = run_bench(['--dry-run-cpu', '--gpus', '2', '--steps', '1', '--warmup', '0', '--inject-failure', 'bma@1:after'], world=2, launcher=False)
+    assert rc != 0 and 'rank1:bma' in line['errors']
+
+
+def test_the_compact_line_is_bounded_whatever_the_legs_return():
+    """compact_line() on a record as large as round 4's (27.7 KB: six parity trials, 40 kernel entries ...) and on one with huge
+    error strings stays under the bound and keeps every contract key."""
+    sys.path.insert(0, ROOT)
+    import importlib
+    bench = importlib.import_module('bench')
+    big = json.load(open(os.path.join(ROOT, 'profiles', 'r04_bench_line_driver_cmd.json')))
+    assert len(json.dumps(big)) > 20000
+    out = bench.compact_line(big, 'gpurun_out/bench_detail_c2.json')
+    assert len(json.dumps(out)) < 8000 and KEYS <= set(out) and out['value'] == big['value'] and out['detail']
+    assert out['roofline']['frac'] == big['roofline']['frac'] and out['cpu_baseline']['cores'] == big['cpu_baseline']['cores']
+    assert out['parity']['pass'] is True and 'trials' not in out['parity']
+    big['errors'] = {f'rank{r}:leg': 'x' * 5000 for r in range(8)}
+    big['roofline_kernels'] = {f'k{i}': {'frac': 0.5, 'us': 1.0} for i in range(2000)}
+    out = bench.compact_line(big, 'd.json')
+    assert len(json.dumps(out)) < 8000 and KEYS <= set(out) and len(out['errors']) == 8 and 'roofline' in out and 'cpu_baseline' in out
