@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define URSA_ABI_VERSION 4
+#define URSA_ABI_VERSION 5
 
 typedef void* ursa_stream_t; /* hipStream_t */
 
@@ -306,6 +306,7 @@ int ursa_bn_relu_bwd_f32(const float* x /* the normalised input: z_out if the fo
                          float* dgamma, float* dbeta, float* ws, int64_t N, int64_t C, int64_t HW,
                          uint32_t flags, ursa_stream_t stream);
 
+#ifdef URSA_DEBUG_KNOBS   /* parked experiment, NOT part of the product ABI: only csrc/libursa_hip_knobs.so exports these */
 /* The same forward / backward that ALSO store their output channels-last (NHWC, [N, HW, C]) as a second tensor: y_nhwc /
  * dx_nhwc hold the same floats as y / dx (dx + dz in the residual form). Why: MIOpen's fastest weight-gradient kernel for the
  * benchmark networks works on NHWC operands and transposes NCHW ones itself (15-20 % of a training step's kernel time);
@@ -325,6 +326,7 @@ int ursa_bn_relu_bwd_nhwc_f32(const float* x, const float* dy, const float* dz /
                               const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
                               float* dgamma, float* dbeta, float* ws, int64_t N, int64_t C, int64_t HW, uint32_t flags,
                               ursa_stream_t stream);
+#endif /* URSA_DEBUG_KNOBS */
 
 /* The same backward with the ReLU gates of LISTED elements given instead of recomputed: a parity instrument, not a
  * production launch (binary search per element; always the two-launch kernels; URSA_BN_RELU required).

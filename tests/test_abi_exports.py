@@ -8,10 +8,14 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
+def _declared_symbols(knobs=False):
+    """Function names the header declares: the product ABI (knobs=False: everything outside `#ifdef URSA_DEBUG_KNOBS`) or the
+    experiment-only entry points inside it (knobs=True)."""
     src = open(os.path.join(ROOT, 'include', 'ursa_hip.h')).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
-    return sorted(set(re.findall(r'\b(ursa_[a-z0-9_]+)\s*\(', src)))
+    inside = ''.join(re.findall(r'#ifdef URSA_DEBUG_KNOBS(.*?)#endif', src, flags=re.S))
+    outside = re.sub(r'#ifdef URSA_DEBUG_KNOBS.*?#endif', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(ursa_[a-z0-9_]+)\s*\(', inside if knobs else outside)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -24,6 +28,7 @@ def test_library_exports_every_declared_symbol():
     for sym in declared:
         assert hasattr(lib, sym), f'{sym} declared in include/ursa_hip.h but not exported'
     assert sorted(_native.SIGNATURES) == declared, 'binding table and header disagree'
+    assert sorted(_native.KNOBS_SIGNATURES) == _declared_symbols(knobs=True)
     assert lib.ursa_abi_version() == _native.ABI_VERSION
     assert lib.ursa_strerror(-1).decode() == 'required pointer is NULL'
 
@@ -77,6 +82,28 @@ def test_the_shipped_library_reads_no_environment():
         knobs = subprocess.run(['nm', '-D', '--undefined-only', _native.KNOBS_LIB_PATH], capture_output=True, text=True, check=True).stdout
         assert 'getenv' in knobs
         assert _native.load_library(_native.KNOBS_LIB_PATH).ursa_abi_version() == _native.ABI_VERSION
+
+
+def test_parked_experiments_are_not_in_the_product_abi():
+    """the NHWC-twin launches (measured -2 % on the workload) live in the knobs build only: `nm` of
+    the shipped library shows no nhwc symbol - neither an entry point nor a kernel - and nothing under ursabench_amd/ names them
+    outside the binding's knobs table."""
+    import subprocess
+    from ursabench_amd import _native
+    syms = subprocess.run(['nm', '-D', '--defined-only', _native.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert 'nhwc' not in syms.lower() and 'k_bn_fwd_apply_4' not in syms and 'k_bn_bwd_dx_4' not in syms
+    lib = _native.load_library()
+    for sym in _declared_symbols(knobs=True):
+        assert not hasattr(lib, sym), f'{sym} is exported by the shipped library'
+    if os.path.exists(_native.KNOBS_LIB_PATH):
+        knobs = _native.load_library(_native.KNOBS_LIB_PATH)
+        assert all(hasattr(knobs, sym) for sym in _declared_symbols(knobs=True))
+    pkg = os.path.join(ROOT, 'ursabench_amd')
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py') and f != '_native.py':
+                assert 'nhwc' not in open(os.path.join(d, f)).read().lower(), os.path.join(d, f)
+    assert not os.path.exists(os.path.join(pkg, 'fused_conv.py'))
 
 
 def test_wrappers_refuse_cpu_tensors():

@@ -70,30 +70,40 @@ def test_wide_and_bottleneck_blocks_return_pending_sums():
     assert p(torch.randn(2, 3, 32, 32)).shape == (2, 100)
 
 
-def test_several_streams_context_nests_and_restores():
-    """What ChainGroup's branches and bn_update_many's member streams run under: the held form (ONE launch in flight per
-    device, csrc/ursa_bn.hip) is not taken inside, whatever the nesting, and the previous setting comes back - also after
-    an exception."""
-    assert fused_bn.held() is True
+def test_held_form_is_opt_in_and_several_streams_nests_and_restores():
+    """The held form (ONE launch in flight per device with nothing beside it, csrc/ursa_bn.hip) is OFF unless opted in
+    (VERDICT r4 #4 / ADVICE r4 high). Opted in, `several_streams()` - what ChainGroup's branches and bn_update_many's member
+    streams run under - switches it off for THIS thread's forwards, whatever the nesting, restores the previous state also
+    after an exception, and does not leak into other threads (a module-global flag did)."""
+    import threading
+    assert fused_bn.held() is False and fused_bn.held_allowed() is False
     with fused_bn.several_streams():
-        assert fused_bn.held() is False
-        with fused_bn.several_streams():
-            assert fused_bn.held() is False
-        assert fused_bn.held() is False
-    assert fused_bn.held() is True
+        assert fused_bn.held_allowed() is False
+    old = fused_bn.held(True)
     try:
+        assert fused_bn.held() is True and fused_bn.held_allowed() is True
         with fused_bn.several_streams():
-            raise KeyError('x')
-    except KeyError:
-        pass
-    assert fused_bn.held() is True
-    old = fused_bn.held(False)
-    try:
-        with fused_bn.several_streams():
+            assert fused_bn.held_allowed() is False and fused_bn.held() is True
+            with fused_bn.several_streams():
+                assert fused_bn.held_allowed() is False
+            assert fused_bn.held_allowed() is False
+            seen = []
+            t = threading.Thread(target=lambda: seen.append(fused_bn.held_allowed()))
+            t.start()
+            t.join()
+            assert seen == [True]                     # another thread's forwards are not inside this thread's context
+        assert fused_bn.held_allowed() is True
+        try:
+            with fused_bn.several_streams():
+                raise KeyError('x')
+        except KeyError:
             pass
-        assert fused_bn.held() is False            # an outer "off" survives the context
+        assert fused_bn.held_allowed() is True
     finally:
         fused_bn.held(old)
+    assert fused_bn.held_allowed() is False
+    assert fused_bn.held_in_use() is False
+    fused_bn.check_held()                             # no held scratch registered: no device access, no error
 
 
 def test_bn_update_many_gives_every_model_bn_updates_statistics_on_cpu():

@@ -621,43 +621,95 @@ def test_one_held_launch_at_its_largest_split():
     assert torch.equal(y, y_ref) and torch.equal(dx, dx_ref)
 
 
-def test_module_path_shares_one_zeroed_scratch_and_check_held_is_loud():
-    """fused_bn: every held launch of a width shares ONE persistent zeroed scratch per device (one at a time by contract;
-    no memset per call), and check_held() - called by the samplers at their host syncs - raises when a launch left its
-    error word there."""
+def test_module_path_keeps_one_private_scratch_per_layer_and_check_held_is_loud():
+    """fused_bn, held form opted in: every LAYER owns one persistent zeroed scratch (no memset per call; two layers of equal
+    width never share), the backward reuses the forward's scratch and decision, and check_held() - called by
+    the samplers at their host syncs - raises when a launch left its error word there, then clears it."""
     from ursabench_amd import fused_bn
     C, shape = 16, (512, 16, 32, 32)                    # 34 MB: the backward takes the held form
-    bn = nn.BatchNorm2d(C).cuda().train()
+    bn, bn_b = nn.BatchNorm2d(C).cuda().train(), nn.BatchNorm2d(C).cuda().train()
     x = torch.randn(shape, device='cuda', requires_grad=True)
-    fused_bn._held_ws.pop((x.device.index, C), None)
-    for _ in range(2):
-        y = fused_bn.bn_relu(bn, x)
-        y.backward(torch.randn_like(y))
-    ws = fused_bn._held_ws[(x.device.index, C)]
-    torch.cuda.synchronize()
-    assert not _sync_words(ws, C).any()
-    fused_bn.check_held()                               # quiet
-    ws.view(torch.int32)[C * 512 + 33] = 1              # what a starved launch leaves behind
-    with pytest.raises(RuntimeError, match='starved'):
-        fused_bn.check_held(x.device)
-    ws.view(torch.int32)[C * 512 + 33] = 0
-    fused_bn.check_held()
-    with fused_bn.several_streams():                    # overlapping callers: private, unzeroed scratch, two-launch form
-        s1, h1 = fused_bn._scratch(x, C)
-        assert h1 is False and s1.data_ptr() != ws.data_ptr()
+    assert fused_bn.held() is False                     # opt-in
+    y = fused_bn.bn_relu(bn, x)
+    y.backward(torch.randn_like(y))
+    assert bn not in fused_bn._held_ws and not fused_bn.held_in_use()        # default: two-launch form, nothing registered
+    old = fused_bn.held(True)
+    try:
+        for _ in range(2):
+            for m in (bn, bn_b):
+                y = fused_bn.bn_relu(m, x)
+                y.backward(torch.randn_like(y))
+        (ws, c1), (ws_b, _) = fused_bn._held_ws[bn], fused_bn._held_ws[bn_b]
+        assert c1 == C and ws.data_ptr() != ws_b.data_ptr() and fused_bn.held_in_use()
+        torch.cuda.synchronize()
+        assert not _sync_words(ws, C).any() and not _sync_words(ws_b, C).any()
+        fused_bn.check_held()                               # quiet
+        ws_b.view(torch.int32)[C * 512 + 33] = 1            # what a starved launch leaves behind
+        with pytest.raises(RuntimeError, match='starved'):
+            fused_bn.check_held(x.device)
+        fused_bn.check_held()                               # cleared by the raise: the next check speaks of the next launches
+        with fused_bn.several_streams():                    # overlapping callers: private, unzeroed scratch, two-launch form
+            s1, h1 = fused_bn._scratch(bn, x, C)
+            assert h1 is False and s1.data_ptr() != ws.data_ptr()
+    finally:
+        fused_bn.held(old)
+    del bn, bn_b, y
+    import gc
+    gc.collect()
+    assert not fused_bn.held_in_use()                       # the scratch goes with its layer
+
+
+def test_a_starved_held_launch_poisons_its_outputs_with_nan():
+    """round 4's held launch, when its bounded wait ran out, went on with incomplete sums - plausible wrong
+    numbers, the err word the only signal. Now the sums are NaN: y / dx of the starved pieces, the channel's saved and running
+    statistics, dgamma / dbeta are NaN on the device itself. Starvation is provoked deterministically: the ticket counter
+    starts at 1, so piece 0 of channel 0 is never handed out and that channel's other pieces wait out their bound (~3 s)."""
+    from ursabench_amd import _native
+    K = _native.default_kernels()
+    C, shape = 64, (256, 64, 32, 32)                    # 67 MB: forward (>= 48 MiB) and backward take the held form
+    g = torch.Generator().manual_seed(3)
+    x, dy = torch.randn(shape, generator=g).cuda(), torch.randn(shape, generator=g).cuda()
+    w, bb = (torch.rand(C, generator=g) + 0.5).cuda(), torch.randn(C, generator=g).cuda()
+    new = lambda: torch.zeros(C, device='cuda')
+    for direction in ('forward', 'backward'):
+        ws = torch.zeros(_native.bn_ws_floats(C), device='cuda')
+        y, sm, si, rm, rv = torch.zeros_like(x), new(), new(), new(), new() + 1
+        if direction == 'backward':
+            K.bn_relu_forward(x, y, w, bb, None, None, sm, si, ws, eps=1e-5, momentum=0.0, held=True)
+            torch.cuda.synchronize()
+            assert not _sync_words(ws, C).any() and not torch.isnan(y).any()
+        ws.view(torch.int32)[C * 512] = 1               # BnSync.ticket
+        dx, dg, db = torch.zeros_like(x), new(), new()
+        if direction == 'forward':
+            K.bn_relu_forward(x, y, w, bb, rm, rv, sm, si, ws, eps=1e-5, momentum=0.1, held=True)
+        else:
+            K.bn_relu_backward(x, dy, dx, w, bb, sm, si, dg, db, ws, held=True)
+        torch.cuda.synchronize()
+        assert int(ws.view(torch.int32)[C * 512 + 33]) != 0, 'the err word was not raised'
+        out = y if direction == 'forward' else dx
+        assert torch.isnan(out[:, 0]).any(), 'a starved channel produced numbers'
+        assert not torch.isnan(out[:, 1:]).any()        # the other channels drained normally
+        if direction == 'forward':
+            assert torch.isnan(sm[0]) and torch.isnan(si[0]) and torch.isnan(rm[0]) and torch.isnan(rv[0])
+        else:
+            assert torch.isnan(dg[0]) and torch.isnan(db[0])
 
 
 def test_several_streams_context_switches_the_held_form_off():
     """fused_bn.several_streams(): what ChainGroup's branches and bn_update_many's member streams run under - a large
     activation then takes the two-launch form (its scratch is not the zeroed kind the held form needs)."""
     from ursabench_amd import fused_bn
-    assert fused_bn.held() is True
-    with fused_bn.several_streams():
-        assert fused_bn.held() is False
+    old = fused_bn.held(True)
+    try:
+        assert fused_bn.held_allowed() is True
         with fused_bn.several_streams():
-            assert fused_bn.held() is False
-        assert fused_bn.held() is False
-    assert fused_bn.held() is True
+            assert fused_bn.held_allowed() is False
+            with fused_bn.several_streams():
+                assert fused_bn.held_allowed() is False
+            assert fused_bn.held_allowed() is False
+        assert fused_bn.held_allowed() is True
+    finally:
+        fused_bn.held(old)
 
 
 def test_held_form_on_parallel_streams_and_through_the_module_path():

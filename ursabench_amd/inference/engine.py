@@ -160,4 +160,6 @@ class ChainEngine:
             seen += b
             steps += 1
         self.opt.ctl_end(steps)
+        if fused_bn.held_in_use():      # K6's held form was opted into (off by default): one small read per epoch; a starved
+            fused_bn.check_held(self.device)   # launch - NaN outputs already - raises here instead of at the next predictive
         return seen

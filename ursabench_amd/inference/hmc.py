@@ -26,7 +26,7 @@ import math
 
 import torch
 
-from .. import _native
+from .. import _native, fused_bn
 from .._capture import capture, side_streams
 from ..arena import FlatArena, MemberBank
 from ..util import reset_model
@@ -196,6 +196,7 @@ class HMC(_Inference):
                        flags=_native.LEAP_KICK, kinetic_out=self._acc, ws=self._ws)
             H1 = U1 + self._acc[0]
             rho = min(0.0, float(H0 - H1))                  # the one host sync per proposal (MH test)
+            fused_bn.check_held(self.device)                # (no-op unless K6's held form was opted into: a starved launch raises here)
             if debug:
                 print({'proposal': n, 'H0': float(H0), 'H1': float(H1), 'rho': rho})
             if math.isfinite(rho) and rho >= math.log(mh_uniform(self.seed, proposal)):

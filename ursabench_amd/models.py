@@ -21,8 +21,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .fused_bn import TWIN_DX, TWIN_Y, add_bn_relu, bn_relu
-from .fused_conv import conv2d
+from .fused_bn import add_bn_relu, bn_relu
 
 __all__ = ['LeNet5', 'MLP', 'MLP_dropout', 'PreResNet', 'PreResNet_dropout', 'WideResNet', 'MLP200MNIST',
            'MLP200MNIST_dropout', 'LeNet5MNIST', 'PreResNet8', 'PreResNet20', 'PreResNet164', 'WideResNet28x10']
@@ -93,12 +92,9 @@ class _PreActBasic(nn.Module):
         """`x`: a tensor or the pending sum (a, b) the previous block returned; returns the pending sum
         (conv output, shortcut): the `out += residual` of preresnet.py:49-52 is done by whoever consumes it - the next
         block's bn1 or the network's final bn (`fused_bn.add_bn_relu`: same values, one launch less each way)."""
-        # twins: relu(bn(.)) outputs that feed a 3x3 convolution (and the gradients that come back out of one) are also
-        # stored channels-last by the same launches, for that convolution's weight gradient (fused_conv.py). bn1's input
-        # gradient is the dy of the PREVIOUS block's conv2 (or of the stem convolution).
-        x, h = add_bn_relu(self.bn1, x, twins=TWIN_Y | TWIN_DX)
-        y = conv2d(self.conv1, h)
-        y = conv2d(self.conv2, bn_relu(self.bn2, y, twins=TWIN_Y | TWIN_DX))
+        x, h = add_bn_relu(self.bn1, x)
+        y = self.conv1(h)
+        y = self.conv2(bn_relu(self.bn2, y))
         return y, (x if self.downsample is None else self.downsample(x))
 
 
@@ -118,9 +114,9 @@ class _PreActBottleneck(nn.Module):
 
     def forward(self, x):
         x, h = add_bn_relu(self.bn1, x)                 # pending sums in and out, as in _PreActBasic
-        y = self.conv1(h)                               # 1x1: rocBLAS GEMMs, no transposes to save
-        y = conv2d(self.conv2, bn_relu(self.bn2, y, twins=TWIN_Y))          # the block's 3x3: input twin from bn2 ...
-        y = self.conv3(bn_relu(self.bn3, y, twins=TWIN_DX))                 # ... output-gradient twin from bn3's backward
+        y = self.conv1(h)
+        y = self.conv2(bn_relu(self.bn2, y))
+        y = self.conv3(bn_relu(self.bn3, y))
         return y, (x if self.downsample is None else self.downsample(x))
 
 
@@ -176,7 +172,7 @@ class PreResNet(nn.Module):
 
     def forward(self, x):
         x = self.layer3(self.layer2(self.layer1(self.conv1(x))))     # the last block's pending sum
-        return self.fc(_pool8(add_bn_relu(self.bn, x, twins=TWIN_DX)[1], self.avgpool))      # its dx: the last conv2's dy
+        return self.fc(_pool8(add_bn_relu(self.bn, x)[1], self.avgpool))
 
 
 class PreResNet_dropout(PreResNet):
@@ -190,7 +186,7 @@ class PreResNet_dropout(PreResNet):
 
     def forward(self, x):
         x = self.layer3(self.layer2(self.layer1(self.conv1(x))))
-        return self.fc(F.dropout(_pool8(add_bn_relu(self.bn, x, twins=TWIN_DX)[1], self.avgpool), p=self.dropout))
+        return self.fc(F.dropout(_pool8(add_bn_relu(self.bn, x)[1], self.avgpool), p=self.dropout))
 
 
 # ---- wide ResNet -------------------------------------------------------------------------
@@ -207,9 +203,9 @@ class _WideBlock(nn.Module):
             self.shortcut = nn.Sequential(nn.Conv2d(cin, planes, 1, stride, bias=True))
 
     def forward(self, x):
-        x, h = add_bn_relu(self.bn1, x, twins=TWIN_Y | TWIN_DX)     # pending sums in and out, as in _PreActBasic
-        y = self.dropout(conv2d(self.conv1, h))         # (dropout_rate 0, the benchmark's setting, hands the gradient through as it is)
-        y = conv2d(self.conv2, bn_relu(self.bn2, y, twins=TWIN_Y | TWIN_DX))
+        x, h = add_bn_relu(self.bn1, x)                 # pending sums in and out, as in _PreActBasic
+        y = self.dropout(self.conv1(h))
+        y = self.conv2(bn_relu(self.bn2, y))
         return y, self.shortcut(x)
 
 
@@ -236,7 +232,7 @@ class WideResNet(nn.Module):
 
     def forward(self, x):
         x = self.layer3(self.layer2(self.layer1(self.conv1(x))))
-        return self.linear(_pool8(add_bn_relu(self.bn1, x, twins=TWIN_DX)[1]))
+        return self.linear(_pool8(add_bn_relu(self.bn1, x)[1]))
 
 
 # ---- config classes: `.base/.args/.kwargs` like URSABench/models (preresnet.py:154-169) ----

@@ -189,3 +189,5 @@ def bn_update_many(loader, models, subset=None, device=None, streams=None, **kwa
         for m in bns:
             m.momentum = momenta[m]
         model.train(tr)
+    if fused_bn.held_in_use():          # K6's held form was opted into: a starved launch (NaN statistics) raises here, not later
+        fused_bn.check_held(device)
