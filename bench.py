@@ -67,7 +67,7 @@ def parse(argv=None):
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
     ap.add_argument('--chains-per-gpu', type=int, default=1, help='>1: ChainGroup (parallel graph branches); the headline config is 1')
     ap.add_argument('--multi-chain-probe', type=int, default=None, help='(older scripts) 0 = --multi-chain-sweep ""')
-    ap.add_argument('--multi-chain-sweep', default='2,4,8,16', help='chains per GPU of the multi_chain_per_gpu sweep at N=1 (empty: skip)')
+    ap.add_argument('--multi-chain-sweep', default='4,8', help='chains per GPU of the multi_chain_per_gpu sweep at N=1 (empty: skip)')
     ap.add_argument('--bma-members', type=int, default=30, help='c2: ensemble size of the BMA leg (the reference configs use 30-50): the '
                     'chain\'s own samples, topped up with further snapshots of the continuing chain; 0: only the timed samples')
     ap.add_argument('--sanity-legs', action='store_true', help='c2: also walk the C4 / C5 code paths at reduced size (not a measurement; off by '
@@ -79,7 +79,7 @@ def parse(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--force-dist', action='store_true', help='join a process group even when WORLD_SIZE is 1')
-    ap.add_argument('--cpu-steps', type=int, default=200, help='minibatch steps of the CPU port to time')
+    ap.add_argument('--cpu-steps', type=int, default=150, help='minibatch steps of the CPU port to time')
     ap.add_argument('--ref-style-steps', type=int, default=150, help='eager reference-style GPU steps to time (0: skip)')
     ap.add_argument('--large-n', type=int, default=1 << 26, help='elements of the roofline-sized K1 launch')
     ap.add_argument('--c4-epochs', type=int, default=3, help='c4: SGD trajectory epochs over the 50,000 images (1 burn-in + rest collected)')
@@ -106,6 +106,7 @@ class Legs:
 
     def __init__(self, inject=''):
         self.errors = {}
+        self.seconds = {}                # wall time per leg (detail file: where the run's minutes go)
         # "leg", "leg@rank" or "leg@rank:after" (tests). ":after" raises once the leg's work — collectives included — is
         # done: a rank that leaves a leg BEFORE its collectives strands the other ranks in them (until the process group's
         # timeout), which no bookkeeping on this side can repair.
@@ -115,6 +116,7 @@ class Legs:
         self.inject_after = when == 'after'
 
     def run(self, name, fn, *args, **kw):
+        t0 = time.perf_counter()
         try:
             if self.inject == name and not self.inject_after:
                 raise RuntimeError(f'injected failure in leg {name!r}')
@@ -128,6 +130,8 @@ class Legs:
             self.errors[name] = ''.join(traceback.format_exception(type(e), e, e.__traceback__))[-1500:]
             sys.stderr.write(f'[bench] leg {name!r} failed:\n{self.errors[name]}\n')
             return None
+        finally:
+            self.seconds[name] = round(self.seconds.get(name, 0.0) + time.perf_counter() - t0, 2)
 
 
 def load_port():
@@ -194,7 +198,7 @@ def pmc_traffic(kernel_key, elements):
     passes, tools/pmc_run.sh). PMC needs the profiler, so this is NOT measured in this run: it is the committed
     measurement under profiles/ for a launch of this kernel at this size (within 0.1 %: arena padding; scaled by
     the element ratio). Returns (bytes or None, source string) — the source travels in the line as `traffic_source`."""
-    for name in ('r04_pmc.json', 'r03_pmc.json', 'r02_pmc.json', 'r01_k1_pmc.json'):
+    for name in ('r05_pmc.json', 'r04_pmc.json', 'r03_pmc.json', 'r02_pmc.json', 'r01_k1_pmc.json'):
         path = os.path.join(ROOT, 'profiles', name)
         if not os.path.exists(path):
             continue
@@ -207,7 +211,7 @@ def pmc_traffic(kernel_key, elements):
     return None, 'none (no committed PMC pass for this kernel and size)'
 
 
-def rocprof_average(kernel_substr, files=('r04_bench_kernel_stats.csv', 'r03_bench_kernel_stats.csv')):
+def rocprof_average(kernel_substr, files=('r05_bench_kernel_stats.csv', 'r04_bench_kernel_stats.csv', 'r03_bench_kernel_stats.csv')):
     """Average duration of a kernel in the committed `rocprofv3 --kernel-trace --stats` summary of THIS command
     (profiles/rNN_bench_kernel_stats.csv, written by tools/r04_evidence.sh). The profiler cannot run inside the
     measurement, so this is read from the file and named: a reader recomputes frac_rocprof = bytes / us from it.
@@ -227,11 +231,13 @@ def rocprof_average(kernel_substr, files=('r04_bench_kernel_stats.csv', 'r03_ben
     return None
 
 
-def pmc_bytes(kernel_substr, name='r04_pmc.json'):
+def pmc_bytes(kernel_substr, names=('r05_pmc.json', 'r04_pmc.json')):
     """HBM bytes per launch of a kernel from the committed PMC passes (like pmc_traffic, keyed by kernel name only: the
     entries of the K6 launches at [1024, 64, 32, 32]). (bytes or None, source)."""
-    path = os.path.join(ROOT, 'profiles', name)
-    if os.path.exists(path):
+    for name in names:
+        path = os.path.join(ROOT, 'profiles', name)
+        if not os.path.exists(path):
+            continue
         for k, v in json.load(open(path))['kernels'].items():
             if kernel_substr in k and 'hbm_bytes_per_launch_corrected' in v:
                 return int(v['hbm_bytes_per_launch_corrected']), (f'profiles/{name}: {v.get("label", k)} (rocprofv3 --pmc passes of this kernel at '
@@ -304,7 +310,14 @@ def parity_trial(dev, seed_offset, steps_per_sample=1, samples=3, rows=128, test
         pred.update_statistics(members, output_performance=False)
         return pred.ensemble_proba, pred.expected_data_uncertainty
 
-    def gpu_run(force):
+    def gpu_run(force, fused=True):
+        was = fused_bn.enabled(fused)        # fused=False: MIOpen's BatchNorm + ATen's ReLU / add launches in K6's place (natural gates only)
+        try:
+            return _gpu_run(force)
+        finally:
+            fused_bn.enabled(was)
+
+    def _gpu_run(force):
         # the product path with the port's noise injected through the kernel's eps input
         train = DeviceLoader(xtr.to(dev), ytr.to(dev), rows)
         s = inference.SGHMC(dict(hyp), copy.deepcopy(net0), train, device=dev, seed=1, use_graph=True)
@@ -372,6 +385,9 @@ def parity_trial(dev, seed_offset, steps_per_sample=1, samples=3, rows=128, test
            'natural': gpu_run(False)}
     if given_gates:
         out['given'] = gpu_run(True)
+        # the same natural run with the STOCK BatchNorm / ReLU launches: differing gates come from the convolutions' last bits, not
+        # from the BatchNorm arithmetic, so K6 must not be worse in distribution (VERDICT r4 #5 i)
+        out['natural_stock_bn'] = gpu_run(False, fused=False)
     return out
 
 
@@ -404,7 +420,10 @@ def parity_block(dev, steps_per_sample=1, samples=3, rows=128, test_rows=64, dep
       pass_gate_equal    : every natural trial (`rows` and `small_rows`) is held to 1e-5 on its gate-equal prefix - the
                            samples before the first differing gate (about half of the 32-row first steps are gate-equal;
                            at 128 rows 1-7 of the 24 M gates differ on most seeds);
-      bma_same_members   : every run, natural or given (it compares the evaluation path, not the trajectory).
+      bma_same_members   : every run, natural or given (it compares the evaluation path, not the trajectory);
+      k6_not_worse_than_stock : the natural runs at the workload batch repeated with MIOpen's BatchNorm + ATen's ReLU launches in
+                           K6's place, same seeds: K6's median error (first sample, last sample) <= 3 x the stock launches' + 1e-5
+                           (the criterion of tests/test_gate_parity_gpu.py on G16); both sets side by side in the detail file.
     Natural errors after a differing gate are reported per sample, never asserted, never hidden."""
     plan = [(rows, off, True) for off in seeds] + [(small_rows, off, False) for off in seeds]
     trials, ok_work, ok_equal, ok_bma, n_equal = [], True, True, True, 0
@@ -425,6 +444,16 @@ def parity_block(dev, steps_per_sample=1, samples=3, rows=128, test_rows=64, dep
             ok_work &= all(gv['no_gate_outside_the_band_differs_per_step'])
             ok_bma &= gv['bma_same_members']['max_rel_err_proba'] <= PARITY_RTOL
     worst = lambda key: max(ps['max_rel_err_proba'] for t in trials if key in t for ps in t[key]['per_sample'])
+    # K6 vs MIOpen's BatchNorm launches on the same seeds at the workload batch, natural gates, side by side
+    paired = [t for t in trials if 'natural_stock_bn' in t]
+    med = lambda xs: float(sorted(xs)[len(xs) // 2])
+    side = {str(t['seed_offset']): {'k6_err_per_sample': [ps['max_rel_err_proba'] for ps in t['natural']['per_sample']],
+                                    'stock_err_per_sample': [ps['max_rel_err_proba'] for ps in t['natural_stock_bn']['per_sample']],
+                                    'k6_differing_gates_per_step': t['natural']['gate_flips_per_step'],
+                                    'stock_differing_gates_per_step': t['natural_stock_bn']['gate_flips_per_step']} for t in paired}
+    k6_final, st_final = [v['k6_err_per_sample'][-1] for v in side.values()], [v['stock_err_per_sample'][-1] for v in side.values()]
+    k6_first, st_first = [v['k6_err_per_sample'][0] for v in side.values()], [v['stock_err_per_sample'][0] for v in side.values()]
+    ok_stock = bool(paired) and med(k6_final) <= 3 * med(st_final) + PARITY_RTOL and med(k6_first) <= 3 * med(st_first) + PARITY_RTOL
     out = {'what': f'PreResNet-{depth} SGHMC at the workload hyper-parameters, identical init / inputs / injected noise, predictive '
                    f'on {test_rows} test rows after each of {samples} samples of {steps_per_sample} minibatch step(s); GPU path (every '
                    'compared step a hipGraph replay reading the injected noise) vs torch-CPU port of the reference path; '
@@ -433,7 +462,13 @@ def parity_block(dev, steps_per_sample=1, samples=3, rows=128, test_rows=64, dep
            'pass_workload_rows': bool(ok_work), 'pass_gate_equal': bool(ok_equal), 'gate_equal_samples_asserted': n_equal,
            'pass_bma_same_members': bool(ok_bma),
            'worst_max_rel_err_proba_gates_given': worst('given'), 'worst_max_rel_err_proba_natural_reported': worst('natural'),
-           'trials': trials, 'pass': bool(ok_work and ok_equal and ok_bma)}
+           'natural_k6_vs_stock_bn_rows_workload': side,
+           'natural_first_step_k6_vs_stock': {'k6': k6_first, 'stock_bn': st_first, 'median_k6': med(k6_first) if paired else None,
+                                              'median_stock_bn': med(st_first) if paired else None,
+                                              'median_final_k6': med(k6_final) if paired else None,
+                                              'median_final_stock_bn': med(st_final) if paired else None},
+           'pass_k6_not_worse_than_stock': ok_stock,
+           'trials': trials, 'pass': bool(ok_work and ok_equal and ok_bma and ok_stock)}
     if not out['pass']:
         raise AssertionError(f'parity: predictive probabilities beyond {PARITY_RTOL} relative: {json.dumps(out)}')
     return out
@@ -653,19 +688,18 @@ def roofline_kernels_block(dev, large_n):
         e = x.numel()
         one = C >= 48 and e // C <= 32768                       # csrc/ursa_bn.hip bn_one_pass
         big = e * 4 >= _native.BN_HELD_MIN_BYTES and not one
-        held_f, held_b = big and e * 4 >= _native.BN_HELD_MIN_BYTES_FWD, big      # forward from 48 MiB, backward from 24 MiB (kHeldMinFloat4*)
-        form_f = 'one-pass (1 launch)' if one else 'held (1 launch, inputs read once)' if held_f else 'two-launch'
-        form_b = 'one-pass (1 launch)' if one else 'held (1 launch, inputs read once)' if held_b else 'two-launch'
-        entry(f'k6_bn_relu_fwd_{label}', 8 * e, lambda: K.bn_relu_forward(x, y, w, b, rm, rv, sm, si, wsb, eps=1e-5, momentum=0.1, held=big),
-              cache_resident=resident, shape=list(shape), form_bytes=(8 if one or held_f else 12) * e, form=form_f)
-        entry(f'k6_bn_relu_bwd_{label}', 12 * e, lambda: K.bn_relu_backward(x, dy, dx, w, b, sm, si, dg, db, wsb, held=big),
-              cache_resident=resident, shape=list(shape), form_bytes=(12 if one or held_b else 20) * e, form=form_b)
-        if big:                                                 # the two-launch form of the same layer beside it
-            entry(f'k6_bn_relu_fwd_two_launch_{label}', 8 * e, lambda: K.bn_relu_forward(x, y, w, b, rm, rv, sm, si, wsb, eps=1e-5, momentum=0.1, two_launch=True),
-                  cache_resident=resident, shape=list(shape), form_bytes=12 * e, form='two-launch')
-            entry(f'k6_bn_relu_bwd_two_launch_{label}', 12 * e, lambda: K.bn_relu_backward(x, dy, dx, w, b, sm, si, dg, db, wsb, two_launch=True),
-                  cache_resident=resident, shape=list(shape), form_bytes=20 * e, form='two-launch')
-            wsb[C * 256:].zero_()
+        held_f, held_b = big and e * 4 >= _native.BN_HELD_MIN_BYTES_FWD, big      # the OPT-IN held form: forward from 48 MiB, backward from 24 MiB
+        form = 'one-pass (1 launch)' if one else 'two-launch'   # what the product issues by default (URSA_BN_HELD is opt-in since round 5)
+        entry(f'k6_bn_relu_fwd_{label}', 8 * e, lambda: K.bn_relu_forward(x, y, w, b, rm, rv, sm, si, wsb, eps=1e-5, momentum=0.1),
+              cache_resident=resident, shape=list(shape), form_bytes=(8 if one else 12) * e, form=form)
+        entry(f'k6_bn_relu_bwd_{label}', 12 * e, lambda: K.bn_relu_backward(x, dy, dx, w, b, sm, si, dg, db, wsb),
+              cache_resident=resident, shape=list(shape), form_bytes=(12 if one else 20) * e, form=form)
+        if big:                                                 # the opt-in held form of the same layer beside it (1 launch, inputs read once)
+            wsb.zero_()
+            entry(f'k6_bn_relu_fwd_held_opt_in_{label}', 8 * e, lambda: K.bn_relu_forward(x, y, w, b, rm, rv, sm, si, wsb, eps=1e-5, momentum=0.1, held=True),
+                  cache_resident=resident, shape=list(shape), form_bytes=(8 if held_f else 12) * e, form='held (1 launch, inputs read once)' if held_f else 'two-launch')
+            entry(f'k6_bn_relu_bwd_held_opt_in_{label}', 12 * e, lambda: K.bn_relu_backward(x, dy, dx, w, b, sm, si, dg, db, wsb, held=True),
+                  cache_resident=resident, shape=list(shape), form_bytes=(12 if held_b else 20) * e, form='held (1 launch, inputs read once)' if held_b else 'two-launch')
         entry(f'k6_bn_relu_eval_{label}', 8 * e, lambda: K.bn_relu_eval(x, y, w, b, rm, rv, eps=1e-5),
               cache_resident=resident, shape=list(shape), form_bytes=8 * e, form='1 launch')
         del x, dy, y, dx
@@ -735,7 +769,8 @@ def cpu_baseline_block(steps):
     ck = {}
     for label, nel, reps in (('workload', 273408, 40), ('roofline_size', 1 << 26, 1)):
         rng = np.random.default_rng(0)
-        th, gr, mo = (rng.standard_normal(nel, dtype=np.float32) for _ in range(3))
+        base = rng.standard_normal(1 << 16, dtype=np.float32)              # (tiled: drawing 3 x 2^26 normals costs seconds of numpy time)
+        th, gr, mo = (np.tile(np.roll(base, 17 * k), (nel + base.size - 1) // base.size)[:nel].copy() for k in range(3))
         sc = O.step_scalars(HYP['lr'], 1 - HYP['alpha'], 1 / HYP['prior_std'] ** 2, N_TRAIN)
         O.sgmcmc_step(th[:4096], gr[:4096], mo[:4096], flags=O.STEP_NOISE | O.STEP_WD, seed=1, step=0, **sc)
         t0 = time.perf_counter()
@@ -1058,28 +1093,27 @@ def roofline_k6_object(rk):
     """A second roofline object for the largest HAND-WRITTEN share of a training step (K6: relu(bn(x)) + residual sums;
     17 % of a step's kernel time against K1's 1 %), from this run's roofline_kernels entries: at the workload's own
     layers (cache-resident, latency-bound: us per call is the figure) and at one HBM-sized layer (PreResNet-164 at the
-    HMC batch, 268 MB: the held form - one launch, inputs read once - with the two-launch form of the same layer beside
-    it), achieved = ALGORITHMIC minimum bytes (8 B/element forward, 12 backward) / time. rocprof's average for the same
-    kernels in the committed profile of this command beside it."""
+    HMC batch, 268 MB) in the form the product issues by default - two launches - with the opt-in held form (one launch,
+    inputs read once; URSA_BN_HELD=1) of the same layer beside it. achieved = ALGORITHMIC minimum bytes (8 B/element
+    forward, 12 backward) / time. rocprof's average for the same kernels in the committed profile of this command beside it."""
     if not rk:
         return None
     big_f, big_b = rk['k6_bn_relu_fwd_1024x64x32x32'], rk['k6_bn_relu_bwd_1024x64x32x32']
-    prof = {k: rocprof_average(k) for k in ('k_bn_stats<4', 'k_bn_fwd_apply<4', 'k_bn_bwd_reduce<4', 'k_bn_bwd_dx<4', 'k_bn_fwd_one<', 'k_bn_bwd_one<',
-                                            'k_bn_fwd_held<', 'k_bn_bwd_held<')}
-    two = {d: rk.get(f'k6_bn_relu_{d}_two_launch_1024x64x32x32') for d in ('fwd', 'bwd')}
+    prof = {k: rocprof_average(k) for k in ('k_bn_stats<4', 'k_bn_fwd_apply<4', 'k_bn_bwd_reduce<4', 'k_bn_bwd_dx<4', 'k_bn_fwd_one<', 'k_bn_bwd_one<')}
+    held = {d: rk.get(f'k6_bn_relu_{d}_held_opt_in_1024x64x32x32') for d in ('fwd', 'bwd')}
     return {'bound': 'hbm', 'kernel': 'K6 relu(bn(x)) forward at [1024, 64, 32, 32] (268 MB, beyond the Infinity Cache)',
-            'two_launch_form_of_the_same_layer': {d: None if v is None else {'us_per_launch': v['us'], 'frac': v['frac'], 'form_bytes': v['form_bytes']}
-                                                  for d, v in two.items()},
+            'held_form_opt_in_same_layer': {d: None if v is None else {'us_per_launch': v['us'], 'frac': v['frac'], 'form_bytes': v['form_bytes'],
+                                                                        'traffic': pmc_bytes('k_bn_fwd_held' if d == 'fwd' else 'k_bn_bwd_held')[0]}
+                                            for d, v in held.items()},
             'achieved': big_f['GBps'], 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': big_f['frac'],
-            'traffic': pmc_bytes('k_bn_fwd_held')[0], 'traffic_source': pmc_bytes('k_bn_fwd_held')[1],
+            'traffic': None, 'traffic_source': 'none for the two-launch form at this size (the form reads its inputs twice: form_bytes)',
             'bytes_per_launch': big_f['bytes'], 'us_per_launch': big_f['us'], 'form': big_f.get('form'), 'form_bytes': big_f.get('form_bytes'),
             'backward': {'achieved': big_b['GBps'], 'frac': big_b['frac'], 'bytes_per_launch': big_b['bytes'], 'us_per_launch': big_b['us'],
-                         'traffic': pmc_bytes('k_bn_bwd_held')[0],
-                         'form': big_b.get('form'), 'form_bytes': big_b.get('form_bytes')},
+                         'traffic': None, 'form': big_b.get('form'), 'form_bytes': big_b.get('form_bytes')},
             'workload_layers_us_per_call': {k[len('k6_bn_relu_'):]: {'us': v['us'], 'frac_of_algorithmic_minimum': v['frac'], 'form': v.get('form')}
                                             for k, v in rk.items() if k.startswith('k6_') and ('128x16x32x32' in k or '128x64x8x8' in k)},
             'rocprof_average_us_in_the_training_step': {k: v for k, v in prof.items() if v},
-            'share_of_step_kernel_time': 'profiles/r04_bench_kernel_stats.csv (Percentage column, k_bn_* rows)'}
+            'share_of_step_kernel_time': 'profiles/r05_bench_kernel_stats.csv (Percentage column, k_bn_* rows)'}
 
 
 def sanity_block(a, job):
@@ -1303,7 +1337,9 @@ def compact_line(line, detail_path):
     if k6:
         out['roofline_k6'] = {'workload_layers_us_per_call': {k: v.get('us') for k, v in (k6.get('workload_layers_us_per_call') or {}).items()},
                               'large_layer': _pick(k6, ('kernel', 'form', 'frac', 'us_per_launch', 'traffic')),
-                              'large_layer_backward': _pick(k6.get('backward'), ('form', 'frac', 'us_per_launch', 'traffic'))}
+                              'large_layer_backward': _pick(k6.get('backward'), ('form', 'frac', 'us_per_launch', 'traffic')),
+                              'large_layer_held_opt_in': {d: _pick(v, ('frac', 'us_per_launch', 'traffic'))
+                                                          for d, v in (k6.get('held_form_opt_in_same_layer') or {}).items()}}
     rk = line.get('roofline_kernels')
     if rk:
         out['roofline_kernels_frac'] = {k: v.get('frac') for k, v in rk.items() if not v.get('note')}     # HBM-sized entries only
@@ -1394,6 +1430,7 @@ def main(argv=None):
         errors = job.gather_errors(legs.errors)
         if job.rank == 0:
             line['errors'] = errors
+            line['leg_seconds'] = legs.seconds
             if a.full_line:
                 print(json.dumps(line), flush=True)
             else:

@@ -273,16 +273,19 @@ int ursa_sumsq_f32(const float* x, int64_t n, float* out, float* ws, ursa_stream
  */
 #define URSA_BN_RELU        0x1u
 #define URSA_BN_TWO_LAUNCH  0x2u   /* keep the two-launch form where the one-pass / held form would apply (A/B, tests) */
-#define URSA_BN_HELD        0x4u   /* the caller vouches that ws from URSA_BN_WS_HELD_OFFSET_FLOATS(C) on is ZERO: the library may then run the
-                                      held form - ONE launch, every input read once - on activations of >= 24 MiB (backward) / >= 48 MiB (forward; 32 MiB with an addend) whose
-                                      channels do not fit one workgroup (per-channel workgroups hold their chunk in registers,
-                                      exchange double partial sums through ws and wait for each other; bounded wait; that part
-                                      of ws is zero again when the launch has drained and no other form writes there, so a ws
-                                      zeroed once can be reused call after call). Same floats as the two-launch form. ONE such launch
-                                      in flight per device at a time: launches that may overlap with other BatchNorm launches on the
-                                      device (parallel streams / graph branches) must not carry the flag (they can starve each other
-                                      into the bounded wait: error word in ws, wrong numbers). Without
-                                      the flag ws needs no initialisation and the held form is never taken. */
+#define URSA_BN_HELD        0x4u   /* OPT-IN. The caller vouches that ws from URSA_BN_WS_HELD_OFFSET_FLOATS(C) on is ZERO: the library may then run
+                                      the held form - ONE launch, every input read once - on activations of >= 24 MiB (backward) / >= 48 MiB
+                                      (forward; 32 MiB with an addend) whose channels do not fit one workgroup (per-channel workgroups hold
+                                      their chunk in registers, exchange double partial sums through ws and wait for each other; that part
+                                      of ws is zero again when the launch has drained and no other form writes there, so a ws zeroed once
+                                      can be reused call after call - by ONE layer: never share it between launches that may overlap). Same
+                                      floats as the two-launch form. The wait is starvation-free only while NOTHING ELSE occupies the device
+                                      beside the launch (other streams, graph branches, collectives, other processes): launches that may
+                                      overlap with anything must not carry the flag. The wait is bounded (~3 s); a launch that runs into the
+                                      bound raises the err word in ws (float offset 512 C + 33, as uint32) and POISONS ITS OUTPUTS: y / dx of
+                                      the starved pieces, save_mean / save_invstd / running statistics / dgamma / dbeta of the channel are NaN.
+                                      Without the flag (the default of every caller in this repository) ws needs no initialisation and the
+                                      held form is never taken. */
 #define URSA_BN_ALLFLAGS    0x7u
 /* [two-launch form: partial sums, C x 64 x {double, double}] [held form: its partial-sum slots, the same size; then its
  * counters, one 128-byte line each: ticket, {done, err}, one per channel] */

@@ -92,10 +92,11 @@ def test_given_the_references_gates_every_step_of_every_seed_holds_1e5(golden_di
     assert r['engine']['graph_replays'] == 3 and r['engine']['eager_steps'] == 1, r['engine']
     for st in r['steps']:
         # The criterion: 1e-5 on the predictive with the listed gates given. Beside it: no pre-activation BEYOND the 1e-4 band
-        # changed sides - true in every run but one of ~15 of this suite (MIOpen's weight gradients add with atomics, so the
-        # weights of steps 2-4 differ in their last bits from run to run, and an element sitting just outside the band can
-        # cross once in a while): a couple of such elements are tolerated and reported, the 1e-5 bar is not moved.
-        assert st['outside_band_changed'] <= 2, (sd, st)
+        # changed sides. Round 4 tolerated "<= 2" such elements for a once-in-15-runs flake it put down to atomics in MIOpen's
+        # weight gradients; the open-gate counters it was read from went through torch's multi-workgroup reduction inside the
+        # replayed graph, whose output is not reliable on this stack (GateProbe._count_open; test below). With the counters
+        # taken without that reduction the side condition is exact again: zero.
+        assert st['outside_band_changed'] == 0, (sd, st)
         assert st['proba_ok'] and st['entropy_ok'], (sd, st)
 
 
@@ -103,7 +104,35 @@ def test_forced_gates_eager_equals_graph_replay_claim(golden_dir):
     """The same through eager launches (one seed): the instrument does not depend on the capture."""
     r = replay(golden_dir, 3, fused=True, force=True, use_graph=False)
     assert r['engine']['graph_replays'] == 0
-    assert all(st['proba_ok'] and st['entropy_ok'] and st['outside_band_changed'] <= 2 for st in r['steps']), r
+    assert all(st['proba_ok'] and st['entropy_ok'] and st['outside_band_changed'] == 0 for st in r['steps']), r
+
+
+@pytest.mark.parametrize('sd', [0, 3])
+def test_open_gate_counters_survive_small_allocations_between_replays(golden_dir, sd, monkeypatch):
+    """Regression test for the "GateProbe.n_open overwrite" (root cause in
+    profiles/r05_gate_probe_root_cause.txt). With a small-pool allocation at the end of every epoch - what an automatic
+    fused_bn.check_held() in ChainEngine.run_epoch amounts to - round 4's `n_open[k].copy_((flat > 0).sum())` came back with
+    float bit patterns in counter 1 (seed 0) / counters 1 and 6 (seed 3) on the third hipGraph replay, 12 runs of 12: the
+    output of torch's own multi-workgroup reduction inside the replayed graph (ATen's ROCm build skips the fences around its
+    staging buffer), not an overwrite by any kernel of this repository - MIOpen's BatchNorm launches in K6's place show it too.
+    GateProbe now counts without that reduction; this test fails on the old observe() and passes on the new one."""
+    from ursabench_amd.inference import engine as E
+    orig = E.ChainEngine.run_epoch
+
+    def run_epoch(self, *a, **k):
+        out = orig(self, *a, **k)
+        torch.zeros(8193, dtype=torch.int32, device=self.device)          # the epoch-end small-pool allocation
+        return out
+    monkeypatch.setattr(E.ChainEngine, 'run_epoch', run_epoch)
+    for fused in (True, False):                       # K6, and MIOpen's BatchNorm launches (observation only)
+        _cache.pop((sd, fused, fused, True), None)
+        r = replay(golden_dir, sd, fused=fused, force=fused, use_graph=True)
+        _cache.pop((sd, fused, fused, True), None)    # (not a result the other tests may reuse: run_epoch was patched)
+        assert r['engine']['graph_replays'] == 3
+        worst = max(st['outside_band_changed'] for st in r['steps'])
+        assert worst < 10 ** 6, f'a counter holds garbage: {r["steps"]}'
+        if fused:
+            assert worst == 0, r['steps']
 
 
 @pytest.mark.parametrize('sd', SEEDS)

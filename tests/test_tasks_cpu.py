@@ -179,8 +179,10 @@ def test_distilled_tasks_vs_reference(golden_dir):
 
 
 def test_private_miopen_directories_of_dead_processes_are_swept(tmp_path, monkeypatch):
-    """ursabench_amd.tuning: a directory whose owner no longer runs goes away the next time a process asks for one; a live
-    owner's directory and unmarked directories stay."""
+    """ursabench_amd.tuning: a directory whose owner no longer runs HERE goes away the next time a process asks for one; a live
+    owner's directory and unmarked directories stay - and so does one whose marker was written on another host / in another pid
+    namespace or boot (a temp directory shared between nodes: "no such pid" here says nothing about a process there)
+    or in the old pid-only format."""
     import subprocess
     import sys
     import tempfile
@@ -191,13 +193,20 @@ def test_private_miopen_directories_of_dead_processes_are_swept(tmp_path, monkey
     dead.mkdir()
     p = subprocess.Popen([sys.executable, '-c', 'pass'])
     p.wait()
-    (dead / tuning._OWNER).write_text(str(p.pid))
+    (dead / tuning._OWNER).write_text(f'{p.pid} {tuning._here()}')
     alive = tmp_path / 'ursa_x_miopen_alive'
     alive.mkdir()
-    (alive / tuning._OWNER).write_text(str(os.getpid()))
+    (alive / tuning._OWNER).write_text(f'{os.getpid()} {tuning._here()}')
+    elsewhere = tmp_path / 'ursa_x_miopen_other_host'
+    elsewhere.mkdir()
+    (elsewhere / tuning._OWNER).write_text(f'{p.pid} some-other-node|0000-boot|pid:[4026531836]')
+    old_format = tmp_path / 'ursa_x_miopen_old_marker'
+    old_format.mkdir()
+    (old_format / tuning._OWNER).write_text(str(p.pid))
     foreign = tmp_path / 'ursa_x_miopen_unmarked'
     foreign.mkdir()
     mine = tuning.use_shipped_miopen_db('ursa_t_miopen_')
     monkeypatch.delenv('MIOPEN_USER_DB_PATH', raising=False)
     assert not dead.exists() and alive.exists() and foreign.exists() and os.path.isdir(mine)
-    assert open(os.path.join(mine, tuning._OWNER)).read() == str(os.getpid())
+    assert elsewhere.exists() and old_format.exists()
+    assert open(os.path.join(mine, tuning._OWNER)).read() == f'{os.getpid()} {tuning._here()}'

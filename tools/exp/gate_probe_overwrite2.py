@@ -33,12 +33,14 @@ VARIANT = {'name': 'base'}
 LOG = []
 
 orig_init, orig_collect, orig_run_epoch = FB.GateProbe.__init__, FB.GateProbe.collect, E.ChainEngine.run_epoch
+orig_observe = FB.GateProbe.observe
 
 
 def init(self, n_calls, capacity, device, force):
     orig_init(self, n_calls, capacity, device, force)
     self._reads = []
     self._tmps = []
+    self._ptmp = torch.zeros(n_calls, dtype=torch.int64, device=device) if VARIANT['name'] == 'plain_persist_tmp' else None
     if VARIANT['name'].startswith('plain'):     # the round-4 layout exactly: no canary buffer
         self._buf = None
         return
@@ -48,14 +50,24 @@ def init(self, n_calls, capacity, device, force):
 
 
 def observe(self, k, y):
+    v = VARIANT['name']
+    if v == 'plain_product':
+        return orig_observe(self, k, y)
     flat = y.detach().reshape(-1)
     at = self.idx[k].clamp(max=flat.numel() - 1).long()
     self.seen[k].copy_(flat[at] > 0)
-    v = VARIANT['name']
     if v in ('sum_out', 'plain_sum_out'):       # no temporary, no memcpy node
         torch.sum(flat > 0, dim=0, keepdim=True, out=self.n_open[k:k + 1])
     elif v == 'plain_kernel_copy':              # the same temporary, copied by a KERNEL instead of a memcpy node
         torch.add((flat > 0).sum().view(1), 0, out=self.n_open[k:k + 1])
+    elif v == 'plain_product':                  # the product's observe() as it is now (rows of 4096 reduced per workgroup, then the row sums)
+        return orig_observe(self, k, y)
+    elif v == 'plain_two_stage_tmp':            # no multi-workgroup reduction, but still a graph-pool temporary + memcpy node
+        part = (flat > 0).view(-1, 4096).sum(1)
+        self.n_open[k].copy_(part.sum())
+    elif v == 'plain_persist_tmp':              # the reduction writes a PERSISTENT temporary (default pool, allocated before the
+        torch.sum(flat > 0, dim=0, keepdim=True, out=self._ptmp[k:k + 1])     # capture); the memcpy node copies persistent -> persistent
+        self.n_open[k].copy_(self._ptmp[k])
     elif v == 'plain_hold_tmp':                 # the memcpy node stays, but its source is never freed inside the capture
         t = (flat > 0).sum()
         self._tmps.append(t)
@@ -70,12 +82,22 @@ def collect(self):
         rec = orig_collect(self)                 # no read of our own: an extra synchronize + re-read made the effect go away in round 4
         raw = np.asarray(rec['n_open_as_reference'], np.int64)
         extra = {}
-        if len(self._reads) == 3:                # the LAST step (nothing follows that a further read could perturb): read again,
+        if len(self._reads) == 3 and True:                # the LAST step (nothing follows that a further read could perturb): read again,
             a = self.n_open.cpu().numpy().copy()  # synchronize, read once more - does the device still hold the pattern?
             torch.cuda.synchronize()
             b = self.n_open.cpu().numpy().copy()
             extra = dict(second_read=[int(x) for x in a], third_read_after_sync=[int(x) for x in b])
             raw = a
+            if self._tmps:
+                held = [int(t) for t in self._tmps[-self.n_calls:]]          # the capture's own temporaries (graph pool), still alive
+                extra['held_tmps_of_the_capture'] = held
+                extra['tmp_ptrs'] = [hex(t.data_ptr()) for t in self._tmps[-self.n_calls:]]
+                extra['n_open_ptr'] = hex(self.n_open.data_ptr())
+                print('   held temporaries of the capture:', held, '| n_open now', [int(x) for x in b], flush=True)
+                print('   tmp ptrs', extra['tmp_ptrs'], 'n_open ptr', extra['n_open_ptr'], flush=True)
+                print('   pools:', [where_ptr(t.data_ptr()) for t in self._tmps[-self.n_calls:]], 'n_open:', where_ptr(self.n_open.data_ptr()), flush=True)
+                for nm, ptr, th, cap in BWD_ALLOCS[-6:]:
+                    print('   allocation made by', nm, 'thread', th, 'capturing', cap, '->', where_ptr(ptr), flush=True)
         bad = [int(i) for i in np.nonzero((raw < 0) | (raw > 10 ** 9))[0]]
         self._reads.append(dict(guards_ok=True, bad_entries=bad, raw=[int(x) for x in raw], bad_guard_words=[],
                                 bad_as_floats=[[float(f) for f in np.array([raw[i]], np.int64).view(np.float32)] for i in bad],
@@ -103,8 +125,85 @@ def run_epoch(self, *a, **k):
     return r
 
 
+_cb = torch.cuda.CUDAGraph.capture_begin
+
+
+def capture_begin(self, *a, **k):
+    try:
+        self.enable_debug_mode()
+    except Exception as e:      # noqa: BLE001
+        print('enable_debug_mode failed', repr(e))
+    return _cb(self, *a, **k)
+
+
+torch.cuda.CUDAGraph.capture_begin = capture_begin
+_ecap = E.ChainEngine._capture
+DOTS = []
+
+
+def ecap(self, x, y):
+    _ecap(self, x, y)
+    os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+    path = os.path.join(ROOT, 'gpurun_out', f'step_graph_{len(DOTS)}.dot')
+    try:
+        self._graph.debug_dump(path)
+        txt = open(path).read()
+        import re
+        edges = re.findall(r'"?(\w+)"?\s*->\s*"?(\w+)"?', txt)
+        outdeg, indeg = {}, {}
+        for a_, b_ in edges:
+            outdeg[a_] = outdeg.get(a_, 0) + 1
+            indeg[b_] = indeg.get(b_, 0) + 1
+        kinds = {kw: txt.count(kw) for kw in ('KERNEL', 'MEMCPY', 'MEMSET', 'EMPTY', 'EVENT')}
+        print('   captured step graph:', len(edges), 'edges; nodes with >1 successors', sum(1 for v in outdeg.values() if v > 1),
+              '; nodes with >1 predecessors', sum(1 for v in indeg.values() if v > 1), '; node kinds', kinds, flush=True)
+        DOTS.append(path)
+    except Exception as e:      # noqa: BLE001
+        print('   debug_dump failed:', repr(e), flush=True)
+
+
+E.ChainEngine._capture = ecap
 FB.GateProbe.__init__, FB.GateProbe.observe, FB.GateProbe.collect = init, observe, collect
 E.ChainEngine.run_epoch = run_epoch
+
+import threading
+BWD_ALLOCS = []
+
+
+def where_ptr(ptr):
+    """(pool id, segment address, block state) of the caching-allocator block that contains `ptr`."""
+    for seg in torch.cuda.memory_snapshot():
+        a = seg['address']
+        if a <= ptr < a + seg['total_size']:
+            off = a
+            for blk in seg['blocks']:
+                if off <= ptr < off + blk['size']:
+                    return dict(pool=tuple(seg.get('segment_pool_id', ())), seg=hex(a), seg_kind=seg['segment_type'], block_state=blk['state'],
+                                block_off=off - a, block_size=blk['size'])
+                off += blk['size']
+    return None
+
+
+class _Spy(torch.autograd.Function):
+    """Identity whose backward runs on the autograd engine's thread: allocates a small tensor there and records where it came from."""
+
+    @staticmethod
+    def forward(ctx, x):
+        t = x.new_empty(8)
+        BWD_ALLOCS.append(('forward', t.data_ptr(), threading.current_thread().name, torch.cuda.is_current_stream_capturing()))
+        ctx._keep = t
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        t = g.new_empty(8)
+        BWD_ALLOCS.append(('backward', t.data_ptr(), threading.current_thread().name, torch.cuda.is_current_stream_capturing()))
+        ctx._keep2 = t
+        return g
+
+
+_fb = E.ChainEngine.forward_backward
+
 
 import ursabench_amd.inference as INF
 SAMPLERS = []
@@ -117,6 +216,15 @@ def sinit(self, *a, **k):
 
 
 INF.SGHMC.__init__ = sinit
+_ecrit = E.ChainEngine.__init__
+
+
+def einit(self, model, optimizer, loss_criterion, device, use_graph=None):
+    crit = loss_criterion
+    _ecrit(self, model, optimizer, (lambda logits, y: crit(_Spy.apply(logits), y)) if 'spy' in VARIANT.get('mods', '') else crit, device, use_graph)
+
+
+E.ChainEngine.__init__ = einit
 
 
 def where_is(f):
@@ -135,11 +243,13 @@ def where_is(f):
 
 out = {}
 for variant in (sys.argv[2].split(',') if len(sys.argv) > 2 else ('plain', 'base', 'sum_out', 'sync_read', 'clone_read', 'plain')):
-    VARIANT['name'] = variant
+    VARIANT['name'], _, mods = variant.partition('@')
+    VARIANT['mods'] = mods
+    FUSED, GRAPH = 'stock' not in mods, 'eager' not in mods          # name@stock: MIOpen's BatchNorm launches (observation only); name@eager: no hipGraph
     runs = []
     for rep in range(REPEATS):
         for sd in (0, 3):
-            T._cache.pop((sd, True, True, True), None)
+            T._cache.pop((sd, FUSED, FUSED, GRAPH), None)
             probes = []
             old = FB.GateProbe.__init__
 
@@ -148,7 +258,7 @@ for variant in (sys.argv[2].split(',') if len(sys.argv) > 2 else ('plain', 'base
                 probes.append(self)
             FB.GateProbe.__init__ = spy
             try:
-                r = T.replay(GOLD, sd, fused=True, force=True, use_graph=True)
+                r = T.replay(GOLD, sd, fused=FUSED, force=FUSED, use_graph=GRAPH)
             finally:
                 FB.GateProbe.__init__ = old
             reads = probes[-1]._reads

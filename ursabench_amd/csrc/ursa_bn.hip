@@ -139,25 +139,25 @@ __global__ __launch_bounds__(kBnBlock) void k_bn_stats(const float* __restrict__
     const int64_t lo = (int64_t)blockIdx.x * g.chunk;
     const int64_t hi = lo + g.chunk < g.per_ch ? lo + g.chunk : g.per_ch;
     double s1 = 0.0, s2 = 0.0;
-    int64_t i = lo + threadIdx.x;
-    for (; i + 3 * kBnBlock < hi; i += 4 * kBnBlock) {      // four (ADD: eight) loads in flight
+    // batches of four (ADD: eight) loads in flight, the last batch predicated: a chunk of two units per thread (the workload's
+    // 32x32 layers: 64 splits of a 16-channel activation) issues both loads at once instead of one after the other (round 4's
+    // tail loop). Accumulation order per thread is unchanged (ascending unit index): the same doubles.
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 4 * kBnBlock) {
         T v[4], w[4];
         int64_t o[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { o[u] = bn_off(g, c, i + u * kBnBlock); v[u] = xv[o[u]]; if (ADD) w[u] = av[o[u]]; }
+        for (int u = 0; u < 4; ++u) {
+            const int64_t iu = i + u * kBnBlock;
+            if (iu < hi) { o[u] = bn_off(g, c, iu); v[u] = xv[o[u]]; if (ADD) w[u] = av[o[u]]; }
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if (ADD) { v[u] = vadd(v[u], w[u]); zv[o[u]] = v[u]; }
+            if (i + u * kBnBlock < hi) {
+                if (ADD) { v[u] = vadd(v[u], w[u]); zv[o[u]] = v[u]; }
 #pragma unroll
-            for (int k = 0; k < V; ++k) { const double d = (double)comp(v[u], k); s1 += d; s2 = fma(d, d, s2); }
+                for (int k = 0; k < V; ++k) { const double d = (double)comp(v[u], k); s1 += d; s2 = fma(d, d, s2); }
+            }
         }
-    }
-    for (; i < hi; i += kBnBlock) {
-        const int64_t o = bn_off(g, c, i);
-        T v = xv[o];
-        if (ADD) { v = vadd(v, av[o]); zv[o] = v; }
-#pragma unroll
-        for (int k = 0; k < V; ++k) { const double d = (double)comp(v, k); s1 += d; s2 = fma(d, d, s2); }
     }
     bn_block_sum2(s1, s2, sh);
     if (threadIdx.x == 0) partial[(int64_t)c * gridDim.x + blockIdx.x] = make_double2(s1, s2);
@@ -187,6 +187,21 @@ __global__ __launch_bounds__(kBnBlock) void k_bn_fwd_apply(const float* __restri
     using T = typename Vec<V>::T;
     __shared__ float sh[2];
     const int c = blockIdx.y;
+    const T* __restrict__ xv = reinterpret_cast<const T*>(x);
+    T* __restrict__ yv = reinterpret_cast<T*>(y);
+    const int64_t lo = (int64_t)blockIdx.x * g.chunk;
+    const int64_t hi = lo + g.chunk < g.per_ch ? lo + g.chunk : g.per_ch;
+    // The first batch of x loads does not depend on the statistics: issue it BEFORE the merge prologue, so that the prologue's
+    // own dependent chain (partials load -> wave sums -> LDS -> barrier, ~1 us) runs under the loads' latency instead of in
+    // front of it (round 4 merged first). At the workload's layers a workgroup's whole chunk is this one batch.
+    const int64_t i0 = lo + threadIdx.x;
+    T v0[4];
+    int64_t o0[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t iu = i0 + u * kBnBlock;
+        if (iu < hi) { o0[u] = bn_off(g, c, iu); v0[u] = xv[o0[u]]; }
+    }
     if (threadIdx.x < 64) {
         double mean, var;
         const double n = (double)g.per_ch * V;
@@ -209,29 +224,30 @@ __global__ __launch_bounds__(kBnBlock) void k_bn_fwd_apply(const float* __restri
     }
     __syncthreads();
     const float scale = sh[0], shift = sh[1];
-    const T* __restrict__ xv = reinterpret_cast<const T*>(x);
-    T* __restrict__ yv = reinterpret_cast<T*>(y);
-    const int64_t lo = (int64_t)blockIdx.x * g.chunk;
-    const int64_t hi = lo + g.chunk < g.per_ch ? lo + g.chunk : g.per_ch;
-    int64_t i = lo + threadIdx.x;
-    for (; i + 3 * kBnBlock < hi; i += 4 * kBnBlock) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (i0 + u * kBnBlock < hi) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) { const float t = fmaf(comp(v0[u], k), scale, shift); setc(v0[u], k, RELU ? bn_relu_fwd(t) : t); }
+            yv[o0[u]] = v0[u];
+        }
+    }
+    for (int64_t i = i0 + 4 * kBnBlock; i < hi; i += 4 * kBnBlock) {
         T v[4];
         int64_t o[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { o[u] = bn_off(g, c, i + u * kBnBlock); v[u] = xv[o[u]]; }
+        for (int u = 0; u < 4; ++u) {
+            const int64_t iu = i + u * kBnBlock;
+            if (iu < hi) { o[u] = bn_off(g, c, iu); v[u] = xv[o[u]]; }
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
+            if (i + u * kBnBlock < hi) {
 #pragma unroll
-            for (int k = 0; k < V; ++k) { const float t = fmaf(comp(v[u], k), scale, shift); setc(v[u], k, RELU ? bn_relu_fwd(t) : t); }
-            yv[o[u]] = v[u];
+                for (int k = 0; k < V; ++k) { const float t = fmaf(comp(v[u], k), scale, shift); setc(v[u], k, RELU ? bn_relu_fwd(t) : t); }
+                yv[o[u]] = v[u];
+            }
         }
-    }
-    for (; i < hi; i += kBnBlock) {
-        const int64_t o = bn_off(g, c, i);
-        T v = xv[o];
-#pragma unroll
-        for (int k = 0; k < V; ++k) { const float t = fmaf(comp(v, k), scale, shift); setc(v, k, RELU ? bn_relu_fwd(t) : t); }
-        yv[o] = v;
     }
 }
 
@@ -379,6 +395,21 @@ __global__ __launch_bounds__(kBnBlock) void k_bn_bwd_dx(const float* __restrict_
     __shared__ float sh[2];
     const int c = blockIdx.y;
     const float mean = save_mean[c], invstd = save_invstd[c], w = gamma[c];
+    const T* __restrict__ xv = reinterpret_cast<const T*>(x);
+    const T* __restrict__ dv = reinterpret_cast<const T*>(dy);
+    const T* __restrict__ rv = reinterpret_cast<const T*>(dz);
+    T* __restrict__ ov = reinterpret_cast<T*>(dx);
+    const int64_t lo = (int64_t)blockIdx.x * g.chunk;
+    const int64_t hi = lo + g.chunk < g.per_ch ? lo + g.chunk : g.per_ch;
+    // first batch of loads (x, dy, dz of two units) BEFORE the merge prologue: see k_bn_fwd_apply
+    const int64_t i0 = lo + threadIdx.x;
+    T a0[2], b0[2], r0[2];
+    int64_t o0[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int64_t iu = i0 + u * kBnBlock;
+        if (iu < hi) { o0[u] = bn_off(g, c, iu); a0[u] = xv[o0[u]]; b0[u] = dv[o0[u]]; if (RES) r0[u] = rv[o0[u]]; }
+    }
     if (threadIdx.x < 64) {
         double a = 0.0, b = 0.0;
         if ((int)threadIdx.x < S) { const double2 p = partial[(int64_t)c * S + threadIdx.x]; a = p.x; b = p.y; }
@@ -395,46 +426,44 @@ __global__ __launch_bounds__(kBnBlock) void k_bn_bwd_dx(const float* __restrict_
     const float gm = sh[0], kk = sh[1];
     const float scale = invstd * w;
     const float shift = fmaf(-mean, scale, beta[c]);
-    const T* __restrict__ xv = reinterpret_cast<const T*>(x);
-    const T* __restrict__ dv = reinterpret_cast<const T*>(dy);
-    const T* __restrict__ rv = reinterpret_cast<const T*>(dz);
-    T* __restrict__ ov = reinterpret_cast<T*>(dx);
-    const int64_t lo = (int64_t)blockIdx.x * g.chunk;
-    const int64_t hi = lo + g.chunk < g.per_ch ? lo + g.chunk : g.per_ch;
-    int64_t i = lo + threadIdx.x;
-    for (; i + kBnBlock < hi; i += 2 * kBnBlock) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if (i0 + u * kBnBlock < hi) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const float xe = comp(a0[u], k);
+                float ge = comp(b0[u], k);
+                bool open = fmaf(xe, scale, shift) > 0.f;
+                if (GATED) open = bn_gate(open, o0[u] * V + k, gt);
+                if (RELU && !open) ge = 0.f;
+                setc(b0[u], k, (((ge - gm) - (xe - mean) * kk) * invstd) * w);
+            }
+            ov[o0[u]] = RES ? vadd(r0[u], b0[u]) : b0[u];
+        }
+    }
+    for (int64_t i = i0 + 2 * kBnBlock; i < hi; i += 2 * kBnBlock) {
         T a[2], b[2], r[2];
         int64_t o[2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) { o[u] = bn_off(g, c, i + u * kBnBlock); a[u] = xv[o[u]]; b[u] = dv[o[u]]; if (RES) r[u] = rv[o[u]]; }
+        for (int u = 0; u < 2; ++u) {
+            const int64_t iu = i + u * kBnBlock;
+            if (iu < hi) { o[u] = bn_off(g, c, iu); a[u] = xv[o[u]]; b[u] = dv[o[u]]; if (RES) r[u] = rv[o[u]]; }
+        }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
+            if (i + u * kBnBlock < hi) {
 #pragma unroll
-            for (int k = 0; k < V; ++k) {
-                const float xe = comp(a[u], k);
-                float ge = comp(b[u], k);
-                bool open = fmaf(xe, scale, shift) > 0.f;
-                if (GATED) open = bn_gate(open, o[u] * V + k, gt);
-                if (RELU && !open) ge = 0.f;
-                setc(b[u], k, (((ge - gm) - (xe - mean) * kk) * invstd) * w);
+                for (int k = 0; k < V; ++k) {
+                    const float xe = comp(a[u], k);
+                    float ge = comp(b[u], k);
+                    bool open = fmaf(xe, scale, shift) > 0.f;
+                    if (GATED) open = bn_gate(open, o[u] * V + k, gt);
+                    if (RELU && !open) ge = 0.f;
+                    setc(b[u], k, (((ge - gm) - (xe - mean) * kk) * invstd) * w);
+                }
+                ov[o[u]] = RES ? vadd(r[u], b[u]) : b[u];
             }
-            ov[o[u]] = RES ? vadd(r[u], b[u]) : b[u];
         }
-    }
-    for (; i < hi; i += kBnBlock) {
-        const int64_t o = bn_off(g, c, i);
-        const T a = xv[o];
-        T b = dv[o];
-#pragma unroll
-        for (int k = 0; k < V; ++k) {
-            const float xe = comp(a, k);
-            float ge = comp(b, k);
-            bool open = fmaf(xe, scale, shift) > 0.f;
-            if (GATED) open = bn_gate(open, o * V + k, gt);
-            if (RELU && !open) ge = 0.f;
-            setc(b, k, (((ge - gm) - (xe - mean) * kk) * invstd) * w);
-        }
-        ov[o] = RES ? vadd(rv[o], b) : b;
     }
 }
 

@@ -199,11 +199,35 @@ class GateProbe:
     def gates(self, k):
         return (self.idx[k], self.open[k]) if self.force else None
 
+    ROW = 4096      # elements one workgroup of torch's reduction kernel sums by itself (no cross-workgroup staging)
+
+    @classmethod
+    def _count_open(cls, flat, out):
+        """out[0] = number of positive elements of `flat`, WITHOUT a multi-workgroup ("global") torch reduction.
+
+        Round 4's `n_open[k].copy_((flat > 0).sum())` came back holding float bit patterns on the third hipGraph replay of the
+        G16 runs (profiles/r05_gate_probe_root_cause.txt): the garbage is the OUTPUT of torch's own reduction launch, with
+        MIOpen's BatchNorm in K6's place as well, never with eager launches. ATen's multi-workgroup reduction stages per-
+        workgroup partial sums in a scratch buffer and lets the last workgroup add them up; its ROCm build writes the partials
+        with committed stores and SKIPS both fences of that hand-off (ATen/native/cuda/Reduce.cuh, "[CMTSTRS]"), so the last
+        workgroup's plain loads can be served by a stale line of ITS OWN XCD's L2 - what the scratch block held for its
+        previous tenant (here: the previous replay's per-channel gradients) - when no cache invalidate separates the two, as
+        between the kernels of one replayed graph. Rows of <= 4096 elements are reduced by one workgroup each and the few
+        hundred row sums by one more: two launches, no staging buffer, nothing to go stale; and the result lands in the
+        probe's persistent counter directly."""
+        part = flat > 0
+        while part.numel() > cls.ROW:
+            n = part.numel()
+            if n % cls.ROW:
+                part = F.pad(part, (0, cls.ROW - n % cls.ROW))
+            part = part.view(-1, cls.ROW).sum(1)
+        torch.sum(part, dim=0, keepdim=True, out=out)
+
     def observe(self, k, y):
         flat = y.detach().reshape(-1)
         at = self.idx[k].clamp(max=flat.numel() - 1).long()
         self.seen[k].copy_(flat[at] > 0)
-        self.n_open[k].copy_((flat > 0).sum())
+        self._count_open(flat, self.n_open[k:k + 1])
 
     def collect(self):
         """Host copy of what the last forward pass observed (a device sync)."""

@@ -21,10 +21,29 @@ SHIPPED = os.path.join(_HERE, 'miopen_db')
 _OWNER = 'ursa_owner.pid'
 
 
+def _here():
+    """Which machine AND pid namespace this process lives in: hostname, boot id, and the pid-namespace inode. `os.kill(pid, 0)`
+    only says something about pids of THIS namespace on THIS host: with a temp directory shared between nodes or containers
+    (cluster scratch, a bind-mounted /tmp) a rank elsewhere would find "no such pid" for a live owner and delete its MIOpen
+    databases in the middle of a run. A marker written elsewhere is therefore never acted upon."""
+    import socket
+    parts = [socket.gethostname()]
+    for path in ('/proc/sys/kernel/random/boot_id',):
+        try:
+            parts.append(open(path).read().strip())
+        except OSError:
+            parts.append('?')
+    try:
+        parts.append(os.readlink('/proc/self/ns/pid'))
+    except OSError:
+        parts.append('?')
+    return '|'.join(parts)
+
+
 def _sweep_dead_owners():
     """Every bench rank, experiment / time_script main and smoke() makes a private directory; long sweeps used to pile
     them up under the temp directory. A directory is removed by the NEXT process that comes through here once its owner
-    (the pid in its marker file) no longer runs - not at the owner's own exit, where MIOpen may still be flushing its
+    (the pid in its marker file, written together with the host / boot / pid-namespace it is valid in) no longer runs HERE - not at the owner's own exit, where MIOpen may still be flushing its
     databases into it. Directories without a marker (made by something else) are never touched."""
     tmp = tempfile.gettempdir()
     try:
@@ -36,8 +55,11 @@ def _sweep_dead_owners():
         if not (name.startswith('ursa_') and 'miopen' in name and os.path.isdir(d)):
             continue
         try:
-            pid = int(open(os.path.join(d, _OWNER)).read().strip())
+            pid_s, _, where = open(os.path.join(d, _OWNER)).read().strip().partition(' ')
+            pid = int(pid_s)
         except (OSError, ValueError):
+            continue
+        if where != _here():                      # another host / container / boot (or an old-format marker): not ours to judge
             continue
         try:
             os.kill(pid, 0)                       # signal 0: existence check only
@@ -55,7 +77,7 @@ def use_shipped_miopen_db(prefix='ursa_miopen_'):
     _sweep_dead_owners()
     d = tempfile.mkdtemp(prefix=prefix)
     with open(os.path.join(d, _OWNER), 'w') as f:
-        f.write(str(os.getpid()))
+        f.write(f'{os.getpid()} {_here()}')
     if os.environ.get('URSA_NO_SHIPPED_MIOPEN_DB') != '1' and os.path.isdir(SHIPPED):
         for f in os.listdir(SHIPPED):
             if f.endswith('.txt'):
