@@ -292,11 +292,17 @@ int ursa_sumsq_f32(const float* x, int64_t n, float* out, float* ws, ursa_stream
 #define URSA_BN_WS_FLOATS(C) ((int64_t)(C) * 64 * 8 + ((int64_t)(C) + 2) * 32)
 #define URSA_BN_WS_HELD_OFFSET_FLOATS(C) ((int64_t)(C) * 64 * 4)
 
+/* save_gate (2 C floats, or NULL): alpha_c and beta'_c exactly as this forward used them, [alpha_0..alpha_{C-1}, beta'_0..beta'_{C-1}].
+ * Handed to the backward as `gate`, the ReLU gate is recomputed from THESE instead of from the live gamma / beta: a parameter
+ * changed in place between forward and backward by a raw-pointer launch (K1 updates the arena the parameters are views of; autograd's
+ * version counters cannot see such a write) then cannot move a gate away from the one the forward took. gate == NULL: the forward's
+ * expressions on the live parameters (the same bits while nobody touched them). dx's factor gamma_c is read live either way, like
+ * torch's own backward. */
 int ursa_bn_relu_fwd_f32(const float* x, const float* addend /* or NULL */, float* z_out /* iff addend */,
                          float* y, const float* gamma, const float* beta,
                          float* running_mean /* or NULL */, float* running_var /* or NULL */,
-                         float* save_mean, float* save_invstd, float* ws, int64_t N, int64_t C,
-                         int64_t HW, float eps, float momentum, uint32_t flags, ursa_stream_t stream);
+                         float* save_mean, float* save_invstd, float* save_gate /* 2 C floats, or NULL */, float* ws,
+                         int64_t N, int64_t C, int64_t HW, float eps, float momentum, uint32_t flags, ursa_stream_t stream);
 
 int ursa_bn_relu_eval_f32(const float* x, const float* addend /* or NULL */, float* z_out /* iff addend */,
                           float* y, const float* gamma, const float* beta,
@@ -306,6 +312,7 @@ int ursa_bn_relu_eval_f32(const float* x, const float* addend /* or NULL */, flo
 int ursa_bn_relu_bwd_f32(const float* x /* the normalised input: z_out if the forward had an addend */,
                          const float* dy, const float* dz /* or NULL */, float* dx, const float* gamma,
                          const float* beta, const float* save_mean, const float* save_invstd,
+                         const float* gate /* the forward's save_gate, or NULL */,
                          float* dgamma, float* dbeta, float* ws, int64_t N, int64_t C, int64_t HW,
                          uint32_t flags, ursa_stream_t stream);
 
@@ -345,7 +352,7 @@ int ursa_bn_relu_bwd_nhwc_f32(const float* x, const float* dy, const float* dz /
  * (URSABench/models/preresnet.py:40-41 has one device); oracle twin: oracle_bn_relu_bwd_gated_f32. */
 int ursa_bn_relu_bwd_gated_f32(const float* x, const float* dy, const float* dz /* or NULL */, float* dx,
                                const float* gamma, const float* beta, const float* save_mean,
-                               const float* save_invstd, float* dgamma, float* dbeta, float* ws, int64_t N,
+                               const float* save_invstd, const float* gate /* or NULL */, float* dgamma, float* dbeta, float* ws, int64_t N,
                                int64_t C, int64_t HW, uint32_t flags, const int32_t* gate_idx,
                                const uint8_t* gate_open, int64_t n_gates, ursa_stream_t stream);
 

@@ -130,16 +130,16 @@ int main(void)
         for (int c = 0; c < C; ++c) { hg[c] = 1.0f + 0.5f * frand(&sd); hb[c] = 0.3f * frand(&sd); }
         oracle_bn_relu_fwd_f32(hx, oy, hg, hb, NULL, NULL, osm, osi, N, C, HW, 1e-5f, 0.0f, 1);
         oracle_bn_relu_bwd_f32(hx, hdy, odx, hg, hb, osm, osi, odg, odb, N, C, HW, 1);
-        float *dx_, *ddy, *dy_, *ddx, *dg_, *db_, *dsm, *dsi, *ddg, *ddb, *dws;
+        float *dx_, *ddy, *dy_, *ddx, *dg_, *db_, *dsm, *dsi, *ddg, *ddb, *dws, *dgate;   /* dgate: the forward's scale / shift (2 C floats) */
         CHECK(hipMalloc((void**)&dx_, tot * 4)); CHECK(hipMalloc((void**)&ddy, tot * 4));
         CHECK(hipMalloc((void**)&dy_, tot * 4)); CHECK(hipMalloc((void**)&ddx, tot * 4));
         CHECK(hipMalloc((void**)&dg_, 24)); CHECK(hipMalloc((void**)&db_, 24)); CHECK(hipMalloc((void**)&dsm, 24));
-        CHECK(hipMalloc((void**)&dsi, 24)); CHECK(hipMalloc((void**)&ddg, 24)); CHECK(hipMalloc((void**)&ddb, 24));
+        CHECK(hipMalloc((void**)&dsi, 24)); CHECK(hipMalloc((void**)&ddg, 24)); CHECK(hipMalloc((void**)&ddb, 24)); CHECK(hipMalloc((void**)&dgate, 48));
         CHECK(hipMalloc((void**)&dws, URSA_BN_WS_FLOATS(C) * 4));
         CHECK(hipMemcpy(dx_, hx, tot * 4, hipMemcpyHostToDevice)); CHECK(hipMemcpy(ddy, hdy, tot * 4, hipMemcpyHostToDevice));
         CHECK(hipMemcpy(dg_, hg, 24, hipMemcpyHostToDevice)); CHECK(hipMemcpy(db_, hb, 24, hipMemcpyHostToDevice));
-        CHECK(ursa_bn_relu_fwd_f32(dx_, NULL, NULL, dy_, dg_, db_, NULL, NULL, dsm, dsi, dws, N, C, HW, 1e-5f, 0.0f, URSA_BN_RELU, st));
-        CHECK(ursa_bn_relu_bwd_f32(dx_, ddy, NULL, ddx, dg_, db_, dsm, dsi, ddg, ddb, dws, N, C, HW, URSA_BN_RELU, st));
+        CHECK(ursa_bn_relu_fwd_f32(dx_, NULL, NULL, dy_, dg_, db_, NULL, NULL, dsm, dsi, dgate, dws, N, C, HW, 1e-5f, 0.0f, URSA_BN_RELU, st));
+        CHECK(ursa_bn_relu_bwd_f32(dx_, ddy, NULL, ddx, dg_, db_, dsm, dsi, dgate, ddg, ddb, dws, N, C, HW, URSA_BN_RELU, st));
         CHECK(hipStreamSynchronize(st));
         CHECK(hipMemcpy(hy, dy_, tot * 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(hdx, ddx, tot * 4, hipMemcpyDeviceToHost));
         CHECK(hipMemcpy(gsm, dsm, 24, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(gsi, dsi, 24, hipMemcpyDeviceToHost));
@@ -158,14 +158,14 @@ int main(void)
             int32_t* didx; uint8_t* dop;
             CHECK(hipMalloc((void**)&didx, sizeof hidx)); CHECK(hipMalloc((void**)&dop, sizeof hop));
             CHECK(hipMemcpy(didx, hidx, sizeof hidx, hipMemcpyHostToDevice)); CHECK(hipMemcpy(dop, hop, sizeof hop, hipMemcpyHostToDevice));
-            CHECK(ursa_bn_relu_bwd_gated_f32(dx_, ddy, NULL, ddx, dg_, db_, dsm, dsi, ddg, ddb, dws, N, C, HW, URSA_BN_RELU, didx, dop, 4, st));
+            CHECK(ursa_bn_relu_bwd_gated_f32(dx_, ddy, NULL, ddx, dg_, db_, dsm, dsi, NULL, ddg, ddb, dws, N, C, HW, URSA_BN_RELU, didx, dop, 4, st));
             CHECK(hipStreamSynchronize(st));
             CHECK(hipMemcpy(hdx, ddx, tot * 4, hipMemcpyDeviceToHost));
             CHECK(hipMemcpy(gdg, ddg, 24, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(gdb, ddb, 24, hipMemcpyDeviceToHost));
             if (memcmp(gdg, odg, 24) || memcmp(gdb, odb, 24) || memcmp(hdx, odx, tot * 4)) { printf("FAIL K6 gated backward differs from the oracle\n"); return 1; }
         }
-        if (ursa_bn_relu_fwd_f32(dx_, NULL, NULL, dy_, dg_, db_, NULL, NULL, dsm, dsi, dws, 1, C, 1, 1e-5f, 0.0f, 0, st) != URSA_EVALUE) { printf("FAIL K6 evalue\n"); return 1; }
-        if (ursa_bn_relu_fwd_f32(dx_, NULL, NULL, dy_, dg_, db_, NULL, NULL, dsm, dsi, dws, N, C, HW, 1e-5f, 0.0f, 0x10u, st) != URSA_EFLAGS) { printf("FAIL K6 eflags\n"); return 1; }
+        if (ursa_bn_relu_fwd_f32(dx_, NULL, NULL, dy_, dg_, db_, NULL, NULL, dsm, dsi, NULL, dws, 1, C, 1, 1e-5f, 0.0f, 0, st) != URSA_EVALUE) { printf("FAIL K6 evalue\n"); return 1; }
+        if (ursa_bn_relu_fwd_f32(dx_, NULL, NULL, dy_, dg_, db_, NULL, NULL, dsm, dsi, NULL, dws, N, C, HW, 1e-5f, 0.0f, 0x10u, st) != URSA_EFLAGS) { printf("FAIL K6 eflags\n"); return 1; }
     }
     /* argument errors come back as codes, not crashes */
     if (ursa_sgmcmc_step_f32(NULL, NULL, NULL, NULL, NULL, 8, 0, 0, 0, 0, 1, 0, 0, 0, st) != URSA_ENULL) { printf("FAIL enull\n"); return 1; }

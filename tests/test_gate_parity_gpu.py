@@ -112,7 +112,7 @@ def test_open_gate_counters_survive_small_allocations_between_replays(golden_dir
     """Regression test for the "GateProbe.n_open overwrite" (root cause in
     profiles/r05_gate_probe_root_cause.txt). With a small-pool allocation at the end of every epoch - what an automatic
     fused_bn.check_held() in ChainEngine.run_epoch amounts to - round 4's `n_open[k].copy_((flat > 0).sum())` came back with
-    float bit patterns in counter 1 (seed 0) / counters 1 and 6 (seed 3) on the third hipGraph replay, 12 runs of 12: the
+    float bit patterns in counter 1 (seed 0) / counters 1 and 6 (seed 3) on the third hipGraph replay, 28 runs of 28: the
     output of torch's own multi-workgroup reduction inside the replayed graph (ATen's ROCm build skips the fences around its
     staging buffer), not an overwrite by any kernel of this repository - MIOpen's BatchNorm launches in K6's place show it too.
     GateProbe now counts without that reduction; this test fails on the old observe() and passes on the new one."""

@@ -57,10 +57,10 @@ SIGNATURES = {
     'ursa_bma_accumulate_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _f, _f, _u32, _vp]),
     'ursa_leapfrog_f32': (ctypes.c_int, [_vp, _vp, _vp, _i64, _f, _f, _f, _u32, _vp, _vp, _vp]),
     'ursa_sumsq_f32': (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp]),
-    'ursa_bn_relu_fwd_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f, _f, _u32, _vp]),
+    'ursa_bn_relu_fwd_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f, _f, _u32, _vp]),
     'ursa_bn_relu_eval_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f, _u32, _vp]),
-    'ursa_bn_relu_bwd_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _u32, _vp]),
-    'ursa_bn_relu_bwd_gated_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _u32,
+    'ursa_bn_relu_bwd_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _u32, _vp]),
+    'ursa_bn_relu_bwd_gated_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _u32,
                                                   _vp, _vp, _i64, _vp]),
 }
 
@@ -349,11 +349,12 @@ class HipKernels:
         return N, C, x.numel() // max(N * C, 1)
 
     def bn_relu_forward(self, x, y, gamma, beta, running_mean, running_var, save_mean, save_invstd, ws, *, eps,
-                        momentum, relu=True, addend=None, z_out=None, two_launch=False, held=False, y_nhwc=None):
+                        momentum, relu=True, addend=None, z_out=None, two_launch=False, held=False, y_nhwc=None, save_gate=None):
         """Training-mode BatchNorm (+ ReLU) of a contiguous [N, C, *] tensor: batch statistics, running statistics
         updated in place (skipped when both are None), mean / invstd saved for the backward. With `addend` the
         normalised tensor is z = x + addend, also stored to `z_out` (the residual sum folded into the statistics pass).
-        held=True: `ws` is ZEROED (at least its sync words) - the library may then take the one-launch held form."""
+        held=True: `ws` is ZEROED (at least its sync words) - the library may then take the one-launch held form.
+        save_gate: 2*C floats that receive the scale / shift this forward applied (hand them to bn_relu_backward as `gate`)."""
         if (addend is None) != (z_out is None):
             raise ValueError('addend and z_out go together')
         N, C, HW = self._bn_dims(x)
@@ -365,11 +366,14 @@ class HipKernels:
         tail = (_ptr(gamma, 'gamma', C, dev), _ptr(beta, 'beta', C, dev),
                 _ptr(running_mean, 'running_mean', C, dev, optional=True),
                 _ptr(running_var, 'running_var', C, dev, optional=True), _ptr(save_mean, 'save_mean', C, dev),
-                _ptr(save_invstd, 'save_invstd', C, dev), _ptr(ws, 'ws', None, dev), N, C, HW, eps, momentum,
+                _ptr(save_invstd, 'save_invstd', C, dev), _ptr(save_gate, 'save_gate', 2 * C, dev, optional=True),
+                _ptr(ws, 'ws', None, dev), N, C, HW, eps, momentum,
                 (BN_RELU if relu else 0) | (BN_TWO_LAUNCH if two_launch else 0) | _held_flags(held and y_nhwc is None), _stream(dev))
         with torch.cuda.device(dev):
             if y_nhwc is not None:              # (knobs build only) second output: the same floats channels-last (nhwc_twin() allocates it)
-                rc = self._knob('ursa_bn_relu_fwd_nhwc_f32')(*head, _twin_ptr(y_nhwc, x), *tail)
+                if save_gate is not None:
+                    raise ValueError('the NHWC-twin experiment has no save_gate')
+                rc = self._knob('ursa_bn_relu_fwd_nhwc_f32')(*head, _twin_ptr(y_nhwc, x), *(tail[:6] + tail[7:]))
             else:
                 rc = self.lib.ursa_bn_relu_fwd_f32(*head, *tail)
         _check(self.lib, rc, 'ursa_bn_relu_fwd_f32')
@@ -388,16 +392,18 @@ class HipKernels:
         _check(self.lib, rc, 'ursa_bn_relu_eval_f32')
 
     def bn_relu_backward(self, x, dy, dx, gamma, beta, save_mean, save_invstd, dgamma, dbeta, ws, *, relu=True, dz=None,
-                         two_launch=False, gates=None, held=False, dx_nhwc=None):
+                         two_launch=False, gates=None, held=False, dx_nhwc=None, gate=None):
         """`x` is the tensor the forward normalised (z_out in the residual form); with `dz` the result is dx + dz.
         `gates=(idx int32 [n], open uint8 [n])`: the parity instrument ursa_bn_relu_bwd_gated_f32 - the ReLU gates of the
-        listed element offsets (ascending; INT32_MAX = padding) are taken from `open` instead of recomputed."""
+        listed element offsets (ascending; INT32_MAX = padding) are taken from `open` instead of recomputed.
+        `gate`: the forward's `save_gate` (2*C floats): the ReLU gate is recomputed from the scale / shift the forward applied
+        instead of from the live gamma / beta."""
         N, C, HW = self._bn_dims(x)
         dev, n = x.device, x.numel()
         if ws.numel() < bn_ws_floats(C):
             raise ValueError(f'ws must hold {bn_ws_floats(C)} floats')
         if dx_nhwc is not None:
-            if gates is not None:
+            if gates is not None or gate is not None:
                 raise ValueError('the gated backward has no NHWC twin')
             with torch.cuda.device(dev):
                 rc = self._knob('ursa_bn_relu_bwd_nhwc_f32')(
@@ -410,7 +416,8 @@ class HipKernels:
             return
         args = (_ptr(x, 'x'), _ptr(dy, 'dy', n, dev), _ptr(dz, 'dz', n, dev, optional=True), _ptr(dx, 'dx', n, dev),
                 _ptr(gamma, 'gamma', C, dev), _ptr(beta, 'beta', C, dev), _ptr(save_mean, 'save_mean', C, dev),
-                _ptr(save_invstd, 'save_invstd', C, dev), _ptr(dgamma, 'dgamma', C, dev), _ptr(dbeta, 'dbeta', C, dev),
+                _ptr(save_invstd, 'save_invstd', C, dev), _ptr(gate, 'gate', 2 * C, dev, optional=True),
+                _ptr(dgamma, 'dgamma', C, dev), _ptr(dbeta, 'dbeta', C, dev),
                 _ptr(ws, 'ws', None, dev), N, C, HW,
                 (BN_RELU if relu else 0) | (BN_TWO_LAUNCH if two_launch else 0) | (_held_flags(held) if gates is None else 0))
         if gates is not None:

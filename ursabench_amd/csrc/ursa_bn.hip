@@ -39,6 +39,13 @@ struct BnGeom {
     int hw_shift;     // log2(hw) if hw is a power of two, else -1
     int chunk;        // units per workgroup (multiple of kBnBlock)
     int64_t per_ch;   // N * hw
+    // Not geometry, but every K6 kernel already receives this struct: the optional gate scalars (ursa_hip.h, `save_gate` / `gate`).
+    // Forward: alpha_c = invstd_c * gamma_c and beta'_c = fma(-mean_c, alpha_c, beta_c) as THIS forward used them are stored to
+    // gate_out[c], gate_out[C + c]; backward: with gate_in the ReLU gate is recomputed from those instead of from the live
+    // gamma / beta - a parameter changed in place between forward and backward by a raw-pointer kernel (which autograd's version
+    // counters cannot see) then cannot move a gate away from the one the forward took.
+    float* gate_out;
+    const float* gate_in;
 };
 
 template <int V> struct Vec;
@@ -60,6 +67,19 @@ __device__ inline int64_t bn_off(const BnGeom& g, int c, int64_t i)
     if (g.hw_shift >= 0) n = i >> g.hw_shift; else n = i / g.hw;
     const int64_t j = i - n * g.hw;
     return (n * g.C + c) * (int64_t)g.hw + j;
+}
+
+__device__ __forceinline__ void bn_save_gate(const BnGeom& g, int c, float alpha, float shift)
+{
+    if (g.gate_out) { g.gate_out[c] = alpha; g.gate_out[g.C + c] = shift; }
+}
+// scale / shift of the forward's y = fma(x, scale, shift): the saved ones if given, else the forward's own expressions on the
+// live parameters (same bits as long as nobody changed them in between)
+__device__ __forceinline__ void bn_gate_scalars(const BnGeom& g, int c, float mean, float invstd, const float* __restrict__ gamma,
+                                                const float* __restrict__ beta, float& scale, float& shift)
+{
+    if (g.gate_in) { scale = g.gate_in[c]; shift = g.gate_in[g.C + c]; }
+    else { scale = invstd * gamma[c]; shift = fmaf(-mean, scale, beta[c]); }
 }
 
 // Sum of a double over the 64 lanes of a wave on the VALU (DPP butterflies inside a 16-lane row, v_readlane across
@@ -215,6 +235,7 @@ __global__ __launch_bounds__(kBnBlock) void k_bn_fwd_apply(const float* __restri
             if (blockIdx.x == 0) {
                 save_mean[c] = meanf;
                 save_invstd[c] = invstd;
+                bn_save_gate(g, c, alpha, sh[1]);
                 if (running_mean) {      // torch: running = momentum * batch + (1 - momentum) * running, unbiased variance
                     running_mean[c] = momentum * meanf + (1.0f - momentum) * running_mean[c];
                     running_var[c] = momentum * (float)(var * (n / (n - 1.0))) + (1.0f - momentum) * running_var[c];
@@ -332,8 +353,8 @@ __global__ __launch_bounds__(kBnBlock) void k_bn_bwd_reduce(const float* __restr
     __shared__ double sh[2 * kBnBlock / 64];
     const int c = blockIdx.y;
     const float mean = save_mean[c], invstd = save_invstd[c];
-    const float scale = invstd * gamma[c];                   // the forward's own expressions: same bits, same gates
-    const float shift = fmaf(-mean, scale, beta[c]);
+    float scale, shift;                                      // the forward's own scalars (saved, or its expressions on the live
+    bn_gate_scalars(g, c, mean, invstd, gamma, beta, scale, shift);      // parameters): same bits, same gates
     const double meand = (double)mean;
     const T* __restrict__ xv = reinterpret_cast<const T*>(x);
     const T* __restrict__ dv = reinterpret_cast<const T*>(dy);
@@ -424,8 +445,8 @@ __global__ __launch_bounds__(kBnBlock) void k_bn_bwd_dx(const float* __restrict_
     }
     __syncthreads();
     const float gm = sh[0], kk = sh[1];
-    const float scale = invstd * w;
-    const float shift = fmaf(-mean, scale, beta[c]);
+    float scale, shift;
+    bn_gate_scalars(g, c, mean, invstd, gamma, beta, scale, shift);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         if (i0 + u * kBnBlock < hi) {
@@ -538,6 +559,7 @@ __global__ __launch_bounds__(kOneBlock) void k_bn_fwd_one(const float* __restric
         shf[1] = fmaf(-meanf, alpha, beta[c]);
         save_mean[c] = meanf;
         save_invstd[c] = invstd;
+        bn_save_gate(g, c, alpha, shf[1]);
         if (running_mean) {
             running_mean[c] = momentum * meanf + (1.0f - momentum) * running_mean[c];
             running_var[c] = momentum * (float)(var * (n / (n - 1.0))) + (1.0f - momentum) * running_var[c];
@@ -575,8 +597,8 @@ __global__ __launch_bounds__(kOneBlock) void k_bn_bwd_one(const float* __restric
     float4* __restrict__ ov = reinterpret_cast<float4*>(dx);
     const int c = blockIdx.x, per_ch = (int)g.per_ch;
     const float mean = save_mean[c], invstd = save_invstd[c], w = gamma[c];
-    const float scale = invstd * w;
-    const float shift = fmaf(-mean, scale, beta[c]);
+    float scale, shift;
+    bn_gate_scalars(g, c, mean, invstd, gamma, beta, scale, shift);
     const double meand = (double)mean;
     float4 a[EPT], b[EPT];
 #pragma unroll
@@ -877,6 +899,7 @@ __global__ __launch_bounds__(kHeldFwdBlock) void k_bn_fwd_held(         // no re
             if (sp == 0 || mean != mean) {                       // (a starved piece - NaN sums - poisons the channel's statistics too)
                 save_mean[c] = meanf;
                 save_invstd[c] = invstd;
+                bn_save_gate(g, c, alpha, shf[1]);
                 if (running_mean) {
                     running_mean[c] = momentum * meanf + (1.0f - momentum) * running_mean[c];
                     running_var[c] = momentum * (float)(var * (n / (n - 1.0))) + (1.0f - momentum) * running_var[c];
@@ -935,8 +958,8 @@ __global__ __launch_bounds__(kHeldBwdBlock) void k_bn_bwd_held(const float* __re
     const float4* __restrict__ rv = reinterpret_cast<const float4*>(dz);
     float4* __restrict__ ov = reinterpret_cast<float4*>(dx);
     const float mean = save_mean[c], invstd = save_invstd[c], w = gamma[c];
-    const float scale = invstd * w;
-    const float shift = fmaf(-mean, scale, beta[c]);
+    float scale, shift;
+    bn_gate_scalars(g, c, mean, invstd, gamma, beta, scale, shift);
     const double meand = (double)mean;
     const int lo = sp * g.chunk;
     const int hi = lo + g.chunk < (int)g.per_ch ? lo + g.chunk : (int)g.per_ch;
@@ -1092,6 +1115,7 @@ __global__ __launch_bounds__(kBnBlock) void k_bn_fwd_apply_4(const float* __rest
             if (blockIdx.x == 0) {
                 save_mean[c] = meanf;
                 save_invstd[c] = invstd;
+                bn_save_gate(g, c, alpha, sh[2 * (threadIdx.x >> 6) + 1]);
                 if (running_mean) {
                     running_mean[c] = momentum * meanf + (1.0f - momentum) * running_mean[c];
                     running_var[c] = momentum * (float)(var * (cnt / (cnt - 1.0))) + (1.0f - momentum) * running_var[c];
@@ -1161,8 +1185,8 @@ __global__ __launch_bounds__(kBnBlock) void k_bn_bwd_dx_4(const float* __restric
     for (int r = 0; r < 4; ++r) {
         const int c = c0 + r;
         const float mean = save_mean[c], invstd = save_invstd[c], w = gamma[c];
-        const float scale = invstd * w;
-        const float shift = fmaf(-mean, scale, beta[c]);
+        float scale, shift;
+        bn_gate_scalars(g, c, mean, invstd, gamma, beta, scale, shift);
         const float gm = sh[2 * r], kk = sh[2 * r + 1];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -1230,6 +1254,8 @@ inline int bn_plan(int64_t N, int64_t C, int64_t HW, bool vec_ok, BnPlan* p)
     for (int s = 0; s < 31; ++s) if ((1ll << s) == hw) p->g.hw_shift = s;
     p->g.chunk = (int)chunk;
     p->g.per_ch = per_ch;
+    p->g.gate_out = nullptr;
+    p->g.gate_in = nullptr;
     return URSA_OK;
 }
 
@@ -1334,7 +1360,7 @@ extern "C" {
 
 static int bn_fwd_impl(const float* x, const float* addend, float* z_out, float* y, float* y_nhwc,
                        const float* gamma, const float* beta,
-                       float* running_mean, float* running_var, float* save_mean, float* save_invstd, float* ws,
+                       float* running_mean, float* running_var, float* save_mean, float* save_invstd, float* save_gate, float* ws,
                        int64_t N, int64_t C, int64_t HW, float eps, float momentum, uint32_t flags, ursa_stream_t stream)
 {
     if (flags & ~URSA_BN_ALLFLAGS) return URSA_EFLAGS;
@@ -1347,6 +1373,8 @@ static int bn_fwd_impl(const float* x, const float* addend, float* z_out, float*
     BnPlan p;
     const int rc = bn_plan(N, C, HW, bn_aligned16(x) && bn_aligned16(y) && bn_aligned16(addend) && bn_aligned16(z_out), &p);
     if (rc) return rc;
+    if (!bn_aligned4(save_gate)) return URSA_EALIGN;
+    p.g.gate_out = save_gate;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(p.S, p.g.C), block(kBnBlock);
     double2* part = reinterpret_cast<double2*>(ws);
@@ -1425,10 +1453,10 @@ static int bn_fwd_impl(const float* x, const float* addend, float* z_out, float*
 }
 
 int ursa_bn_relu_fwd_f32(const float* x, const float* addend, float* z_out, float* y, const float* gamma, const float* beta,
-                         float* running_mean, float* running_var, float* save_mean, float* save_invstd, float* ws,
+                         float* running_mean, float* running_var, float* save_mean, float* save_invstd, float* save_gate, float* ws,
                          int64_t N, int64_t C, int64_t HW, float eps, float momentum, uint32_t flags, ursa_stream_t stream)
 {
-    return bn_fwd_impl(x, addend, z_out, y, nullptr, gamma, beta, running_mean, running_var, save_mean, save_invstd, ws, N, C, HW,
+    return bn_fwd_impl(x, addend, z_out, y, nullptr, gamma, beta, running_mean, running_var, save_mean, save_invstd, save_gate, ws, N, C, HW,
                        eps, momentum, flags, stream);
 }
 
@@ -1439,7 +1467,7 @@ int ursa_bn_relu_fwd_nhwc_f32(const float* x, const float* addend, float* z_out,
                               uint32_t flags, ursa_stream_t stream)
 {
     if (!y_nhwc) return URSA_ENULL;
-    return bn_fwd_impl(x, addend, z_out, y, y_nhwc, gamma, beta, running_mean, running_var, save_mean, save_invstd, ws, N, C, HW,
+    return bn_fwd_impl(x, addend, z_out, y, y_nhwc, gamma, beta, running_mean, running_var, save_mean, save_invstd, nullptr, ws, N, C, HW,
                        eps, momentum, flags, stream);
 }
 #endif
@@ -1474,7 +1502,7 @@ int ursa_bn_relu_eval_f32(const float* x, const float* addend, float* z_out, flo
 
 static int bn_bwd_impl(const float* x, const float* dy, const float* dz, float* dx, float* dx_nhwc,
                        const float* gamma, const float* beta,
-                       const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, float* ws,
+                       const float* save_mean, const float* save_invstd, const float* gate, float* dgamma, float* dbeta, float* ws,
                        int64_t N, int64_t C, int64_t HW, uint32_t flags, const BnGates* gates, ursa_stream_t stream)
 {
     if (flags & ~URSA_BN_ALLFLAGS) return URSA_EFLAGS;
@@ -1484,6 +1512,8 @@ static int bn_bwd_impl(const float* x, const float* dy, const float* dz, float* 
     BnPlan p;
     const int rc = bn_plan(N, C, HW, bn_aligned16(x) && bn_aligned16(dy) && bn_aligned16(dz) && bn_aligned16(dx), &p);
     if (rc) return rc;
+    if (!bn_aligned4(gate)) return URSA_EALIGN;
+    p.g.gate_in = gate;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(p.S, p.g.C), block(kBnBlock);
     double2* part = reinterpret_cast<double2*>(ws);
@@ -1565,10 +1595,10 @@ static int bn_bwd_impl(const float* x, const float* dy, const float* dz, float* 
 }
 
 int ursa_bn_relu_bwd_f32(const float* x, const float* dy, const float* dz, float* dx, const float* gamma, const float* beta,
-                         const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, float* ws,
+                         const float* save_mean, const float* save_invstd, const float* gate, float* dgamma, float* dbeta, float* ws,
                          int64_t N, int64_t C, int64_t HW, uint32_t flags, ursa_stream_t stream)
 {
-    return bn_bwd_impl(x, dy, dz, dx, nullptr, gamma, beta, save_mean, save_invstd, dgamma, dbeta, ws, N, C, HW, flags, nullptr, stream);
+    return bn_bwd_impl(x, dy, dz, dx, nullptr, gamma, beta, save_mean, save_invstd, gate, dgamma, dbeta, ws, N, C, HW, flags, nullptr, stream);
 }
 
 #ifdef URSA_DEBUG_KNOBS
@@ -1578,13 +1608,13 @@ int ursa_bn_relu_bwd_nhwc_f32(const float* x, const float* dy, const float* dz, 
                               ursa_stream_t stream)
 {
     if (!dx_nhwc) return URSA_ENULL;
-    return bn_bwd_impl(x, dy, dz, dx, dx_nhwc, gamma, beta, save_mean, save_invstd, dgamma, dbeta, ws, N, C, HW, flags, nullptr,
+    return bn_bwd_impl(x, dy, dz, dx, dx_nhwc, gamma, beta, save_mean, save_invstd, nullptr, dgamma, dbeta, ws, N, C, HW, flags, nullptr,
                        stream);
 }
 #endif
 
 int ursa_bn_relu_bwd_gated_f32(const float* x, const float* dy, const float* dz, float* dx, const float* gamma,
-                               const float* beta, const float* save_mean, const float* save_invstd, float* dgamma,
+                               const float* beta, const float* save_mean, const float* save_invstd, const float* gate, float* dgamma,
                                float* dbeta, float* ws, int64_t N, int64_t C, int64_t HW, uint32_t flags,
                                const int32_t* gate_idx, const uint8_t* gate_open, int64_t n_gates, ursa_stream_t stream)
 {
@@ -1593,7 +1623,7 @@ int ursa_bn_relu_bwd_gated_f32(const float* x, const float* dy, const float* dz,
     if (!bn_aligned4(gate_idx)) return URSA_EALIGN;
     if (N > 0 && C > 0 && HW > 0 && N * C > (int64_t)0x7ffffffe / HW) return URSA_ESIZE;      // 32-bit element offsets
     const BnGates gt{gate_idx, gate_open, (int)n_gates};
-    return bn_bwd_impl(x, dy, dz, dx, nullptr, gamma, beta, save_mean, save_invstd, dgamma, dbeta, ws, N, C, HW, flags, &gt, stream);
+    return bn_bwd_impl(x, dy, dz, dx, nullptr, gamma, beta, save_mean, save_invstd, gate, dgamma, dbeta, ws, N, C, HW, flags, &gt, stream);
 }
 
 }  // extern "C"

@@ -1167,7 +1167,10 @@ __global__ __launch_bounds__(kSBlock) void k_leapfrog_v(float* __restrict__ thet
 // Grid-stride form: also used when the kinetic energy is wanted (bounded number of block partials). NT: non-temporal
 // accesses when the vectors touched exceed the Infinity Cache, as in the streaming form (round 2 left this form on
 // plain accesses: kick + kinetic read 0.63 of the HBM peak at 2^26 elements against 0.78 for the streaming kick).
-constexpr int kLeapU = 4;
+#ifndef URSA_LEAP_U
+#define URSA_LEAP_U 4
+#endif
+constexpr int kLeapU = URSA_LEAP_U;
 template <bool VEC, bool NT>
 __global__ __launch_bounds__(kBlock) void k_leapfrog(float* __restrict__ theta, float* __restrict__ mom,
                                                      const float* __restrict__ grad, int64_t n, float kick,
@@ -1182,14 +1185,13 @@ __global__ __launch_bounds__(kBlock) void k_leapfrog(float* __restrict__ theta, 
         const float4* mv = reinterpret_cast<const float4*>(mom);
         const float4* gv = reinterpret_cast<const float4*>(grad);
         const float4* tv = reinterpret_cast<const float4*>(theta);
-        // Every workgroup owns one CONTIGUOUS span of the vectors and walks it in batches of kLeapU adjacent 1 KB-per-wave tiles, all
-        // loads of a batch in flight before the first use (round 4: a grid-stride loop with one float4 per vector in flight per
-        // thread - every iteration waited for its own loads, and the kick + kinetic form ran at 0.70 of the HBM peak against 0.80
-        // for the streaming kick; batches at the grid stride, 8 MB apart, were slower still: 0.66).
-        const int64_t span = ((n4 + gridDim.x - 1) / gridDim.x + kBlock - 1) / kBlock * kBlock;
-        const int64_t lo = (int64_t)blockIdx.x * span;
-        const int64_t hi = lo + span < n4 ? lo + span : n4;
-        for (int64_t i = lo + threadIdx.x; i < hi; i += kLeapU * kBlock) {
+        // Grid-stride over BATCHES of kLeapU adjacent 4 KB tiles: all loads of a batch in flight before the first use, and the
+        // workgroups of the launch together still sweep ONE contiguous window of the vectors (round 4: one float4 per vector in
+        // flight per thread, 0.70 of the HBM peak for kick + kinetic against 0.80 for the streaming kick. Round 5 A/B, 2^26
+        // elements: batches whose members sit a whole grid stride - 8 MB - apart 0.66; one contiguous span per workgroup, i.e.
+        // 2,048 separate streams, 0.66; this form: see DESIGN.md).
+        const int64_t hi = n4;
+        for (int64_t i = (int64_t)blockIdx.x * (kLeapU * kBlock) + threadIdx.x; i < hi; i += (int64_t)gridDim.x * (kLeapU * kBlock)) {
             float4 p[kLeapU], g[kLeapU], t[kLeapU];
 #pragma unroll
             for (int u = 0; u < kLeapU; ++u) if (i + u * kBlock < hi) p[u] = ld4<NT>(mv + i + u * kBlock);
@@ -1246,10 +1248,8 @@ __global__ __launch_bounds__(kBlock) void k_sumsq(const float* __restrict__ x, i
     if (VEC) {
         const int64_t n4 = n >> 2;
         const float4* __restrict__ xv = reinterpret_cast<const float4*>(x);
-        const int64_t span = ((n4 + gridDim.x - 1) / gridDim.x + kBlock - 1) / kBlock * kBlock;      // contiguous span per workgroup,
-        const int64_t lo = (int64_t)blockIdx.x * span;                                               // batches of kLeapU adjacent tiles
-        const int64_t hi = lo + span < n4 ? lo + span : n4;                                          // (see k_leapfrog)
-        for (int64_t i = lo + threadIdx.x; i < hi; i += kLeapU * kBlock) {
+        const int64_t hi = n4;                                                  // grid-stride over batches of kLeapU adjacent tiles (see k_leapfrog)
+        for (int64_t i = (int64_t)blockIdx.x * (kLeapU * kBlock) + threadIdx.x; i < hi; i += (int64_t)gridDim.x * (kLeapU * kBlock)) {
             float4 v[kLeapU];
 #pragma unroll
             for (int u = 0; u < kLeapU; ++u) if (i + u * kBlock < hi) v[u] = xv[i + u * kBlock];

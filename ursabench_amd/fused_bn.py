@@ -272,9 +272,10 @@ class _BNReLUTrain(torch.autograd.Function):
         K = _native.default_kernels()
         C = x.shape[1]
         y = torch.empty_like(x)
-        stats = x.new_empty(2, C)                       # save_mean, save_invstd
+        stats = x.new_empty(4, C)                       # save_mean, save_invstd, and the scale / shift the forward applied: the
+        #                                                 backward recomputes the ReLU gate from THOSE, not from the live gamma / beta
         K.bn_relu_forward(x, y, weight, bias, running_mean, running_var, stats[0], stats[1], ws, eps=eps,
-                          momentum=momentum, relu=relu, two_launch=_two_launch, held=hd)
+                          momentum=momentum, relu=relu, two_launch=_two_launch, held=hd, save_gate=stats[2:])
         ctx.save_for_backward(x, weight, bias, stats)
         ctx.relu, ctx.gates = relu, gates
         ctx.held_ws = ws if hd else None                # the forward's decision travels: same scratch, same form allowed
@@ -292,7 +293,7 @@ class _BNReLUTrain(torch.autograd.Function):
         hd = ctx.held_ws is not None
         ws = ctx.held_ws if hd else x.new_empty(_native.bn_ws_floats(C))
         K.bn_relu_backward(x, dy, dx, weight, bias, stats[0], stats[1], dwb[0], dwb[1], ws, relu=ctx.relu,
-                           two_launch=_two_launch, gates=ctx.gates, held=hd)
+                           two_launch=_two_launch, gates=ctx.gates, held=hd, gate=stats[2:])
         return dx, dwb[0], dwb[1], None, None, None, None, None, None, None, None
 
 
@@ -305,9 +306,9 @@ class _AddBNReLUTrain(torch.autograd.Function):
         K = _native.default_kernels()
         C = a.shape[1]
         z, y = torch.empty_like(a), torch.empty_like(a)
-        stats = a.new_empty(2, C)
+        stats = a.new_empty(4, C)
         K.bn_relu_forward(a, y, weight, bias, running_mean, running_var, stats[0], stats[1], ws, eps=eps,
-                          momentum=momentum, relu=relu, addend=b, z_out=z, two_launch=_two_launch, held=hd)
+                          momentum=momentum, relu=relu, addend=b, z_out=z, two_launch=_two_launch, held=hd, save_gate=stats[2:])
         ctx.save_for_backward(z, weight, bias, stats)
         ctx.relu, ctx.gates = relu, gates
         ctx.held_ws = ws if hd else None
@@ -328,7 +329,7 @@ class _AddBNReLUTrain(torch.autograd.Function):
         hd = ctx.held_ws is not None
         ws = ctx.held_ws if hd else z.new_empty(_native.bn_ws_floats(C))
         K.bn_relu_backward(z, dy, dx, weight, bias, stats[0], stats[1], dwb[0], dwb[1], ws, relu=ctx.relu, dz=dz,
-                           two_launch=_two_launch, gates=ctx.gates, held=hd)
+                           two_launch=_two_launch, gates=ctx.gates, held=hd, gate=stats[2:])
         return dx, dx, dwb[0], dwb[1], None, None, None, None, None, None, None, None
 
 
