@@ -252,7 +252,7 @@ def load_gate_lists():
     return gate_lists
 
 
-def parity_trial(dev, seed_offset, steps_per_sample=1, samples=3, rows=128, test_rows=64, depth=20, n_noise=N_TRAIN,
+def parity_trial(dev, seed_offset, steps_per_sample=1, samples=3, rows=128, test_rows=128, depth=20, n_noise=N_TRAIN,
                  given_gates=True):
     """One (rows, seed) of parity_block: the torch-CPU port once (recording its near-zero ReLU gates), then the GPU path
     on the same init / inputs / noise - `natural` (gates as the GPU's own convolutions decide them; differing ones
@@ -394,7 +394,7 @@ def parity_trial(dev, seed_offset, steps_per_sample=1, samples=3, rows=128, test
 PARITY_SEEDS = (0, 10, 20)       # fixed list: every trial runs, every trial is in the line, nothing is selected
 
 
-def parity_block(dev, steps_per_sample=1, samples=3, rows=128, test_rows=64, depth=20, n_noise=N_TRAIN, small_rows=32,
+def parity_block(dev, steps_per_sample=1, samples=3, rows=128, test_rows=128, depth=20, n_noise=N_TRAIN, small_rows=32,
                  seeds=PARITY_SEEDS):
     """§8(d): before timing, the GPU path against the reference CPU path (its torch-CPU port,
     oracle/torch_cpu_path.py — pinned bitwise to the imported reference in tests/test_cpu_port.py) on

@@ -11,4 +11,12 @@ tail -3 "$out/pytest_gpu.log"
 python -c "import __graft_entry__ as g; g.smoke()" > "$out/smoke.log" 2>&1; echo "smoke rc=$?" | tee -a "$out/rc.txt"
 tail -2 "$out/smoke.log"
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$out/bench.json" 2> "$out/bench.err"; echo "bench rc=$?" | tee -a "$out/rc.txt"
-tail -c 1500 "$out/bench.json"
+cp gpurun_out/bench_detail_c2.json "$out/bench_detail.json" 2>/dev/null
+# what the driver does with stdout: the LAST line must parse by itself (round 4's 27.7 KB line did not fit its tail buffer)
+python3 - "$out/bench.json" <<'PY' | tee -a "$out/rc.txt"
+import json, sys
+last = open(sys.argv[1]).read().rstrip("\n").splitlines()[-1]
+d = json.loads(last)
+print(f"bench line: {len(last.encode())} bytes, parses alone; value={d['value']} {d['unit']} ms_per_step={d['ms_per_step']} "
+      f"roofline.frac={d['roofline']['frac']} cpu_baseline.value={d['cpu_baseline']['value']} parity.pass={d['parity']['pass']} errors={d['errors']}")
+PY

@@ -3,7 +3,7 @@
 # configurations. A gpurun call is limited to 20
 # minutes, so the work is cut into parts; each part is one call on a fresh box, all of them at the same commit
 # (r05_sha256.txt is written by every part and must agree):
-#   for p in a b c d e; do /usr/local/graft/bin/gpurun --timeout 1200 -- "bash tools/r05_evidence.sh $p"; done
+#   for p in a b c d e f; do /usr/local/graft/bin/gpurun --timeout 1200 -- "bash tools/r05_evidence.sh $p"; done
 # Outputs: gpurun_out/r05_evidence/ (copy into profiles/).
 part=${1:-a}
 R=$GRAFT_REPO_ROOT
@@ -62,6 +62,12 @@ d)  # C4 and C5 at full size
   python3 bench.py --config c5 --c5-batch 1024 --detail-out $out/r05_c5_bench_detail.json > $out/r05_c5_bench_line.json 2> $out/c5.err; echo "c5 rc=$?"
   URSA_BN_HELD=1 python3 bench.py --config c5 --c5-batch 1024 --detail-out $out/r05_c5_bench_detail_held_opt_in.json > $out/r05_c5_bench_line_held_opt_in.json 2> $out/c5_held.err; echo "c5 held opt-in rc=$?"
   python3 bench.py --config c4 --detail-out $out/r05_c4_bench_detail.json > $out/r05_c4_bench_line.json 2> $out/c4.err; echo "c4 rc=$?"
+  ;;
+f)  # one minibatch step of configs[1] dispatch by dispatch (tools/step_timeline.py on a kernel trace of the sampling leg)
+  cd /tmp && export TMPDIR=/tmp
+  rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -- python3 $R/bench.py --steps 2 --warmup 1 --no-parity --no-cpu-baseline --ref-style-steps 0 --multi-chain-sweep "" --detail-out $out/tl_detail.json > $out/tl_line.json 2> $out/tl.err; echo "trace rc=$?"
+  cd $R
+  python3 tools/step_timeline.py /tmp/tl $out/r05_step_timeline.json > /dev/null; echo "step_timeline rc=$?"
   ;;
 e)  # C4 with the held form opted in (A/B of part d's C4 line)
   URSA_BN_HELD=1 python3 bench.py --config c4 --detail-out $out/r05_c4_bench_detail_held_opt_in.json > $out/r05_c4_bench_line_held_opt_in.json 2> $out/c4_held.err; echo "c4 held opt-in rc=$?"
