@@ -983,3 +983,31 @@ def test_backward_takes_its_gates_from_the_forwards_saved_scalars(K, shape, held
     for a, b in zip(ref, backward(moved, gate)):
         assert torch.equal(a, b), 'with the saved scalars a changed beta must not matter'
     assert not torch.equal(ref[0], backward(moved, None)[0]), 'the control: without them gates do move'
+
+
+@pytest.mark.parametrize('shape', [(1030, 20, 16, 16), (220, 50, 20, 20), (300, 50, 12, 12), (4100, 16, 8, 8), (128, 160, 32, 32), (67, 33, 40, 40)])
+@pytest.mark.parametrize('relu', [True, False])
+def test_linear_evaluation_launch_equals_the_oracle_bit_for_bit(K, shape, relu):
+    """Round 5: from 16 MiB of activation on (8 MiB with an addend) the evaluation launch streams the tensor front to back - one
+    contiguous 16 KB span per workgroup, the channel of every float4 looked up in a per-workgroup table - instead of walking
+    channel by channel (csrc/ursa_bn.hip k_bn_eval_lin; profiles/r05_bn_eval_lin_ab.json). Same arithmetic per element, so the
+    same bits as the oracle (and as torch's CPU kernel): shapes whose H*W/4 is and is not a power of two, channel counts that are
+    not, a last workgroup that is not full, plain and residual forms, with and without ReLU."""
+    import oracle_lib as O
+    g = torch.Generator().manual_seed(41 + sum(shape))
+    C = shape[1]
+    x, a = torch.randn(shape, generator=g), torch.randn(shape, generator=g)
+    w, b = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    rm, rv = torch.randn(C, generator=g) * 0.2, torch.rand(C, generator=g) + 0.5
+    dw, db, drm, drv = (t.cuda() for t in (w, b, rm, rv))
+    big_enough_plain = x.numel() * 4 >= (16 << 20)
+    want = O.bn_relu_eval(x.numpy(), w.numpy(), b.numpy(), rm.numpy(), rv.numpy(), eps=1e-5, relu=relu)
+    y = torch.full(shape, float('nan'), device='cuda')
+    K.bn_relu_eval(x.cuda(), y, dw, db, drm, drv, eps=1e-5, relu=relu)
+    assert np.array_equal(y.cpu().numpy(), want), ('plain', big_enough_plain)
+    z_ref = x + a                                                   # one fp32 add, as torch's (and the launch's)
+    want_r = O.bn_relu_eval(z_ref.numpy(), w.numpy(), b.numpy(), rm.numpy(), rv.numpy(), eps=1e-5, relu=relu)
+    y, z = torch.full(shape, float('nan'), device='cuda'), torch.full(shape, float('nan'), device='cuda')
+    K.bn_relu_eval(x.cuda(), y, dw, db, drm, drv, eps=1e-5, relu=relu, addend=a.cuda(), z_out=z)
+    assert torch.equal(z.cpu(), z_ref) and np.array_equal(y.cpu().numpy(), want_r), 'residual'
+    assert x.numel() * 4 >= (8 << 20), 'the shape does not reach the linear form: the test does not test what it says'

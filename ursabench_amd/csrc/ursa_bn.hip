@@ -321,6 +321,57 @@ __global__ __launch_bounds__(kBnBlock) void k_bn_eval(const float* __restrict__ 
     }
 }
 
+// ---- evaluation mode, LINEAR form (round 5; float4 path): the launch needs no per-channel reduction, so nothing ties a
+//      workgroup to a channel. The channel-grid kernel above walks channel c as N runs of H*W floats that sit C*H*W apart
+//      (4 KB pieces at a 64 KB - 2.6 MB stride: 0.57 of the HBM peak at [128, 640, 8, 8], 0.69 at [1024, 64, 32, 32]); this one
+//      streams the tensor front to back like K1 - workgroup b owns float4 [b * 1024, (b + 1) * 1024), one contiguous 16 KB - and
+//      looks the channel of every float4 up: plane = float4 index / (H*W/4) = n * C + c. The (scale, shift) pairs of the planes a
+//      workgroup touches (at most 1024 / (H*W/4) + 1) are built once per workgroup in LDS, AFTER the workgroup's loads have been
+//      issued (their latency covers the table's dependent chain: parameter loads -> rsqrt -> LDS -> barrier). Same arithmetic
+//      per element as k_bn_eval (and as torch's CPU kernel): invstd = 1 / sqrtf(var + eps); alpha = invstd * gamma;
+//      beta' = fma(-mean, alpha, beta); y = fma(x, alpha, beta') - the same bits.
+constexpr int kEvalU = 4;
+constexpr int kEvalSpan = kBnBlock * kEvalU;
+template <bool RELU, bool ADD, bool NT>
+__global__ __launch_bounds__(kBnBlock) void k_bn_eval_lin(const float4* __restrict__ xv, const float4* __restrict__ av,
+                                                          float4* __restrict__ zv, float4* __restrict__ yv,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ running_mean,
+                                                          const float* __restrict__ running_var, float eps, int C, int hw4,
+                                                          int hw_shift, int64_t total4)
+{
+    __shared__ float2 tab[kEvalSpan + 1];
+    const int64_t base = (int64_t)blockIdx.x * kEvalSpan;
+    const int64_t end = base + kEvalSpan < total4 ? base + kEvalSpan : total4;
+    float4 v[kEvalU], w[kEvalU];
+#pragma unroll
+    for (int u = 0; u < kEvalU; ++u) {
+        const int64_t i = base + threadIdx.x + u * kBnBlock;
+        if (i < end) { v[u] = ev_ld<NT>(xv + i); if (ADD) w[u] = ev_ld<NT>(av + i); }
+    }
+    const int64_t p0 = hw_shift >= 0 ? (base >> hw_shift) : (base / hw4);
+    const int64_t p1 = hw_shift >= 0 ? ((end - 1) >> hw_shift) : ((end - 1) / hw4);
+    const int np = (int)(p1 - p0) + 1;
+    for (int k = threadIdx.x; k < np; k += kBnBlock) {
+        const int c = (int)((p0 + k) % C);
+        const float invstd = 1.0f / sqrtf(running_var[c] + eps);
+        const float scale = invstd * gamma[c];
+        tab[k] = make_float2(scale, fmaf(-running_mean[c], scale, beta[c]));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kEvalU; ++u) {
+        const int64_t i = base + threadIdx.x + u * kBnBlock;
+        if (i < end) {
+            const float2 ss = tab[(int)((hw_shift >= 0 ? (i >> hw_shift) : (i / hw4)) - p0)];
+            if (ADD) { v[u] = vadd(v[u], w[u]); ev_st<NT>(zv + i, v[u]); }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float t = fmaf(comp(v[u], k), ss.x, ss.y); setc(v[u], k, RELU ? bn_relu_fwd(t) : t); }
+            ev_st<NT>(yv + i, v[u]);
+        }
+    }
+}
+
 // ---- parity instrument (ursa_bn_relu_bwd_gated_f32): a sorted list of element offsets whose ReLU gate is GIVEN instead
 //      of recomputed - the reference CPU run's gates at the pre-activations within rounding of zero, where MIOpen's and
 //      oneDNN's convolutions (inputs of this layer) decide the sign by their last bits. Binary search per element: this
@@ -1489,6 +1540,37 @@ int ursa_bn_relu_eval_f32(const float* x, const float* addend, float* z_out, flo
     const bool relu = flags & URSA_BN_RELU;
     // beyond the 256 MiB Infinity Cache the streams go past it (as K1-K4 and the held forms do)
     const bool nt = p.V == 4 && N * C * HW * 4 * (addend ? 4 : 2) > (256ll << 20) && !bn_eval_no_nt();
+#ifdef URSA_DEBUG_KNOBS                    // A/B (tools/exp/bn_eval_lin_ab.py): URSA_BN_EVAL_GRID=1 keeps the channel-grid kernel
+    static const bool eval_grid = [] { const char* e = getenv("URSA_BN_EVAL_GRID"); return e && e[0] && e[0] != '0'; }();
+#else
+    constexpr bool eval_grid = false;
+#endif
+    // Linear form from 16 MiB of activation on (8 MiB with an addend): measured over 13 layer shapes with the linear form forced
+    // everywhere (tools/exp/bn_eval_lin_ab.py, profiles/r05_bn_eval_lin_ab.json): 67-268 MB activations 20.3 vs 24.8 us
+    // ([4096,64,8,8]: 0.83 vs 0.68 of the HBM peak), 38.5 vs 41.4, 88 vs 95 us (0.76 vs 0.70); residual form 80.7 vs 123.7 us at
+    // [4096,32,16,16]; the two 1 GB residual cases lose 3 %. Below ~10 MB the launch is latency-bound and the table's barrier costs
+    // more than the channel grid's per-thread scalars (2 MB: 2.7 vs 2.2 us): those keep the channel grid.
+    const bool eval_lin = p.V == 4 && !eval_grid && p.g.per_ch * p.g.C * 16 >= ((addend ? 8ll : 16ll) << 20);
+    if (eval_lin) {
+        // one contiguous 16 KB span per workgroup (see k_bn_eval_lin)
+        const int64_t total4 = p.g.per_ch * p.g.C;
+        const int64_t wgs = (total4 + kEvalSpan - 1) / kEvalSpan;
+        if (wgs < (1ll << 31)) {
+            const dim3 gl((unsigned)wgs);
+            const float4* x4 = reinterpret_cast<const float4*>(x);
+            const float4* a4 = reinterpret_cast<const float4*>(addend);
+            float4* z4 = reinterpret_cast<float4*>(z_out);
+            float4* y4 = reinterpret_cast<float4*>(y);
+#define URSA_BN_EVAL_L(R, A, T) hipLaunchKernelGGL((k_bn_eval_lin<R, A, T>), gl, block, 0, st, x4, a4, z4, y4, gamma, beta, running_mean, \
+                                                   running_var, eps, p.g.C, p.g.hw, p.g.hw_shift, total4)
+#define URSA_BN_EVAL_L2(R, A) do { if (nt) URSA_BN_EVAL_L(R, A, true); else URSA_BN_EVAL_L(R, A, false); } while (0)
+            if (relu) { if (addend) URSA_BN_EVAL_L2(true, true); else URSA_BN_EVAL_L2(true, false); }
+            else      { if (addend) URSA_BN_EVAL_L2(false, true); else URSA_BN_EVAL_L2(false, false); }
+#undef URSA_BN_EVAL_L2
+#undef URSA_BN_EVAL_L
+            return bn_launch_status();
+        }
+    }
 #define URSA_BN_EVAL(V, R, A) do { \
     if (nt) hipLaunchKernelGGL((k_bn_eval<V, R, A, true>), grid, block, 0, st, x, addend, z_out, y, gamma, beta, running_mean, running_var, eps, p.g); \
     else hipLaunchKernelGGL((k_bn_eval<V, R, A, false>), grid, block, 0, st, x, addend, z_out, y, gamma, beta, running_mean, running_var, eps, p.g); } while (0)
