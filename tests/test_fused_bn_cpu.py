@@ -1,6 +1,7 @@
 """Host side of fused_bn (no GPU): on host tensors `bn_relu` / `add_bn_relu` ARE the reference's ops — the module's
 forward, the in-place ReLU, torch's add — so the CPU replays of the reference's runs stay op for op; the pending-sum
 plumbing of the networks computes what `out += residual` followed by the next block computes."""
+import pytest
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -122,3 +123,25 @@ def test_bn_update_many_gives_every_model_bn_updates_statistics_on_cpu():
     util.bn_update_many(data, nets)
     util.bn_update(data, one)
     assert torch.equal(nets[0][1].running_mean, one[1].running_mean) and torch.equal(nets[0][1].running_var, one[1].running_var)
+
+
+def test_check_held_reads_raises_and_clears_the_layers_error_words():
+    """fused_bn.check_held(): one batched read of every registered layer's error word (BnSync.err at float offset 512 C + 33 of
+    the layer's scratch, csrc/ursa_bn.hip), raises naming the layer's device / width / word, and clears the word so that the next
+    check speaks of the next launches. Host tensors stand in for the scratch here (the bookkeeping, not the launches)."""
+    import torch.nn as nn
+    a, b = nn.BatchNorm2d(4), nn.BatchNorm2d(8)
+    wa, wb = torch.zeros(4 * 512 + 6 * 32), torch.zeros(8 * 512 + 10 * 32)
+    assert not fused_bn.held_in_use()
+    fused_bn._held_ws[a], fused_bn._held_ws[b] = (wa, 4), (wb, 8)
+    try:
+        assert fused_bn.held_in_use()
+        fused_bn.check_held()
+        wb.view(torch.int32)[8 * 512 + 33] = 1
+        with pytest.raises(RuntimeError, match='starved'):
+            fused_bn.check_held()
+        assert int(wb.view(torch.int32)[8 * 512 + 33]) == 0
+        fused_bn.check_held()
+    finally:
+        del fused_bn._held_ws[a], fused_bn._held_ws[b]
+    assert not fused_bn.held_in_use()

@@ -120,7 +120,12 @@ def check_held(device=None):
     if not ents:
         return
     words = [ws.view(torch.int32)[C * 512 + 33:C * 512 + 34] for ws, C in ents]       # BnSync.err: csrc/ursa_bn.hip (counters start at float C * 512)
-    err = torch.cat(words).cpu()
+    by_dev = {}
+    for i, w in enumerate(words):                    # one batched read per device (one process per GPU: normally one)
+        by_dev.setdefault(w.device, []).append(i)
+    err = torch.zeros(len(words), dtype=torch.int32)
+    for dev, idx in by_dev.items():
+        err[idx] = torch.cat([words[i] for i in idx]).cpu()
     bad = [(ents[i][0].device.index, ents[i][1], int(e)) for i, e in enumerate(err.tolist()) if e]
     if bad:
         for i, e in enumerate(err.tolist()):
