@@ -46,6 +46,7 @@ struct BnGeom {
     // counters cannot see) then cannot move a gate away from the one the forward took.
     float* gate_out;
     const float* gate_in;
+    int cfirst;       // launch geometry: 0 = grid (splits, channels), 1 = grid (channels, splits) - see bn_channel_first()
 };
 
 template <int V> struct Vec;
@@ -68,6 +69,13 @@ __device__ inline int64_t bn_off(const BnGeom& g, int c, int64_t i)
     const int64_t j = i - n * g.hw;
     return (n * g.C + c) * (int64_t)g.hw + j;
 }
+
+// Which workgroup handles which (channel, split): with cfirst the CHANNEL is the fast grid dimension, so workgroups that start
+// together read adjacent H*W planes of the same images (consecutive channels are adjacent in NCHW) - the launch as a whole sweeps
+// contiguous windows of the tensor - instead of one channel's chunks that sit N/S images (MBs) apart.
+__device__ __forceinline__ int bn_channel(const BnGeom& g) { return g.cfirst ? (int)blockIdx.x : (int)blockIdx.y; }
+__device__ __forceinline__ int bn_split(const BnGeom& g) { return g.cfirst ? (int)blockIdx.y : (int)blockIdx.x; }
+__device__ __forceinline__ int bn_nsplit(const BnGeom& g) { return g.cfirst ? (int)gridDim.y : (int)gridDim.x; }
 
 __device__ __forceinline__ void bn_save_gate(const BnGeom& g, int c, float alpha, float shift)
 {
@@ -155,8 +163,8 @@ __global__ __launch_bounds__(kBnBlock) void k_bn_stats(const float* __restrict__
     const T* __restrict__ xv = reinterpret_cast<const T*>(x);
     const T* __restrict__ av = reinterpret_cast<const T*>(addend);
     T* __restrict__ zv = reinterpret_cast<T*>(z);
-    const int c = blockIdx.y;
-    const int64_t lo = (int64_t)blockIdx.x * g.chunk;
+    const int c = bn_channel(g);
+    const int64_t lo = (int64_t)bn_split(g) * g.chunk;
     const int64_t hi = lo + g.chunk < g.per_ch ? lo + g.chunk : g.per_ch;
     double s1 = 0.0, s2 = 0.0;
     // batches of four (ADD: eight) loads in flight, the last batch predicated: a chunk of two units per thread (the workload's
@@ -180,7 +188,7 @@ __global__ __launch_bounds__(kBnBlock) void k_bn_stats(const float* __restrict__
         }
     }
     bn_block_sum2(s1, s2, sh);
-    if (threadIdx.x == 0) partial[(int64_t)c * gridDim.x + blockIdx.x] = make_double2(s1, s2);
+    if (threadIdx.x == 0) partial[(int64_t)c * bn_nsplit(g) + bn_split(g)] = make_double2(s1, s2);
 }
 
 // Merge of a channel's partials by wave 0 of the calling workgroup, in double; same result in lanes 0..63.
@@ -206,10 +214,10 @@ __global__ __launch_bounds__(kBnBlock) void k_bn_fwd_apply(const float* __restri
 {
     using T = typename Vec<V>::T;
     __shared__ float sh[2];
-    const int c = blockIdx.y;
+    const int c = bn_channel(g);
     const T* __restrict__ xv = reinterpret_cast<const T*>(x);
     T* __restrict__ yv = reinterpret_cast<T*>(y);
-    const int64_t lo = (int64_t)blockIdx.x * g.chunk;
+    const int64_t lo = (int64_t)bn_split(g) * g.chunk;
     const int64_t hi = lo + g.chunk < g.per_ch ? lo + g.chunk : g.per_ch;
     // The first batch of x loads does not depend on the statistics: issue it BEFORE the merge prologue, so that the prologue's
     // own dependent chain (partials load -> wave sums -> LDS -> barrier, ~1 us) runs under the loads' latency instead of in
@@ -232,7 +240,7 @@ __global__ __launch_bounds__(kBnBlock) void k_bn_fwd_apply(const float* __restri
             const float alpha = invstd * gamma[c];
             sh[0] = alpha;
             sh[1] = fmaf(-meanf, alpha, beta[c]);
-            if (blockIdx.x == 0) {
+            if (bn_split(g) == 0) {
                 save_mean[c] = meanf;
                 save_invstd[c] = invstd;
                 bn_save_gate(g, c, alpha, sh[1]);
@@ -287,7 +295,7 @@ __global__ __launch_bounds__(kBnBlock) void k_bn_eval(const float* __restrict__ 
                                                       const float* __restrict__ running_var, float eps, BnGeom g)
 {
     using T = typename Vec<V>::T;
-    const int c = blockIdx.y;
+    const int c = bn_channel(g);
     const float invstd = 1.0f / sqrtf(running_var[c] + eps);
     const float scale = invstd * gamma[c];
     const float shift = fmaf(-running_mean[c], scale, beta[c]);
@@ -295,7 +303,7 @@ __global__ __launch_bounds__(kBnBlock) void k_bn_eval(const float* __restrict__ 
     const T* __restrict__ av = reinterpret_cast<const T*>(addend);
     T* __restrict__ zv = reinterpret_cast<T*>(z);
     T* __restrict__ yv = reinterpret_cast<T*>(y);
-    const int64_t lo = (int64_t)blockIdx.x * g.chunk;
+    const int64_t lo = (int64_t)bn_split(g) * g.chunk;
     const int64_t hi = lo + g.chunk < g.per_ch ? lo + g.chunk : g.per_ch;
     int64_t i = lo + threadIdx.x;
     for (; i + 3 * kBnBlock < hi; i += 4 * kBnBlock) {
@@ -402,14 +410,14 @@ __global__ __launch_bounds__(kBnBlock) void k_bn_bwd_reduce(const float* __restr
 {
     using T = typename Vec<V>::T;
     __shared__ double sh[2 * kBnBlock / 64];
-    const int c = blockIdx.y;
+    const int c = bn_channel(g);
     const float mean = save_mean[c], invstd = save_invstd[c];
     float scale, shift;                                      // the forward's own scalars (saved, or its expressions on the live
     bn_gate_scalars(g, c, mean, invstd, gamma, beta, scale, shift);      // parameters): same bits, same gates
     const double meand = (double)mean;
     const T* __restrict__ xv = reinterpret_cast<const T*>(x);
     const T* __restrict__ dv = reinterpret_cast<const T*>(dy);
-    const int64_t lo = (int64_t)blockIdx.x * g.chunk;
+    const int64_t lo = (int64_t)bn_split(g) * g.chunk;
     const int64_t hi = lo + g.chunk < g.per_ch ? lo + g.chunk : g.per_ch;
     double s1 = 0.0, s2 = 0.0;
     int64_t i = lo + threadIdx.x;
@@ -446,7 +454,7 @@ __global__ __launch_bounds__(kBnBlock) void k_bn_bwd_reduce(const float* __restr
         }
     }
     bn_block_sum2(s1, s2, sh);
-    if (threadIdx.x == 0) partial[(int64_t)c * gridDim.x + blockIdx.x] = make_double2(s1, s2);
+    if (threadIdx.x == 0) partial[(int64_t)c * bn_nsplit(g) + bn_split(g)] = make_double2(s1, s2);
 }
 
 // ---- backward, launch 2: torch's CPU association (native_batch_norm_backward, training):
@@ -465,13 +473,13 @@ __global__ __launch_bounds__(kBnBlock) void k_bn_bwd_dx(const float* __restrict_
 {
     using T = typename Vec<V>::T;
     __shared__ float sh[2];
-    const int c = blockIdx.y;
+    const int c = bn_channel(g);
     const float mean = save_mean[c], invstd = save_invstd[c], w = gamma[c];
     const T* __restrict__ xv = reinterpret_cast<const T*>(x);
     const T* __restrict__ dv = reinterpret_cast<const T*>(dy);
     const T* __restrict__ rv = reinterpret_cast<const T*>(dz);
     T* __restrict__ ov = reinterpret_cast<T*>(dx);
-    const int64_t lo = (int64_t)blockIdx.x * g.chunk;
+    const int64_t lo = (int64_t)bn_split(g) * g.chunk;
     const int64_t hi = lo + g.chunk < g.per_ch ? lo + g.chunk : g.per_ch;
     // first batch of loads (x, dy, dz of two units) BEFORE the merge prologue: see k_bn_fwd_apply
     const int64_t i0 = lo + threadIdx.x;
@@ -491,7 +499,7 @@ __global__ __launch_bounds__(kBnBlock) void k_bn_bwd_dx(const float* __restrict_
             const double n = (double)g.per_ch * V, iv = (double)invstd;
             sh[0] = (float)(a / n);
             sh[1] = (float)(b * iv * iv / n);
-            if (blockIdx.x == 0) { dbeta[c] = (float)a; dgamma[c] = (float)(b * iv); }
+            if (bn_split(g) == 0) { dbeta[c] = (float)a; dgamma[c] = (float)(b * iv); }
         }
     }
     __syncthreads();
@@ -1278,6 +1286,21 @@ inline bool bn_aligned4(const void* p) { return (reinterpret_cast<uintptr_t>(p) 
 
 // One geometry per (N, C, HW): the backward's partials are laid out by the same S as its own first launch, and the
 // forward's by its own; nothing is shared between calls except through `ws` within one call.
+// Channel-first grids up to 16 MiB of activation - the workload's layers. Measured (tools/exp/bn_cfirst_ab.py,
+// profiles/r05_bn_cfirst_ab.json; us per call inside a hipGraph, grid (channels, splits) vs (splits, channels)): [128,16,32,32]
+// forward 6.27 vs 6.84, residual forward 7.92 vs 10.1, backward 6.93 vs 7.61; [128,32,16,16] 5.22 vs 5.66 / 5.56 vs 5.98 (residual
+// backward 5.64 vs 6.50); neutral at 34-134 MB; +14...29 % SLOWER at 268 MB (there the runs of one channel are what streams well):
+// hence the bound. Same partial sums in the same slots either way: the same floats. (Knobs build: URSA_BN_CFIRST_MAX_MIB, -1 = never.)
+inline bool bn_channel_first(int64_t bytes)
+{
+    int64_t max_mib = 16;
+#ifdef URSA_DEBUG_KNOBS
+    static const int64_t knob = [] { const char* e = getenv("URSA_BN_CFIRST_MAX_MIB"); return e && e[0] ? (int64_t)atoll(e) : (int64_t)-2; }();
+    if (knob != -2) max_mib = knob;
+#endif
+    return max_mib >= 0 && bytes <= (max_mib << 20);
+}
+
 inline int bn_plan(int64_t N, int64_t C, int64_t HW, bool vec_ok, BnPlan* p)
 {
     if (N <= 0 || C <= 0 || HW <= 0 || C > 65535 || HW > (1 << 30) || N > (1ll << 31)) return URSA_ESIZE;
@@ -1307,6 +1330,7 @@ inline int bn_plan(int64_t N, int64_t C, int64_t HW, bool vec_ok, BnPlan* p)
     p->g.per_ch = per_ch;
     p->g.gate_out = nullptr;
     p->g.gate_in = nullptr;
+    p->g.cfirst = bn_channel_first(per_ch * C * (V == 4 ? 16 : 4)) ? 1 : 0;
     return URSA_OK;
 }
 
@@ -1427,7 +1451,7 @@ static int bn_fwd_impl(const float* x, const float* addend, float* z_out, float*
     if (!bn_aligned4(save_gate)) return URSA_EALIGN;
     p.g.gate_out = save_gate;
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid(p.S, p.g.C), block(kBnBlock);
+    const dim3 grid = p.g.cfirst ? dim3(p.g.C, p.S) : dim3(p.S, p.g.C), block(kBnBlock);
     double2* part = reinterpret_cast<double2*>(ws);
     const bool relu = flags & URSA_BN_RELU;
 #ifdef URSA_DEBUG_KNOBS
@@ -1536,7 +1560,7 @@ int ursa_bn_relu_eval_f32(const float* x, const float* addend, float* z_out, flo
     const int rc = bn_plan(N, C, HW, bn_aligned16(x) && bn_aligned16(y) && bn_aligned16(addend) && bn_aligned16(z_out), &p);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid(p.S, p.g.C), block(kBnBlock);
+    const dim3 grid = p.g.cfirst ? dim3(p.g.C, p.S) : dim3(p.S, p.g.C), block(kBnBlock);
     const bool relu = flags & URSA_BN_RELU;
     // beyond the 256 MiB Infinity Cache the streams go past it (as K1-K4 and the held forms do)
     const bool nt = p.V == 4 && N * C * HW * 4 * (addend ? 4 : 2) > (256ll << 20) && !bn_eval_no_nt();
@@ -1597,7 +1621,7 @@ static int bn_bwd_impl(const float* x, const float* dy, const float* dz, float* 
     if (!bn_aligned4(gate)) return URSA_EALIGN;
     p.g.gate_in = gate;
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid(p.S, p.g.C), block(kBnBlock);
+    const dim3 grid = p.g.cfirst ? dim3(p.g.C, p.S) : dim3(p.S, p.g.C), block(kBnBlock);
     double2* part = reinterpret_cast<double2*>(ws);
     const bool relu = flags & URSA_BN_RELU;
 #ifdef URSA_DEBUG_KNOBS
