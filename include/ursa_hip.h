@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define URSA_ABI_VERSION 5
+#define URSA_ABI_VERSION 6
 
 typedef void* ursa_stream_t; /* hipStream_t */
 
@@ -355,6 +355,26 @@ int ursa_bn_relu_bwd_gated_f32(const float* x, const float* dy, const float* dz 
                                const float* save_invstd, const float* gate /* or NULL */, float* dgamma, float* dbeta, float* ws, int64_t N,
                                int64_t C, int64_t HW, uint32_t flags, const int32_t* gate_idx,
                                const uint8_t* gate_open, int64_t n_gates, ursa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K7  weight gradient of the 3x3 convolutions      `loss.backward()` URSABench/inference/sghmc.py:80 (and the same call
+ *     of every sampler) -> ATen convolution_backward for the nn.Conv2d(…, kernel_size=3, padding=1, bias=False) layers of
+ *     URSABench/models/preresnet.py:25-27,62-64
+ *
+ *     dw[co][ci][kh][kw] = sum_{n, oh, ow} dy[n][co][oh][ow] * x[n][ci][oh*stride + kh - 1][ow*stride + kw - 1]   (zero padded)
+ *
+ * x: [N, Cin, H, W], dy: [N, Cout, H/stride, W/stride], dw: [Cout, Cin, 3, 3], all contiguous NCHW fp32, x / dy / ws 16-byte
+ * aligned. Exact fp32 on v_mfma_f32_16x16x4_f32 (every product rounded once, fma chains); the batch x position sum is split
+ * over workgroups and reduced in a FIXED order by a second launch (no atomics: the same inputs give the same bits every
+ * run). Two launches, nothing transposed, nothing zero-filled.
+ * Shapes covered: stride 1, (Cin, Cout, H = W) in {(16, 16, 32), (32, 32, 16), (64, 64, 8)}, any N - the three stages of the
+ * CIFAR pre-activation ResNets. ursa_conv3x3_wgrad_ws_floats() returns the scratch `ws` must hold for a shape, 0 when the
+ * shape is not covered (the caller then keeps the stock weight gradient; ursa_conv3x3_wgrad_f32 returns URSA_EVALUE).
+ * Algorithmic HBM traffic: 4 B x (N*Cin*H*W + N*Cout*OH*OW + Cout*Cin*9); the partials (ws) are written and read once more.
+ */
+int64_t ursa_conv3x3_wgrad_ws_floats(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, int32_t stride);
+int ursa_conv3x3_wgrad_f32(const float* x, const float* dy, float* dw, float* ws, int64_t ws_floats, int64_t N,
+                           int64_t Cin, int64_t Cout, int64_t H, int64_t W, int32_t stride, ursa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------ */
 int ursa_abi_version(void);

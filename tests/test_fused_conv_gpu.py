@@ -1,0 +1,155 @@
+"""GPU: K7 (ursa_conv3x3_wgrad_f32) through the C ABI against the oracle (the sum taken in double, rounded once: what
+every fp32 summation order approximates - pinned against torch's CPU op in tests/test_fused_conv_cpu.py), and
+`fused_conv.Conv2d` inside the benchmark network against the stock launches and against the reference's CPU path."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import oracle_lib
+from ursabench_amd import _native, fused_conv, models
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device('cuda', 0)
+STAGES = [(16, 16, 32), (32, 32, 16), (64, 64, 8)]
+# fp32 fma chains over K = N*H*W products per element, split in S ordered partial sums: |err| <= ~sqrt(K) eps sum|a b|; measured
+# 2.5e-7 of max|dw| at K = 131,072 (tools/exp/conv_wgrad_probe.py; MIOpen's own launch: 4e-7..8e-7). Bound used: 2e-6.
+RTOL_OF_MAX = 2e-6
+
+
+def _k7(x, dy, cout, stride=1):
+    k = _native.default_kernels()
+    ws = torch.empty(k.conv3x3_wgrad_ws_floats(x.shape, cout, stride), device=DEV)
+    dw = torch.full((cout, x.shape[1], 3, 3), float('nan'), device=DEV)
+    k.conv3x3_wgrad(x, dy, dw, ws, stride)
+    return dw
+
+
+@pytest.mark.parametrize('cin,cout,hw', STAGES)
+@pytest.mark.parametrize('n', [1, 2, 3, 5, 80, 128])
+def test_k7_equals_the_oracle(cin, cout, hw, n):
+    rng = np.random.default_rng(1000 * n + cin)
+    x = rng.standard_normal((n, cin, hw, hw), dtype=np.float32)
+    dy = rng.standard_normal((n, cout, hw, hw), dtype=np.float32)
+    want = oracle_lib.conv3x3_wgrad(x, dy)
+    got = _k7(torch.from_numpy(x).to(DEV), torch.from_numpy(dy).to(DEV), cout).cpu().numpy()
+    assert np.isfinite(got).all()
+    assert np.abs(got - want).max() <= RTOL_OF_MAX * np.abs(want).max()
+
+
+@pytest.mark.parametrize('cin,cout,hw', STAGES)
+def test_k7_structured_inputs_exactly(cin, cout, hw):
+    """Small integers: every product and partial sum is exact in fp32, so ANY indexing slip (a tap, a halo column, a band edge, a
+    channel pair) shows as a wrong integer, and the result must equal the oracle bit for bit."""
+    rng = np.random.default_rng(7)
+    n = 3
+    x = rng.integers(-3, 4, (n, cin, hw, hw)).astype(np.float32)
+    dy = rng.integers(-2, 3, (n, cout, hw, hw)).astype(np.float32)
+    want = oracle_lib.conv3x3_wgrad(x, dy)
+    got = _k7(torch.from_numpy(x).to(DEV), torch.from_numpy(dy).to(DEV), cout).cpu().numpy()
+    assert np.array_equal(got, want)
+    # one hot: a single (n, co, oh, ow) and a single (ci, ih, iw) set - exactly one tap of one (co, ci) is non-zero when they touch
+    x = np.zeros((n, cin, hw, hw), np.float32)
+    dy = np.zeros((n, cout, hw, hw), np.float32)
+    x[2, cin - 1, 0, hw - 1] = 2.0
+    dy[2, cout - 3, 1, hw - 1] = 3.0                 # ih = oh + kh - 1 -> kh = 0; iw = ow + kw - 1 -> kw = 1
+    got = _k7(torch.from_numpy(x).to(DEV), torch.from_numpy(dy).to(DEV), cout).cpu().numpy()
+    want = np.zeros((cout, cin, 3, 3), np.float32)
+    want[cout - 3, cin - 1, 0, 1] = 6.0
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize('cin,cout,hw', STAGES)
+def test_k7_is_bit_reproducible_and_ignores_its_scratch(cin, cout, hw):
+    torch.manual_seed(0)
+    x, dy = torch.randn(128, cin, hw, hw, device=DEV), torch.randn(128, cout, hw, hw, device=DEV)
+    k = _native.default_kernels()
+    ws = torch.full((k.conv3x3_wgrad_ws_floats(x.shape, cout, 1),), float('nan'), device=DEV)
+    a, b = torch.empty(cout, cin, 3, 3, device=DEV), torch.empty(cout, cin, 3, 3, device=DEV)
+    k.conv3x3_wgrad(x, dy, a, ws, 1)
+    ws.fill_(123.0)
+    k.conv3x3_wgrad(x, dy, b, ws, 1)
+    assert torch.equal(a, b) and torch.isfinite(a).all()
+
+
+def test_wrapper_refuses_what_the_library_does_not_cover():
+    k = _native.default_kernels()
+    x, dy = torch.randn(4, 3, 32, 32, device=DEV), torch.randn(4, 16, 32, 32, device=DEV)
+    dw, ws = torch.empty(16, 3, 3, 3, device=DEV), torch.empty(1 << 20, device=DEV)
+    with pytest.raises(ValueError, match='ursa error -5'):
+        k.conv3x3_wgrad(x, dy, dw, ws, 1)
+    x = torch.randn(4, 16, 32, 32, device=DEV)
+    with pytest.raises(ValueError, match='ursa error -2'):                    # scratch too small
+        k.conv3x3_wgrad(x, dy, torch.empty(16, 16, 3, 3, device=DEV), torch.empty(64, device=DEV), 1)
+    with pytest.raises(ValueError, match='shapes do not belong'):
+        k.conv3x3_wgrad(x, dy[:, :8].contiguous(), torch.empty(16, 16, 3, 3, device=DEV), ws, 1)
+
+
+def _grads(net, x, y):
+    for p in net.parameters():
+        p.grad = None
+    nn.functional.cross_entropy(net(x), y).backward()
+    return {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+
+
+def test_network_gradients_k7_vs_stock_vs_cpu():
+    """PreResNet-20 at the workload's batch: every parameter's gradient with K7's weight gradients against the same step with
+    MIOpen's (URSA_FUSED_CONV=0's path) and against the reference's CPU path (the same module on the host). The forward is the
+    same launches in both GPU runs, so the two differ by the weight gradients' rounding only."""
+    torch.manual_seed(3)
+    net = models.PreResNet(10, 20).to(DEV).train()
+    x, y = torch.randn(128, 3, 32, 32, device=DEV), torch.randint(0, 10, (128,), device=DEV)
+    host = copy.deepcopy(net).cpu()
+    old = fused_conv.enabled(True)
+    try:
+        g7 = _grads(net, x, y)
+        fused_conv.enabled(False)
+        gs = _grads(net, x, y)
+    finally:
+        fused_conv.enabled(old)
+    gc = _grads(host, x.cpu(), y.cpu())
+    taken = 0
+    for k in g7:
+        scale = float(gc[k].abs().max()) + 1e-12
+        assert float((g7[k] - gs[k]).abs().max()) <= 2e-5 * scale, k           # same forward; K7 vs MIOpen's atomics order
+        # vs the CPU path the forward itself differs in the last bits (MIOpen's Winograd vs oneDNN): the stock launches' own
+        # distance to the CPU path is the yardstick, K7 must not be further away than 2x that (+ 1e-5)
+        d7, ds = float((g7[k].cpu() - gc[k]).abs().max()), float((gs[k].cpu() - gc[k]).abs().max())
+        assert d7 <= 2 * ds + 1e-5 * scale, (k, d7, ds, scale)
+        taken += k.endswith('conv1.weight') or k.endswith('conv2.weight')
+    assert taken >= 18
+
+
+def test_conv2d_takes_k7_only_where_covered():
+    calls = []
+    k = _native.default_kernels()
+    orig = k.conv3x3_wgrad
+
+    def spy(x, dy, dw, ws, stride=1):
+        calls.append(tuple(x.shape))
+        return orig(x, dy, dw, ws, stride)
+    k.conv3x3_wgrad = spy
+    try:
+        for cin, cout, hw, stride, ksz, covered in ((16, 16, 32, 1, 3, True), (3, 16, 32, 1, 3, False), (16, 32, 32, 2, 3, False),
+                                                    (16, 32, 32, 2, 1, False), (64, 64, 8, 1, 3, True)):
+            m = fused_conv.Conv2d(cin, cout, ksz, stride, ksz // 2, bias=False).to(DEV)
+            ref = nn.Conv2d(cin, cout, ksz, stride, ksz // 2, bias=False).to(DEV)
+            ref.load_state_dict(m.state_dict())
+            x = torch.randn(4, cin, hw, hw, device=DEV)
+            xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+            n0 = len(calls)
+            ya, yb = m(xa), ref(xb)
+            ya.square().sum().backward()
+            yb.square().sum().backward()
+            assert (len(calls) > n0) == covered
+            assert torch.equal(ya, yb) and torch.allclose(xa.grad, xb.grad, rtol=1e-4, atol=1e-4)
+            scale = float(ref.weight.grad.abs().max())
+            assert float((m.weight.grad - ref.weight.grad).abs().max()) <= 1e-5 * scale
+        with torch.no_grad():                                   # no gradient recorded: the stock module
+            n0 = len(calls)
+            fused_conv.Conv2d(16, 16, 3, 1, 1, bias=False).to(DEV)(torch.randn(2, 16, 32, 32, device=DEV))
+            assert len(calls) == n0
+    finally:
+        del k.conv3x3_wgrad

@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libursa_hip.so')
 KNOBS_LIB_PATH = os.path.join(_HERE, 'csrc', 'libursa_hip_knobs.so')   # -DURSA_DEBUG_KNOBS build: tests / tools only
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # flags (mirror include/ursa_hip.h)
 STEP_NOISE, STEP_FIRST, STEP_ZERO_GRAD, STEP_WD, STEP_SGD, STEP_ADVANCE = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
@@ -62,6 +62,8 @@ SIGNATURES = {
     'ursa_bn_relu_bwd_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _u32, _vp]),
     'ursa_bn_relu_bwd_gated_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _u32,
                                                   _vp, _vp, _i64, _vp]),
+    'ursa_conv3x3_wgrad_ws_floats': (_i64, [_i64, _i64, _i64, _i64, _i64, _i32]),
+    'ursa_conv3x3_wgrad_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp]),
 }
 
 
@@ -434,6 +436,27 @@ class HipKernels:
         with torch.cuda.device(dev):
             rc = self.lib.ursa_bn_relu_bwd_f32(*args, _stream(dev))
         _check(self.lib, rc, 'ursa_bn_relu_bwd_f32')
+
+    # K7 ------------------------------------------------------------------------------
+    def conv3x3_wgrad_ws_floats(self, x_shape, cout, stride=1):
+        """Scratch floats K7 needs for the weight gradient of a 3x3 / pad 1 convolution over an input of `x_shape`
+        ([N, Cin, H, W]) with `cout` output channels; 0 = shape not covered (the caller keeps the stock weight gradient)."""
+        n, cin, h, w = (int(v) for v in x_shape)
+        return int(self.lib.ursa_conv3x3_wgrad_ws_floats(n, cin, int(cout), h, w, int(stride)))
+
+    def conv3x3_wgrad(self, x, dy, dw, ws, stride=1):
+        """dw[Cout, Cin, 3, 3] = the weight gradient of conv2d(x, w, stride=stride, padding=1) for the output gradient dy."""
+        if x.dim() != 4 or dy.dim() != 4 or dw.dim() != 4:
+            raise ValueError('x, dy, dw must be 4-d (NCHW / OIHW)')
+        N, Cin, H, W = x.shape
+        Cout = dw.shape[0]
+        dev = x.device
+        if tuple(dw.shape) != (Cout, Cin, 3, 3) or tuple(dy.shape) != (N, Cout, H // stride, W // stride):
+            raise ValueError(f'shapes do not belong to one 3x3 convolution: x {tuple(x.shape)}, dy {tuple(dy.shape)}, dw {tuple(dw.shape)}')
+        with torch.cuda.device(dev):
+            rc = self.lib.ursa_conv3x3_wgrad_f32(_ptr(x, 'x'), _ptr(dy, 'dy', None, dev), _ptr(dw, 'dw', None, dev),
+                                                 _ptr(ws, 'ws', None, dev), ws.numel(), N, Cin, Cout, H, W, int(stride), _stream(dev))
+        _check(self.lib, rc, 'ursa_conv3x3_wgrad_f32')
 
 
 def knobs_kernels():

@@ -1,8 +1,8 @@
 """The networks the benchmark configurations name (BASELINE.json `configs`), as plain nn.Modules.
 
-Convolutions and linear layers stay stock PyTorch-ROCm (MIOpen / rocBLAS): the hot path this
-package replaces is the sampler update and the ensemble reduction. The one thing these modules do
-differently from the reference's on a HIP device is `relu(bn(x))`: every BatchNorm of the
+Convolution forwards / input gradients and linear layers stay stock PyTorch-ROCm (MIOpen / rocBLAS). Two things these
+modules do differently from the reference's on a HIP device: the weight gradient of the small-channel 3x3 convolutions
+(`fused_conv.Conv2d`, K7: two launches instead of MIOpen's five to six per layer) and `relu(bn(x))`: every BatchNorm of the
 pre-activation networks is followed by a ReLU, and that pair runs as the K6 launches of
 `fused_bn.bn_relu` (2 forward + 2 backward per layer instead of 5-9 MIOpen / ATen launches: the
 BatchNorm + ReLU share of a PreResNet-20 training step was 31 % of its kernel time). Host tensors
@@ -22,6 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .fused_bn import add_bn_relu, bn_relu
+from .fused_conv import Conv2d
 
 __all__ = ['LeNet5', 'MLP', 'MLP_dropout', 'PreResNet', 'PreResNet_dropout', 'WideResNet', 'MLP200MNIST',
            'MLP200MNIST_dropout', 'LeNet5MNIST', 'PreResNet8', 'PreResNet20', 'PreResNet164', 'WideResNet28x10']
@@ -83,9 +84,9 @@ class _PreActBasic(nn.Module):
         super().__init__()
         self.bn1 = nn.BatchNorm2d(cin)
         self.relu = nn.ReLU(inplace=True)
-        self.conv1 = nn.Conv2d(cin, planes, 3, stride, 1, bias=False)
+        self.conv1 = Conv2d(cin, planes, 3, stride, 1, bias=False)
         self.bn2 = nn.BatchNorm2d(planes)
-        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.conv2 = Conv2d(planes, planes, 3, 1, 1, bias=False)
         self.downsample = downsample
 
     def forward(self, x):
@@ -104,11 +105,11 @@ class _PreActBottleneck(nn.Module):
     def __init__(self, cin, planes, stride=1, downsample=None):
         super().__init__()
         self.bn1 = nn.BatchNorm2d(cin)
-        self.conv1 = nn.Conv2d(cin, planes, 1, bias=False)
+        self.conv1 = Conv2d(cin, planes, 1, bias=False)
         self.bn2 = nn.BatchNorm2d(planes)
-        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
+        self.conv2 = Conv2d(planes, planes, 3, stride, 1, bias=False)
         self.bn3 = nn.BatchNorm2d(planes)
-        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.conv3 = Conv2d(planes, planes * 4, 1, bias=False)
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
 
@@ -145,7 +146,7 @@ class PreResNet(nn.Module):
                 raise AssertionError('depth should be 6n+2')
             reps, block = (depth - 2) // 6, _PreActBasic
         self.inplanes = 16
-        self.conv1 = nn.Conv2d(3, 16, 3, padding=1, bias=False)
+        self.conv1 = Conv2d(3, 16, 3, padding=1, bias=False)
         self.layer1 = self._stage(block, 16, reps, 1)
         self.layer2 = self._stage(block, 32, reps, 2)
         self.layer3 = self._stage(block, 64, reps, 2)
@@ -164,7 +165,7 @@ class PreResNet(nn.Module):
     def _stage(self, block, planes, reps, stride):
         down = None
         if stride != 1 or self.inplanes != planes * block.expansion:
-            down = nn.Sequential(nn.Conv2d(self.inplanes, planes * block.expansion, 1, stride, bias=False))
+            down = nn.Sequential(Conv2d(self.inplanes, planes * block.expansion, 1, stride, bias=False))
         blocks = [block(self.inplanes, planes, stride, down)]
         self.inplanes = planes * block.expansion
         blocks += [block(self.inplanes, planes) for _ in range(1, reps)]
@@ -194,13 +195,13 @@ class _WideBlock(nn.Module):
     def __init__(self, cin, planes, dropout_rate, stride=1):
         super().__init__()
         self.bn1 = nn.BatchNorm2d(cin)
-        self.conv1 = nn.Conv2d(cin, planes, 3, padding=1, bias=True)
+        self.conv1 = Conv2d(cin, planes, 3, padding=1, bias=True)
         self.dropout = nn.Dropout(p=dropout_rate)
         self.bn2 = nn.BatchNorm2d(planes)
-        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=True)
+        self.conv2 = Conv2d(planes, planes, 3, stride, 1, bias=True)
         self.shortcut = nn.Sequential()
         if stride != 1 or cin != planes:
-            self.shortcut = nn.Sequential(nn.Conv2d(cin, planes, 1, stride, bias=True))
+            self.shortcut = nn.Sequential(Conv2d(cin, planes, 1, stride, bias=True))
 
     def forward(self, x):
         x, h = add_bn_relu(self.bn1, x)                 # pending sums in and out, as in _PreActBasic
@@ -216,7 +217,7 @@ class WideResNet(nn.Module):
             raise AssertionError('Wide-resnet depth should be 6n+4')
         reps, k = (depth - 4) // 6, widen_factor
         self.in_planes = 16
-        self.conv1 = nn.Conv2d(3, 16, 3, padding=1, bias=True)
+        self.conv1 = Conv2d(3, 16, 3, padding=1, bias=True)
         self.layer1 = self._stage(16 * k, reps, dropout_rate, 1)
         self.layer2 = self._stage(32 * k, reps, dropout_rate, 2)
         self.layer3 = self._stage(64 * k, reps, dropout_rate, 2)
