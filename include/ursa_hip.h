@@ -357,24 +357,41 @@ int ursa_bn_relu_bwd_gated_f32(const float* x, const float* dy, const float* dz 
                                const uint8_t* gate_open, int64_t n_gates, ursa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
- * K7  weight gradient of the 3x3 convolutions      `loss.backward()` URSABench/inference/sghmc.py:80 (and the same call
- *     of every sampler) -> ATen convolution_backward for the nn.Conv2d(…, kernel_size=3, padding=1, bias=False) layers of
- *     URSABench/models/preresnet.py:25-27,62-64
+ * K7  weight gradient of the ResNets' convolutions      `loss.backward()` URSABench/inference/sghmc.py:80 (and the same
+ *     call of every sampler) -> ATen convolution_backward for the nn.Conv2d(.., bias=False) layers of
+ *     URSABench/models/preresnet.py:25-27,100,130-136
  *
- *     dw[co][ci][kh][kw] = sum_{n, oh, ow} dy[n][co][oh][ow] * x[n][ci][oh*stride + kh - 1][ow*stride + kw - 1]   (zero padded)
+ *     dw[co][ci][kh][kw] = sum_{n, oh, ow} dy[n][co][oh][ow] * x[n][ci][oh*stride + kh - p][ow*stride + kw - p]   (zero padded)
  *
- * x: [N, Cin, H, W], dy: [N, Cout, H/stride, W/stride], dw: [Cout, Cin, 3, 3], all contiguous NCHW fp32, x / dy / ws 16-byte
- * aligned. Exact fp32 on v_mfma_f32_16x16x4_f32 (every product rounded once, fma chains); the batch x position sum is split
- * over workgroups and reduced in a FIXED order by a second launch (no atomics: the same inputs give the same bits every
- * run). Two launches, nothing transposed, nothing zero-filled.
- * Shapes covered: stride 1, (Cin, Cout, H = W) in {(16, 16, 32), (32, 32, 16), (64, 64, 8)}, any N - the three stages of the
- * CIFAR pre-activation ResNets. ursa_conv3x3_wgrad_ws_floats() returns the scratch `ws` must hold for a shape, 0 when the
- * shape is not covered (the caller then keeps the stock weight gradient; ursa_conv3x3_wgrad_f32 returns URSA_EVALUE).
- * Algorithmic HBM traffic: 4 B x (N*Cin*H*W + N*Cout*OH*OW + Cout*Cin*9); the partials (ws) are written and read once more.
+ * ksize 3 (p = 1) or 1 (p = 0). x: [N, Cin, H, W], dy: [N, Cout, H/stride, W/stride], dw: [Cout, Cin, ksize, ksize], all
+ * contiguous NCHW fp32, x / dy / ws 16-byte aligned. Exact fp32 on v_mfma_f32_16x16x4_f32 (every product rounded once, fma
+ * chains); the batch x position sum is split over workgroups (K slices, partial copies of dW in `ws`) and reduced in a FIXED
+ * order by a second launch (no atomics: the same inputs give the same bits every run). Nothing transposed, nothing zero-filled.
+ * Shapes covered (any N; H = W): every convolution of the CIFAR pre-activation ResNets with BasicBlocks -
+ *     3x3 stride 1: (Cin, Cout, H) in {(3, 16, 32), (16, 16, 32), (32, 32, 16), (64, 64, 8)}
+ *     3x3 stride 2: (16, 32, 32), (32, 64, 16)            1x1 stride 2: (16, 32, 32), (32, 64, 16)
+ * ursa_conv_wgrad_ws_floats() returns the scratch `ws` must hold for a shape, 0 when the shape is not covered (the caller
+ * then keeps the stock weight gradient; the launches return URSA_EVALUE).
+ *   ursa_conv_wgrad_f32          both launches.
+ *   ursa_conv_wgrad_partial_f32  the first launch only: `ws` then holds the K slices' partial sums ...
+ *   ursa_conv_wgrad_reduce_f32   ... and this takes the second launch for `n` such layers at once (one launch per 48 layers):
+ *                                a backward pass costs one launch per layer plus one. Every item is checked before anything
+ *                                is launched; `ws` of every item must stay untouched between its two launches.
+ * Algorithmic HBM traffic: 4 B x (N*Cin*H*W + N*Cout*OH*OW + Cout*Cin*k*k); the partials (ws) are written and read once more.
  */
-int64_t ursa_conv3x3_wgrad_ws_floats(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, int32_t stride);
-int ursa_conv3x3_wgrad_f32(const float* x, const float* dy, float* dw, float* ws, int64_t ws_floats, int64_t N,
-                           int64_t Cin, int64_t Cout, int64_t H, int64_t W, int32_t stride, ursa_stream_t stream);
+typedef struct ursa_conv_pending {
+    const float* ws;   /* the partial sums ursa_conv_wgrad_partial_f32 left for this layer */
+    float* dw;         /* [Cout, Cin, ksize, ksize] */
+    int64_t N, Cin, Cout, H, W;
+    int32_t ksize, stride;
+} ursa_conv_pending;
+
+int64_t ursa_conv_wgrad_ws_floats(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, int32_t ksize, int32_t stride);
+int ursa_conv_wgrad_f32(const float* x, const float* dy, float* dw, float* ws, int64_t ws_floats, int64_t N,
+                        int64_t Cin, int64_t Cout, int64_t H, int64_t W, int32_t ksize, int32_t stride, ursa_stream_t stream);
+int ursa_conv_wgrad_partial_f32(const float* x, const float* dy, float* ws, int64_t ws_floats, int64_t N, int64_t Cin,
+                                int64_t Cout, int64_t H, int64_t W, int32_t ksize, int32_t stride, ursa_stream_t stream);
+int ursa_conv_wgrad_reduce_f32(const ursa_conv_pending* items, int32_t n, ursa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------ */
 int ursa_abi_version(void);

@@ -429,37 +429,37 @@ int oracle_bn_relu_eval_f32(const float* x, float* y, const float* gamma, const 
 }
 
 /* ---------------------------------------------------------------------------------------
- * K7  weight gradient of a 3x3 / pad 1 convolution    `loss.backward()` URSABench/inference/sghmc.py:80 -> ATen
- *     convolution_backward on the CPU path (oneDNN) for the nn.Conv2d(.., 3, padding=1, bias=False) layers of
- *     URSABench/models/preresnet.py:25-27,62-64.
+ * K7  weight gradient of a k x k convolution, pad k/2    `loss.backward()` URSABench/inference/sghmc.py:80 -> ATen
+ *     convolution_backward on the CPU path (oneDNN) for the nn.Conv2d(.., bias=False) layers of
+ *     URSABench/models/preresnet.py:25-27,62-64,100,130-136.
  *
- *     dw[co][ci][kh][kw] = sum_{n, oh, ow} dy[n][co][oh][ow] * x[n][ci][oh*stride + kh - 1][ow*stride + kw - 1]
+ *     dw[co][ci][kh][kw] = sum_{n, oh, ow} dy[n][co][oh][ow] * x[n][ci][oh*stride + kh - k/2][ow*stride + kw - k/2]
  *
  * oneDNN's summation order is not part of any contract (it changes with thread count and ISA), so the restatement takes
  * the sum in double and rounds once: the value every fp32 order approximates. tests/test_fused_conv_cpu.py pins it against
  * torch's own CPU op (float64: equal to rounding; float32: within the fp32 order's error bound).
- * x: [N, Cin, H, W], dy: [N, Cout, H/stride, W/stride], dw: [Cout, Cin, 3, 3].
+ * x: [N, Cin, H, W], dy: [N, Cout, H/stride, W/stride], dw: [Cout, Cin, k, k].
  */
-int oracle_conv3x3_wgrad_f32(const float* x, const float* dy, float* dw, int64_t N, int64_t Cin, int64_t Cout, int64_t H,
-                             int64_t W, int64_t stride)
+int oracle_conv_wgrad_f32(const float* x, const float* dy, float* dw, int64_t N, int64_t Cin, int64_t Cout, int64_t H,
+                          int64_t W, int64_t ksize, int64_t stride)
 {
-    const int64_t OH = H / stride, OW = W / stride;
+    const int64_t OH = H / stride, OW = W / stride, pad = ksize / 2;
     for (int64_t co = 0; co < Cout; ++co)
         for (int64_t ci = 0; ci < Cin; ++ci)
-            for (int64_t kh = 0; kh < 3; ++kh)
-                for (int64_t kw = 0; kw < 3; ++kw) {
+            for (int64_t kh = 0; kh < ksize; ++kh)
+                for (int64_t kw = 0; kw < ksize; ++kw) {
                     double acc = 0.0;
                     for (int64_t n = 0; n < N; ++n)
                         for (int64_t oh = 0; oh < OH; ++oh) {
-                            const int64_t ih = oh * stride + kh - 1;
+                            const int64_t ih = oh * stride + kh - pad;
                             if (ih < 0 || ih >= H) continue;
                             for (int64_t ow = 0; ow < OW; ++ow) {
-                                const int64_t iw = ow * stride + kw - 1;
+                                const int64_t iw = ow * stride + kw - pad;
                                 if (iw < 0 || iw >= W) continue;
                                 acc += (double)dy[((n * Cout + co) * OH + oh) * OW + ow] * (double)x[((n * Cin + ci) * H + ih) * W + iw];
                             }
                         }
-                    dw[((co * Cin + ci) * 3 + kh) * 3 + kw] = (float)acc;
+                    dw[((co * Cin + ci) * ksize + kh) * ksize + kw] = (float)acc;
                 }
     return 0;
 }

@@ -146,15 +146,15 @@ def bn_relu_eval(x, gamma, beta, running_mean, running_var, *, eps=1e-5, relu=Tr
     return y
 
 
-_L.oracle_conv3x3_wgrad_f32.argtypes = [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64]
+_L.oracle_conv_wgrad_f32.argtypes = [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64]
 
 
-def conv3x3_wgrad(x, dy, stride=1):
-    """dw[Cout, Cin, 3, 3] of a 3x3 / pad 1 convolution: x [N, Cin, H, W], dy [N, Cout, H/stride, W/stride]."""
+def conv_wgrad(x, dy, ksize=3, stride=1):
+    """dw[Cout, Cin, k, k] of a k x k / pad k // 2 convolution: x [N, Cin, H, W], dy [N, Cout, H/stride, W/stride]."""
     N, Cin, H, W = x.shape
     Cout = dy.shape[1]
     assert dy.shape == (N, Cout, H // stride, W // stride)
-    dw = np.empty((Cout, Cin, 3, 3), np.float32)
-    rc = _L.oracle_conv3x3_wgrad_f32(_p(x), _p(dy), _p(dw), N, Cin, Cout, H, W, stride)
+    dw = np.empty((Cout, Cin, ksize, ksize), np.float32)
+    rc = _L.oracle_conv_wgrad_f32(_p(x), _p(dy), _p(dw), N, Cin, Cout, H, W, ksize, stride)
     assert rc == 0
     return dw

@@ -11,19 +11,20 @@ import torch.nn as nn
 import oracle_lib
 from ursabench_amd import _native, fused_conv, models
 
-SHAPES = [(3, 16, 16, 32, 1), (2, 32, 32, 16, 1), (2, 64, 64, 8, 1), (2, 16, 32, 32, 2), (1, 3, 16, 32, 1)]
+SHAPES = [(3, 16, 16, 32, 3, 1), (2, 32, 32, 16, 3, 1), (2, 64, 64, 8, 3, 1), (2, 16, 32, 32, 3, 2), (1, 3, 16, 32, 3, 1),
+          (2, 16, 32, 32, 1, 2), (2, 32, 64, 16, 1, 2), (2, 32, 64, 16, 3, 2)]
 
 
-@pytest.mark.parametrize('n,cin,cout,hw,stride', SHAPES)
-def test_oracle_is_torchs_cpu_weight_gradient(n, cin, cout, hw, stride):
+@pytest.mark.parametrize('n,cin,cout,hw,ksize,stride', SHAPES)
+def test_oracle_is_torchs_cpu_weight_gradient(n, cin, cout, hw, ksize, stride):
     rng = np.random.default_rng(n * 100 + cin)
     x = rng.standard_normal((n, cin, hw, hw), dtype=np.float32)
     dy = rng.standard_normal((n, cout, hw // stride, hw // stride), dtype=np.float32)
-    dw = torch.from_numpy(oracle_lib.conv3x3_wgrad(x, dy, stride))
-    shape = (cout, cin, 3, 3)
-    ref64 = torch.nn.grad.conv2d_weight(torch.from_numpy(x).double(), shape, torch.from_numpy(dy).double(), stride, 1)
+    dw = torch.from_numpy(oracle_lib.conv_wgrad(x, dy, ksize, stride))
+    shape = (cout, cin, ksize, ksize)
+    ref64 = torch.nn.grad.conv2d_weight(torch.from_numpy(x).double(), shape, torch.from_numpy(dy).double(), stride, ksize // 2)
     assert torch.equal(dw, ref64.float())                 # the sum in double, rounded once: bit for bit torch's float64 op
-    ref32 = torch.nn.grad.conv2d_weight(torch.from_numpy(x), shape, torch.from_numpy(dy), stride, 1)
+    ref32 = torch.nn.grad.conv2d_weight(torch.from_numpy(x), shape, torch.from_numpy(dy), stride, ksize // 2)
     bound = 4e-6 * float(ref64.abs().max())               # any fp32 summation order over <= 6,144 products per element
     assert float((dw - ref32).abs().max()) <= bound
 
@@ -61,15 +62,30 @@ def test_enabled_switch():
         fused_conv.enabled(old)
 
 
-def test_plan_covers_the_three_resnet_stages_only():
+COVERED = [(3, 16, 32, 3, 1), (16, 16, 32, 3, 1), (32, 32, 16, 3, 1), (64, 64, 8, 3, 1), (16, 32, 32, 3, 2), (32, 64, 16, 3, 2),
+           (16, 32, 32, 1, 2), (32, 64, 16, 1, 2)]          # (Cin, Cout, H = W, ksize, stride): every convolution of PreResNet-20
+
+
+def test_plan_covers_the_basic_block_resnets_convolutions_only():
     k = _native.default_kernels()
     for n in (1, 80, 128, 1000):
-        for shape, cout, stride in (((n, 16, 32, 32), 16, 1), ((n, 32, 16, 16), 32, 1), ((n, 64, 8, 8), 64, 1)):
-            f = k.conv3x3_wgrad_ws_floats(shape, cout, stride)
-            assert f > 0 and f % (cout * shape[1] * 9) == 0          # whole partial copies of dW
-    for shape, cout, stride in (((128, 3, 32, 32), 16, 1), ((128, 16, 32, 32), 32, 2), ((128, 16, 16, 16), 16, 1),
-                                ((128, 160, 32, 32), 160, 1), ((0, 16, 32, 32), 16, 1), ((128, 16, 32, 16), 16, 1)):
-        assert k.conv3x3_wgrad_ws_floats(shape, cout, stride) == 0
+        for cin, cout, hw, ks, st in COVERED:
+            f = k.conv_wgrad_ws_floats((n, cin, hw, hw), cout, ks, st)
+            assert f > 0 and f % ((cout // 16) * ((cin + 15) // 16) * ks * ks * 256) == 0      # whole partial copies, tile order
+    for shape, cout, ks, st in (((128, 16, 16, 16), 16, 3, 1), ((128, 160, 32, 32), 160, 3, 1), ((0, 16, 32, 32), 16, 3, 1),
+                                ((128, 16, 32, 16), 16, 3, 1), ((128, 16, 32, 32), 16, 1, 1), ((128, 16, 32, 32), 16, 5, 1),
+                                ((128, 16, 32, 32), 64, 1, 1), ((128, 64, 8, 8), 64, 3, 2)):
+        assert k.conv_wgrad_ws_floats(shape, cout, ks, st) == 0
+    m = models.PreResNet(10, 20)
+    x = torch.zeros(2, 3, 32, 32)
+    shapes = []
+    hooks = [mod.register_forward_hook(lambda mod, i, o: shapes.append((mod.in_channels, mod.out_channels, i[0].shape[2],
+                                                                      mod.kernel_size[0], mod.stride[0])))
+             for mod in m.modules() if isinstance(mod, nn.Conv2d)]
+    m(x)
+    for h in hooks:
+        h.remove()
+    assert len(shapes) == 21 and set(shapes) == set(COVERED)
 
 
 def test_argument_errors_do_not_need_a_gpu():
@@ -78,11 +94,22 @@ def test_argument_errors_do_not_need_a_gpu():
     buf = (ctypes.c_float * 64)()
     p = ctypes.addressof(buf)
     p -= p % 16
-    f = lib.ursa_conv3x3_wgrad_f32
-    assert f(None, p, p, p, 1 << 30, 128, 16, 16, 32, 32, 1, None) == -1          # ENULL
-    assert f(p, p, p, p, 1 << 30, 0, 16, 16, 32, 32, 1, None) == -2               # ESIZE
-    assert f(p + 4, p, p, p, 1 << 30, 128, 16, 16, 32, 32, 1, None) == -3         # EALIGN: x / dy / ws 16 bytes
-    assert f(p, p, p + 2, p, 1 << 30, 128, 16, 16, 32, 32, 1, None) == -3         # dw 4 bytes
-    assert f(p, p, p, p, 1 << 30, 128, 3, 16, 32, 32, 1, None) == -5              # EVALUE: shape not covered
-    assert f(p, p, p, p, 1 << 30, 128, 16, 16, 32, 32, 2, None) == -5
-    assert f(p, p, p, p, 100, 128, 16, 16, 32, 32, 1, None) == -2                 # scratch too small
+    f, part, red = lib.ursa_conv_wgrad_f32, lib.ursa_conv_wgrad_partial_f32, lib.ursa_conv_wgrad_reduce_f32
+    assert f(None, p, p, p, 1 << 30, 128, 16, 16, 32, 32, 3, 1, None) == -1          # ENULL
+    assert f(p, p, None, p, 1 << 30, 128, 16, 16, 32, 32, 3, 1, None) == -1
+    assert f(p, p, p, p, 1 << 30, 0, 16, 16, 32, 32, 3, 1, None) == -2               # ESIZE
+    assert f(p + 4, p, p, p, 1 << 30, 128, 16, 16, 32, 32, 3, 1, None) == -3         # EALIGN: x / dy / ws 16 bytes
+    assert f(p, p, p + 2, p, 1 << 30, 128, 16, 16, 32, 32, 3, 1, None) == -3         # dw 4 bytes
+    assert f(p, p, p, p, 1 << 30, 128, 5, 16, 32, 32, 3, 1, None) == -5              # EVALUE: shape not covered
+    assert f(p, p, p, p, 1 << 30, 128, 16, 16, 32, 32, 3, 2, None) == -5
+    assert f(p, p, p, p, 100, 128, 16, 16, 32, 32, 3, 1, None) == -2                 # scratch too small
+    assert part(p, p, None, 1 << 30, 128, 16, 16, 32, 32, 3, 1, None) == -1
+    assert part(p, p, p, 100, 128, 16, 16, 32, 32, 3, 1, None) == -2
+    assert red(None, 0, None) == 0 and red(None, 2, None) == -1 and red(None, -1, None) == -2
+    items = (_native.ConvPending * 2)()
+    for it in items:
+        it.ws, it.dw, it.N, it.Cin, it.Cout, it.H, it.W, it.ksize, it.stride = p, p, 128, 16, 16, 32, 32, 3, 1
+    items[1].Cin = 5                                                                  # the second item is not covered:
+    assert red(ctypes.cast(items, ctypes.c_void_p), 2, None) == -5                    # nothing is launched for the first either
+    items[1].Cin, items[1].dw = 16, None
+    assert red(ctypes.cast(items, ctypes.c_void_p), 2, None) == -1

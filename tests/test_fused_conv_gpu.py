@@ -1,4 +1,4 @@
-"""GPU: K7 (ursa_conv3x3_wgrad_f32) through the C ABI against the oracle (the sum taken in double, rounded once: what
+"""GPU: K7 (ursa_conv_wgrad_f32) through the C ABI against the oracle (the sum taken in double, rounded once: what
 every fp32 summation order approximates - pinned against torch's CPU op in tests/test_fused_conv_cpu.py), and
 `fused_conv.Conv2d` inside the benchmark network against the stock launches and against the reference's CPU path."""
 import copy
@@ -13,78 +13,104 @@ from ursabench_amd import _native, fused_conv, models
 
 pytestmark = pytest.mark.gpu
 DEV = torch.device('cuda', 0)
-STAGES = [(16, 16, 32), (32, 32, 16), (64, 64, 8)]
-# fp32 fma chains over K = N*H*W products per element, split in S ordered partial sums: |err| <= ~sqrt(K) eps sum|a b|; measured
+# (Cin, Cout, H = W, ksize, stride): every convolution of the BasicBlock pre-activation ResNets
+LAYERS = [(3, 16, 32, 3, 1), (16, 16, 32, 3, 1), (32, 32, 16, 3, 1), (64, 64, 8, 3, 1), (16, 32, 32, 3, 2), (32, 64, 16, 3, 2),
+          (16, 32, 32, 1, 2), (32, 64, 16, 1, 2)]
+# fp32 fma chains over K = N*OH*OW products per element, split in S ordered partial sums: |err| <= ~sqrt(K) eps sum|a b|; measured
 # 2.5e-7 of max|dw| at K = 131,072 (tools/exp/conv_wgrad_probe.py; MIOpen's own launch: 4e-7..8e-7). Bound used: 2e-6.
 RTOL_OF_MAX = 2e-6
 
 
-def _k7(x, dy, cout, stride=1):
+def _k7(x, dy, cout, ksize=3, stride=1):
     k = _native.default_kernels()
-    ws = torch.empty(k.conv3x3_wgrad_ws_floats(x.shape, cout, stride), device=DEV)
-    dw = torch.full((cout, x.shape[1], 3, 3), float('nan'), device=DEV)
-    k.conv3x3_wgrad(x, dy, dw, ws, stride)
+    ws = torch.empty(k.conv_wgrad_ws_floats(x.shape, cout, ksize, stride), device=DEV)
+    dw = torch.full((cout, x.shape[1], ksize, ksize), float('nan'), device=DEV)
+    k.conv_wgrad(x, dy, dw, ws, stride)
     return dw
 
 
-@pytest.mark.parametrize('cin,cout,hw', STAGES)
+@pytest.mark.parametrize('cin,cout,hw,ksize,stride', LAYERS)
 @pytest.mark.parametrize('n', [1, 2, 3, 5, 80, 128])
-def test_k7_equals_the_oracle(cin, cout, hw, n):
+def test_k7_equals_the_oracle(cin, cout, hw, ksize, stride, n):
     rng = np.random.default_rng(1000 * n + cin)
     x = rng.standard_normal((n, cin, hw, hw), dtype=np.float32)
-    dy = rng.standard_normal((n, cout, hw, hw), dtype=np.float32)
-    want = oracle_lib.conv3x3_wgrad(x, dy)
-    got = _k7(torch.from_numpy(x).to(DEV), torch.from_numpy(dy).to(DEV), cout).cpu().numpy()
+    dy = rng.standard_normal((n, cout, hw // stride, hw // stride), dtype=np.float32)
+    want = oracle_lib.conv_wgrad(x, dy, ksize, stride)
+    got = _k7(torch.from_numpy(x).to(DEV), torch.from_numpy(dy).to(DEV), cout, ksize, stride).cpu().numpy()
     assert np.isfinite(got).all()
     assert np.abs(got - want).max() <= RTOL_OF_MAX * np.abs(want).max()
 
 
-@pytest.mark.parametrize('cin,cout,hw', STAGES)
-def test_k7_structured_inputs_exactly(cin, cout, hw):
+@pytest.mark.parametrize('cin,cout,hw,ksize,stride', LAYERS)
+def test_k7_structured_inputs_exactly(cin, cout, hw, ksize, stride):
     """Small integers: every product and partial sum is exact in fp32, so ANY indexing slip (a tap, a halo column, a band edge, a
-    channel pair) shows as a wrong integer, and the result must equal the oracle bit for bit."""
+    channel pair, a padded channel) shows as a wrong integer, and the result must equal the oracle bit for bit."""
     rng = np.random.default_rng(7)
-    n = 3
+    n, ho = 3, hw // stride
     x = rng.integers(-3, 4, (n, cin, hw, hw)).astype(np.float32)
-    dy = rng.integers(-2, 3, (n, cout, hw, hw)).astype(np.float32)
-    want = oracle_lib.conv3x3_wgrad(x, dy)
-    got = _k7(torch.from_numpy(x).to(DEV), torch.from_numpy(dy).to(DEV), cout).cpu().numpy()
+    dy = rng.integers(-2, 3, (n, cout, ho, ho)).astype(np.float32)
+    want = oracle_lib.conv_wgrad(x, dy, ksize, stride)
+    got = _k7(torch.from_numpy(x).to(DEV), torch.from_numpy(dy).to(DEV), cout, ksize, stride).cpu().numpy()
     assert np.array_equal(got, want)
-    # one hot: a single (n, co, oh, ow) and a single (ci, ih, iw) set - exactly one tap of one (co, ci) is non-zero when they touch
+    # one hot: a single (n, co, oh, ow) and a single (ci, ih, iw) set - exactly one tap of one (co, ci) is non-zero
     x = np.zeros((n, cin, hw, hw), np.float32)
-    dy = np.zeros((n, cout, hw, hw), np.float32)
-    x[2, cin - 1, 0, hw - 1] = 2.0
-    dy[2, cout - 3, 1, hw - 1] = 3.0                 # ih = oh + kh - 1 -> kh = 0; iw = ow + kw - 1 -> kw = 1
-    got = _k7(torch.from_numpy(x).to(DEV), torch.from_numpy(dy).to(DEV), cout).cpu().numpy()
-    want = np.zeros((cout, cin, 3, 3), np.float32)
-    want[cout - 3, cin - 1, 0, 1] = 6.0
+    dy = np.zeros((n, cout, ho, ho), np.float32)
+    oh, ow, pad = 1, ho - 1, ksize // 2
+    kh, kw = (0, 1) if ksize == 3 else (0, 0)
+    x[2, cin - 1, oh * stride + kh - pad, ow * stride + kw - pad] = 2.0
+    dy[2, cout - 3, oh, ow] = 3.0
+    got = _k7(torch.from_numpy(x).to(DEV), torch.from_numpy(dy).to(DEV), cout, ksize, stride).cpu().numpy()
+    want = np.zeros((cout, cin, ksize, ksize), np.float32)
+    want[cout - 3, cin - 1, kh, kw] = 6.0
     assert np.array_equal(got, want)
 
 
-@pytest.mark.parametrize('cin,cout,hw', STAGES)
-def test_k7_is_bit_reproducible_and_ignores_its_scratch(cin, cout, hw):
+@pytest.mark.parametrize('cin,cout,hw,ksize,stride', LAYERS)
+def test_k7_is_bit_reproducible_and_ignores_its_scratch(cin, cout, hw, ksize, stride):
     torch.manual_seed(0)
-    x, dy = torch.randn(128, cin, hw, hw, device=DEV), torch.randn(128, cout, hw, hw, device=DEV)
+    x, dy = torch.randn(128, cin, hw, hw, device=DEV), torch.randn(128, cout, hw // stride, hw // stride, device=DEV)
     k = _native.default_kernels()
-    ws = torch.full((k.conv3x3_wgrad_ws_floats(x.shape, cout, 1),), float('nan'), device=DEV)
-    a, b = torch.empty(cout, cin, 3, 3, device=DEV), torch.empty(cout, cin, 3, 3, device=DEV)
-    k.conv3x3_wgrad(x, dy, a, ws, 1)
+    ws = torch.full((k.conv_wgrad_ws_floats(x.shape, cout, ksize, stride),), float('nan'), device=DEV)
+    a, b = torch.empty(cout, cin, ksize, ksize, device=DEV), torch.empty(cout, cin, ksize, ksize, device=DEV)
+    k.conv_wgrad(x, dy, a, ws, stride)
     ws.fill_(123.0)
-    k.conv3x3_wgrad(x, dy, b, ws, 1)
+    k.conv_wgrad(x, dy, b, ws, stride)
     assert torch.equal(a, b) and torch.isfinite(a).all()
+
+
+def test_deferred_second_launch_equals_the_immediate_one():
+    """ursa_conv_wgrad_partial_f32 per layer + ONE ursa_conv_wgrad_reduce_f32 for all of them = ursa_conv_wgrad_f32 per layer,
+    bit for bit (the same partial sums, the same ascending order); 60 layers: more than one launch's 48 items."""
+    k = _native.default_kernels()
+    torch.manual_seed(1)
+    pend, want = [], []
+    for rep in range(8):
+        for cin, cout, hw, ksize, stride in LAYERS[:-1] + LAYERS[-1:] * (1 if rep else 4):
+            n = (5, 128)[rep % 2]
+            x, dy = torch.randn(n, cin, hw, hw, device=DEV), torch.randn(n, cout, hw // stride, hw // stride, device=DEV)
+            ws = torch.empty(k.conv_wgrad_ws_floats(x.shape, cout, ksize, stride), device=DEV)
+            dw = torch.empty(cout, cin, ksize, ksize, device=DEV)
+            k.conv_wgrad(x, dy, dw, ws, stride)
+            want.append(dw)
+            ws2 = torch.empty_like(ws)
+            pend.append((k.conv_wgrad_partial(x, dy, dw.shape, ws2, stride), torch.full_like(dw, float('nan'))))
+    assert len(pend) > 48
+    k.conv_wgrad_reduce(pend)
+    for (_, got), w in zip(pend, want):
+        assert torch.equal(got, w)
 
 
 def test_wrapper_refuses_what_the_library_does_not_cover():
     k = _native.default_kernels()
-    x, dy = torch.randn(4, 3, 32, 32, device=DEV), torch.randn(4, 16, 32, 32, device=DEV)
-    dw, ws = torch.empty(16, 3, 3, 3, device=DEV), torch.empty(1 << 20, device=DEV)
+    x, dy = torch.randn(4, 5, 32, 32, device=DEV), torch.randn(4, 16, 32, 32, device=DEV)
+    dw, ws = torch.empty(16, 5, 3, 3, device=DEV), torch.empty(1 << 20, device=DEV)
     with pytest.raises(ValueError, match='ursa error -5'):
-        k.conv3x3_wgrad(x, dy, dw, ws, 1)
+        k.conv_wgrad(x, dy, dw, ws, 1)
     x = torch.randn(4, 16, 32, 32, device=DEV)
     with pytest.raises(ValueError, match='ursa error -2'):                    # scratch too small
-        k.conv3x3_wgrad(x, dy, torch.empty(16, 16, 3, 3, device=DEV), torch.empty(64, device=DEV), 1)
+        k.conv_wgrad(x, dy, torch.empty(16, 16, 3, 3, device=DEV), torch.empty(64, device=DEV), 1)
     with pytest.raises(ValueError, match='shapes do not belong'):
-        k.conv3x3_wgrad(x, dy[:, :8].contiguous(), torch.empty(16, 16, 3, 3, device=DEV), ws, 1)
+        k.conv_wgrad(x, dy[:, :8].contiguous(), torch.empty(16, 16, 3, 3, device=DEV), ws, 1)
 
 
 def _grads(net, x, y):
@@ -118,22 +144,36 @@ def test_network_gradients_k7_vs_stock_vs_cpu():
         # distance to the CPU path is the yardstick, K7 must not be further away than 2x that (+ 1e-5)
         d7, ds = float((g7[k].cpu() - gc[k]).abs().max()), float((gs[k].cpu() - gc[k]).abs().max())
         assert d7 <= 2 * ds + 1e-5 * scale, (k, d7, ds, scale)
-        taken += k.endswith('conv1.weight') or k.endswith('conv2.weight')
-    assert taken >= 18
+        taken += k.endswith('conv1.weight') or k.endswith('conv2.weight') or k.endswith('downsample.0.weight')
+    assert taken == 21
+    # the engine's form: first launches during backward(), ONE second launch for all 21 layers - the same bits
+    with fused_conv.deferred() as pend:
+        loss = nn.functional.cross_entropy(net(x), y)
+    for p in net.parameters():
+        p.grad = None
+    loss.backward()
+    assert len(pend) == 21 and all(w.grad is None for _, w in pend)
+    out = {id(w): torch.empty_like(w) for _, w in pend}
+    fused_conv.flush(pend, lambda w: out[id(w)])
+    names = {id(p): k for k, p in net.named_parameters()}
+    for i, t in out.items():
+        assert torch.equal(t, g7[names[i]]), names[i]
+    assert all((p.grad is None) == (id(p) in out) for p in net.parameters())
 
 
 def test_conv2d_takes_k7_only_where_covered():
     calls = []
     k = _native.default_kernels()
-    orig = k.conv3x3_wgrad
+    orig = k.conv_wgrad
 
     def spy(x, dy, dw, ws, stride=1):
         calls.append(tuple(x.shape))
         return orig(x, dy, dw, ws, stride)
-    k.conv3x3_wgrad = spy
+    k.conv_wgrad = spy
     try:
-        for cin, cout, hw, stride, ksz, covered in ((16, 16, 32, 1, 3, True), (3, 16, 32, 1, 3, False), (16, 32, 32, 2, 3, False),
-                                                    (16, 32, 32, 2, 1, False), (64, 64, 8, 1, 3, True)):
+        for cin, cout, hw, stride, ksz, covered in ((16, 16, 32, 1, 3, True), (3, 16, 32, 1, 3, True), (16, 32, 32, 2, 3, True),
+                                                    (16, 32, 32, 2, 1, True), (64, 64, 8, 1, 3, True), (16, 16, 16, 1, 3, False),
+                                                    (16, 64, 32, 1, 1, False), (8, 16, 32, 1, 3, False)):
             m = fused_conv.Conv2d(cin, cout, ksz, stride, ksz // 2, bias=False).to(DEV)
             ref = nn.Conv2d(cin, cout, ksz, stride, ksz // 2, bias=False).to(DEV)
             ref.load_state_dict(m.state_dict())
@@ -152,4 +192,4 @@ def test_conv2d_takes_k7_only_where_covered():
             fused_conv.Conv2d(16, 16, 3, 1, 1, bias=False).to(DEV)(torch.randn(2, 16, 32, 32, device=DEV))
             assert len(calls) == n0
     finally:
-        del k.conv3x3_wgrad
+        del k.conv_wgrad

@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 out=$R/gpurun_out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-for v in default 2 4; do
+for v in ${VARIANTS:-default 2 4}; do
   rm -rf /tmp/prof_k7_$v
   if [ $v = default ]; then unset URSA_CONV_IPW; export URSA_PROBE_KNOBS=0; else export URSA_CONV_IPW=$v URSA_PROBE_KNOBS=1; fi
   export URSA_PROBE_OUT=conv_wgrad_probe_$v.json

@@ -62,8 +62,10 @@ SIGNATURES = {
     'ursa_bn_relu_bwd_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _u32, _vp]),
     'ursa_bn_relu_bwd_gated_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _u32,
                                                   _vp, _vp, _i64, _vp]),
-    'ursa_conv3x3_wgrad_ws_floats': (_i64, [_i64, _i64, _i64, _i64, _i64, _i32]),
-    'ursa_conv3x3_wgrad_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp]),
+    'ursa_conv_wgrad_ws_floats': (_i64, [_i64, _i64, _i64, _i64, _i64, _i32, _i32]),
+    'ursa_conv_wgrad_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _vp]),
+    'ursa_conv_wgrad_partial_f32': (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _vp]),
+    'ursa_conv_wgrad_reduce_f32': (ctypes.c_int, [_vp, _i32, _vp]),
 }
 
 
@@ -73,6 +75,12 @@ KNOBS_SIGNATURES = {
     'ursa_bn_relu_fwd_nhwc_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f, _f, _u32, _vp]),
     'ursa_bn_relu_bwd_nhwc_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _u32, _vp]),
 }
+
+class ConvPending(ctypes.Structure):
+    """struct ursa_conv_pending: one layer whose second K7 launch is still to be taken."""
+    _fields_ = [('ws', _vp), ('dw', _vp), ('N', _i64), ('Cin', _i64), ('Cout', _i64), ('H', _i64), ('W', _i64),
+                ('ksize', _i32), ('stride', _i32)]
+
 
 CTL_TICKET_LINES = 16
 
@@ -438,25 +446,56 @@ class HipKernels:
         _check(self.lib, rc, 'ursa_bn_relu_bwd_f32')
 
     # K7 ------------------------------------------------------------------------------
-    def conv3x3_wgrad_ws_floats(self, x_shape, cout, stride=1):
-        """Scratch floats K7 needs for the weight gradient of a 3x3 / pad 1 convolution over an input of `x_shape`
-        ([N, Cin, H, W]) with `cout` output channels; 0 = shape not covered (the caller keeps the stock weight gradient)."""
+    def conv_wgrad_ws_floats(self, x_shape, cout, ksize=3, stride=1):
+        """Scratch floats K7 needs for the weight gradient of a ksize x ksize (pad ksize // 2) convolution over an input of
+        `x_shape` ([N, Cin, H, W]) with `cout` output channels; 0 = shape not covered (the caller keeps the stock gradient)."""
         n, cin, h, w = (int(v) for v in x_shape)
-        return int(self.lib.ursa_conv3x3_wgrad_ws_floats(n, cin, int(cout), h, w, int(stride)))
+        return int(self.lib.ursa_conv_wgrad_ws_floats(n, cin, int(cout), h, w, int(ksize), int(stride)))
 
-    def conv3x3_wgrad(self, x, dy, dw, ws, stride=1):
-        """dw[Cout, Cin, 3, 3] = the weight gradient of conv2d(x, w, stride=stride, padding=1) for the output gradient dy."""
-        if x.dim() != 4 or dy.dim() != 4 or dw.dim() != 4:
+    @staticmethod
+    def _conv_dims(x, dy, dw_shape, stride):
+        if x.dim() != 4 or dy.dim() != 4 or len(dw_shape) != 4:
             raise ValueError('x, dy, dw must be 4-d (NCHW / OIHW)')
         N, Cin, H, W = x.shape
-        Cout = dw.shape[0]
+        Cout, ksize = int(dw_shape[0]), int(dw_shape[2])
+        if tuple(dw_shape) != (Cout, Cin, ksize, ksize) or tuple(dy.shape) != (N, Cout, H // stride, W // stride):
+            raise ValueError(f'shapes do not belong to one convolution: x {tuple(x.shape)}, dy {tuple(dy.shape)}, dw {tuple(dw_shape)}')
+        return N, Cin, Cout, H, W, ksize
+
+    def conv_wgrad(self, x, dy, dw, ws, stride=1):
+        """dw[Cout, Cin, k, k] = the weight gradient of conv2d(x, w, stride=stride, padding=k // 2) for the output gradient dy
+        (both launches)."""
+        N, Cin, Cout, H, W, ksize = self._conv_dims(x, dy, dw.shape, stride)
         dev = x.device
-        if tuple(dw.shape) != (Cout, Cin, 3, 3) or tuple(dy.shape) != (N, Cout, H // stride, W // stride):
-            raise ValueError(f'shapes do not belong to one 3x3 convolution: x {tuple(x.shape)}, dy {tuple(dy.shape)}, dw {tuple(dw.shape)}')
         with torch.cuda.device(dev):
-            rc = self.lib.ursa_conv3x3_wgrad_f32(_ptr(x, 'x'), _ptr(dy, 'dy', None, dev), _ptr(dw, 'dw', None, dev),
-                                                 _ptr(ws, 'ws', None, dev), ws.numel(), N, Cin, Cout, H, W, int(stride), _stream(dev))
-        _check(self.lib, rc, 'ursa_conv3x3_wgrad_f32')
+            rc = self.lib.ursa_conv_wgrad_f32(_ptr(x, 'x'), _ptr(dy, 'dy', None, dev), _ptr(dw, 'dw', None, dev),
+                                              _ptr(ws, 'ws', None, dev), ws.numel(), N, Cin, Cout, H, W, ksize, int(stride), _stream(dev))
+        _check(self.lib, rc, 'ursa_conv_wgrad_f32')
+
+    def conv_wgrad_partial(self, x, dy, dw_shape, ws, stride=1):
+        """The first launch only: `ws` receives the K slices' partial sums. Returns the record `conv_wgrad_reduce` takes."""
+        N, Cin, Cout, H, W, ksize = self._conv_dims(x, dy, dw_shape, stride)
+        dev = x.device
+        with torch.cuda.device(dev):
+            rc = self.lib.ursa_conv_wgrad_partial_f32(_ptr(x, 'x'), _ptr(dy, 'dy', None, dev), _ptr(ws, 'ws', None, dev), ws.numel(),
+                                                      N, Cin, Cout, H, W, ksize, int(stride), _stream(dev))
+        _check(self.lib, rc, 'ursa_conv_wgrad_partial_f32')
+        return (ws, N, Cin, Cout, H, W, ksize, int(stride))
+
+    def conv_wgrad_reduce(self, pending):
+        """The second launch for many layers at once. pending: [(record from conv_wgrad_partial, dw tensor), ...], one device."""
+        if not pending:
+            return
+        arr = (ConvPending * len(pending))()
+        dev = pending[0][1].device
+        for a, ((ws, N, Cin, Cout, H, W, ksize, stride), dw) in zip(arr, pending):
+            if tuple(dw.shape) != (Cout, Cin, ksize, ksize):
+                raise ValueError(f'dw {tuple(dw.shape)} does not belong to the pending record ({Cout}, {Cin}, {ksize}, {ksize})')
+            a.ws, a.dw = _ptr(ws, 'ws', None, dev), _ptr(dw, 'dw', None, dev)
+            a.N, a.Cin, a.Cout, a.H, a.W, a.ksize, a.stride = N, Cin, Cout, H, W, ksize, stride
+        with torch.cuda.device(dev):
+            rc = self.lib.ursa_conv_wgrad_reduce_f32(ctypes.cast(arr, ctypes.c_void_p), len(pending), _stream(dev))
+        _check(self.lib, rc, 'ursa_conv_wgrad_reduce_f32')
 
 
 def knobs_kernels():

@@ -1,20 +1,23 @@
-// K7: weight gradient of the small-channel 3x3 convolutions of the CIFAR pre-activation ResNets, NCHW fp32, gfx950.
+// K7: weight gradient of the small-channel convolutions of the CIFAR pre-activation ResNets, NCHW fp32, gfx950.
 //
 // What it replaces (URSABench/inference/sghmc.py:80 `loss.backward()` -> ATen convolution_backward -> MIOpen): for
-// `dW[co][ci][kh][kw] = sum_{n,oh,ow} dy[n][co][oh][ow] * x[n][ci][oh*s+kh-1][ow*s+kw-1]` at 16..64 channels MIOpen's best
+// `dW[co][ci][kh][kw] = sum_{n,oh,ow} dy[n][co][oh][ow] * x[n][ci][oh*s+kh-p][ow*s+kw-p]` at 16..64 channels MIOpen's best
 // solver on this stack is an NHWC implicit GEMM with atomics: per layer two NCHW->NHWC transposes, a zero fill, the GEMM and a
 // transpose back - 38 us of kernels for 0.6 GFLOP (profiles/r05_step_timeline.json: 92 of a step's 237 launches).
 //
-// Form. The sum is a GEMM with M = Cout, N = Cin*9, K = batch*OH*OW, taken on `v_mfma_f32_16x16x4_f32` (exact fp32: every
+// Form. The sum is a GEMM with M = Cout, N = Cin*taps, K = batch*OH*OW, taken on `v_mfma_f32_16x16x4_f32` (exact fp32: every
 // product rounded once, a k-ordered fma chain - no reduced precision anywhere). One wave owns one (16 co x 16 ci) pair and
-// keeps its nine taps in nine accumulators. K runs over positions in groups of 16 (four quarter-rows of four adjacent `ow`):
-// lane (c = lane & 15, g = lane >> 4) reads ONE float4 of dy (its co = c, four positions) and per `kh` a six-float window of x
-// (its ci = c): the nine taps of those four positions are 36 MFMAs from 7 LDS reads. x and dy tiles are staged in LDS straight
-// from NCHW with coalesced float4 loads (halo columns zero), so no transposed copy of anything exists.
+// keeps its taps in one accumulator each. K runs over positions in groups of 16 (four quarter-rows of four adjacent `ow`):
+// lane (c = lane & 15, g = lane >> 4) reads ONE float4 of dy (its co = c, four positions) and per `kh` a window of x
+// (its ci = c; six floats at stride 1, nine at stride 2): the nine taps of those four positions are 36 MFMAs from 7 (10) LDS
+// reads. x and dy tiles are staged in LDS straight from NCHW with coalesced float4 loads (halo columns zero), so no
+// transposed copy of anything exists. A 1x1 / stride 2 shortcut convolution is the centre tap of the 3x3 / stride 2 form.
 //
 // The K split over workgroups is reduced in a FIXED order: every workgroup stores its partial dW in tile order
-// (coalesced), a second launch sums the S partials of each element in ascending slice order and writes dW[co][ci][3][3].
-// No atomics: the same inputs give the same bits on every run (MIOpen's solver does not).
+// (coalesced), a second launch sums the S partials of each element in ascending slice order and writes dW[co][ci][kh][kw].
+// No atomics: the same inputs give the same bits on every run (MIOpen's solver does not). The second launch can be
+// deferred and taken for many layers at once (ursa_conv_wgrad_reduce_f32): a backward pass then costs one launch per layer
+// plus one.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -31,32 +34,39 @@ constexpr int kThreads = 256;
 constexpr int pitch64p4(int n) { return ((n - 4 + 63) / 64) * 64 + 4; }
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
-// CIN: input channels (all of them are staged); COUT_WG: output channels one workgroup takes (grid.y covers the rest);
-// WO: output width = height; R: output rows per band (grid.x = bands x image groups); STRIDE 1 or 2 (pad 1).
-template <int CIN, int COUT_WG, int WO, int R, int STRIDE>
+// CIN: input channels (all staged; padded to a multiple of 16 by one zero plane); COUT_WG: output channels one workgroup takes
+// (grid.y covers the rest); WO: output width = height; R: output rows per band (grid.x = bands x image groups); STRIDE 1 / 2;
+// TAPS 9 (3x3, pad 1) or 1 (the centre tap alone: 1x1, pad 0, at STRIDE 2); PH: phases per tile (see the kernel).
+template <int CIN, int COUT_WG, int WO, int R, int STRIDE, int TAPS, int PH>
 struct Wg {
+    static constexpr int CINP = (CIN + 15) / 16 * 16;
     static constexpr int WI = WO * STRIDE;                    // input width = height
     static constexpr int RI = (R - 1) * STRIDE + 3;           // input rows a band touches
     static constexpr int WP = WI + 8;                         // row pitch: iw = -1 at column 3, iw = 0 at column 4 (16-byte aligned)
     static constexpr int XPLANE = pitch64p4(RI * WP);
     static constexpr int DPLANE = pitch64p4(R * WO);
-    static constexpr int XS = CIN * XPLANE, DS = COUT_WG * DPLANE;
-    static constexpr int CT = CIN / 16, MT = COUT_WG / 16;
+    static constexpr int NPLANES = CIN + (CINP > CIN ? 1 : 0);   // + one zero plane every padded channel reads
+    static constexpr int XS = NPLANES * XPLANE, DS = COUT_WG * DPLANE;
+    static constexpr int CT = CINP / 16, MT = COUT_WG / 16;
     static constexpr int PW = CT * MT;                        // (co16, ci16) pairs per workgroup: one or more waves each
     static constexpr int KW = 4 / PW;                         // waves that share a pair (they split the K groups)
     static constexpr int G = R * WO / 16;                     // K groups (16 positions) per tile
     static constexpr int BANDS = WO / R;
-    static constexpr int RED = KW > 1 ? 4 * 36 * 64 : 0;      // cross-wave sum of the shared pairs
+    static constexpr int TE = TAPS * 256;                     // floats of one pair's partial tile
+    static constexpr int RED = KW > 1 ? 4 * TE : 0;           // cross-wave sum of the shared pairs
     static constexpr int SMEM = cmax(XS + DS, RED);
-    static_assert(CIN % 16 == 0 && COUT_WG % 16 == 0 && (PW == 1 || PW == 2 || PW == 4), "pairs per workgroup");
-    static_assert(WO % 4 == 0 && WO % R == 0 && (R * WO) % 16 == 0 && G % KW == 0, "tile geometry");
+    static constexpr int RP = R / PH, GP = G / PH;            // output rows / K groups per phase
+    static_assert(COUT_WG % 16 == 0 && (PW == 1 || PW == 2 || PW == 4), "pairs per workgroup");
+    static_assert(WO % 4 == 0 && WO % R == 0 && (R * WO) % 16 == 0, "tile geometry");
+    static_assert(R % PH == 0 && G % PH == 0 && GP % KW == 0 && GP * 16 == RP * WO, "phases");
+    static_assert((TAPS == 9) || (TAPS == 1 && STRIDE == 2), "taps");
     static_assert(SMEM * 4 <= 64 * 1024, "static LDS");
 };
 
-template <int CIN, int COUT_WG, int WO, int R, int STRIDE>
-__global__ __launch_bounds__(kThreads) void k_conv3x3_wgrad(const float* __restrict__ x, const float* __restrict__ dy,
-                                                             float* __restrict__ partial, int N, int Cout, int ipw) {
-    using C = Wg<CIN, COUT_WG, WO, R, STRIDE>;
+template <int CIN, int COUT_WG, int WO, int R, int STRIDE, int TAPS, int PH>
+__global__ __launch_bounds__(kThreads) void k_conv_wgrad(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          float* __restrict__ partial, int N, int Cout, int ipw) {
+    using C = Wg<CIN, COUT_WG, WO, R, STRIDE, TAPS, PH>;
     __shared__ __attribute__((aligned(16))) float smem[C::SMEM];
     float* xs = smem;
     float* ds = smem + C::XS;
@@ -69,41 +79,50 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3_wgrad(const float* __restr
         row[3] = 0.f;
         row[4 + C::WI] = 0.f;
     }
+    if constexpr (C::CINP > CIN)
+        for (int i = tid; i < C::XPLANE; i += kThreads) xs[CIN * C::XPLANE + i] = 0.f;
 
-    f32x4 acc[9];
+    f32x4 acc[TAPS];
 #pragma unroll
-    for (int j = 0; j < 9; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TAPS; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int pair = wave % C::PW, kpart = wave / C::PW;
     const int cot = pair / C::CT, cit = pair % C::CT;
     const int c = lane & 15, g = lane >> 4;
+    const int xplane = (cit * 16 + c < CIN) ? cit * 16 + c : CIN;      // padded channels read the zero plane
 
     // One image's tiles in PH phases of RP output rows. Every thread's global loads are issued together, in the order the
     // phases need them (row-major chunks of 256 float4: x rows first needed by phase p, then dy rows of phase p); phase p stages
-    // its chunks into LDS as they arrive and runs its MFMAs while the later rows are still in flight - the launch is bound by
-    // the stream of its inputs or by the matrix pipe, not by their sum. Chunks of different phases touch disjoint LDS rows, so
-    // one barrier per phase suffices. The next image's loads are issued before the last phase's MFMAs.
-    constexpr int PH = 4, RP = R / PH, GP = C::G / PH;
-    static_assert(R % PH == 0 && C::G % PH == 0 && GP % C::KW == 0 && (GP * 16) == RP * WO, "phases");
+    // its chunks into LDS as they arrive and runs its MFMAs while the later rows are still in flight. Chunks of different
+    // phases touch disjoint LDS rows, so one barrier per phase suffices. Every load is unconditional (rows outside the image
+    // load a valid row and are zeroed when staged; a chunk's tail past the tile re-loads its last element), so the compiler's
+    // wait counts are exact. The next image's loads are issued before the last phase's MFMAs.
     constexpr int XROW = CIN * (C::WI / 4), DROW = COUT_WG * (WO / 4);   // float4 per staged row
     constexpr int XV = XROW * C::RI, DV = DROW * R;
     constexpr int NX = (XV + kThreads - 1) / kThreads, ND = (DV + kThreads - 1) / kThreads;
-    static_assert(STRIDE == 1, "phase bookkeeping below is written for stride 1");
     f32x4 vx[NX], vd[ND];
-    // first phase that reads any row of chunk k (phase p reads x rows <= RP*(p+1)+1 and dy rows < RP*(p+1))
-    auto xphase = [](int k) { const int fr = k * kThreads / XROW; return fr < 2 ? 0 : (fr - 2) / RP < PH ? (fr - 2) / RP : PH - 1; };
-    auto dphase = [](int k) { return (k * kThreads / DROW) / RP; };
+    // first phase that reads any row of chunk k: phase p reads x rows <= STRIDE*(RP*(p+1) - 1) + 2 and dy rows < RP*(p+1)
+    auto xphase = [](int k) {
+        const int fr = k * kThreads / XROW;
+        int p = 0;
+        while (p < PH - 1 && STRIDE * (C::RP * (p + 1) - 1) + 2 < fr) ++p;
+        return p;
+    };
+    auto dphase = [](int k) {
+        const int p = (k * kThreads / DROW) / C::RP;
+        return p < PH ? p : PH - 1;
+    };
     auto load_x = [&](int n, int k) {
-        const int idx = tid + k * kThreads;
+        int idx = tid + k * kThreads;
+        if (XV % kThreads != 0) idx = idx < XV ? idx : XV - 1;
         const int c4 = idx % (C::WI / 4), ci = (idx / (C::WI / 4)) % CIN, r = idx / XROW;
-        int ih = band * R - 1 + r;                             // rows outside the image: a valid row is loaded (every load
-        ih = ih < 0 ? 0 : ih >= C::WI ? C::WI - 1 : ih;        // unconditional, so the waits below count exactly) and zeroed when staged
-        static_assert(XV % kThreads == 0, "whole chunks");
+        int ih = band * R * STRIDE - 1 + r;
+        ih = ih < 0 ? 0 : ih >= C::WI ? C::WI - 1 : ih;
         vx[k] = *reinterpret_cast<const f32x4*>(x + (((size_t)n * CIN + ci) * C::WI + ih) * C::WI + 4 * c4);
     };
     auto load_d = [&](int n, int k) {
-        const int idx = tid + k * kThreads;
+        int idx = tid + k * kThreads;
+        if (DV % kThreads != 0) idx = idx < DV ? idx : DV - 1;
         const int c4 = idx % (WO / 4), co = (idx / (WO / 4)) % COUT_WG, r = idx / DROW;
-        static_assert(DV % kThreads == 0, "whole chunks");
         vd[k] = *reinterpret_cast<const f32x4*>(dy + (((size_t)n * Cout + co_base + co) * WO + band * R + r) * WO + 4 * c4);
     };
     auto issue = [&](int n) {
@@ -124,16 +143,17 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3_wgrad(const float* __restr
             if (xphase(k) != p) continue;
             const int idx = tid + k * kThreads;
             const int c4 = idx % (C::WI / 4), ci = (idx / (C::WI / 4)) % CIN, r = idx / XROW;
-            const int ih = band * R - 1 + r;
+            const int ih = band * R * STRIDE - 1 + r;
             const bool in = ih >= 0 && ih < C::WI;
-            *reinterpret_cast<f32x4*>(xs + ci * C::XPLANE + r * C::WP + 4 + 4 * c4) = in ? vx[k] : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (XV % kThreads == 0 || idx < XV)
+                *reinterpret_cast<f32x4*>(xs + ci * C::XPLANE + r * C::WP + 4 + 4 * c4) = in ? vx[k] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int k = 0; k < ND; ++k) {
             if (dphase(k) != p) continue;
             const int idx = tid + k * kThreads;
             const int c4 = idx % (WO / 4), co = (idx / (WO / 4)) % COUT_WG, r = idx / DROW;
-            *reinterpret_cast<f32x4*>(ds + co * C::DPLANE + r * WO + 4 * c4) = vd[k];
+            if (DV % kThreads == 0 || idx < DV) *reinterpret_cast<f32x4*>(ds + co * C::DPLANE + r * WO + 4 * c4) = vd[k];
         }
     };
 
@@ -147,63 +167,98 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3_wgrad(const float* __restr
             stage(p);
             __syncthreads();
             if (p == PH - 1 && n + 1 < n1) issue(n + 1);
-            for (int t = p * GP + kpart; t < (p + 1) * GP; t += C::KW) {
+            for (int t = p * C::GP + kpart; t < (p + 1) * C::GP; t += C::KW) {
                 const int q = t * 4 + g;                       // this lane group's quarter-row: four adjacent ow of one row
                 const int row = q / (WO / 4), ow0 = 4 * (q % (WO / 4));
                 const f32x4 a = *reinterpret_cast<const f32x4*>(ds + (cot * 16 + c) * C::DPLANE + row * WO + ow0);
-                const float* xb = xs + (cit * 16 + c) * C::XPLANE + row * C::WP + ow0 + 3;   // iw = ow0 - 1
+                const float* xb = xs + xplane * C::XPLANE + row * STRIDE * C::WP + ow0 * STRIDE + 3;   // iw = ow0*s - 1
+                if constexpr (TAPS == 1) {                     // centre tap at stride 2: iw = 2*(ow0 + tt), ih = 2*row
+                    const float* pw = xb + C::WP;
+                    const f32x4 m0 = *reinterpret_cast<const f32x4*>(pw + 1), m1 = *reinterpret_cast<const f32x4*>(pw + 5);
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], m0.x, acc[0], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], m0.z, acc[0], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], m1.x, acc[0], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], m1.z, acc[0], 0, 0, 0);
+                } else {
 #pragma unroll
-                for (int kh = 0; kh < 3; ++kh) {
-                    const float* pw = xb + kh * C::WP;
-                    const float w0 = pw[0], w5 = pw[5];
-                    const f32x4 m = *reinterpret_cast<const f32x4*>(pw + 1);
-                    const float win[6] = {w0, m.x, m.y, m.z, m.w, w5};
+                    for (int kh = 0; kh < 3; ++kh) {
+                        const float* pw = xb + kh * C::WP;
+                        if constexpr (STRIDE == 1) {
+                            const float w0 = pw[0], w5 = pw[5];
+                            const f32x4 m = *reinterpret_cast<const f32x4*>(pw + 1);
+                            const float win[6] = {w0, m.x, m.y, m.z, m.w, w5};
 #pragma unroll
-                    for (int tt = 0; tt < 4; ++tt)
+                            for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-                        for (int kw = 0; kw < 3; ++kw)
-                            acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tt], win[tt + kw], acc[kh * 3 + kw], 0, 0, 0);
+                                for (int kw = 0; kw < 3; ++kw)
+                                    acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tt], win[tt + kw], acc[kh * 3 + kw], 0, 0, 0);
+                        } else {
+                            const float w0 = pw[0];            // iw = 2*ow0 - 1 .. 2*ow0 + 7: nine floats
+                            const f32x4 m0 = *reinterpret_cast<const f32x4*>(pw + 1), m1 = *reinterpret_cast<const f32x4*>(pw + 5);
+                            const float win[9] = {w0, m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+#pragma unroll
+                            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                                for (int kw = 0; kw < 3; ++kw)
+                                    acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tt], win[2 * tt + kw], acc[kh * 3 + kw], 0, 0, 0);
+                        }
+                    }
                 }
             }
         }
     }
 
-    // partial dW of this K slice, tile order: element ((pair * 9 + tap) * 4 + reg) * 64 + lane holds
+    // partial dW of this K slice, tile order: element ((pair * TAPS + tap) * 4 + reg) * 64 + lane holds
     // dW[co = cot*16 + (lane >> 4)*4 + reg][ci = cit*16 + (lane & 15)][tap]
-    const size_t E = (size_t)Cout * CIN * 9;
+    const size_t E = (size_t)(Cout / 16) * C::CT * C::TE;
     float* out = partial + (size_t)blockIdx.x * E;
     if constexpr (C::KW == 1) {
         const int pair_g = (blockIdx.y * C::MT + cot) * C::CT + cit;
 #pragma unroll
-        for (int j = 0; j < 9; ++j)
+        for (int j = 0; j < TAPS; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) out[(size_t)pair_g * 2304 + (j * 4 + r) * 64 + lane] = acc[j][r];
+            for (int r = 0; r < 4; ++r) out[(size_t)pair_g * C::TE + (j * 4 + r) * 64 + lane] = acc[j][r];
     } else {
         __syncthreads();                                       // every wave is done with the tiles: reuse them
         float* red = smem;
 #pragma unroll
-        for (int j = 0; j < 9; ++j)
+        for (int j = 0; j < TAPS; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) red[(wave * 36 + j * 4 + r) * 64 + lane] = acc[j][r];
+            for (int r = 0; r < 4; ++r) red[wave * C::TE + (j * 4 + r) * 64 + lane] = acc[j][r];
         __syncthreads();
-        for (int e = tid; e < C::PW * 2304; e += kThreads) {
-            const int p = e / 2304, rem = e % 2304;
-            float s = red[p * 2304 + rem];                     // waves p, p + PW, p + 2 PW, ...: ascending K part
+        for (int e = tid; e < C::PW * C::TE; e += kThreads) {
+            const int p = e / C::TE, rem = e % C::TE;
+            float s = red[p * C::TE + rem];                    // waves p, p + PW, p + 2 PW, ...: ascending K part
 #pragma unroll
-            for (int kp = 1; kp < C::KW; ++kp) s += red[(p + C::PW * kp) * 2304 + rem];
+            for (int kp = 1; kp < C::KW; ++kp) s += red[(p + C::PW * kp) * C::TE + rem];
             const int pair_g = (blockIdx.y * C::MT + p / C::CT) * C::CT + p % C::CT;
-            out[(size_t)pair_g * 2304 + rem] = s;
+            out[(size_t)pair_g * C::TE + rem] = s;
         }
     }
 }
 
-// Second launch: dW[co][ci][tap] = sum over the S slices, ascending. 16 float4 columns x 16 slice classes per workgroup.
-__global__ __launch_bounds__(kThreads) void k_conv_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ dw, int S,
-                                                                 int E4, int Cin) {
+// Second launch, for up to kMaxItems layers at once: dW[co][ci][tap] = sum over the layer's S slices, ascending.
+// 16 float4 columns x 16 slice classes per workgroup; a workgroup finds its layer by its first block index.
+constexpr int kMaxItems = 48;
+struct ReduceItem {
+    const float* partial;
+    float* dw;
+    int S, E4, Cin, taps, blk0, pad;
+};
+struct ReduceItems {
+    int n, pad;
+    ReduceItem it[kMaxItems];
+};
+
+__global__ __launch_bounds__(kThreads) void k_conv_wgrad_reduce(const ReduceItems items) {
     __shared__ f32x4 red[16][16];
+    int li = 0;
+    while (li + 1 < items.n && (int)blockIdx.x >= items.it[li + 1].blk0) ++li;
+    const ReduceItem& I = items.it[li];
     const int tid = threadIdx.x, col = tid & 15, sp = tid >> 4;
-    const int e4 = blockIdx.x * 16 + col;
-    const f32x4* p4 = reinterpret_cast<const f32x4*>(partial);
+    const int e4 = ((int)blockIdx.x - I.blk0) * 16 + col;
+    const int S = I.S, E4 = I.E4;
+    const f32x4* p4 = reinterpret_cast<const f32x4*>(I.partial);
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     int k = sp;
     for (; k + 16 * 7 < S; k += 16 * 8) {                     // eight loads in flight, added in ascending slice order
@@ -219,12 +274,15 @@ __global__ __launch_bounds__(kThreads) void k_conv_wgrad_reduce(const float* __r
     if (sp == 0) {
         f32x4 t = red[0][col];
 #pragma unroll
-        for (int k = 1; k < 16; ++k) t += red[k][col];
-        const int e = e4 * 4, lane = e & 63, reg = (e >> 6) & 3, tap = (e >> 8) % 9, pr = (e >> 8) / 9;
-        const int CT = Cin / 16, cot = pr / CT, cit = pr % CT;
+        for (int kk = 1; kk < 16; ++kk) t += red[kk][col];
+        const int e = e4 * 4, lane = e & 63, reg = (e >> 6) & 3, tap = (e >> 8) % I.taps, pr = (e >> 8) / I.taps;
+        const int CT = (I.Cin + 15) / 16, cot = pr / CT, cit = pr % CT;
         const int co = cot * 16 + (lane >> 4) * 4 + reg, ci = cit * 16 + (lane & 15);
-        float* o = dw + ((size_t)co * Cin + ci) * 9 + tap;
-        o[0] = t.x, o[9] = t.y, o[18] = t.z, o[27] = t.w;
+        float* o = I.dw + ((size_t)co * I.Cin + ci) * I.taps + tap;
+        const float tv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (ci + j < I.Cin) o[(size_t)j * I.taps] = tv[j];  // (channels padded up to 16 exist in the partial tiles only)
     }
 }
 
@@ -232,21 +290,36 @@ struct Plan {
     int slices;       // grid.x = K slices = partial copies
     int gy;           // grid.y
     int ipw;          // images per workgroup
+    int taps;
+    int64_t E;        // floats of one partial copy
     void (*fn)(const float*, const float*, float*, int, int, int);
 };
 
-// Which shapes K7 takes: the three stages of the CIFAR pre-activation ResNets (URSABench/models/preresnet.py:62-64,149-151),
-// stride 1. Anything else -> slices = 0, and the caller keeps MIOpen's weight gradient.
-Plan plan_for(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, int stride) {
-    Plan p = {0, 0, 0, nullptr};
+// Which shapes K7 takes: every convolution of the CIFAR pre-activation ResNets with BasicBlocks
+// (URSABench/models/preresnet.py:25-27,100,130-136): the three stages' 3x3 / stride 1 layers, the stem (3 -> 16), the two
+// 3x3 / stride 2 layers that open stages 2 and 3 and their 1x1 / stride 2 shortcuts. Anything else -> slices = 0, and the
+// caller keeps MIOpen's weight gradient.
+Plan plan_for(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, int ksize, int stride) {
+    Plan p = {0, 0, 0, 0, 0, nullptr};
     if (N < 1 || N > (1 << 20) || H != W) return p;
     int bands = 0;
-    if (stride == 1 && Cin == 16 && Cout == 16 && W == 32) {
-        p.ipw = 1, bands = 4, p.gy = 1, p.fn = k_conv3x3_wgrad<16, 16, 32, 8, 1>;
-    } else if (stride == 1 && Cin == 32 && Cout == 32 && W == 16) {
-        p.ipw = 1, bands = 2, p.gy = 1, p.fn = k_conv3x3_wgrad<32, 32, 16, 8, 1>;
-    } else if (stride == 1 && Cin == 64 && Cout == 64 && W == 8) {
-        p.ipw = 2, bands = 1, p.gy = 4, p.fn = k_conv3x3_wgrad<64, 16, 8, 8, 1>;
+    const bool k3 = ksize == 3, k1 = ksize == 1;
+    if (k3 && stride == 1 && Cin == 16 && Cout == 16 && W == 32) {
+        p.ipw = 1, bands = 4, p.gy = 1, p.fn = k_conv_wgrad<16, 16, 32, 8, 1, 9, 4>;
+    } else if (k3 && stride == 1 && Cin == 32 && Cout == 32 && W == 16) {
+        p.ipw = 1, bands = 2, p.gy = 1, p.fn = k_conv_wgrad<32, 32, 16, 8, 1, 9, 4>;
+    } else if (k3 && stride == 1 && Cin == 64 && Cout == 64 && W == 8) {
+        p.ipw = 2, bands = 1, p.gy = 4, p.fn = k_conv_wgrad<64, 16, 8, 8, 1, 9, 4>;
+    } else if (k3 && stride == 1 && Cin == 3 && Cout == 16 && W == 32) {
+        p.ipw = 1, bands = 4, p.gy = 1, p.fn = k_conv_wgrad<3, 16, 32, 8, 1, 9, 4>;
+    } else if (k3 && stride == 2 && Cin == 16 && Cout == 32 && W == 32) {
+        p.ipw = 1, bands = 2, p.gy = 1, p.fn = k_conv_wgrad<16, 32, 16, 8, 2, 9, 4>;
+    } else if (k3 && stride == 2 && Cin == 32 && Cout == 64 && W == 16) {
+        p.ipw = 2, bands = 2, p.gy = 2, p.fn = k_conv_wgrad<32, 32, 8, 4, 2, 9, 2>;
+    } else if (k1 && stride == 2 && Cin == 16 && Cout == 32 && W == 32) {
+        p.ipw = 2, bands = 2, p.gy = 1, p.fn = k_conv_wgrad<16, 32, 16, 8, 2, 1, 4>;
+    } else if (k1 && stride == 2 && Cin == 32 && Cout == 64 && W == 16) {
+        p.ipw = 2, bands = 2, p.gy = 2, p.fn = k_conv_wgrad<32, 32, 8, 4, 2, 1, 2>;
     } else {
         return p;
     }
@@ -256,32 +329,79 @@ Plan plan_for(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, int st
         if (v >= 1 && v <= 64) p.ipw = v;
     }
 #endif
+    p.taps = k3 ? 9 : 1;
     p.slices = (int)((N + p.ipw - 1) / p.ipw) * bands;
+    p.E = (Cout / 16) * ((Cin + 15) / 16) * (int64_t)p.taps * 256;
     return p;
+}
+
+int launch_reduce(const ReduceItems& items, int blocks, hipStream_t s) {
+    hipLaunchKernelGGL(k_conv_wgrad_reduce, dim3((unsigned)blocks), dim3(kThreads), 0, s, items);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? URSA_OK : (int)e;
+}
+
+int check_shape(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W) {
+    return (N < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) ? URSA_ESIZE : URSA_OK;
 }
 
 }  // namespace
 
-extern "C" int64_t ursa_conv3x3_wgrad_ws_floats(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, int32_t stride) {
-    const Plan p = plan_for(N, Cin, Cout, H, W, stride);
-    return p.slices ? (int64_t)p.slices * Cout * Cin * 9 : 0;
+extern "C" int64_t ursa_conv_wgrad_ws_floats(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, int32_t ksize,
+                                             int32_t stride) {
+    const Plan p = plan_for(N, Cin, Cout, H, W, ksize, stride);
+    return p.slices ? (int64_t)p.slices * p.E : 0;
 }
 
-extern "C" int ursa_conv3x3_wgrad_f32(const float* x, const float* dy, float* dw, float* ws, int64_t ws_floats, int64_t N,
-                                      int64_t Cin, int64_t Cout, int64_t H, int64_t W, int32_t stride, ursa_stream_t stream) {
-    if (!x || !dy || !dw || !ws) return URSA_ENULL;
-    if (N < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return URSA_ESIZE;
+extern "C" int ursa_conv_wgrad_partial_f32(const float* x, const float* dy, float* ws, int64_t ws_floats, int64_t N, int64_t Cin,
+                                           int64_t Cout, int64_t H, int64_t W, int32_t ksize, int32_t stride,
+                                           ursa_stream_t stream) {
+    if (!x || !dy || !ws) return URSA_ENULL;
+    if (int rc = check_shape(N, Cin, Cout, H, W)) return rc;
     if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)ws) & 15) return URSA_EALIGN;
-    if ((uintptr_t)dw & 3) return URSA_EALIGN;
-    const Plan p = plan_for(N, Cin, Cout, H, W, stride);
-    if (!p.slices) return URSA_EVALUE;                         // shape not covered: ursa_conv3x3_wgrad_ws_floats() said 0
-    const int64_t E = Cout * Cin * 9;
-    if (ws_floats < (int64_t)p.slices * E) return URSA_ESIZE;
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(p.fn, dim3(p.slices * 1, p.gy), dim3(kThreads), 0, s, x, dy, ws, (int)N, (int)Cout, p.ipw);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(k_conv_wgrad_reduce, dim3((unsigned)(E / 64)), dim3(kThreads), 0, s, ws, dw, p.slices, (int)(E / 4), (int)Cin);
-    e = hipGetLastError();
+    const Plan p = plan_for(N, Cin, Cout, H, W, ksize, stride);
+    if (!p.slices) return URSA_EVALUE;                         // shape not covered: ursa_conv_wgrad_ws_floats() said 0
+    if (ws_floats < (int64_t)p.slices * p.E) return URSA_ESIZE;
+    hipLaunchKernelGGL(p.fn, dim3(p.slices, p.gy), dim3(kThreads), 0, (hipStream_t)stream, x, dy, ws, (int)N, (int)Cout, p.ipw);
+    const hipError_t e = hipGetLastError();
     return e == hipSuccess ? URSA_OK : (int)e;
+}
+
+extern "C" int ursa_conv_wgrad_reduce_f32(const ursa_conv_pending* items, int32_t n, ursa_stream_t stream) {
+    if (n < 0) return URSA_ESIZE;
+    if (n == 0) return URSA_OK;
+    if (!items) return URSA_ENULL;
+    for (int i = 0; i < n; ++i) {                               // everything is checked before anything is launched
+        const ursa_conv_pending& q = items[i];
+        if (!q.ws || !q.dw) return URSA_ENULL;
+        if (int rc = check_shape(q.N, q.Cin, q.Cout, q.H, q.W)) return rc;
+        if ((uintptr_t)q.ws & 15 || (uintptr_t)q.dw & 3) return URSA_EALIGN;
+        if (!plan_for(q.N, q.Cin, q.Cout, q.H, q.W, q.ksize, q.stride).slices) return URSA_EVALUE;
+    }
+    ReduceItems r;
+    r.n = 0, r.pad = 0;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const ursa_conv_pending& q = items[i];
+        const Plan p = plan_for(q.N, q.Cin, q.Cout, q.H, q.W, q.ksize, q.stride);
+        ReduceItem& it = r.it[r.n++];
+        it.partial = q.ws, it.dw = q.dw, it.S = p.slices, it.E4 = (int)(p.E / 4), it.Cin = (int)q.Cin, it.taps = p.taps;
+        it.blk0 = blocks, it.pad = 0;
+        blocks += (int)(p.E / 64);
+        if (r.n == kMaxItems || i == n - 1) {
+            if (int rc = launch_reduce(r, blocks, (hipStream_t)stream)) return rc;
+            r.n = 0, blocks = 0;
+        }
+    }
+    return URSA_OK;
+}
+
+extern "C" int ursa_conv_wgrad_f32(const float* x, const float* dy, float* dw, float* ws, int64_t ws_floats, int64_t N,
+                                   int64_t Cin, int64_t Cout, int64_t H, int64_t W, int32_t ksize, int32_t stride,
+                                   ursa_stream_t stream) {
+    if (!dw) return URSA_ENULL;
+    if ((uintptr_t)dw & 3) return URSA_EALIGN;
+    if (int rc = ursa_conv_wgrad_partial_f32(x, dy, ws, ws_floats, N, Cin, Cout, H, W, ksize, stride, stream)) return rc;
+    const ursa_conv_pending one = {ws, dw, N, Cin, Cout, H, W, ksize, stride};
+    return ursa_conv_wgrad_reduce_f32(&one, 1, stream);
 }

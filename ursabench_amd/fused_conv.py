@@ -1,12 +1,17 @@
-"""The weight gradient of the benchmark networks' 3x3 convolutions as gfx950 launches (K7, include/ursa_hip.h).
+"""The weight gradient of the benchmark networks' convolutions as gfx950 launches (K7, include/ursa_hip.h).
 
 `Conv2d` is what `ursabench_amd.models` instantiates where the reference's networks write `nn.Conv2d(...)`
-(URSABench/models/preresnet.py:25-27,62-64,100). It IS an `nn.Conv2d` (same parameters, state_dict keys, initialisation);
-the forward and the input gradient stay MIOpen's. What changes, for the layer shapes K7 covers, on contiguous fp32 NCHW HIP
-tensors while gradients are recorded: the weight gradient of `loss.backward()` (URSABench/inference/sghmc.py:80) is computed
-by `ursa_conv3x3_wgrad_f32` - two launches straight from the NCHW tensors, exact fp32, fixed summation order - instead of
-MIOpen's sequence for these sizes (two layout transposes, a zero fill, an atomics-based implicit GEMM, a transpose back:
-92 of the 237 launches of a PreResNet-20 step, profiles/r05_step_timeline.json).
+(URSABench/models/preresnet.py:25-27,62-64,100,130-136). It IS an `nn.Conv2d` (same parameters, state_dict keys,
+initialisation); the forward and the input gradient stay MIOpen's. What changes, for the layer shapes K7 covers, on contiguous
+fp32 NCHW HIP tensors while gradients are recorded: the weight gradient of `loss.backward()` (URSABench/inference/sghmc.py:80)
+is computed by `ursa_conv_wgrad_f32` - two launches straight from the NCHW tensors, exact fp32, fixed summation order -
+instead of MIOpen's sequence for these sizes (two layout transposes, a zero fill, an atomics-based implicit GEMM, a transpose
+back: 92 of the 237 launches of a PreResNet-20 step, profiles/r05_step_timeline.json).
+
+`deferred()`: whoever owns the destination of the gradients (the chain engine: its flat arena) can take K7's second launch -
+the fixed-order sum over the K slices - for ALL layers of a backward pass at once: the backward of a covered layer applied
+inside the context runs the first launch only and records (partial sums, weight); `flush()` then writes every layer's dW
+where the caller says, in one launch. Outside the context each layer's backward returns its weight gradient as autograd expects.
 
 Anything else - other kernel sizes / strides / channel counts, bias, groups, dilation, host tensors, other dtypes or layouts,
 double backward - takes `nn.Conv2d.forward`, the stock path, unchanged. On a HIP tensor the K7 path needs
@@ -14,6 +19,7 @@ csrc/libursa_hip.so (no silent fallback: a missing library raises). `URSA_FUSED_
 `enabled(False)`, selects the stock path everywhere (A/B runs).
 """
 import os
+import threading
 
 import torch
 import torch.nn as nn
@@ -34,42 +40,86 @@ def enabled(flag=None):
     return old
 
 
-class _Conv3x3(torch.autograd.Function):
-    """y = conv2d(x, w, stride, padding=1): forward and dx are ATen's (MIOpen), dw is K7's."""
+_tls = threading.local()          # deferred(): the sink of the thread that runs the forward
+
+
+class deferred:
+    """Context around a FORWARD pass: the backward of every covered layer applied inside leaves (record of the first K7
+    launch, weight parameter) in the returned list instead of returning a weight gradient - the weight's `.grad` stays None -
+    and the caller hands the list to `flush()` once `backward()` has returned. The decision is taken in the forward (this
+    thread) and travels in the autograd context: the backward runs on autograd's device thread."""
+
+    def __enter__(self):
+        self.old = getattr(_tls, 'sink', None)
+        _tls.sink = sink = []
+        return sink
+
+    def __exit__(self, *exc):
+        _tls.sink = self.old
+        return False
+
+
+def flush(pending, dest):
+    """The second K7 launch for every layer recorded in `pending` (from `deferred()`), at once. dest(weight) -> the contiguous
+    fp32 tensor of the weight's shape that receives its gradient (overwritten). A weight that occurs more than once (a layer
+    applied twice in one forward) gets the sum of its gradients."""
+    if not pending:
+        return
+    items, extra, seen = [], [], {}
+    for rec, w in pending:
+        if id(w) in seen:
+            tmp = torch.empty_like(seen[id(w)])
+            extra.append((seen[id(w)], tmp))
+            items.append((rec, tmp))
+        else:
+            seen[id(w)] = d = dest(w)
+            items.append((rec, d))
+    _native.default_kernels().conv_wgrad_reduce(items)
+    for d, tmp in extra:
+        d.add_(tmp)
+
+
+class _ConvWgrad(torch.autograd.Function):
+    """y = conv2d(x, w, stride, padding=k // 2): forward and dx are ATen's (MIOpen), dw is K7's."""
 
     @staticmethod
     def forward(ctx, x, w, stride, ws_floats):
         ctx.save_for_backward(x, w)
-        ctx.stride, ctx.ws_floats = stride, ws_floats
-        return F.conv2d(x, w, None, stride, 1)
+        ctx.stride, ctx.ws_floats, ctx.weight, ctx.sink = stride, ws_floats, w, getattr(_tls, 'sink', None)
+        return F.conv2d(x, w, None, stride, w.shape[2] // 2)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
-        s = ctx.stride
+        s, pad = ctx.stride, w.shape[2] // 2
         dy = dy.contiguous()
         if dy.data_ptr() % 16:                 # a contiguous view at an odd offset: K7 wants 16-byte aligned operands
             dy = dy.clone()
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            dx = torch.ops.aten.convolution_backward(dy, x, w, None, [s, s], [1, 1], [1, 1], False, [0, 0], 1,
+            dx = torch.ops.aten.convolution_backward(dy, x, w, None, [s, s], [pad, pad], [1, 1], False, [0, 0], 1,
                                                      [True, False, False])[0]
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(w)
-            _native.default_kernels().conv3x3_wgrad(x, dy, dw, x.new_empty(ctx.ws_floats), s)
+            k, ws = _native.default_kernels(), x.new_empty(ctx.ws_floats)
+            if ctx.sink is not None:
+                ctx.sink.append((k.conv_wgrad_partial(x, dy, w.shape, ws, s), ctx.weight))
+            else:
+                dw = torch.empty_like(w)
+                k.conv_wgrad(x, dy, dw, ws, s)
         return dx, dw, None, None
 
 
 def _covered(m, x):
     """Scratch floats if K7 takes this call's weight gradient, else 0."""
+    ks = m.kernel_size[0]
     if not (_on and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and torch.is_grad_enabled()
-            and m.weight.requires_grad and m.bias is None and m.kernel_size == (3, 3) and m.padding == (1, 1)
+            and m.weight.requires_grad and m.bias is None and m.kernel_size in ((3, 3), (1, 1)) and m.padding == (ks // 2, ks // 2)
             and m.dilation == (1, 1) and m.groups == 1 and m.padding_mode == 'zeros' and m.stride[0] == m.stride[1]
             and m.weight.dtype == torch.float32 and x.is_contiguous() and m.weight.is_contiguous()
             and x.data_ptr() % 16 == 0):
         return 0
-    return _native.default_kernels().conv3x3_wgrad_ws_floats(x.shape, m.out_channels, m.stride[0])
+    return _native.default_kernels().conv_wgrad_ws_floats(x.shape, m.out_channels, ks, m.stride[0])
 
 
 class Conv2d(nn.Conv2d):
@@ -78,5 +128,5 @@ class Conv2d(nn.Conv2d):
     def forward(self, x):
         n = _covered(self, x)
         if n:
-            return _Conv3x3.apply(x, self.weight, self.stride[0], n)
+            return _ConvWgrad.apply(x, self.weight, self.stride[0], n)
         return super().forward(x)

@@ -16,7 +16,7 @@ path that is timed — is the path the reference comparisons execute.
 """
 import torch
 
-from .. import fused_bn
+from .. import fused_bn, fused_conv
 from .._capture import capture, side_streams
 from ..util import deferred_bn_counters
 
@@ -34,6 +34,7 @@ class ChainEngine:
         self.use_graph = use_graph
         self.loss_acc = torch.zeros((), device=self.device)     # sum_i loss_i * batch_i, on device
         self._params = list(optimizer.arena.params)
+        self._slot = {id(p): i for i, p in enumerate(self._params)}     # parameter -> its arena view
         optimizer.ctl_zero_grad = False                         # the packed copy overwrites every gradient
         self._graph = None
         self._graph_eps = False          # whether the captured update launch reads the injected-noise buffer
@@ -56,8 +57,8 @@ class ChainEngine:
     def forward_backward(self, x, y):
         """Forward + loss + backward, gradients packed into the arena. Returns what `finish` needs to put back
         the tensors that received no gradient (None almost always)."""
-        with deferred_bn_counters(self.model), fused_bn.probing(self.gate_probe):   # 19 one-element counter kernels -> one multi-tensor add
-            logits = self.model(x)
+        with deferred_bn_counters(self.model), fused_bn.probing(self.gate_probe), fused_conv.deferred() as pend:
+            logits = self.model(x)                  # (deferred_bn_counters: 19 one-element counter kernels -> one multi-tensor add)
         loss = self.crit(logits, y)
         # Gradients: with p.grad = None autograd hands over its freshly computed tensors (no kernel);
         # ONE multi-tensor copy then packs them into the flat arena. Leaving the arena views in
@@ -69,7 +70,25 @@ class ChainEngine:
         grads = [p.grad for p in self._params]
         grad_views = self.opt.arena.grad_views
         keep = None
-        if any(g is None for g in grads):
+        if pend:
+            # K7: the convolutions' weight gradients are still K-sliced partial sums; ONE launch reduces all of them, in a fixed
+            # order, straight into their arena slots (no gradient tensor, no copy for them)
+            slot = self._slot
+            fused_conv.flush(pend, lambda w: grad_views[slot[id(w)]])
+            done = {slot[id(w)] for _, w in pend}
+            for i in done:
+                if grads[i] is not None:            # the same weight also went through a call K7 does not cover
+                    grad_views[i].add_(grads[i])
+            rest = [i for i in range(len(grads)) if i not in done]
+            if any(grads[i] is None for i in rest):
+                pairs = [(grad_views[i], grads[i]) for i in rest if grads[i] is not None]
+                if pairs:
+                    torch._foreach_copy_([v for v, _ in pairs], [g for _, g in pairs])
+                if getattr(self.opt, 'skip_grad_none', True):
+                    keep = self.opt.arena.stash([i for i in rest if grads[i] is None])
+            elif rest:
+                torch._foreach_copy_([grad_views[i] for i in rest], [grads[i] for i in rest])
+        elif any(g is None for g in grads):
             # a parameter that received no gradient (frozen / unused layer) is skipped by the reference
             # altogether (optim_sghmc.py:44-45): no prior pull, no noise. The flat launch covers it, so its
             # theta / momentum slices are copied aside and put back (device-to-device, part of the capture).
