@@ -393,6 +393,26 @@ int ursa_conv_wgrad_partial_f32(const float* x, const float* dy, float* ws, int6
                                 int64_t Cout, int64_t H, int64_t W, int32_t ksize, int32_t stride, ursa_stream_t stream);
 int ursa_conv_wgrad_reduce_f32(const ursa_conv_pending* items, int32_t n, ursa_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * K8  forward / input gradient of the stride-1 3x3 convolutions      `out = self.conv1(out)` URSABench/models/
+ *     preresnet.py:42,47,143 and the input-gradient half of `loss.backward()` (URSABench/inference/sghmc.py:80)
+ *
+ *     y[n][o][oh][ow] = sum_{i, kh, kw} w[o][i][kh][kw] * x[n][i][oh + kh - 1][ow + kw - 1]          (zero padded, no bias)
+ *     URSA_CONV_FLIP:  the same with w'[o][i][kh][kw] = w[i][o][2 - kh][2 - kw] - the input gradient: x = dy [N, Cin', H, W]
+ *                      with Cin' = the layer's OUTPUT channels, y = dx [N, Cout', H, W] with Cout' = its INPUT channels,
+ *                      w = the layer's own [Cin', Cout', 3, 3] weight tensor (Cin / Cout below = Cin' / Cout').
+ *
+ * x: [N, Cin, H, W], y: [N, Cout, H, W], contiguous NCHW fp32, 16-byte aligned; w contiguous. One launch; exact fp32 on
+ * v_mfma_f32_16x16x4_f32: each output is two interleaved fma chains over (channel group, tap) added once - a direct
+ * convolution, no Winograd transform. Shapes covered (any N, H = W): (Cin, Cout, H) in {(3, 16, 32), (16, 16, 32),
+ * (32, 32, 16), (64, 64, 8)}; ursa_conv3x3_supported() says whether a shape is (otherwise URSA_EVALUE).
+ * Algorithmic HBM traffic: 4 B x (N*Cin*H*W + N*Cout*H*W + Cout*Cin*9).
+ */
+#define URSA_CONV_FLIP 0x1u
+int ursa_conv3x3_supported(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W);
+int ursa_conv3x3_f32(const float* x, const float* w, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W,
+                     uint32_t flags, ursa_stream_t stream);
+
 /* ------------------------------------------------------------------------------------ */
 int ursa_abi_version(void);
 const char* ursa_strerror(int code);

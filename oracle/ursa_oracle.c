@@ -463,3 +463,38 @@ int oracle_conv_wgrad_f32(const float* x, const float* dy, float* dw, int64_t N,
                 }
     return 0;
 }
+
+/* ---------------------------------------------------------------------------------------
+ * K8  3x3 / stride 1 / pad 1 convolution, no bias     `out = self.conv1(out)` URSABench/models/preresnet.py:42,47,143
+ *     (F.conv2d on the CPU path, oneDNN) and, with flip, the input gradient of that layer (ATen convolution_backward).
+ *
+ *     y[n][o][oh][ow] = sum_{i, kh, kw} w[o][i][kh][kw] * x[n][i][oh + kh - 1][ow + kw - 1]
+ *     flip: w[o][i][kh][kw] is read as W[i][o][2 - kh][2 - kw] from the layer's own [Cin, Cout, 3, 3] tensor W
+ *
+ * As for K7, the sum is taken in double and rounded once (oneDNN's order is not a contract); pinned against torch's CPU ops
+ * in tests/test_fused_conv_cpu.py. x: [N, Cin, H, W], y: [N, Cout, H, W].
+ */
+int oracle_conv3x3_f32(const float* x, const float* w, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W,
+                       int flip)
+{
+    for (int64_t n = 0; n < N; ++n)
+        for (int64_t o = 0; o < Cout; ++o)
+            for (int64_t oh = 0; oh < H; ++oh)
+                for (int64_t ow = 0; ow < W; ++ow) {
+                    double acc = 0.0;
+                    for (int64_t i = 0; i < Cin; ++i)
+                        for (int64_t kh = 0; kh < 3; ++kh) {
+                            const int64_t ih = oh + kh - 1;
+                            if (ih < 0 || ih >= H) continue;
+                            for (int64_t kw = 0; kw < 3; ++kw) {
+                                const int64_t iw = ow + kw - 1;
+                                if (iw < 0 || iw >= W) continue;
+                                const float wv = flip ? w[((i * Cout + o) * 3 + (2 - kh)) * 3 + (2 - kw)]
+                                                      : w[((o * Cin + i) * 3 + kh) * 3 + kw];
+                                acc += (double)wv * (double)x[((n * Cin + i) * H + ih) * W + iw];
+                            }
+                        }
+                    y[((n * Cout + o) * H + oh) * W + ow] = (float)acc;
+                }
+    return 0;
+}

@@ -149,9 +149,14 @@ def test_natural_run_holds_1e5_on_every_gate_equal_prefix(golden_dir, sd):
 def test_k6_vs_stock_launches_paired(golden_dir):
     """Every seed with K6 and with MIOpen's BatchNorm + ATen's ReLU launches (URSA_FUSED_BN=0's path), natural gates.
     Differing gates come from the convolutions, not from the BatchNorm arithmetic, so neither path may be
-    systematically worse: K6's median final error <= 3x the stock launches' (the seed-to-seed spread of either is
-    more than 10x), its median count of differing gates <= 2x + 2, and on seeds where BOTH runs are gate-equal
-    throughout both hold 1e-5."""
+    systematically worse: K6's median final error <= 3x the stock launches' + 1e-5 (the seed-to-seed spread of either is
+    more than 10x), its count of differing gates after the FIRST step, summed over the seeds, <= 2x the stock launches' + 4,
+    and on seeds where BOTH runs are gate-equal throughout both hold 1e-5.
+    (Why the first step: a seed's later counts are decided by whether step 1 had a differing gate at all - 0 grows to
+    ~5 by step 4, 1 grows to ~200, profiles/r05_g16_gate_parity.json - so a median over 8 seeds of four-step totals is a
+    coin flip that any change of convolution rounding re-tosses: 115 vs 417 with MIOpen's convolutions, 359 vs 121 with K8's,
+    while the first-step sums were 6 vs 9 and 8 vs 6. Round 4's form of this assertion, on the totals' median, held by
+    luck of that toss.)"""
     rows = []
     for sd in SEEDS:
         k6 = replay(golden_dir, sd, fused=True, force=False, use_graph=True)
@@ -179,7 +184,7 @@ def test_k6_vs_stock_launches_paired(golden_dir):
     assert summary['max_err_k6_given_gates'] <= RTOL * 1.0 + 1e-12 or all(
         s_['proba_ok'] for sd in SEEDS for s_ in replay(golden_dir, sd, True, True, True)['steps'])
     assert summary['median_final_err_k6'] <= 3 * summary['median_final_err_stock'] + RTOL, summary
-    assert summary['median_flips_k6'] <= 2 * summary['median_flips_stock'] + 2, summary
+    assert sum(summary['first_step_flips_k6']) <= 2 * sum(summary['first_step_flips_stock']) + 4, summary
     for r in rows:
         if sum(r['k6']['flips']) == 0 and sum(r['stock']['flips']) == 0:
             assert max(r['k6']['err_proba']) <= 2 * RTOL and max(r['stock']['err_proba']) <= 2 * RTOL, r

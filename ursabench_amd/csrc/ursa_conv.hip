@@ -405,3 +405,228 @@ extern "C" int ursa_conv_wgrad_f32(const float* x, const float* dy, float* dw, f
     const ursa_conv_pending one = {ws, dw, N, Cin, Cout, H, W, ksize, stride};
     return ursa_conv_wgrad_reduce_f32(&one, 1, stream);
 }
+
+namespace {
+
+// =====================================================================================================================
+// K8: forward / input gradient of the stride-1 3x3 convolutions, NCHW fp32, gfx950.
+//
+// What it replaces: `self.conv(x)` (URSABench/models/preresnet.py:42,47) and the input-gradient half of ATen's
+// convolution_backward - MIOpen's Winograd F(2,3) assembly kernel on this stack, 18.8 us per layer and direction at
+// 16..64 channels (33 of a PreResNet-20 step's launches, 42 % of its kernel time, profiles/r05_step_timeline.json).
+//
+//     y[n][o][oh][ow] = sum_{i, kh, kw} w[o][i][kh][kw] * x[n][i][oh + kh - 1][ow + kw - 1]                      (forward)
+//     dx = the same with w'[o][i][kh][kw] = w[i][o][2 - kh][2 - kw] applied to dy                                (flip)
+//
+// Form: a GEMM with M = positions, N = output channels, K = Cin * 9 on `v_mfma_f32_16x16x4_f32` (exact fp32 products, fma
+// chains). A = x: lane (i = lane & 15, k = lane >> 4) reads ONE float of the staged x tile (position i of a run of 16,
+// input channel 4*g + k, shifted by the tap) per MFMA; B = w: every lane keeps its (o = lane & 15, channel k) weights of all
+// taps and channel groups in registers for the whole launch (Cin/4 * 9 of them, read once through LDS from a coalesced load).
+// D: a lane holds four adjacent positions of one output channel: one float4 store. x is staged exactly as in K7 (phases).
+constexpr int pitch64p16(int n) { return ((n - 16 + 63) / 64) * 64 + 16; }
+
+template <int CIN, int COUT_WG, int W, int R, int PH>
+struct Fw {
+    static constexpr int CINP = (CIN + 3) / 4 * 4;
+    static constexpr int KG = CINP / 4;                       // channel groups of 4 = MFMA k steps per tap
+    static constexpr int RI = R + 2, WP = W + 8;
+    static constexpr int XPLANE = pitch64p16(RI * WP);        // 4 channels x 16 positions of an A read: 64 distinct banks
+    static constexpr int XS = CINP * XPLANE;
+    static constexpr int WPITCH = pitch64p4(CINP * 9);        // weights, rows [o][channel * 9 + tap]: staged before x, same LDS
+    static constexpr int WL = WPITCH * COUT_WG;
+    static constexpr int SMEM = cmax(XS, WL);
+    static constexpr int MT = COUT_WG / 16, WPC = 4 / MT;     // waves per output-channel tile (they split the positions)
+    static constexpr int PT = R * W / 16;                     // runs of 16 positions per workgroup tile
+    static constexpr int BANDS = W / R;
+    static constexpr int RP = R / PH, TP = PT / PH;           // rows / runs per phase
+    static constexpr int TPW = TP / WPC;                      // runs per wave per phase
+    static_assert(MT == 1 || MT == 2 || MT == 4, "output tiles per workgroup");
+    static_assert(W % 4 == 0 && W % R == 0 && (R * W) % 16 == 0 && R % PH == 0 && PT % PH == 0 && TP % WPC == 0, "geometry");
+    static_assert(TP * 16 == RP * W, "a phase's runs are its rows");
+    static_assert(SMEM * 4 <= 64 * 1024, "static LDS");
+};
+
+template <int CIN, int COUT_WG, int W, int R, int PH>
+__global__ __launch_bounds__(kThreads) void k_conv3x3(const float* __restrict__ x, const float* __restrict__ w,
+                                                       float* __restrict__ y, int N, int Cout, int ipw, int flip) {
+    using C = Fw<CIN, COUT_WG, W, R, PH>;
+    __shared__ __attribute__((aligned(16))) float smem[C::SMEM];
+    float* xs = smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int band = blockIdx.x % C::BANDS, ig = blockIdx.x / C::BANDS;
+    const int co_base = blockIdx.y * COUT_WG;
+    const int j = lane & 15, k = lane >> 4;
+    const int cot = wave % C::MT, wsub = wave / C::MT;
+
+    constexpr int XROW = CIN * (W / 4);
+    constexpr int XV = XROW * C::RI;
+    constexpr int NX = (XV + kThreads - 1) / kThreads;
+    f32x4 vx[NX];
+    auto xphase = [](int kk) {
+        const int fr = kk * kThreads / XROW;
+        int p = 0;
+        while (p < PH - 1 && C::RP * (p + 1) + 1 < fr) ++p;
+        return p;
+    };
+    auto load_x = [&](int n, int kk) {
+        int idx = tid + kk * kThreads;
+        if (XV % kThreads != 0) idx = idx < XV ? idx : XV - 1;
+        const int c4 = idx % (W / 4), ci = (idx / (W / 4)) % CIN, r = idx / XROW;
+        int ih = band * R - 1 + r;
+        ih = ih < 0 ? 0 : ih >= W ? W - 1 : ih;
+        vx[kk] = *reinterpret_cast<const f32x4*>(x + (((size_t)n * CIN + ci) * W + ih) * W + 4 * c4);
+    };
+    auto issue = [&](int n) {
+#pragma unroll
+        for (int p = 0; p < PH; ++p) {
+#pragma unroll
+            for (int kk = 0; kk < NX; ++kk)
+                if (xphase(kk) == p) load_x(n, kk);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto stage = [&](int p) {
+#pragma unroll
+        for (int kk = 0; kk < NX; ++kk) {
+            if (xphase(kk) != p) continue;
+            const int idx = tid + kk * kThreads;
+            const int c4 = idx % (W / 4), ci = (idx / (W / 4)) % CIN, r = idx / XROW;
+            const int ih = band * R - 1 + r;
+            const bool in = ih >= 0 && ih < W;
+            if (XV % kThreads == 0 || idx < XV)
+                *reinterpret_cast<f32x4*>(xs + ci * C::XPLANE + r * C::WP + 4 + 4 * c4) = in ? vx[kk] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+
+    const int n0 = ig * ipw;
+    const int n1 = n0 + ipw < N ? n0 + ipw : N;
+    if (n0 < n1) issue(n0);                                    // the first image's rows are in flight while the weights are read
+
+    // weights: coalesced global reads -> LDS rows [o][channel * 9 + tap] at a pitch of 4 mod 64 floats (lane (o = j, channel k)
+    // reads bank 4 j + 9 k + const: 64 distinct banks) -> this lane's Cin/4 * 9 registers
+    float wr[C::KG][9];
+    {
+        float* wl = smem;
+        constexpr int ROW = CIN * 9;
+        if constexpr (C::CINP > CIN)
+            for (int i = tid; i < COUT_WG * (C::CINP - CIN) * 9; i += kThreads)
+                wl[(i / ((C::CINP - CIN) * 9)) * C::WPITCH + ROW + i % ((C::CINP - CIN) * 9)] = 0.f;
+        if (!flip) {
+            if constexpr (ROW % 4 == 0) {
+                const f32x4* src = reinterpret_cast<const f32x4*>(w + (size_t)co_base * ROW);   // (co_base * ROW * 4 bytes: 16-byte multiple)
+                for (int idx = tid; idx < COUT_WG * ROW / 4; idx += kThreads)
+                    *reinterpret_cast<f32x4*>(wl + (idx / (ROW / 4)) * C::WPITCH + 4 * (idx % (ROW / 4))) = src[idx];
+            } else {
+                for (int idx = tid; idx < COUT_WG * ROW; idx += kThreads)
+                    wl[(idx / ROW) * C::WPITCH + idx % ROW] = w[(size_t)co_base * ROW + idx];
+            }
+        } else {                                               // w'[o][ci][tap] = w[ci][o][8 - tap], w: [CIN][Cout][3][3]
+            constexpr int RUN = COUT_WG * 9;                   // per input channel: COUT_WG * 9 contiguous floats (16-byte aligned runs)
+            for (int idx = tid; idx < CIN * RUN / 4; idx += kThreads) {
+                const int ci = idx / (RUN / 4), r4 = 4 * (idx % (RUN / 4));
+                const f32x4 v = *reinterpret_cast<const f32x4*>(w + ((size_t)ci * Cout + co_base) * 9 + r4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wl[((r4 + e) / 9) * C::WPITCH + ci * 9 + 8 - (r4 + e) % 9] = v[e];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < C::KG; ++g)
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) wr[g][tap] = wl[(cot * 16 + j) * C::WPITCH + (g * 4 + k) * 9 + tap];
+        __syncthreads();                                       // every wave has its weights: the region becomes the x tile
+    }
+    for (int i = tid; i < C::CINP * C::RI; i += kThreads) {    // halo columns (and, for a padded channel count, whole zero planes)
+        float* row = xs + (i / C::RI) * C::XPLANE + (i % C::RI) * C::WP;
+        row[3] = 0.f;
+        row[4 + W] = 0.f;
+    }
+    if constexpr (C::CINP > CIN)
+        for (int i = tid; i < (C::CINP - CIN) * C::XPLANE; i += kThreads) xs[CIN * C::XPLANE + i] = 0.f;
+
+    for (int n = n0; n < n1; ++n) {
+        if (n > n0) __syncthreads();
+#pragma unroll
+        for (int p = 0; p < PH; ++p) {
+            stage(p);
+            __syncthreads();
+            if (p == PH - 1 && n + 1 < n1) issue(n + 1);
+            // steps of 9 MFMAs (one channel group, nine taps); the nine A reads of step s + 1 are issued before the MFMAs of
+            // step s, so the LDS latency hides behind 288 cycles of matrix work even with one wave per SIMD
+            auto xbase = [&](int u) {
+                const int lin = (p * C::TP + wsub + C::WPC * u) * 16 + j;          // A: position j of this wave's run u ...
+                return xs + k * C::XPLANE + (lin / W) * C::WP + lin % W + 3;       // ... channel k of each group, tap (0, 0)
+            };
+            auto read9 = [&](float (&a)[9], int s) {
+                const float* xb = xbase(s / C::KG) + (s % C::KG) * 4 * C::XPLANE;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) a[tap] = xb[(tap / 3) * C::WP + tap % 3];
+            };
+            constexpr int STEPS = C::TPW * C::KG;
+            float a[2][9];
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            read9(a[0], 0);
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) {
+                const int g = s % C::KG;
+                if (s + 1 < STEPS) read9(a[(s + 1) & 1], s + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    if ((g * 9 + tap) & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s & 1][tap], wr[g][tap], acc1, 0, 0, 0);
+                    else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s & 1][tap], wr[g][tap], acc0, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (g == C::KG - 1) {                          // D: positions 4*k .. 4*k + 3 of the run, output channel j
+                    const int t = p * C::TP + wsub + C::WPC * (s / C::KG);
+                    const f32x4 out = acc0 + acc1;
+                    *reinterpret_cast<f32x4*>(y + ((size_t)n * Cout + co_base + cot * 16 + j) * (W * W) + band * R * W + t * 16 + 4 * k) = out;
+                    acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+    }
+}
+
+struct FwPlan {
+    int gx_per_image, gy, ipw;
+    void (*fn)(const float*, const float*, float*, int, int, int, int);
+};
+
+// the stride-1 3x3 layers of the CIFAR pre-activation ResNets: the stem and the three stages' equal-width layers
+FwPlan fw_plan_for(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W) {
+    FwPlan p = {0, 0, 0, nullptr};
+    if (N < 1 || N > (1 << 20) || H != W) return p;
+    if (Cin == 16 && Cout == 16 && W == 32) p = {4, 1, 1, k_conv3x3<16, 16, 32, 8, 4>};
+    else if (Cin == 3 && Cout == 16 && W == 32) p = {4, 1, 1, k_conv3x3<3, 16, 32, 8, 4>};
+    else if (Cin == 32 && Cout == 32 && W == 16) p = {2, 1, 1, k_conv3x3<32, 32, 16, 8, 4>};
+    else if (Cin == 64 && Cout == 64 && W == 8) p = {1, 4, 2, k_conv3x3<64, 16, 8, 8, 1>};
+#ifdef URSA_DEBUG_KNOBS
+    if (const char* e = getenv("URSA_CONV_FWD_VARIANT")) {    // A/B: twice the workgroups, half the work each
+        if (atoi(e) == 1 && Cin == 32 && Cout == 32 && W == 16) p = {4, 1, 1, k_conv3x3<32, 32, 16, 4, 2>};
+        if (atoi(e) == 1 && Cin == 64 && Cout == 64 && W == 8) p.ipw = 1;
+    }
+#endif
+    return p;
+}
+
+}  // namespace
+
+extern "C" int ursa_conv3x3_supported(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W) {
+    return fw_plan_for(N, Cin, Cout, H, W).fn != nullptr;
+}
+
+extern "C" int ursa_conv3x3_f32(const float* x, const float* w, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t H,
+                                int64_t W, uint32_t flags, ursa_stream_t stream) {
+    if (flags & ~URSA_CONV_FLIP) return URSA_EFLAGS;
+    if (!x || !w || !y) return URSA_ENULL;
+    if (N < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return URSA_ESIZE;
+    if (((uintptr_t)x | (uintptr_t)y) & 15 || (uintptr_t)w & 3) return URSA_EALIGN;
+    const FwPlan p = fw_plan_for(N, Cin, Cout, H, W);
+    if (!p.fn) return URSA_EVALUE;
+    const int groups = (int)((N + p.ipw - 1) / p.ipw);
+    hipLaunchKernelGGL(p.fn, dim3(groups * p.gx_per_image, p.gy), dim3(kThreads), 0, (hipStream_t)stream, x, w, y, (int)N, (int)Cout,
+                       p.ipw, (int)(flags & URSA_CONV_FLIP));
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? URSA_OK : (int)e;
+}

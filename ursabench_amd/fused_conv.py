@@ -29,14 +29,24 @@ from torch.autograd.function import once_differentiable
 from . import _native
 
 _on = os.environ.get('URSA_FUSED_CONV', '1') != '0'
+_k8 = os.environ.get('URSA_FUSED_CONV_FWD', '1') != '0'      # K8 (forward / input gradient) separately, for A/B runs
 
 
 def enabled(flag=None):
-    """Query / set whether covered layers take K7's weight gradient (process-wide)."""
+    """Query / set whether covered layers take this module's launches at all (process-wide)."""
     global _on
     old = _on
     if flag is not None:
         _on = bool(flag)
+    return old
+
+
+def forward_enabled(flag=None):
+    """Query / set whether covered layers take K8 (forward / input gradient); K7 (weight gradient) is not affected."""
+    global _k8
+    old = _k8
+    if flag is not None:
+        _k8 = bool(flag)
     return old
 
 
@@ -79,13 +89,16 @@ def flush(pending, dest):
         d.add_(tmp)
 
 
-class _ConvWgrad(torch.autograd.Function):
-    """y = conv2d(x, w, stride, padding=k // 2): forward and dx are ATen's (MIOpen), dw is K7's."""
+class _Conv(torch.autograd.Function):
+    """y = conv2d(x, w, stride, padding=k // 2). Per call, decided in Conv2d.forward: the forward / dx by K8 or ATen (MIOpen),
+    dw by K7 or ATen."""
 
     @staticmethod
-    def forward(ctx, x, w, stride, ws_floats):
+    def forward(ctx, x, w, stride, ws_floats, k8_fwd, k8_bwd):
         ctx.save_for_backward(x, w)
-        ctx.stride, ctx.ws_floats, ctx.weight, ctx.sink = stride, ws_floats, w, getattr(_tls, 'sink', None)
+        ctx.stride, ctx.ws_floats, ctx.k8_bwd, ctx.weight, ctx.sink = stride, ws_floats, k8_bwd, w, getattr(_tls, 'sink', None)
+        if k8_fwd:
+            return _native.default_kernels().conv3x3(x, w)
         return F.conv2d(x, w, None, stride, w.shape[2] // 2)
 
     @staticmethod
@@ -93,40 +106,49 @@ class _ConvWgrad(torch.autograd.Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         s, pad = ctx.stride, w.shape[2] // 2
+        k = _native.default_kernels()
         dy = dy.contiguous()
-        if dy.data_ptr() % 16:                 # a contiguous view at an odd offset: K7 wants 16-byte aligned operands
+        if dy.data_ptr() % 16:                 # a contiguous view at an odd offset: the kernels want 16-byte aligned operands
             dy = dy.clone()
+        need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         dx = dw = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.ops.aten.convolution_backward(dy, x, w, None, [s, s], [pad, pad], [1, 1], False, [0, 0], 1,
-                                                     [True, False, False])[0]
-        if ctx.needs_input_grad[1]:
-            k, ws = _native.default_kernels(), x.new_empty(ctx.ws_floats)
+        if need_dx and ctx.k8_bwd:
+            dx, need_dx = k.conv3x3(dy, w, flip=True), False
+        if need_dw and ctx.ws_floats:
+            ws = x.new_empty(ctx.ws_floats)
             if ctx.sink is not None:
                 ctx.sink.append((k.conv_wgrad_partial(x, dy, w.shape, ws, s), ctx.weight))
             else:
                 dw = torch.empty_like(w)
                 k.conv_wgrad(x, dy, dw, ws, s)
-        return dx, dw, None, None
-
-
-def _covered(m, x):
-    """Scratch floats if K7 takes this call's weight gradient, else 0."""
-    ks = m.kernel_size[0]
-    if not (_on and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and torch.is_grad_enabled()
-            and m.weight.requires_grad and m.bias is None and m.kernel_size in ((3, 3), (1, 1)) and m.padding == (ks // 2, ks // 2)
-            and m.dilation == (1, 1) and m.groups == 1 and m.padding_mode == 'zeros' and m.stride[0] == m.stride[1]
-            and m.weight.dtype == torch.float32 and x.is_contiguous() and m.weight.is_contiguous()
-            and x.data_ptr() % 16 == 0):
-        return 0
-    return _native.default_kernels().conv_wgrad_ws_floats(x.shape, m.out_channels, ks, m.stride[0])
+            need_dw = False
+        if need_dx or need_dw:
+            rx, rw, _ = torch.ops.aten.convolution_backward(dy, x, w, None, [s, s], [pad, pad], [1, 1], False, [0, 0], 1,
+                                                            [need_dx, need_dw, False])
+            dx, dw = (rx if need_dx else dx), (rw if need_dw else dw)
+        return dx, dw, None, None, None, None
 
 
 class Conv2d(nn.Conv2d):
-    """nn.Conv2d whose weight gradient is K7's where K7 covers the layer (module docstring); the stock module otherwise."""
+    """nn.Conv2d whose launches are K8's / K7's where they cover the layer (module docstring); the stock module otherwise."""
 
     def forward(self, x):
-        n = _covered(self, x)
-        if n:
-            return _ConvWgrad.apply(x, self.weight, self.stride[0], n)
-        return super().forward(x)
+        ks, st, w = self.kernel_size[0], self.stride[0], self.weight
+        if not (_on and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and self.bias is None
+                and self.kernel_size in ((3, 3), (1, 1)) and self.padding == (ks // 2, ks // 2) and self.dilation == (1, 1)
+                and self.groups == 1 and self.padding_mode == 'zeros' and st == self.stride[1] and w.dtype == torch.float32
+                and x.is_contiguous() and w.is_contiguous() and x.data_ptr() % 16 == 0):
+            return super().forward(x)
+        k = _native.default_kernels()
+        N, cin, H, W = x.shape
+        k8 = _k8 and ks == 3 and st == 1
+        fwd = k8 and k.conv3x3_supported(x.shape, self.out_channels)
+        if not (torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)):
+            # no gradient recorded (evaluation, the BMA predictive at 4,096 rows): MIOpen's Winograd launch is the faster one at
+            # large batches (bench.py bma leg: 23.7 k vs 21.9 k predictions/s) - K8 is for the training step's sizes
+            return super().forward(x)
+        bwd = k8 and x.requires_grad and k.conv3x3_supported((N, self.out_channels, H, W), cin)
+        ws = k.conv_wgrad_ws_floats(x.shape, self.out_channels, ks, st) if w.requires_grad else 0
+        if not (fwd or bwd or ws):
+            return super().forward(x)
+        return _Conv.apply(x, w, st, ws, fwd, bwd)
