@@ -49,6 +49,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); measured float4 copy ceiling: 6290
+MFMA_FP32_PEAK_TFLOPS = 157.3   # dense fp32-input matrix peak (v_mfma_f32_16x16x4_f32 / 32x32x2), MI355X_MICROARCH.md
 HBM_COPY_GBPS = 6290.0
 PARITY_RTOL = 1e-5              # north_star: fp32 predictive probabilities within 1e-5 relative of the CPU path
 
@@ -703,6 +704,36 @@ def roofline_kernels_block(dev, large_n):
         entry(f'k6_bn_relu_eval_{label}', 8 * e, lambda: K.bn_relu_eval(x, y, w, b, rm, rv, eps=1e-5),
               cache_resident=resident, shape=list(shape), form_bytes=8 * e, form='1 launch')
         del x, dy, y, dx
+    # K7 / K8: the convolution launches of the training step at the workload's layer shapes (batch 128; 0.6 GFLOP each; 2-8 MB
+    # operands, cache-resident as in the step). Bound: the fp32-input matrix pipe - frac = flops / time / 157.3 TFLOP/s; `GBps` /
+    # `frac_hbm` = the algorithmic bytes (operands read once, result written once) against 8 TB/s, for the record.
+    def entry_mfma(name, flops, nbytes, fn, **extra):
+        batches = sorted(event_time_ms(fn, 1024, stream, graph_batch=128) for _ in range(5))
+        ms = batches[2]
+        out[name] = dict(us=round(ms * 1e3, 3), bound='mfma', flops=int(flops), TFLOPs=round(flops / (ms * 1e-3) / 1e12, 2),
+                         frac=round(flops / (ms * 1e-3) / 1e12 / MFMA_FP32_PEAK_TFLOPS, 4), peak_TFLOPs=MFMA_FP32_PEAK_TFLOPS,
+                         bytes=int(nbytes), GBps=round(nbytes / (ms * 1e-3) / 1e9, 1), frac_hbm=round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                         us_batches=[round(b * 1e3, 3) for b in batches], **extra)
+
+    for cin, cout, hw, ks, st in ((16, 16, 32, 3, 1), (32, 32, 16, 3, 1), (64, 64, 8, 3, 1), (16, 32, 32, 3, 2), (16, 32, 32, 1, 2)):
+        ho = hw // st
+        x, dy = torch.randn(128, cin, hw, hw, device=dev), torch.randn(128, cout, ho, ho, device=dev)
+        w, dw = torch.randn(cout, cin, ks, ks, device=dev) * 0.1, torch.empty(cout, cin, ks, ks, device=dev)
+        flops = 2 * 128 * ho * ho * cin * cout * ks * ks
+        nbytes = 4 * (x.numel() + dy.numel() + w.numel())
+        label = f'128x{cin}x{hw}x{hw}_to_{cout}_k{ks}s{st}'
+        wsf = torch.empty(K.conv_wgrad_ws_floats(x.shape, cout, ks, st), device=dev)
+        entry_mfma(f'k7_conv_wgrad_{label}', flops, nbytes, lambda: K.conv_wgrad(x, dy, dw, wsf, st), shape=[128, cin, hw, hw],
+                   launches='2 (K-sliced partial sums, then their fixed-order sum; the engine takes the second launch once per step for all layers)',
+                   partial_bytes=int(wsf.numel() * 4))
+        entry_mfma(f'k7_conv_wgrad_first_launch_{label}', flops, nbytes, lambda: K.conv_wgrad_partial(x, dy, dw.shape, wsf, st),
+                   shape=[128, cin, hw, hw], launches=1)
+        if ks == 3 and st == 1:
+            y, dx = torch.empty_like(dy), torch.empty_like(x)
+            entry_mfma(f'k8_conv3x3_fwd_{label}', flops, nbytes, lambda: K.conv3x3(x, w, y), shape=[128, cin, hw, hw], launches=1)
+            entry_mfma(f'k8_conv3x3_dgrad_{label}', flops, nbytes, lambda: K.conv3x3(dy, w, dx, flip=True), shape=[128, cout, hw, hw], launches=1)
+            del y, dx
+        del x, dy, w, dw, wsf
     return out
 
 
@@ -967,6 +998,17 @@ def _bn_relu_path(job):
             + (', two-launch form only (URSA_BN_TWO_LAUNCH=1)' if fused_bn._two_launch else ''))
 
 
+def _conv_path(job):
+    from ursabench_amd import fused_conv
+    if job.cpu:
+        return 'torch ops (host tensors)'
+    if not fused_conv.enabled():
+        return 'stock MIOpen launches (URSA_FUSED_CONV=0)'
+    if not fused_conv.forward_enabled():
+        return 'K7 weight gradients; forward / input gradient MIOpen (URSA_FUSED_CONV_FWD=0)'
+    return 'K8 forward / input gradient of the stride-1 3x3 layers + K7 weight gradients (ursabench_amd/fused_conv.py); other launches MIOpen'
+
+
 def base_line(a, job, metric, unit, workload):
     return {'metric': metric, 'value': None, 'unit': unit, 'n_gpus': job.world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': None, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
@@ -975,7 +1017,7 @@ def base_line(a, job, metric, unit, workload):
                        'torch': torch.__version__, 'hip': torch.version.hip, 'abi': None if job.cpu else _abi_version(),
                        'miopen_user_db': 'shipped tuned databases (ursabench_amd/miopen_db, MIOPEN_FIND_ENFORCE=3 search; stock MIOpen solvers)'
                        if any(f.endswith('.txt') for f in os.listdir(MIOPEN_DB)) else 'empty private database (quick search per layer)',
-                       'bn_relu': _bn_relu_path(job)}}
+                       'bn_relu': _bn_relu_path(job), 'conv': _conv_path(job)}}
 
 
 def run_c2(a, job, legs, line):
@@ -1322,7 +1364,7 @@ def compact_line(line, detail_path):
     cfg = line.get('config') or {}
     out['config'] = _pick(cfg, ('workload', 'device', 'abi', 'n_train', 'n_test', 'batch', 'hyper', 'chains', 'chains_per_gpu', 'hip_graph',
                                 'minibatch_steps_per_sample', 'params', 'members', 'members_on_rank0', 'full_batch', 'chains_on_rank0',
-                                'ranks_without_a_chain', 'bn_relu'))
+                                'ranks_without_a_chain', 'bn_relu', 'conv'))
     for k in ('minibatch_steps_per_s', 'bma_preds_per_s', 'bma_members', 'bma_member_forwards_per_s', 'bma_nll', 'bma_seconds',
               'trajectory_seconds', 'leapfrog_steps_per_s', 'acceptance_rate_rank0', 'accepted_rank0', 'engine'):
         if k in line:

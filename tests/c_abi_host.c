@@ -25,6 +25,9 @@ int oracle_bn_relu_bwd_f32(const float*, const float*, float*, const float*, con
 int oracle_bn_relu_bwd_gated_f32(const float*, const float*, float*, const float*, const float*, const float*, const float*,
                                  float*, float*, int64_t, int64_t, int64_t, int, const int32_t*, const uint8_t*, int64_t);
 
+int oracle_conv_wgrad_f32(const float*, const float*, float*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t);
+int oracle_conv3x3_f32(const float*, const float*, float*, int64_t, int64_t, int64_t, int64_t, int64_t, int);
+
 #define CHECK(x) do { int rc_ = (x); if (rc_) { printf("FAIL %s -> %d (%s)\n", #x, rc_, ursa_strerror(rc_)); return 1; } } while (0)
 
 static float frand(unsigned* s) { *s = *s * 1664525u + 1013904223u; return ((*s >> 8) / 8388608.0f) - 1.0f; }
@@ -167,11 +170,52 @@ int main(void)
         if (ursa_bn_relu_fwd_f32(dx_, NULL, NULL, dy_, dg_, db_, NULL, NULL, dsm, dsi, NULL, dws, 1, C, 1, 1e-5f, 0.0f, 0, st) != URSA_EVALUE) { printf("FAIL K6 evalue\n"); return 1; }
         if (ursa_bn_relu_fwd_f32(dx_, NULL, NULL, dy_, dg_, db_, NULL, NULL, dsm, dsi, NULL, dws, N, C, HW, 1e-5f, 0.0f, 0x10u, st) != URSA_EFLAGS) { printf("FAIL K6 eflags\n"); return 1; }
     }
+    /* ABI 6: K8 (forward / input gradient) and K7 (weight gradient, both launches and the deferred pair) of one 16-channel 3x3
+     * layer on small integers - every product and partial sum exact in fp32, so the device must equal the oracle bit for bit */
+    {
+        const int64_t N = 3, C = 16, H = 32, tot = N * C * H * H, wn = C * C * 9;
+        float *hx = malloc(tot * 4), *hdy = malloc(tot * 4), *hw = malloc(wn * 4), *want = malloc(tot * 4), *got = malloc(tot * 4);
+        float *wantw = malloc(wn * 4), *gotw = malloc(wn * 4);
+        unsigned s2 = 99u;
+        for (int64_t i = 0; i < tot; ++i) { hx[i] = floorf(3.99f * frand(&s2)); hdy[i] = floorf(2.99f * frand(&s2)); }
+        for (int64_t i = 0; i < wn; ++i) hw[i] = floorf(2.99f * frand(&s2));
+        float *dx_, *ddy, *dw_, *dy_, *ddw, *dws;
+        const int64_t wsf = ursa_conv_wgrad_ws_floats(N, C, C, H, H, 3, 1);
+        if (wsf <= 0 || !ursa_conv3x3_supported(N, C, C, H, H)) { printf("FAIL K7 / K8 do not cover the 16-channel layer\n"); return 1; }
+        CHECK(hipMalloc((void**)&dx_, tot * 4)); CHECK(hipMalloc((void**)&ddy, tot * 4)); CHECK(hipMalloc((void**)&dy_, tot * 4));
+        CHECK(hipMalloc((void**)&dw_, wn * 4)); CHECK(hipMalloc((void**)&ddw, wn * 4)); CHECK(hipMalloc((void**)&dws, wsf * 4));
+        CHECK(hipMemcpy(dx_, hx, tot * 4, hipMemcpyHostToDevice)); CHECK(hipMemcpy(ddy, hdy, tot * 4, hipMemcpyHostToDevice));
+        CHECK(hipMemcpy(dw_, hw, wn * 4, hipMemcpyHostToDevice));
+        CHECK(ursa_conv3x3_f32(dx_, dw_, dy_, N, C, C, H, H, 0, st));
+        CHECK(hipStreamSynchronize(st));
+        CHECK(hipMemcpy(got, dy_, tot * 4, hipMemcpyDeviceToHost));
+        oracle_conv3x3_f32(hx, hw, want, N, C, C, H, H, 0);
+        if (memcmp(got, want, tot * 4)) { printf("FAIL K8 forward differs from the oracle\n"); return 1; }
+        CHECK(ursa_conv3x3_f32(ddy, dw_, dy_, N, C, C, H, H, URSA_CONV_FLIP, st));
+        CHECK(hipStreamSynchronize(st));
+        CHECK(hipMemcpy(got, dy_, tot * 4, hipMemcpyDeviceToHost));
+        oracle_conv3x3_f32(hdy, hw, want, N, C, C, H, H, 1);
+        if (memcmp(got, want, tot * 4)) { printf("FAIL K8 input gradient differs from the oracle\n"); return 1; }
+        oracle_conv_wgrad_f32(hx, hdy, wantw, N, C, C, H, H, 3, 1);
+        CHECK(ursa_conv_wgrad_f32(dx_, ddy, ddw, dws, wsf, N, C, C, H, H, 3, 1, st));
+        CHECK(hipStreamSynchronize(st));
+        CHECK(hipMemcpy(gotw, ddw, wn * 4, hipMemcpyDeviceToHost));
+        if (memcmp(gotw, wantw, wn * 4)) { printf("FAIL K7 differs from the oracle\n"); return 1; }
+        CHECK(hipMemset(ddw, 0xff, wn * 4));
+        CHECK(ursa_conv_wgrad_partial_f32(dx_, ddy, dws, wsf, N, C, C, H, H, 3, 1, st));
+        const ursa_conv_pending pend = {dws, ddw, N, C, C, H, H, 3, 1};
+        CHECK(ursa_conv_wgrad_reduce_f32(&pend, 1, st));
+        CHECK(hipStreamSynchronize(st));
+        CHECK(hipMemcpy(gotw, ddw, wn * 4, hipMemcpyDeviceToHost));
+        if (memcmp(gotw, wantw, wn * 4)) { printf("FAIL K7 (deferred second launch) differs from the oracle\n"); return 1; }
+        if (ursa_conv3x3_f32(dx_, dw_, dy_, N, 5, C, H, H, 0, st) != URSA_EVALUE) { printf("FAIL K8 evalue\n"); return 1; }
+        if (ursa_conv_wgrad_f32(dx_, ddy, ddw, dws, 16, N, C, C, H, H, 3, 1, st) != URSA_ESIZE) { printf("FAIL K7 esize\n"); return 1; }
+    }
     /* argument errors come back as codes, not crashes */
     if (ursa_sgmcmc_step_f32(NULL, NULL, NULL, NULL, NULL, 8, 0, 0, 0, 0, 1, 0, 0, 0, st) != URSA_ENULL) { printf("FAIL enull\n"); return 1; }
     if (ursa_bma_accumulate_f32(dz, dp, de, NULL, NULL, S, B, 5000, omg, goc, 0, st) != URSA_EVALUE) { printf("FAIL evalue\n"); return 1; }
     if (ursa_sgmcmc_step_multi_f32(dth, dgr, dmo, NULL, NULL, 64, 2, 62, NULL, st) != URSA_ESIZE) { printf("FAIL esize (stride < n)\n"); return 1; }
     printf("C-ABI host OK: K1 bit-equal to the oracle over 3 steps (n=%lld), 2 chains in one self-advancing launch bit-equal, "
-           "generator self-test clean, K5 max relative error %.2e, K6 forward + backward + gated backward bit-equal\n", (long long)n, worst);
+           "generator self-test clean, K5 max relative error %.2e, K6 forward + backward + gated backward bit-equal, K7 / K8 bit-equal on integer inputs\n", (long long)n, worst);
     return 0;
 }

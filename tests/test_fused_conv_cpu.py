@@ -150,3 +150,4 @@ def test_k8_plan_and_argument_errors():
     assert f(p, p + 2, p, 128, 16, 16, 32, 32, 0, None) == -3
     assert f(p, p, p, 128, 16, 3, 32, 32, 1, None) == -5               # EVALUE: the stem's input gradient is not covered
     assert f(p, p, p, 128, 16, 32, 32, 32, 0, None) == -5
+    assert f(p, p, p, 128, 3, 16, 32, 32, 1, None) == -5               # flipped form: equal-width layers only

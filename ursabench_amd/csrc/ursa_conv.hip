@@ -329,6 +329,7 @@ Plan plan_for(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, int ks
         if (v >= 1 && v <= 64) p.ipw = v;
     }
 #endif
+    while ((N + p.ipw - 1) / p.ipw * bands > 768) p.ipw *= 2;   // large batches (HMC's 1,024-row chunks): longer K slices, not more
     p.taps = k3 ? 9 : 1;
     p.slices = (int)((N + p.ipw - 1) / p.ipw) * bands;
     p.E = (Cout / 16) * ((Cin + 15) / 16) * (int64_t)p.taps * 256;
@@ -511,23 +512,38 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3(const float* __restrict__ 
         if constexpr (C::CINP > CIN)
             for (int i = tid; i < COUT_WG * (C::CINP - CIN) * 9; i += kThreads)
                 wl[(i / ((C::CINP - CIN) * 9)) * C::WPITCH + ROW + i % ((C::CINP - CIN) * 9)] = 0.f;
-        if (!flip) {
-            if constexpr (ROW % 4 == 0) {
-                const f32x4* src = reinterpret_cast<const f32x4*>(w + (size_t)co_base * ROW);   // (co_base * ROW * 4 bytes: 16-byte multiple)
-                for (int idx = tid; idx < COUT_WG * ROW / 4; idx += kThreads)
-                    *reinterpret_cast<f32x4*>(wl + (idx / (ROW / 4)) * C::WPITCH + 4 * (idx % (ROW / 4))) = src[idx];
-            } else {
-                for (int idx = tid; idx < COUT_WG * ROW; idx += kThreads)
-                    wl[(idx / ROW) * C::WPITCH + idx % ROW] = w[(size_t)co_base * ROW + idx];
-            }
-        } else {                                               // w'[o][ci][tap] = w[ci][o][8 - tap], w: [CIN][Cout][3][3]
-            constexpr int RUN = COUT_WG * 9;                   // per input channel: COUT_WG * 9 contiguous floats (16-byte aligned runs)
-            for (int idx = tid; idx < CIN * RUN / 4; idx += kThreads) {
-                const int ci = idx / (RUN / 4), r4 = 4 * (idx % (RUN / 4));
-                const f32x4 v = *reinterpret_cast<const f32x4*>(w + ((size_t)ci * Cout + co_base) * 9 + r4);
+        // every thread's loads are issued together (unrolled, unconditional: a tail index re-loads the last element), then
+        // written: one L2 round trip for the whole tile instead of one per loop iteration
+        if constexpr (ROW % 4 == 0) {
+            constexpr int TOT4 = COUT_WG * ROW / 4, NW = (TOT4 + kThreads - 1) / kThreads;
+            f32x4 tw[NW];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) wl[((r4 + e) / 9) * C::WPITCH + ci * 9 + 8 - (r4 + e) % 9] = v[e];
+            for (int i = 0; i < NW; ++i) {
+                int idx = tid + i * kThreads;
+                idx = idx < TOT4 ? idx : TOT4 - 1;
+                if (!flip) {
+                    tw[i] = reinterpret_cast<const f32x4*>(w + (size_t)co_base * ROW)[idx];   // (co_base * ROW * 4 bytes: 16-byte multiple)
+                } else {                                       // per input channel: COUT_WG * 9 contiguous floats (16-byte aligned runs)
+                    constexpr int RUN4 = COUT_WG * 9 / 4;
+                    tw[i] = *reinterpret_cast<const f32x4*>(w + ((size_t)(idx / RUN4) * Cout + co_base) * 9 + 4 * (idx % RUN4));
+                }
             }
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                const int idx = tid + i * kThreads;
+                if (idx >= TOT4) continue;
+                if (!flip) {
+                    *reinterpret_cast<f32x4*>(wl + (idx / (ROW / 4)) * C::WPITCH + 4 * (idx % (ROW / 4))) = tw[i];
+                } else {                                       // w'[o][ci][tap] = w[ci][o][8 - tap], w: [CIN][Cout][3][3]
+                    constexpr int RUN4 = COUT_WG * 9 / 4;
+                    const int ci = idx / RUN4, r4 = 4 * (idx % RUN4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) wl[((r4 + e) / 9) * C::WPITCH + ci * 9 + 8 - (r4 + e) % 9] = tw[i][e];
+                }
+            }
+        } else {                                               // the stem (27 floats per row): scalar loads, forward only
+            for (int idx = tid; idx < COUT_WG * ROW; idx += kThreads)
+                wl[(idx / ROW) * C::WPITCH + idx % ROW] = w[(size_t)co_base * ROW + idx];
         }
         __syncthreads();
 #pragma unroll
@@ -605,6 +621,12 @@ FwPlan fw_plan_for(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W) {
     if (const char* e = getenv("URSA_CONV_FWD_VARIANT")) {    // A/B: twice the workgroups, half the work each
         if (atoi(e) == 1 && Cin == 32 && Cout == 32 && W == 16) p = {4, 1, 1, k_conv3x3<32, 32, 16, 4, 2>};
         if (atoi(e) == 1 && Cin == 64 && Cout == 64 && W == 8) p.ipw = 1;
+        if (atoi(e) == 2 && Cin == 16 && Cout == 16 && W == 32) p = {4, 1, 1, k_conv3x3<16, 16, 32, 8, 2>};   // fewer, longer phases
+        if (atoi(e) == 2 && Cin == 32 && Cout == 32 && W == 16) p = {2, 1, 1, k_conv3x3<32, 32, 16, 8, 2>};
+        if (atoi(e) == 3 && Cin == 16 && Cout == 16 && W == 32) p = {4, 1, 1, k_conv3x3<16, 16, 32, 8, 1>};
+        if (atoi(e) == 3 && Cin == 32 && Cout == 32 && W == 16) p = {2, 1, 1, k_conv3x3<32, 32, 16, 8, 1>};
+        if (atoi(e) == 4 && Cin == 16 && Cout == 16 && W == 32) p = {2, 1, 1, k_conv3x3<16, 16, 32, 16, 4>};  // half the workgroups, twice the rows
+        if (atoi(e) == 4 && Cin == 64 && Cout == 64 && W == 8) p.ipw = 4;
     }
 #endif
     return p;
@@ -623,7 +645,7 @@ extern "C" int ursa_conv3x3_f32(const float* x, const float* w, float* y, int64_
     if (N < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return URSA_ESIZE;
     if (((uintptr_t)x | (uintptr_t)y) & 15 || (uintptr_t)w & 3) return URSA_EALIGN;
     const FwPlan p = fw_plan_for(N, Cin, Cout, H, W);
-    if (!p.fn) return URSA_EVALUE;
+    if (!p.fn || ((flags & URSA_CONV_FLIP) && Cin != Cout)) return URSA_EVALUE;   // flipped: the equal-width layers only
     const int groups = (int)((N + p.ipw - 1) / p.ipw);
     hipLaunchKernelGGL(p.fn, dim3(groups * p.gx_per_image, p.gy), dim3(kThreads), 0, (hipStream_t)stream, x, w, y, (int)N, (int)Cout,
                        p.ipw, (int)(flags & URSA_CONV_FLIP));
