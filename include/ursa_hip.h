@@ -413,6 +413,23 @@ int ursa_conv3x3_supported(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int6
 int ursa_conv3x3_f32(const float* x, const float* w, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W,
                      uint32_t flags, ursa_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * K9  the 1x1 / stride 2 shortcut convolutions (`downsample`, URSABench/models/preresnet.py:130-136), forward and input
+ *     gradient; no bias, no padding.
+ *
+ *     y[n][o][oh][ow] = sum_i w[o][i] * x[n][i][2 oh][2 ow]                 x: [N, Cin, H, W] -> y: [N, Cout, H/2, W/2]
+ *     URSA_CONV_FLIP:   the input gradient: x = dy [N, Cin', H, W] (Cin' = the layer's OUTPUT channels, H = W = dy's size),
+ *                       y = dx [N, Cout', 2H, 2W] (Cout' = the layer's INPUT channels), w = the layer's own [Cin', Cout']
+ *                       tensor; dx is zero wherever the forward did not read x.
+ * Plain fp32 fma chains (ascending input channel), one launch. Shapes covered (any N, H = W): forward (Cin, Cout, H) in
+ * {(16, 32, 32), (32, 64, 16)}; flipped (Cin', Cout', H) in {(32, 16, 16), (64, 32, 8)} - the same two layers.
+ * Algorithmic HBM traffic: forward 4 B x (N*Cin*H*W/2 + N*Cout*H*W/4) (only even rows of x are read, in whole cache lines);
+ * flipped 4 B x (N*Cin'*H*W + 4*N*Cout'*H*W).
+ */
+int ursa_conv1x1s2_supported(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, uint32_t flags);
+int ursa_conv1x1s2_f32(const float* x, const float* w, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W,
+                       uint32_t flags, ursa_stream_t stream);
+
 /* ------------------------------------------------------------------------------------ */
 int ursa_abi_version(void);
 const char* ursa_strerror(int code);

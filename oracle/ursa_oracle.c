@@ -498,3 +498,37 @@ int oracle_conv3x3_f32(const float* x, const float* w, float* y, int64_t N, int6
                 }
     return 0;
 }
+
+/* ---------------------------------------------------------------------------------------
+ * K9  1x1 / stride 2 convolution, no bias, no padding (`downsample`, URSABench/models/preresnet.py:130-136) and, with flip,
+ *     its input gradient (zero wherever the forward did not read). Sums in double, rounded once (as K7 / K8's restatements).
+ *     forward: x [N, Cin, H, W] -> y [N, Cout, H/2, W/2], w [Cout, Cin]; flip: x = dy [N, Cin, H, W] -> y = dx [N, Cout, 2H, 2W],
+ *     w = the layer's [Cin, Cout] tensor.
+ */
+int oracle_conv1x1s2_f32(const float* x, const float* w, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W,
+                         int flip)
+{
+    if (!flip) {
+        const int64_t OH = H / 2, OW = W / 2;
+        for (int64_t n = 0; n < N; ++n)
+            for (int64_t o = 0; o < Cout; ++o)
+                for (int64_t oh = 0; oh < OH; ++oh)
+                    for (int64_t ow = 0; ow < OW; ++ow) {
+                        double acc = 0.0;
+                        for (int64_t i = 0; i < Cin; ++i) acc += (double)w[o * Cin + i] * (double)x[((n * Cin + i) * H + 2 * oh) * W + 2 * ow];
+                        y[((n * Cout + o) * OH + oh) * OW + ow] = (float)acc;
+                    }
+    } else {
+        const int64_t OH = 2 * H, OW = 2 * W;
+        for (int64_t n = 0; n < N; ++n)
+            for (int64_t i = 0; i < Cout; ++i)
+                for (int64_t ih = 0; ih < OH; ++ih)
+                    for (int64_t iw = 0; iw < OW; ++iw) {
+                        double acc = 0.0;
+                        if (ih % 2 == 0 && iw % 2 == 0)
+                            for (int64_t o = 0; o < Cin; ++o) acc += (double)w[o * Cout + i] * (double)x[((n * Cin + o) * H + ih / 2) * W + iw / 2];
+                        y[((n * Cout + i) * OH + ih) * OW + iw] = (float)acc;
+                    }
+    }
+    return 0;
+}

@@ -172,3 +172,17 @@ def conv3x3(x, w, flip=False):
     rc = _L.oracle_conv3x3_f32(_p(x), _p(w), _p(y), N, Cin, Cout, H, W, int(flip))
     assert rc == 0
     return y
+
+
+_L.oracle_conv1x1s2_f32.argtypes = [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32]
+
+
+def conv1x1s2(x, w, flip=False):
+    """y = conv2d(x, w, stride 2) for w [Cout, Cin, 1, 1]; flip: the input gradient for the output gradient `x`."""
+    N, Cin, H, W = x.shape
+    Cout = w.shape[1 if flip else 0]
+    assert w.shape[0 if flip else 1] == Cin and w.shape[2:] == (1, 1)
+    y = np.empty((N, Cout, 2 * H, 2 * W) if flip else (N, Cout, H // 2, W // 2), np.float32)
+    rc = _L.oracle_conv1x1s2_f32(_p(x), _p(np.ascontiguousarray(w.reshape(w.shape[0], w.shape[1]))), _p(y), N, Cin, Cout, H, W, int(flip))
+    assert rc == 0
+    return y

@@ -151,3 +151,35 @@ def test_k8_plan_and_argument_errors():
     assert f(p, p, p, 128, 16, 3, 32, 32, 1, None) == -5               # EVALUE: the stem's input gradient is not covered
     assert f(p, p, p, 128, 16, 32, 32, 32, 0, None) == -5
     assert f(p, p, p, 128, 3, 16, 32, 32, 1, None) == -5               # flipped form: equal-width layers only
+
+
+@pytest.mark.parametrize('n,cin,cout,hw', [(2, 16, 32, 32), (2, 32, 64, 16), (1, 5, 7, 6)])
+def test_k9_oracle_is_torchs_cpu_convolution(n, cin, cout, hw):
+    rng = np.random.default_rng(n + cin)
+    x = rng.standard_normal((n, cin, hw, hw), dtype=np.float32)
+    w = rng.standard_normal((cout, cin, 1, 1), dtype=np.float32)
+    dy = rng.standard_normal((n, cout, hw // 2, hw // 2), dtype=np.float32)
+    tx, tw, tdy = torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(dy)
+    assert torch.equal(torch.from_numpy(oracle_lib.conv1x1s2(x, w)), torch.nn.functional.conv2d(tx.double(), tw.double(), None, 2, 0).float())
+    assert torch.equal(torch.from_numpy(oracle_lib.conv1x1s2(dy, w, flip=True)),
+                       torch.nn.grad.conv2d_input(x.shape, tw.double(), tdy.double(), 2, 0).float())
+
+
+def test_k9_plan_and_argument_errors():
+    import ctypes
+    k = _native.default_kernels()
+    assert k.conv1x1s2_supported((128, 16, 32, 32), 32) and k.conv1x1s2_supported((3, 32, 16, 16), 64)
+    assert k.conv1x1s2_supported((128, 32, 16, 16), 16, flip=True) and k.conv1x1s2_supported((3, 64, 8, 8), 32, flip=True)
+    assert not k.conv1x1s2_supported((128, 16, 32, 32), 16) and not k.conv1x1s2_supported((128, 32, 16, 16), 16)
+    assert not k.conv1x1s2_supported((128, 16, 32, 32), 32, flip=True) and not k.conv1x1s2_supported((0, 16, 32, 32), 32)
+    lib = _native.load_library()
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.addressof(buf)
+    p -= p % 16
+    f = lib.ursa_conv1x1s2_f32
+    assert f(p, p, p, 128, 16, 32, 32, 32, 0x2, None) == -4
+    assert f(None, p, p, 128, 16, 32, 32, 32, 0, None) == -1
+    assert f(p, p, p, 0, 16, 32, 32, 32, 0, None) == -2
+    assert f(p + 4, p, p, 128, 16, 32, 32, 32, 0, None) == -3
+    assert f(p, p, p, 128, 16, 16, 32, 32, 0, None) == -5
+    assert f(p, p, p, 128, 16, 32, 32, 32, 1, None) == -5               # the flipped form of that layer is (32, 16, 16)

@@ -281,3 +281,55 @@ def test_network_forward_and_gradients_k8_vs_stock_vs_cpu():
         #                                                           2e-2 seen): a loose cap - indexing is pinned exactly by the integer cases above
         worse += d8 > 2 * ds + 1e-5 * scale
     assert worse <= len(g8) // 4, worse                           # ... and no systematic loss against the stock launches
+
+
+# ---- K9: the 1x1 / stride 2 shortcuts -------------------------------------------------------------------------------------
+@pytest.mark.parametrize('cin,cout,hw', [(16, 32, 32), (32, 64, 16)])
+@pytest.mark.parametrize('n', [1, 3, 80, 128])
+def test_k9_equals_the_oracle(cin, cout, hw, n):
+    rng = np.random.default_rng(5 * n + cin)
+    k = _native.default_kernels()
+    x = rng.standard_normal((n, cin, hw, hw), dtype=np.float32)
+    w = (rng.standard_normal((cout, cin, 1, 1)) * 0.3).astype(np.float32)
+    dy = rng.standard_normal((n, cout, hw // 2, hw // 2), dtype=np.float32)
+    got = k.conv1x1s2(torch.from_numpy(x).to(DEV), torch.from_numpy(w).to(DEV)).cpu().numpy()
+    want = oracle_lib.conv1x1s2(x, w)
+    assert np.abs(got - want).max() <= 1e-6 * np.abs(want).max()          # fma chains over 16 / 32 products
+    dx = torch.full((n, cin, hw, hw), float('nan'), device=DEV)            # every element must be written (the zeros too)
+    k.conv1x1s2(torch.from_numpy(dy).to(DEV), torch.from_numpy(w).to(DEV), dx, flip=True)
+    want = oracle_lib.conv1x1s2(dy, w, flip=True)
+    got = dx.cpu().numpy()
+    assert np.isfinite(got).all() and np.abs(got - want).max() <= 1e-6 * np.abs(want).max()
+    assert np.array_equal(got == 0, want == 0) or np.count_nonzero((got == 0) != (want == 0)) <= 2    # the zero pattern (exact zeros of a sum aside)
+    # integers: exact, bit for bit
+    xi = rng.integers(-3, 4, x.shape).astype(np.float32)
+    wi = rng.integers(-2, 3, w.shape).astype(np.float32)
+    di = rng.integers(-3, 4, dy.shape).astype(np.float32)
+    assert np.array_equal(k.conv1x1s2(torch.from_numpy(xi).to(DEV), torch.from_numpy(wi).to(DEV)).cpu().numpy(), oracle_lib.conv1x1s2(xi, wi))
+    assert np.array_equal(k.conv1x1s2(torch.from_numpy(di).to(DEV), torch.from_numpy(wi).to(DEV), flip=True).cpu().numpy(),
+                          oracle_lib.conv1x1s2(di, wi, flip=True))
+
+
+def test_every_convolution_of_the_network_takes_a_hand_written_launch():
+    """PreResNet-20 training step with gradients recorded: no MIOpen convolution launch is left except the stride-2 3x3 layers'
+    forward / input gradient (2 layers)."""
+    k = _native.default_kernels()
+    seen = dict(conv3x3=0, conv1x1s2=0, conv_wgrad=0)
+    origs = {n: getattr(k, n) for n in seen}
+
+    def wrap(name):
+        def f(*a, **kw):
+            seen[name] += 1
+            return origs[name](*a, **kw)
+        return f
+    for n in seen:
+        setattr(k, n, wrap(n))
+    try:
+        torch.manual_seed(0)
+        net = models.PreResNet(10, 20).to(DEV).train()
+        x, y = torch.randn(16, 3, 32, 32, device=DEV), torch.randint(0, 10, (16,), device=DEV)
+        _grads(net, x, y)
+    finally:
+        for n in seen:
+            delattr(k, n)
+    assert seen == dict(conv3x3=17 + 16, conv1x1s2=2 + 2, conv_wgrad=21), seen

@@ -652,3 +652,105 @@ extern "C" int ursa_conv3x3_f32(const float* x, const float* w, float* y, int64_
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? URSA_OK : (int)e;
 }
+
+// =====================================================================================================================
+// K9: the 1x1 / stride 2 shortcut convolutions (URSABench/models/preresnet.py:130-136 `downsample`), forward and input
+// gradient, NCHW fp32. 33 MFLOP per call at the workload's sizes: memory- and launch-bound, plain FMAs (MIOpen runs these as an
+// NHWC implicit GEMM between layout transposes and a zero fill: 12 launches, 70 us per step for the two layers both ways).
+//
+//     forward:  y[n][o][oh][ow]  = sum_i w[o][i] * x[n][i][2 oh][2 ow]                   (fma chain over i, ascending)
+//     flipped:  dx[n][i][ih][iw] = ih, iw even ? sum_o w[o][i] * dy[n][o][ih/2][iw/2] : 0   (fma chain over o, ascending)
+//
+// One thread: two adjacent output columns (one float4 of an even input row) x CG channels of the result; the weights are
+// uniform over a workgroup's threads (scalar loads).
+namespace {
+
+template <int CIN, int COUT, int CG, bool FLIP>
+__global__ __launch_bounds__(256) void k_conv1x1s2(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
+                                                    int N, int OW) {
+    // forward: x [N, CIN, 2 OW, 2 OW] -> y [N, COUT, OW, OW]; flipped: x = dy [N, CIN(= the layer's outputs), OW, OW] ->
+    // y = dx [N, COUT(= the layer's inputs), 2 OW, 2 OW], w = the layer's [CIN, COUT] tensor
+    const int half = OW / 2;                                  // column pairs per output row
+    const int per_image = OW * half;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int cg = blockIdx.y * CG;                           // first result channel of this workgroup
+    if (idx >= N * per_image) return;
+    const int n = idx / per_image, r = idx % per_image, oh = r / half, j = r % half;
+    float a0[CG], a1[CG];
+#pragma unroll
+    for (int c = 0; c < CG; ++c) a0[c] = 0.f, a1[c] = 0.f;
+    if constexpr (!FLIP) {
+        const int WI = 2 * OW;
+        const float* xp = x + (((size_t)n * CIN) * WI + 2 * oh) * WI + 4 * j;
+#pragma unroll 4
+        for (int i = 0; i < CIN; ++i) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(xp + (size_t)i * WI * WI);
+#pragma unroll
+            for (int c = 0; c < CG; ++c) {
+                const float wv = w[(cg + c) * CIN + i];
+                a0[c] = fmaf(wv, v.x, a0[c]);
+                a1[c] = fmaf(wv, v.z, a1[c]);
+            }
+        }
+        float* yp = y + (((size_t)n * COUT + cg) * OW + oh) * OW + 2 * j;
+#pragma unroll
+        for (int c = 0; c < CG; ++c) *reinterpret_cast<float2*>(yp + (size_t)c * OW * OW) = make_float2(a0[c], a1[c]);
+    } else {
+        const float* xp = x + (((size_t)n * CIN) * OW + oh) * OW + 2 * j;
+#pragma unroll 4
+        for (int o = 0; o < CIN; ++o) {
+            const float2 v = *reinterpret_cast<const float2*>(xp + (size_t)o * OW * OW);
+#pragma unroll
+            for (int c = 0; c < CG; ++c) {
+                const float wv = w[o * COUT + cg + c];
+                a0[c] = fmaf(wv, v.x, a0[c]);
+                a1[c] = fmaf(wv, v.y, a1[c]);
+            }
+        }
+        const int WI = 2 * OW;
+        float* yp = y + (((size_t)n * COUT + cg) * WI + 2 * oh) * WI + 4 * j;
+#pragma unroll
+        for (int c = 0; c < CG; ++c) {
+            *reinterpret_cast<f32x4*>(yp + (size_t)c * WI * WI) = f32x4{a0[c], 0.f, a1[c], 0.f};
+            *reinterpret_cast<f32x4*>(yp + (size_t)c * WI * WI + WI) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+}
+
+struct S2Plan {
+    int gy;
+    void (*fn)(const float*, const float*, float*, int, int);
+};
+
+// (Cin, Cout, H) of the layer; flipped launches take (Cout, Cin) as their (input, result) channel counts
+S2Plan s2_plan_for(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, bool flip) {
+    S2Plan p = {0, nullptr};
+    if (N < 1 || N > (1 << 20) || H != W) return p;
+    if (!flip && Cin == 16 && Cout == 32 && W == 32) p = {2, k_conv1x1s2<16, 32, 16, false>};
+    else if (!flip && Cin == 32 && Cout == 64 && W == 16) p = {8, k_conv1x1s2<32, 64, 8, false>};
+    else if (flip && Cin == 32 && Cout == 16 && W == 16) p = {2, k_conv1x1s2<32, 16, 8, true>};    // dy [N, 32, 16, 16] -> dx [N, 16, 32, 32]
+    else if (flip && Cin == 64 && Cout == 32 && W == 8) p = {4, k_conv1x1s2<64, 32, 8, true>};      // dy [N, 64, 8, 8] -> dx [N, 32, 16, 16]
+    return p;
+}
+
+}  // namespace
+
+extern "C" int ursa_conv1x1s2_supported(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, uint32_t flags) {
+    return !(flags & ~URSA_CONV_FLIP) && s2_plan_for(N, Cin, Cout, H, W, flags & URSA_CONV_FLIP).fn != nullptr;
+}
+
+extern "C" int ursa_conv1x1s2_f32(const float* x, const float* w, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t H,
+                                  int64_t W, uint32_t flags, ursa_stream_t stream) {
+    if (flags & ~URSA_CONV_FLIP) return URSA_EFLAGS;
+    if (!x || !w || !y) return URSA_ENULL;
+    if (N < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return URSA_ESIZE;
+    if (((uintptr_t)x | (uintptr_t)y) & 15 || (uintptr_t)w & 3) return URSA_EALIGN;
+    const bool flip = flags & URSA_CONV_FLIP;
+    const S2Plan p = s2_plan_for(N, Cin, Cout, H, W, flip);
+    if (!p.fn) return URSA_EVALUE;
+    const int OW = flip ? (int)W : (int)W / 2;                 // the low-resolution side's width
+    const int64_t threads = N * OW * (OW / 2);
+    hipLaunchKernelGGL(p.fn, dim3((unsigned)((threads + 255) / 256), p.gy), dim3(256), 0, (hipStream_t)stream, x, w, y, (int)N, OW);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? URSA_OK : (int)e;
+}
