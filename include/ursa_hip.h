@@ -394,22 +394,25 @@ int ursa_conv_wgrad_partial_f32(const float* x, const float* dy, float* ws, int6
 int ursa_conv_wgrad_reduce_f32(const ursa_conv_pending* items, int32_t n, ursa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
- * K8  forward / input gradient of the stride-1 3x3 convolutions      `out = self.conv1(out)` URSABench/models/
+ * K8  forward / input gradient of the 3x3 convolutions      `out = self.conv1(out)` URSABench/models/
  *     preresnet.py:42,47,143 and the input-gradient half of `loss.backward()` (URSABench/inference/sghmc.py:80)
  *
- *     y[n][o][oh][ow] = sum_{i, kh, kw} w[o][i][kh][kw] * x[n][i][oh + kh - 1][ow + kw - 1]          (zero padded, no bias)
- *     URSA_CONV_FLIP:  the same with w'[o][i][kh][kw] = w[i][o][2 - kh][2 - kw] - the input gradient: x = dy [N, Cin', H, W]
- *                      with Cin' = the layer's OUTPUT channels, y = dx [N, Cout', H, W] with Cout' = its INPUT channels,
- *                      w = the layer's own [Cin', Cout', 3, 3] weight tensor (Cin / Cout below = Cin' / Cout').
+ *     y[n][o][oh][ow] = sum_{i, kh, kw} w[o][i][kh][kw] * x[n][i][s oh + kh - 1][s ow + kw - 1]      (zero padded, no bias)
+ *     s = 1, or 2 with URSA_CONV_STRIDE2 (x: [N, Cin, H, W] -> y: [N, Cout, H/s, W/s]).
+ *     URSA_CONV_FLIP: the input gradient of such a layer: x = dy [N, Cin', H, W] with Cin' = the layer's OUTPUT channels
+ *                     (H = W = dy's size), y = dx [N, Cout', s H, s W] with Cout' = its INPUT channels, w = the layer's own
+ *                     [Cin', Cout', 3, 3] weight tensor (Cin / Cout below = Cin' / Cout').
  *
- * x: [N, Cin, H, W], y: [N, Cout, H, W], contiguous NCHW fp32, 16-byte aligned; w contiguous. One launch; exact fp32 on
- * v_mfma_f32_16x16x4_f32: each output is two interleaved fma chains over (channel group, tap) added once - a direct
- * convolution, no Winograd transform. Shapes covered (any N, H = W): (Cin, Cout, H) in {(3, 16, 32), (16, 16, 32),
- * (32, 32, 16), (64, 64, 8)}; ursa_conv3x3_supported() says whether a shape is (otherwise URSA_EVALUE).
- * Algorithmic HBM traffic: 4 B x (N*Cin*H*W + N*Cout*H*W + Cout*Cin*9).
+ * Contiguous NCHW fp32, x / y 16-byte aligned; w contiguous. One launch; exact fp32 on v_mfma_f32_16x16x4_f32: each output
+ * is a few interleaved fma chains over (channel group, tap) - a direct convolution, no Winograd transform. Shapes covered
+ * (any N, H = W):   stride 1 (Cin, Cout, H): (3, 16, 32) forward only; (16, 16, 32), (32, 32, 16), (64, 64, 8) both forms
+ *                   stride 2 forward: (16, 32, 32), (32, 64, 16);   stride 2 flipped (Cin', Cout', H of dy): (32, 16, 16), (64, 32, 8)
+ * ursa_conv3x3_supported() says whether a (shape, flags) is covered (otherwise URSA_EVALUE).
+ * Algorithmic HBM traffic: 4 B x (elements of x + elements of y + Cout*Cin*9).
  */
-#define URSA_CONV_FLIP 0x1u
-int ursa_conv3x3_supported(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W);
+#define URSA_CONV_FLIP    0x1u
+#define URSA_CONV_STRIDE2 0x2u
+int ursa_conv3x3_supported(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, uint32_t flags);
 int ursa_conv3x3_f32(const float* x, const float* w, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W,
                      uint32_t flags, ursa_stream_t stream);
 

@@ -465,7 +465,7 @@ int oracle_conv_wgrad_f32(const float* x, const float* dy, float* dw, int64_t N,
 }
 
 /* ---------------------------------------------------------------------------------------
- * K8  3x3 / stride 1 / pad 1 convolution, no bias     `out = self.conv1(out)` URSABench/models/preresnet.py:42,47,143
+ * K8  3x3 / pad 1 convolution (stride 1 or 2), no bias     `out = self.conv1(out)` URSABench/models/preresnet.py:42,47,143
  *     (F.conv2d on the CPU path, oneDNN) and, with flip, the input gradient of that layer (ATen convolution_backward).
  *
  *     y[n][o][oh][ow] = sum_{i, kh, kw} w[o][i][kh][kw] * x[n][i][oh + kh - 1][ow + kw - 1]
@@ -475,26 +475,49 @@ int oracle_conv_wgrad_f32(const float* x, const float* dy, float* dw, int64_t N,
  * in tests/test_fused_conv_cpu.py. x: [N, Cin, H, W], y: [N, Cout, H, W].
  */
 int oracle_conv3x3_f32(const float* x, const float* w, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W,
-                       int flip)
+                       int flip, int64_t stride)
 {
+    /* forward: x [N, Cin, H, W] -> y [N, Cout, H/stride, W/stride]. flip (the layer's input gradient): x = dy [N, Cin, H, W] ->
+     * y = dx [N, Cout, H*stride, W*stride], w = the layer's [Cin, Cout, 3, 3] tensor: dx[i][ih][iw] = sum over (o, kh, kw) with
+     * ih = stride*oh + kh - 1, iw = stride*ow + kw - 1 of w[o][i][kh][kw] * dy[o][oh][ow] */
+    if (!flip) {
+        const int64_t OH = H / stride, OW = W / stride;
+        for (int64_t n = 0; n < N; ++n)
+            for (int64_t o = 0; o < Cout; ++o)
+                for (int64_t oh = 0; oh < OH; ++oh)
+                    for (int64_t ow = 0; ow < OW; ++ow) {
+                        double acc = 0.0;
+                        for (int64_t i = 0; i < Cin; ++i)
+                            for (int64_t kh = 0; kh < 3; ++kh) {
+                                const int64_t ih = oh * stride + kh - 1;
+                                if (ih < 0 || ih >= H) continue;
+                                for (int64_t kw = 0; kw < 3; ++kw) {
+                                    const int64_t iw = ow * stride + kw - 1;
+                                    if (iw < 0 || iw >= W) continue;
+                                    acc += (double)w[((o * Cin + i) * 3 + kh) * 3 + kw] * (double)x[((n * Cin + i) * H + ih) * W + iw];
+                                }
+                            }
+                        y[((n * Cout + o) * OH + oh) * OW + ow] = (float)acc;
+                    }
+        return 0;
+    }
+    const int64_t IH = H * stride, IW = W * stride;
     for (int64_t n = 0; n < N; ++n)
-        for (int64_t o = 0; o < Cout; ++o)
-            for (int64_t oh = 0; oh < H; ++oh)
-                for (int64_t ow = 0; ow < W; ++ow) {
+        for (int64_t i = 0; i < Cout; ++i)
+            for (int64_t ih = 0; ih < IH; ++ih)
+                for (int64_t iw = 0; iw < IW; ++iw) {
                     double acc = 0.0;
-                    for (int64_t i = 0; i < Cin; ++i)
+                    for (int64_t o = 0; o < Cin; ++o)
                         for (int64_t kh = 0; kh < 3; ++kh) {
-                            const int64_t ih = oh + kh - 1;
-                            if (ih < 0 || ih >= H) continue;
+                            const int64_t th = ih + 1 - kh;
+                            if (th < 0 || th % stride || th / stride >= H) continue;
                             for (int64_t kw = 0; kw < 3; ++kw) {
-                                const int64_t iw = ow + kw - 1;
-                                if (iw < 0 || iw >= W) continue;
-                                const float wv = flip ? w[((i * Cout + o) * 3 + (2 - kh)) * 3 + (2 - kw)]
-                                                      : w[((o * Cin + i) * 3 + kh) * 3 + kw];
-                                acc += (double)wv * (double)x[((n * Cin + i) * H + ih) * W + iw];
+                                const int64_t tw = iw + 1 - kw;
+                                if (tw < 0 || tw % stride || tw / stride >= W) continue;
+                                acc += (double)w[((o * Cout + i) * 3 + kh) * 3 + kw] * (double)x[((n * Cin + o) * H + th / stride) * W + tw / stride];
                             }
                         }
-                    y[((n * Cout + o) * H + oh) * W + ow] = (float)acc;
+                    y[((n * Cout + i) * IH + ih) * IW + iw] = (float)acc;
                 }
     return 0;
 }

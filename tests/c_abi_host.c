@@ -26,7 +26,7 @@ int oracle_bn_relu_bwd_gated_f32(const float*, const float*, float*, const float
                                  float*, float*, int64_t, int64_t, int64_t, int, const int32_t*, const uint8_t*, int64_t);
 
 int oracle_conv_wgrad_f32(const float*, const float*, float*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t);
-int oracle_conv3x3_f32(const float*, const float*, float*, int64_t, int64_t, int64_t, int64_t, int64_t, int);
+int oracle_conv3x3_f32(const float*, const float*, float*, int64_t, int64_t, int64_t, int64_t, int64_t, int, int64_t);
 
 #define CHECK(x) do { int rc_ = (x); if (rc_) { printf("FAIL %s -> %d (%s)\n", #x, rc_, ursa_strerror(rc_)); return 1; } } while (0)
 
@@ -181,7 +181,7 @@ int main(void)
         for (int64_t i = 0; i < wn; ++i) hw[i] = floorf(2.99f * frand(&s2));
         float *dx_, *ddy, *dw_, *dy_, *ddw, *dws;
         const int64_t wsf = ursa_conv_wgrad_ws_floats(N, C, C, H, H, 3, 1);
-        if (wsf <= 0 || !ursa_conv3x3_supported(N, C, C, H, H)) { printf("FAIL K7 / K8 do not cover the 16-channel layer\n"); return 1; }
+        if (wsf <= 0 || !ursa_conv3x3_supported(N, C, C, H, H, 0)) { printf("FAIL K7 / K8 do not cover the 16-channel layer\n"); return 1; }
         CHECK(hipMalloc((void**)&dx_, tot * 4)); CHECK(hipMalloc((void**)&ddy, tot * 4)); CHECK(hipMalloc((void**)&dy_, tot * 4));
         CHECK(hipMalloc((void**)&dw_, wn * 4)); CHECK(hipMalloc((void**)&ddw, wn * 4)); CHECK(hipMalloc((void**)&dws, wsf * 4));
         CHECK(hipMemcpy(dx_, hx, tot * 4, hipMemcpyHostToDevice)); CHECK(hipMemcpy(ddy, hdy, tot * 4, hipMemcpyHostToDevice));
@@ -189,12 +189,12 @@ int main(void)
         CHECK(ursa_conv3x3_f32(dx_, dw_, dy_, N, C, C, H, H, 0, st));
         CHECK(hipStreamSynchronize(st));
         CHECK(hipMemcpy(got, dy_, tot * 4, hipMemcpyDeviceToHost));
-        oracle_conv3x3_f32(hx, hw, want, N, C, C, H, H, 0);
+        oracle_conv3x3_f32(hx, hw, want, N, C, C, H, H, 0, 1);
         if (memcmp(got, want, tot * 4)) { printf("FAIL K8 forward differs from the oracle\n"); return 1; }
         CHECK(ursa_conv3x3_f32(ddy, dw_, dy_, N, C, C, H, H, URSA_CONV_FLIP, st));
         CHECK(hipStreamSynchronize(st));
         CHECK(hipMemcpy(got, dy_, tot * 4, hipMemcpyDeviceToHost));
-        oracle_conv3x3_f32(hdy, hw, want, N, C, C, H, H, 1);
+        oracle_conv3x3_f32(hdy, hw, want, N, C, C, H, H, 1, 1);
         if (memcmp(got, want, tot * 4)) { printf("FAIL K8 input gradient differs from the oracle\n"); return 1; }
         oracle_conv_wgrad_f32(hx, hdy, wantw, N, C, C, H, H, 3, 1);
         CHECK(ursa_conv_wgrad_f32(dx_, ddy, ddw, dws, wsf, N, C, C, H, H, 3, 1, st));

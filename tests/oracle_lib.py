@@ -160,16 +160,16 @@ def conv_wgrad(x, dy, ksize=3, stride=1):
     return dw
 
 
-_L.oracle_conv3x3_f32.argtypes = [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32]
+_L.oracle_conv3x3_f32.argtypes = [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _i64]
 
 
-def conv3x3(x, w, flip=False):
-    """y = conv2d(x, w, stride 1, pad 1); flip: the input gradient for the output gradient `x` of the layer whose weight is `w`."""
+def conv3x3(x, w, flip=False, stride=1):
+    """y = conv2d(x, w, stride, pad 1); flip: the input gradient for the output gradient `x` of the layer whose weight is `w`."""
     N, Cin, H, W = x.shape
     Cout = w.shape[1 if flip else 0]
     assert w.shape[0 if flip else 1] == Cin and w.shape[2:] == (3, 3)
-    y = np.empty((N, Cout, H, W), np.float32)
-    rc = _L.oracle_conv3x3_f32(_p(x), _p(w), _p(y), N, Cin, Cout, H, W, int(flip))
+    y = np.empty((N, Cout, H * stride, W * stride) if flip else (N, Cout, H // stride, W // stride), np.float32)
+    rc = _L.oracle_conv3x3_f32(_p(x), _p(w), _p(y), N, Cin, Cout, H, W, int(flip), stride)
     assert rc == 0
     return y
 

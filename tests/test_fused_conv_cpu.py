@@ -115,19 +115,20 @@ def test_argument_errors_do_not_need_a_gpu():
     assert red(ctypes.cast(items, ctypes.c_void_p), 2, None) == -1
 
 
-@pytest.mark.parametrize('n,cin,cout,hw', [(2, 16, 16, 32), (2, 3, 16, 32), (1, 32, 32, 16), (2, 64, 64, 8), (1, 5, 7, 6)])
-def test_k8_oracle_is_torchs_cpu_convolution(n, cin, cout, hw):
+@pytest.mark.parametrize('n,cin,cout,hw,stride', [(2, 16, 16, 32, 1), (2, 3, 16, 32, 1), (1, 32, 32, 16, 1), (2, 64, 64, 8, 1), (1, 5, 7, 6, 1),
+                                                 (2, 16, 32, 32, 2), (2, 32, 64, 16, 2), (1, 5, 7, 6, 2)])
+def test_k8_oracle_is_torchs_cpu_convolution(n, cin, cout, hw, stride):
     rng = np.random.default_rng(n + cin)
     x = rng.standard_normal((n, cin, hw, hw), dtype=np.float32)
     w = rng.standard_normal((cout, cin, 3, 3), dtype=np.float32)
-    dy = rng.standard_normal((n, cout, hw, hw), dtype=np.float32)
+    dy = rng.standard_normal((n, cout, hw // stride, hw // stride), dtype=np.float32)
     tx, tw, tdy = torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(dy)
-    y = torch.from_numpy(oracle_lib.conv3x3(x, w))
-    assert torch.equal(y, torch.nn.functional.conv2d(tx.double(), tw.double(), None, 1, 1).float())
-    y32 = torch.nn.functional.conv2d(tx, tw, None, 1, 1)
+    y = torch.from_numpy(oracle_lib.conv3x3(x, w, stride=stride))
+    assert torch.equal(y, torch.nn.functional.conv2d(tx.double(), tw.double(), None, stride, 1).float())
+    y32 = torch.nn.functional.conv2d(tx, tw, None, stride, 1)
     assert float((y - y32).abs().max()) <= 4e-6 * float(y.abs().max())
-    dx = torch.from_numpy(oracle_lib.conv3x3(dy, w, flip=True))
-    assert torch.equal(dx, torch.nn.grad.conv2d_input(x.shape, tw.double(), tdy.double(), 1, 1).float())
+    dx = torch.from_numpy(oracle_lib.conv3x3(dy, w, flip=True, stride=stride))
+    assert torch.equal(dx, torch.nn.grad.conv2d_input(x.shape, tw.double(), tdy.double(), stride, 1).float())
 
 
 def test_k8_plan_and_argument_errors():
@@ -138,12 +139,16 @@ def test_k8_plan_and_argument_errors():
     for shape, cout in (((128, 16, 32, 32), 3), ((128, 16, 16, 16), 16), ((128, 16, 32, 32), 32), ((0, 16, 32, 32), 16),
                         ((128, 160, 32, 32), 160), ((2, 16, 32, 16), 16)):
         assert not k.conv3x3_supported(shape, cout)
+    assert k.conv3x3_supported((128, 16, 32, 32), 32, stride=2) and k.conv3x3_supported((5, 32, 16, 16), 64, stride=2)
+    assert k.conv3x3_supported((128, 32, 16, 16), 16, flip=True, stride=2) and k.conv3x3_supported((5, 64, 8, 8), 32, flip=True, stride=2)
+    assert k.conv3x3_supported((128, 16, 32, 32), 16, flip=True) and not k.conv3x3_supported((128, 16, 32, 32), 3, flip=True)
+    assert not k.conv3x3_supported((128, 16, 32, 32), 16, stride=2) and not k.conv3x3_supported((128, 16, 32, 32), 32, flip=True, stride=2)
     lib = _native.load_library()
     buf = (ctypes.c_float * 64)()
     p = ctypes.addressof(buf)
     p -= p % 16
     f = lib.ursa_conv3x3_f32
-    assert f(p, p, p, 128, 16, 16, 32, 32, 0x2, None) == -4            # EFLAGS
+    assert f(p, p, p, 128, 16, 16, 32, 32, 0x4, None) == -4            # EFLAGS
     assert f(None, p, p, 128, 16, 16, 32, 32, 0, None) == -1           # ENULL
     assert f(p, p, p, 0, 16, 16, 32, 32, 0, None) == -2                # ESIZE
     assert f(p + 4, p, p, 128, 16, 16, 32, 32, 0, None) == -3          # EALIGN

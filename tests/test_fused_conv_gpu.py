@@ -173,7 +173,7 @@ def test_conv2d_takes_k7_only_where_covered():
         return orig(x, dy, dw, ws, stride)
     k.conv_wgrad = spy
     try:
-        for cin, cout, hw, stride, ksz, covered in ((16, 16, 32, 1, 3, True), (3, 16, 32, 1, 3, True), (16, 32, 32, 2, 3, True),
+        for cin, cout, hw, stride, ksz, covered in ((16, 16, 32, 1, 3, True), (3, 16, 32, 1, 3, True), (16, 32, 32, 2, 3, True), (32, 64, 16, 2, 3, True),
                                                     (16, 32, 32, 2, 1, True), (64, 64, 8, 1, 3, True), (16, 16, 16, 1, 3, False),
                                                     (16, 64, 32, 1, 1, False), (8, 16, 32, 1, 3, False)):
             m = fused_conv.Conv2d(cin, cout, ksz, stride, ksz // 2, bias=False).to(DEV)
@@ -310,9 +310,35 @@ def test_k9_equals_the_oracle(cin, cout, hw, n):
                           oracle_lib.conv1x1s2(di, wi, flip=True))
 
 
+@pytest.mark.parametrize('cin,cout,hw', [(16, 32, 32), (32, 64, 16)])
+@pytest.mark.parametrize('n', [1, 3, 80, 128])
+def test_k8_stride2_equals_the_oracle(cin, cout, hw, n):
+    rng = np.random.default_rng(9 * n + cin)
+    k = _native.default_kernels()
+    x = rng.standard_normal((n, cin, hw, hw), dtype=np.float32)
+    w = (rng.standard_normal((cout, cin, 3, 3)) * 0.2).astype(np.float32)
+    dy = rng.standard_normal((n, cout, hw // 2, hw // 2), dtype=np.float32)
+    dw = torch.from_numpy(w).to(DEV)
+    got = k.conv3x3(torch.from_numpy(x).to(DEV), dw, stride=2).cpu().numpy()
+    want = oracle_lib.conv3x3(x, w, stride=2)
+    assert got.shape == want.shape and np.abs(got - want).max() <= K8_RTOL_OF_MAX * np.abs(want).max()
+    dx = torch.full((n, cin, hw, hw), float('nan'), device=DEV)
+    k.conv3x3(torch.from_numpy(dy).to(DEV), dw, dx, flip=True, stride=2)
+    want = oracle_lib.conv3x3(dy, w, flip=True, stride=2)
+    got = dx.cpu().numpy()
+    assert np.isfinite(got).all() and np.abs(got - want).max() <= K8_RTOL_OF_MAX * np.abs(want).max()
+    # integers: exact, bit for bit (taps, parity classes, halos, band edges)
+    xi = rng.integers(-3, 4, x.shape).astype(np.float32)
+    wi = rng.integers(-2, 3, w.shape).astype(np.float32)
+    di = rng.integers(-3, 4, dy.shape).astype(np.float32)
+    dwi = torch.from_numpy(wi).to(DEV)
+    assert np.array_equal(k.conv3x3(torch.from_numpy(xi).to(DEV), dwi, stride=2).cpu().numpy(), oracle_lib.conv3x3(xi, wi, stride=2))
+    assert np.array_equal(k.conv3x3(torch.from_numpy(di).to(DEV), dwi, flip=True, stride=2).cpu().numpy(),
+                          oracle_lib.conv3x3(di, wi, flip=True, stride=2))
+
+
 def test_every_convolution_of_the_network_takes_a_hand_written_launch():
-    """PreResNet-20 training step with gradients recorded: no MIOpen convolution launch is left except the stride-2 3x3 layers'
-    forward / input gradient (2 layers)."""
+    """PreResNet-20 training step with gradients recorded: no MIOpen convolution launch is left."""
     k = _native.default_kernels()
     seen = dict(conv3x3=0, conv1x1s2=0, conv_wgrad=0)
     origs = {n: getattr(k, n) for n in seen}
@@ -332,4 +358,4 @@ def test_every_convolution_of_the_network_takes_a_hand_written_launch():
     finally:
         for n in seen:
             delattr(k, n)
-    assert seen == dict(conv3x3=17 + 16, conv1x1s2=2 + 2, conv_wgrad=21), seen
+    assert seen == dict(conv3x3=19 + 18, conv1x1s2=2 + 2, conv_wgrad=21), seen

@@ -26,7 +26,7 @@ BMA_SMOOTHED = 0x1
 LEAP_KICK, LEAP_DRIFT = 0x1, 0x2
 REDUCE_WS_FLOATS = 2048
 BN_RELU, BN_TWO_LAUNCH, BN_HELD = 0x1, 0x2, 0x4
-CONV_FLIP = 0x1
+CONV_FLIP, CONV_STRIDE2 = 0x1, 0x2
 
 
 def bn_ws_floats(channels):
@@ -67,7 +67,7 @@ SIGNATURES = {
     'ursa_conv_wgrad_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _vp]),
     'ursa_conv_wgrad_partial_f32': (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _vp]),
     'ursa_conv_wgrad_reduce_f32': (ctypes.c_int, [_vp, _i32, _vp]),
-    'ursa_conv3x3_supported': (ctypes.c_int, [_i64, _i64, _i64, _i64, _i64]),
+    'ursa_conv3x3_supported': (ctypes.c_int, [_i64, _i64, _i64, _i64, _i64, _u32]),
     'ursa_conv3x3_f32': (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _u32, _vp]),
     'ursa_conv1x1s2_supported': (ctypes.c_int, [_i64, _i64, _i64, _i64, _i64, _u32]),
     'ursa_conv1x1s2_f32': (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _u32, _vp]),
@@ -504,29 +504,36 @@ class HipKernels:
 
 
     # K8 ------------------------------------------------------------------------------
-    def conv3x3_supported(self, x_shape, cout):
-        """Whether K8 takes a stride-1 3x3 / pad 1 convolution of an input of `x_shape` ([N, Cin, H, W]) to `cout` channels."""
+    def conv3x3_supported(self, x_shape, cout, flip=False, stride=1):
+        """Whether K8 takes a 3x3 / pad 1 convolution of an input of `x_shape` ([N, Cin, H, W]) to `cout` channels at `stride`
+        (flip: `x_shape` is the output gradient's shape and `cout` the layer's input channels)."""
         n, cin, h, w = (int(v) for v in x_shape)
-        return bool(self.lib.ursa_conv3x3_supported(n, cin, int(cout), h, w))
+        return bool(self.lib.ursa_conv3x3_supported(n, cin, int(cout), h, w, self._conv_flags(flip, stride)))
 
-    def conv3x3(self, x, w, y=None, flip=False):
-        """y = conv2d(x, w, stride=1, padding=1) (w: [Cout, Cin, 3, 3]); flip=True: the input gradient of that layer - `x` is
-        dy [N, Cout, H, W], the result dx [N, Cin, H, W], `w` the layer's own weight."""
+    @staticmethod
+    def _conv_flags(flip, stride):
+        if stride not in (1, 2):
+            raise ValueError('stride must be 1 or 2')
+        return (CONV_FLIP if flip else 0) | (CONV_STRIDE2 if stride == 2 else 0)
+
+    def conv3x3(self, x, w, y=None, flip=False, stride=1):
+        """y = conv2d(x, w, stride=stride, padding=1) (w: [Cout, Cin, 3, 3]); flip=True: the input gradient of that layer - `x`
+        is dy [N, Cout, H/stride, W/stride], the result dx [N, Cin, H, W], `w` the layer's own weight."""
         if x.dim() != 4 or w.dim() != 4 or tuple(w.shape[2:]) != (3, 3) or w.shape[0 if flip else 1] != x.shape[1]:
             raise ValueError(f'not a 3x3 convolution: x {tuple(x.shape)}, w {tuple(w.shape)}, flip={flip}')
         N, Cin, H, W = x.shape
         Cout = w.shape[1 if flip else 0]
         dev = x.device
+        shape = (N, Cout, H * stride, W * stride) if flip else (N, Cout, H // stride, W // stride)
         if y is None:
-            y = x.new_empty((N, Cout, H, W))
-        elif tuple(y.shape) != (N, Cout, H, W):
-            raise ValueError(f'y {tuple(y.shape)} should be {(N, Cout, H, W)}')
+            y = x.new_empty(shape)
+        elif tuple(y.shape) != shape:
+            raise ValueError(f'y {tuple(y.shape)} should be {shape}')
         with torch.cuda.device(dev):
             rc = self.lib.ursa_conv3x3_f32(_ptr(x, 'x'), _ptr(w, 'w', None, dev), _ptr(y, 'y', None, dev), N, Cin, Cout, H, W,
-                                           CONV_FLIP if flip else 0, _stream(dev))
+                                           self._conv_flags(flip, stride), _stream(dev))
         _check(self.lib, rc, 'ursa_conv3x3_f32')
         return y
-
 
     # K9 ------------------------------------------------------------------------------
     def conv1x1s2_supported(self, x_shape, cout, flip=False):

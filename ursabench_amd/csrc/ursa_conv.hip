@@ -426,12 +426,18 @@ namespace {
 // D: a lane holds four adjacent positions of one output channel: one float4 store. x is staged exactly as in K7 (phases).
 constexpr int pitch64p16(int n) { return ((n - 16 + 63) / 64) * 64 + 16; }
 
-template <int CIN, int COUT_WG, int W, int R, int PH>
+// MODE 0: stride 1 (forward, or the flipped form = input gradient); the position grid (W x W) is the output's = the input's.
+// MODE 1: stride 2 forward: positions = the OUTPUT grid (W x W), the staged tensor x is 2W x 2W.
+// MODE 2: stride 2 input gradient: positions = the grid of the staged tensor dy (W x W); every position produces the 2 x 2
+//         cell of dx above it: dx[2a + ph][2b + pw] = sum over the taps of parity class (ph, pw):
+//         ph = 0: kh = 1 (dy row a);  ph = 1: kh = 0 (dy row a + 1) and kh = 2 (dy row a);  the same for pw / kw / columns.
+template <int CIN, int COUT_WG, int W, int R, int PH, int MODE>
 struct Fw {
     static constexpr int CINP = (CIN + 3) / 4 * 4;
     static constexpr int KG = CINP / 4;                       // channel groups of 4 = MFMA k steps per tap
-    static constexpr int RI = R + 2, WP = W + 8;
-    static constexpr int XPLANE = pitch64p16(RI * WP);        // 4 channels x 16 positions of an A read: 64 distinct banks
+    static constexpr int WIN = MODE == 1 ? 2 * W : W;         // the staged tensor's width = height
+    static constexpr int RI = MODE == 0 ? R + 2 : MODE == 1 ? 2 * R + 1 : R + 1, WP = WIN + 8;
+    static constexpr int XPLANE = pitch64p16(RI * WP);        // 4 channels x 16 positions of an A read: 64 distinct banks (stride 1)
     static constexpr int XS = CINP * XPLANE;
     static constexpr int WPITCH = pitch64p4(CINP * 9);        // weights, rows [o][channel * 9 + tap]: staged before x, same LDS
     static constexpr int WL = WPITCH * COUT_WG;
@@ -441,16 +447,19 @@ struct Fw {
     static constexpr int BANDS = W / R;
     static constexpr int RP = R / PH, TP = PT / PH;           // rows / runs per phase
     static constexpr int TPW = TP / WPC;                      // runs per wave per phase
+    static constexpr int NA = MODE == 2 ? 4 : 9;              // distinct A values per step
     static_assert(MT == 1 || MT == 2 || MT == 4, "output tiles per workgroup");
     static_assert(W % 4 == 0 && W % R == 0 && (R * W) % 16 == 0 && R % PH == 0 && PT % PH == 0 && TP % WPC == 0, "geometry");
     static_assert(TP * 16 == RP * W, "a phase's runs are its rows");
     static_assert(SMEM * 4 <= 64 * 1024, "static LDS");
+    // last staged row (relative to the tile's first) that phase p reads
+    static constexpr int need(int p) { return MODE == 0 ? RP * (p + 1) + 1 : MODE == 1 ? 2 * RP * (p + 1) : RP * (p + 1); }
 };
 
-template <int CIN, int COUT_WG, int W, int R, int PH>
+template <int CIN, int COUT_WG, int W, int R, int PH, int MODE>
 __global__ __launch_bounds__(kThreads) void k_conv3x3(const float* __restrict__ x, const float* __restrict__ w,
-                                                       float* __restrict__ y, int N, int Cout, int ipw, int flip) {
-    using C = Fw<CIN, COUT_WG, W, R, PH>;
+                                                       float* __restrict__ y, int N, int Cout, int ipw, int flip_arg) {
+    using C = Fw<CIN, COUT_WG, W, R, PH, MODE>;
     __shared__ __attribute__((aligned(16))) float smem[C::SMEM];
     float* xs = smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -458,24 +467,26 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3(const float* __restrict__ 
     const int co_base = blockIdx.y * COUT_WG;
     const int j = lane & 15, k = lane >> 4;
     const int cot = wave % C::MT, wsub = wave / C::MT;
+    const int flip = MODE == 2 ? 1 : MODE == 1 ? 0 : flip_arg;   // which weight layout is read (MODE 2: the transposed one)
+    const int row0 = MODE == 0 ? band * R - 1 : MODE == 1 ? band * R * 2 - 1 : band * R;   // the tile's first staged row
 
-    constexpr int XROW = CIN * (W / 4);
+    constexpr int XROW = CIN * (C::WIN / 4);
     constexpr int XV = XROW * C::RI;
     constexpr int NX = (XV + kThreads - 1) / kThreads;
     f32x4 vx[NX];
     auto xphase = [](int kk) {
         const int fr = kk * kThreads / XROW;
         int p = 0;
-        while (p < PH - 1 && C::RP * (p + 1) + 1 < fr) ++p;
+        while (p < PH - 1 && C::need(p) < fr) ++p;
         return p;
     };
     auto load_x = [&](int n, int kk) {
         int idx = tid + kk * kThreads;
         if (XV % kThreads != 0) idx = idx < XV ? idx : XV - 1;
-        const int c4 = idx % (W / 4), ci = (idx / (W / 4)) % CIN, r = idx / XROW;
-        int ih = band * R - 1 + r;
-        ih = ih < 0 ? 0 : ih >= W ? W - 1 : ih;
-        vx[kk] = *reinterpret_cast<const f32x4*>(x + (((size_t)n * CIN + ci) * W + ih) * W + 4 * c4);
+        const int c4 = idx % (C::WIN / 4), ci = (idx / (C::WIN / 4)) % CIN, r = idx / XROW;
+        int ih = row0 + r;
+        ih = ih < 0 ? 0 : ih >= C::WIN ? C::WIN - 1 : ih;
+        vx[kk] = *reinterpret_cast<const f32x4*>(x + (((size_t)n * CIN + ci) * C::WIN + ih) * C::WIN + 4 * c4);
     };
     auto issue = [&](int n) {
 #pragma unroll
@@ -491,9 +502,9 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3(const float* __restrict__ 
         for (int kk = 0; kk < NX; ++kk) {
             if (xphase(kk) != p) continue;
             const int idx = tid + kk * kThreads;
-            const int c4 = idx % (W / 4), ci = (idx / (W / 4)) % CIN, r = idx / XROW;
-            const int ih = band * R - 1 + r;
-            const bool in = ih >= 0 && ih < W;
+            const int c4 = idx % (C::WIN / 4), ci = (idx / (C::WIN / 4)) % CIN, r = idx / XROW;
+            const int ih = row0 + r;
+            const bool in = ih >= 0 && ih < C::WIN;
             if (XV % kThreads == 0 || idx < XV)
                 *reinterpret_cast<f32x4*>(xs + ci * C::XPLANE + r * C::WP + 4 + 4 * c4) = in ? vx[kk] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -555,7 +566,7 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3(const float* __restrict__ 
     for (int i = tid; i < C::CINP * C::RI; i += kThreads) {    // halo columns (and, for a padded channel count, whole zero planes)
         float* row = xs + (i / C::RI) * C::XPLANE + (i % C::RI) * C::WP;
         row[3] = 0.f;
-        row[4 + W] = 0.f;
+        row[4 + C::WIN] = 0.f;
     }
     if constexpr (C::CINP > CIN)
         for (int i = tid; i < (C::CINP - CIN) * C::XPLANE; i += kThreads) xs[CIN * C::XPLANE + i] = 0.f;
@@ -567,37 +578,62 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3(const float* __restrict__ 
             stage(p);
             __syncthreads();
             if (p == PH - 1 && n + 1 < n1) issue(n + 1);
-            // steps of 9 MFMAs (one channel group, nine taps); the nine A reads of step s + 1 are issued before the MFMAs of
+            // steps of 9 MFMAs (one channel group, nine taps); the A reads of step s + 1 are issued before the MFMAs of
             // step s, so the LDS latency hides behind 288 cycles of matrix work even with one wave per SIMD
             auto xbase = [&](int u) {
                 const int lin = (p * C::TP + wsub + C::WPC * u) * 16 + j;          // A: position j of this wave's run u ...
-                return xs + k * C::XPLANE + (lin / W) * C::WP + lin % W + 3;       // ... channel k of each group, tap (0, 0)
+                const int prow = lin / W, pcol = lin % W;                          // ... channel k of each group, tap (0, 0)
+                if constexpr (MODE == 0) return xs + k * C::XPLANE + prow * C::WP + pcol + 3;
+                else if constexpr (MODE == 1) return xs + k * C::XPLANE + 2 * prow * C::WP + 2 * pcol + 3;
+                else return xs + k * C::XPLANE + prow * C::WP + pcol + 4;
             };
-            auto read9 = [&](float (&a)[9], int s) {
+            auto reada = [&](float (&a)[C::NA], int s) {
                 const float* xb = xbase(s / C::KG) + (s % C::KG) * 4 * C::XPLANE;
+                if constexpr (MODE == 2) {                     // dy rows a, a + 1 x columns b, b + 1
+                    a[0] = xb[0], a[1] = xb[1], a[2] = xb[C::WP], a[3] = xb[C::WP + 1];
+                } else {
 #pragma unroll
-                for (int tap = 0; tap < 9; ++tap) a[tap] = xb[(tap / 3) * C::WP + tap % 3];
+                    for (int tap = 0; tap < 9; ++tap) a[tap] = xb[(tap / 3) * C::WP + tap % 3];
+                }
             };
             constexpr int STEPS = C::TPW * C::KG;
-            float a[2][9];
-            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-            read9(a[0], 0);
+            float a[2][C::NA];
+            constexpr int NACC = MODE == 2 ? 4 : 2;            // MODE 2: one per parity class; else two interleaved chains
+            f32x4 acc[NACC];
+#pragma unroll
+            for (int c = 0; c < NACC; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            reada(a[0], 0);
 #pragma unroll
             for (int s = 0; s < STEPS; ++s) {
                 const int g = s % C::KG;
-                if (s + 1 < STEPS) read9(a[(s + 1) & 1], s + 1);
+                if (s + 1 < STEPS) reada(a[(s + 1) & 1], s + 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
-                    if ((g * 9 + tap) & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s & 1][tap], wr[g][tap], acc1, 0, 0, 0);
-                    else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s & 1][tap], wr[g][tap], acc0, 0, 0, 0);
+                    if constexpr (MODE == 2) {
+                        const int kh = tap / 3, kw = tap % 3;
+                        const int cls = (kh != 1) * 2 + (kw != 1), src = (kh == 0) * 2 + (kw == 0);
+                        acc[cls] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s & 1][src], wr[g][8 - tap], acc[cls], 0, 0, 0);   // (wr holds w[..][8 - tap])
+                    } else {
+                        acc[(g * 9 + tap) & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s & 1][tap], wr[g][tap], acc[(g * 9 + tap) & 1], 0, 0, 0);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (g == C::KG - 1) {                          // D: positions 4*k .. 4*k + 3 of the run, output channel j
                     const int t = p * C::TP + wsub + C::WPC * (s / C::KG);
-                    const f32x4 out = acc0 + acc1;
-                    *reinterpret_cast<f32x4*>(y + ((size_t)n * Cout + co_base + cot * 16 + j) * (W * W) + band * R * W + t * 16 + 4 * k) = out;
-                    acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+                    float* yo = y + ((size_t)n * Cout + co_base + cot * 16 + j) * (MODE == 2 ? 4 * W * W : W * W);
+                    if constexpr (MODE == 2) {
+                        const int lin0 = t * 16 + 4 * k, prow = band * R + lin0 / W, pcol = lin0 % W;
+                        float* o0 = yo + (size_t)(2 * prow) * (2 * W) + 2 * pcol;
+                        *reinterpret_cast<f32x4*>(o0) = f32x4{acc[0].x, acc[1].x, acc[0].y, acc[1].y};
+                        *reinterpret_cast<f32x4*>(o0 + 4) = f32x4{acc[0].z, acc[1].z, acc[0].w, acc[1].w};
+                        *reinterpret_cast<f32x4*>(o0 + 2 * W) = f32x4{acc[2].x, acc[3].x, acc[2].y, acc[3].y};
+                        *reinterpret_cast<f32x4*>(o0 + 2 * W + 4) = f32x4{acc[2].z, acc[3].z, acc[2].w, acc[3].w};
+                    } else {
+                        *reinterpret_cast<f32x4*>(yo + band * R * W + t * 16 + 4 * k) = acc[0] + acc[1];
+                    }
+#pragma unroll
+                    for (int c = 0; c < NACC; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             }
         }
@@ -609,43 +645,42 @@ struct FwPlan {
     void (*fn)(const float*, const float*, float*, int, int, int, int);
 };
 
-// the stride-1 3x3 layers of the CIFAR pre-activation ResNets: the stem and the three stages' equal-width layers
-FwPlan fw_plan_for(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W) {
+// the 3x3 layers of the CIFAR pre-activation ResNets: stride 1 - the stem and the three stages' equal-width layers (forward and,
+// flipped, their input gradient); stride 2 - the two layers that open stages 2 and 3, forward (Cin, Cout, H of x) and input
+// gradient (flipped: Cin = dy's channels, Cout = dx's channels, H = dy's size)
+FwPlan fw_plan_for(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, uint32_t flags) {
     FwPlan p = {0, 0, 0, nullptr};
     if (N < 1 || N > (1 << 20) || H != W) return p;
-    if (Cin == 16 && Cout == 16 && W == 32) p = {4, 1, 1, k_conv3x3<16, 16, 32, 8, 4>};
-    else if (Cin == 3 && Cout == 16 && W == 32) p = {4, 1, 1, k_conv3x3<3, 16, 32, 8, 4>};
-    else if (Cin == 32 && Cout == 32 && W == 16) p = {2, 1, 1, k_conv3x3<32, 32, 16, 8, 4>};
-    else if (Cin == 64 && Cout == 64 && W == 8) p = {1, 4, 2, k_conv3x3<64, 16, 8, 8, 1>};
-#ifdef URSA_DEBUG_KNOBS
-    if (const char* e = getenv("URSA_CONV_FWD_VARIANT")) {    // A/B: twice the workgroups, half the work each
-        if (atoi(e) == 1 && Cin == 32 && Cout == 32 && W == 16) p = {4, 1, 1, k_conv3x3<32, 32, 16, 4, 2>};
-        if (atoi(e) == 1 && Cin == 64 && Cout == 64 && W == 8) p.ipw = 1;
-        if (atoi(e) == 2 && Cin == 16 && Cout == 16 && W == 32) p = {4, 1, 1, k_conv3x3<16, 16, 32, 8, 2>};   // fewer, longer phases
-        if (atoi(e) == 2 && Cin == 32 && Cout == 32 && W == 16) p = {2, 1, 1, k_conv3x3<32, 32, 16, 8, 2>};
-        if (atoi(e) == 3 && Cin == 16 && Cout == 16 && W == 32) p = {4, 1, 1, k_conv3x3<16, 16, 32, 8, 1>};
-        if (atoi(e) == 3 && Cin == 32 && Cout == 32 && W == 16) p = {2, 1, 1, k_conv3x3<32, 32, 16, 8, 1>};
-        if (atoi(e) == 4 && Cin == 16 && Cout == 16 && W == 32) p = {2, 1, 1, k_conv3x3<16, 16, 32, 16, 4>};  // half the workgroups, twice the rows
-        if (atoi(e) == 4 && Cin == 64 && Cout == 64 && W == 8) p.ipw = 4;
+    const bool flip = flags & URSA_CONV_FLIP;
+    if (flags & URSA_CONV_STRIDE2) {
+        if (!flip && Cin == 16 && Cout == 32 && W == 32) p = {2, 1, 1, k_conv3x3<16, 32, 16, 8, 4, 1>};
+        else if (!flip && Cin == 32 && Cout == 64 && W == 16) p = {1, 2, 1, k_conv3x3<32, 32, 8, 8, 2, 1>};
+        else if (flip && Cin == 32 && Cout == 16 && W == 16) p = {2, 1, 1, k_conv3x3<32, 16, 16, 8, 2, 2>};
+        else if (flip && Cin == 64 && Cout == 32 && W == 8) p = {1, 2, 1, k_conv3x3<64, 16, 8, 8, 1, 2>};
+        return p;
     }
-#endif
+    if (flip && Cin != Cout) return p;                         // flipped stride 1: the equal-width layers only
+    if (Cin == 16 && Cout == 16 && W == 32) p = {4, 1, 1, k_conv3x3<16, 16, 32, 8, 4, 0>};
+    else if (Cin == 3 && Cout == 16 && W == 32) p = {4, 1, 1, k_conv3x3<3, 16, 32, 8, 4, 0>};
+    else if (Cin == 32 && Cout == 32 && W == 16) p = {2, 1, 1, k_conv3x3<32, 32, 16, 8, 4, 0>};
+    else if (Cin == 64 && Cout == 64 && W == 8) p = {1, 4, 2, k_conv3x3<64, 16, 8, 8, 1, 0>};
     return p;
 }
 
 }  // namespace
 
-extern "C" int ursa_conv3x3_supported(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W) {
-    return fw_plan_for(N, Cin, Cout, H, W).fn != nullptr;
+extern "C" int ursa_conv3x3_supported(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, uint32_t flags) {
+    return !(flags & ~(URSA_CONV_FLIP | URSA_CONV_STRIDE2)) && fw_plan_for(N, Cin, Cout, H, W, flags).fn != nullptr;
 }
 
 extern "C" int ursa_conv3x3_f32(const float* x, const float* w, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t H,
                                 int64_t W, uint32_t flags, ursa_stream_t stream) {
-    if (flags & ~URSA_CONV_FLIP) return URSA_EFLAGS;
+    if (flags & ~(URSA_CONV_FLIP | URSA_CONV_STRIDE2)) return URSA_EFLAGS;
     if (!x || !w || !y) return URSA_ENULL;
     if (N < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return URSA_ESIZE;
     if (((uintptr_t)x | (uintptr_t)y) & 15 || (uintptr_t)w & 3) return URSA_EALIGN;
-    const FwPlan p = fw_plan_for(N, Cin, Cout, H, W);
-    if (!p.fn || ((flags & URSA_CONV_FLIP) && Cin != Cout)) return URSA_EVALUE;   // flipped: the equal-width layers only
+    const FwPlan p = fw_plan_for(N, Cin, Cout, H, W, flags);
+    if (!p.fn) return URSA_EVALUE;
     const int groups = (int)((N + p.ipw - 1) / p.ipw);
     hipLaunchKernelGGL(p.fn, dim3(groups * p.gx_per_image, p.gy), dim3(kThreads), 0, (hipStream_t)stream, x, w, y, (int)N, (int)Cout,
                        p.ipw, (int)(flags & URSA_CONV_FLIP));

@@ -99,7 +99,7 @@ class _Conv(torch.autograd.Function):
         ctx.stride, ctx.ws_floats, ctx.k8_bwd, ctx.weight, ctx.sink = stride, ws_floats, k8_bwd, w, getattr(_tls, 'sink', None)
         if k8_fwd:
             k = _native.default_kernels()
-            return k.conv3x3(x, w) if w.shape[2] == 3 else k.conv1x1s2(x, w)
+            return k.conv3x3(x, w, stride=stride) if w.shape[2] == 3 else k.conv1x1s2(x, w)
         return F.conv2d(x, w, None, stride, w.shape[2] // 2)
 
     @staticmethod
@@ -114,7 +114,7 @@ class _Conv(torch.autograd.Function):
         need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         dx = dw = None
         if need_dx and ctx.k8_bwd:
-            dx, need_dx = (k.conv3x3(dy, w, flip=True) if w.shape[2] == 3 else k.conv1x1s2(dy, w, flip=True)), False
+            dx, need_dx = (k.conv3x3(dy, w, flip=True, stride=s) if w.shape[2] == 3 else k.conv1x1s2(dy, w, flip=True)), False
         if need_dw and ctx.ws_floats:
             ws = x.new_empty(ctx.ws_floats)
             if ctx.sink is not None:
@@ -142,13 +142,13 @@ class Conv2d(nn.Conv2d):
             return super().forward(x)
         k = _native.default_kernels()
         N, cin, H, W = x.shape
-        k8, k9 = _k8 and ks == 3 and st == 1, _k8 and ks == 1 and st == 2
-        fwd = (k8 and k.conv3x3_supported(x.shape, self.out_channels)) or (k9 and k.conv1x1s2_supported(x.shape, self.out_channels))
+        k8, k9 = _k8 and ks == 3 and st in (1, 2), _k8 and ks == 1 and st == 2
+        fwd = (k8 and k.conv3x3_supported(x.shape, self.out_channels, stride=st)) or (k9 and k.conv1x1s2_supported(x.shape, self.out_channels))
         if not (torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)):
             # no gradient recorded (evaluation, the BMA predictive at 4,096 rows): MIOpen's Winograd launch is the faster one at
             # large batches (bench.py bma leg: 23.7 k vs 21.9 k predictions/s) - K8 is for the training step's sizes
             return super().forward(x)
-        bwd = x.requires_grad and ((k8 and k.conv3x3_supported((N, self.out_channels, H, W), cin))
+        bwd = x.requires_grad and ((k8 and k.conv3x3_supported((N, self.out_channels, H // st, W // st), cin, flip=True, stride=st))
                                    or (k9 and k.conv1x1s2_supported((N, self.out_channels, H // 2, W // 2), cin, flip=True)))
         ws = k.conv_wgrad_ws_floats(x.shape, self.out_channels, ks, st) if w.requires_grad else 0
         if not (fwd or bwd or ws):
