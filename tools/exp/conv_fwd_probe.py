@@ -1,5 +1,5 @@
-"""K8 (ursa_conv3x3_f32) against the CPU float64 convolution and against MIOpen's launch for the same call, forward and
-input gradient, per stride-1 3x3 layer shape of the CIFAR pre-activation ResNets: error, bit reproducibility, and (run it under
+"""K8 (ursa_conv3x3_f32) and K9 (ursa_conv1x1s2_f32) against the CPU float64 convolution and against MIOpen's launches for the
+same call, forward and input gradient, per layer shape of the CIFAR pre-activation ResNets: error, bit reproducibility, and (run it under
 `rocprofv3 --kernel-trace --stats`) the kernels' durations. 200 calls each, alternating over 8 input buffers so that the
 inputs are not L2-resident from the previous call.
 
@@ -36,36 +36,41 @@ def timed(fn):
 
 
 out = []
-for cin, cout, hw in ((16, 16, 32), (3, 16, 32), (32, 32, 16), (64, 64, 8)):
+for cin, cout, hw, ks, st in ((16, 16, 32, 3, 1), (3, 16, 32, 3, 1), (32, 32, 16, 3, 1), (64, 64, 8, 3, 1), (16, 32, 32, 3, 2), (32, 64, 16, 3, 2),
+                              (16, 32, 32, 1, 2), (32, 64, 16, 1, 2)):
+    pad = ks // 2
+    k_fwd = (lambda x, w, y=None: K.conv3x3(x, w, y, stride=st)) if ks == 3 else (lambda x, w, y=None: K.conv1x1s2(x, w, y))
+    k_bwd = (lambda dy, w, y=None: K.conv3x3(dy, w, y, flip=True, stride=st)) if ks == 3 else (lambda dy, w, y=None: K.conv1x1s2(dy, w, y, flip=True))
     for n in (128, 3):
         torch.manual_seed(n + cin)
         xs = [torch.randn(n, cin, hw, hw, device=dev) for _ in range(8 if n == 128 else 1)]
-        dys = [torch.randn(n, cout, hw, hw, device=dev) for _ in range(8 if n == 128 else 1)]
-        w = torch.randn(cout, cin, 3, 3, device=dev) * 0.1
+        dys = [torch.randn(n, cout, hw // st, hw // st, device=dev) for _ in range(8 if n == 128 else 1)]
+        w = torch.randn(cout, cin, ks, ks, device=dev) * 0.1
         x, dy = xs[0], dys[0]
-        rec = dict(cin=cin, cout=cout, hw=hw, n=n)
-        y = K.conv3x3(x, w)
-        ref = F.conv2d(x.double().cpu(), w.double().cpu(), None, 1, 1)
-        mi = F.conv2d(x, w, None, 1, 1)
+        rec = dict(cin=cin, cout=cout, hw=hw, ksize=ks, stride=st, n=n)
+        y = k_fwd(x, w)
+        ref = F.conv2d(x.double().cpu(), w.double().cpu(), None, st, pad)
+        mi = F.conv2d(x, w, None, st, pad)
         sc = float(ref.abs().max())
-        rec.update(fwd_err_k8=float((y.double().cpu() - ref).abs().max()) / sc, fwd_err_miopen=float((mi.double().cpu() - ref).abs().max()) / sc,
-                   fwd_bit_equal_runs=bool(torch.equal(y, K.conv3x3(x, w))))
-        if K.conv3x3_supported(dy.shape, cin):
-            dx = K.conv3x3(dy, w, flip=True)
-            refd = torch.nn.grad.conv2d_input(x.shape, w.double().cpu(), dy.double().cpu(), 1, 1)
-            mid = torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+        rec.update(fwd_err=float((y.double().cpu() - ref).abs().max()) / sc, fwd_err_miopen=float((mi.double().cpu() - ref).abs().max()) / sc,
+                   fwd_bit_equal_runs=bool(torch.equal(y, k_fwd(x, w))))
+        has_bwd = cin != 3
+        if has_bwd:
+            dx = k_bwd(dy, w)
+            refd = torch.nn.grad.conv2d_input(x.shape, w.double().cpu(), dy.double().cpu(), st, pad)
+            mid = torch.ops.aten.convolution_backward(dy, x, w, None, [st, st], [pad, pad], [1, 1], False, [0, 0], 1, [True, False, False])[0]
             sc = float(refd.abs().max())
-            rec.update(dgrad_err_k8=float((dx.double().cpu() - refd).abs().max()) / sc,
+            rec.update(dgrad_err=float((dx.double().cpu() - refd).abs().max()) / sc,
                        dgrad_err_miopen=float((mid.double().cpu() - refd).abs().max()) / sc)
         if n == 128:
             yb = torch.empty_like(y)
-            rec['us_k8_fwd'] = timed(lambda i: K.conv3x3(xs[i % 8], w, yb))
-            rec['us_miopen_fwd'] = timed(lambda i: F.conv2d(xs[i % 8], w, None, 1, 1))
-            if 'dgrad_err_k8' in rec:
+            rec['us_fwd_host_loop'] = timed(lambda i: k_fwd(xs[i % 8], w, yb))
+            rec['us_miopen_fwd_host_loop'] = timed(lambda i: F.conv2d(xs[i % 8], w, None, st, pad))
+            if has_bwd:
                 db = torch.empty_like(x)
-                rec['us_k8_dgrad'] = timed(lambda i: K.conv3x3(dys[i % 8], w, db, flip=True))
-                rec['us_miopen_dgrad'] = timed(lambda i: torch.ops.aten.convolution_backward(
-                    dys[i % 8], x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False]))
+                rec['us_dgrad_host_loop'] = timed(lambda i: k_bwd(dys[i % 8], w, db))
+                rec['us_miopen_dgrad_host_loop'] = timed(lambda i: torch.ops.aten.convolution_backward(
+                    dys[i % 8], x, w, None, [st, st], [pad, pad], [1, 1], False, [0, 0], 1, [True, False, False]))
         out.append(rec)
         print(rec, flush=True)
 os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)

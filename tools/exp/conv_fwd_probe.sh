@@ -10,7 +10,7 @@ f=$(find /tmp/prof_k8 -name '*kernel_stats.csv' | head -1)
 python3 - "$f" > $out/conv_fwd_probe_kernels.txt <<'P'
 import csv, sys
 for r in csv.DictReader(open(sys.argv[1])):
-    if any(k in r['Name'] for k in ('k_conv', 'miopenSp3', 'igemm', 'transpose', 'SubTensor', 'naive')):
+    if any(k in r['Name'] for k in ('k_conv', 'miopenSp3', 'igemm', 'transpose', 'SubTensor', 'naive', 'Cijk')):
         print(r['Name'][:80], r['Calls'], r['AverageNs'], r['MinNs'], r['MaxNs'])
 P
-cat $out/conv_fwd_probe_kernels.txt; grep -h "fwd_err" $out/conv_fwd_probe.log | cut -c1-420
+cat $out/conv_fwd_probe_kernels.txt; grep -h "fwd_err" $out/conv_fwd_probe.log | cut -c1-460

@@ -87,6 +87,25 @@ if not K6_ONLY:
         wg = 64 * (4 if S >= 12 else 2 if S >= 5 else 1) if C <= 16 else (128 if (B + 3) // 4 >= 2048 and S >= 4 and 64 < C <= 128 else 256)
         note('k_bma_', f'K5 S={S} B={B} C={C}', 4 * S * B * C + 8 * B * (C + 1), shape=[S, B, C], blocks=grid, wg=wg)
     del z, p, e
+if not K6_ONLY:
+    # K7 / K8 at the workload's first-stage layer (16 channels, 32 x 32, batch 128): 8 MB operands; bytes = operands read once +
+    # the result written once (K7's first launch also writes its 4.7 MB of K-sliced partial sums, read back by the second)
+    cx, cdy = torch.randn(128, 16, 32, 32, device='cuda'), torch.randn(128, 16, 32, 32, device='cuda')
+    cw, cy = torch.randn(16, 16, 3, 3, device='cuda') * 0.1, torch.empty(128, 16, 32, 32, device='cuda')
+    cdw = torch.empty_like(cw)
+    cws = torch.empty(K.conv_wgrad_ws_floats(cx.shape, 16, 3, 1), device='cuda')
+    for _ in range(10):
+        K.conv3x3(cx, cw, cy)
+        K.conv3x3(cdy, cw, cy, flip=True)
+        K.conv_wgrad(cx, cdy, cdw, cws, 1)
+    manifest.append(dict(pattern='k_conv3x3<16, 16, 32', label='K8 forward / input gradient 128x16x32x32', blocks=512, wg=256,
+                         algorithmic_bytes_per_launch=4 * (2 * cx.numel() + cw.numel()), flops_per_launch=2 * 128 * 1024 * 16 * 16 * 9))
+    manifest.append(dict(pattern='k_conv_wgrad<16, 16, 32', label='K7 first launch 128x16x32x32', blocks=512, wg=256,
+                         algorithmic_bytes_per_launch=4 * (2 * cx.numel() + cw.numel()), form_bytes=4 * (2 * cx.numel() + cws.numel()),
+                         flops_per_launch=2 * 128 * 1024 * 16 * 16 * 9))
+    manifest.append(dict(pattern='k_conv_wgrad_reduce', label='K7 second launch (512 slices of 2,304 floats)', blocks=36, wg=256,
+                         algorithmic_bytes_per_launch=4 * (cws.numel() + cw.numel())))
+    del cx, cdy, cy, cws
 # K6 relu(bn(x)): the two-launch form on a 268 MB activation (PreResNet-164's first stage at the HMC batch: beyond the
 # Infinity Cache) and the one-pass form on an 84 MB one (WideResNet-28-10's last stage at 4x the batch)
 for shape, one in K6_SHAPES:

@@ -10,7 +10,7 @@ R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/r05_evidence
 mkdir -p $out
 cd $R
-sha256sum ursabench_amd/csrc/libursa_hip.so ursabench_amd/csrc/ursa_kernels.hip ursabench_amd/csrc/ursa_bn.hip bench.py > $out/r05_sha256_part_$part.txt
+sha256sum ursabench_amd/csrc/libursa_hip.so ursabench_amd/csrc/ursa_kernels.hip ursabench_amd/csrc/ursa_bn.hip ursabench_amd/csrc/ursa_conv.hip bench.py > $out/r05_sha256_part_$part.txt
 case $part in
 a)  # kernel micro-benchmarks and diagnostics
   python3 tools/kbench.py > $out/kbench.log 2>&1; echo "kbench rc=$?"; cp gpurun_out/kbench.json $out/r05_kbench.json
@@ -23,6 +23,12 @@ a)  # kernel micro-benchmarks and diagnostics
   (/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -w -o /tmp/bn_tl tools/exp/bn_held_timeline.hip 2>/dev/null && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -w -DTL_BLOCK_THREADS=256 -DTL_EPT=16 -o /tmp/bn_tl256 tools/exp/bn_held_timeline.hip 2>/dev/null && timeout -k 5 60 /tmp/bn_tl > $out/r05_bn_held_timeline.txt && timeout -k 5 60 /tmp/bn_tl256 >> $out/r05_bn_held_timeline.txt); echo "bn_held_timeline rc=$?"
   python3 tools/exp/grouped_conv_ab.py > $out/r05_grouped_conv_ab.json 2> $out/grouped_conv_ab.err; echo "grouped_conv_ab rc=$?"
   K5_ONLY=prefetch,no_prefetch python3 tools/k5_bench.py 30 10000 100 30 10000 64 30 10000 128 30 10000 256 > $out/r05_k5_prefetch_ab.txt 2>&1; echo "k5 prefetch A/B rc=$?"
+  # K7 / K8 / K9 against MIOpen's launches for the same calls, kernel durations under rocprofv3 (tools/exp/conv_*_probe.sh)
+  VARIANTS=default bash tools/exp/conv_wgrad_probe.sh > $out/conv_wgrad_probe.txt 2>&1; echo "conv_wgrad_probe rc=$?"
+  cp gpurun_out/conv_wgrad_probe_default.json $out/r05_conv_wgrad_probe.json; cp gpurun_out/conv_wgrad_probe_default_kernels.txt $out/r05_conv_wgrad_probe_kernels.txt
+  bash tools/exp/conv_fwd_probe.sh > $out/conv_fwd_probe.txt 2>&1; echo "conv_fwd_probe rc=$?"
+  cp gpurun_out/conv_fwd_probe.json $out/r05_conv_fwd_probe.json; cp gpurun_out/conv_fwd_probe_kernels.txt $out/r05_conv_fwd_probe_kernels.txt
+  cd $R
   # the gate-conditioned parity report (G16, eight seeds, K6 vs stock launches paired): written by the GPU test itself
   python3 -m pytest tests/test_gate_parity_gpu.py -q -m gpu > $out/g16_pytest.log 2>&1; echo "g16 gate parity rc=$?"; cp gpurun_out/g16_gate_parity.json $out/r05_g16_gate_parity.json
 
@@ -39,7 +45,7 @@ b)  # rocprofv3 passes: the default bench, C4, C5; PMC counters
   python3 $R/tools/prof_summary.py /tmp/prof_c4 $out/r05_c4_kernel_stats.csv > /dev/null
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_c5 -- python3 $R/bench.py --config c5 --c5-batch 1024 --steps 3 --warmup 0 > $out/c5_line_under_rocprof.json 2> $out/c5_under_rocprof.err; echo "c5 under rocprof rc=$?"
   python3 $R/tools/prof_summary.py /tmp/prof_c5 $out/r05_c5_kernel_stats.csv > /dev/null
-  for grp in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+  for grp in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES"; do
     d=/tmp/pmc_$(echo $grp | tr ' ' '_')
     rm -rf $d
     rocprofv3 --pmc $grp --output-format csv -d $d -- python3 $R/tools/pmc_only.py $out/pmc_manifest.json > /dev/null 2> $out/pmc_last.err; echo "pmc [$grp] rc=$?"
@@ -51,6 +57,7 @@ c)  # the bench lines and the harness drivers
   # (stdout = the ONE compact line the driver parses; --detail-out = the full record of the same run)
   python3 bench.py --detail-out $out/r05_bench_detail.json > $out/r05_bench_line.json 2> $out/bench.err; echo "plain bench rc=$?"
   ( time python3 bench.py --gpus 1 --steps 20 --warmup 5 --detail-out $out/r05_bench_detail_driver_cmd.json > $out/r05_bench_line_driver_cmd.json 2> $out/bench_driver.err ) 2> $out/r05_bench_driver_cmd_wall_time.txt; echo "bench with the driver's flags rc=$?"
+  URSA_FUSED_CONV=0 python3 bench.py --no-cpu-baseline --ref-style-steps 0 --multi-chain-sweep "" --detail-out $out/r05_bench_detail_stock_conv.json > $out/r05_bench_line_stock_conv.json 2> $out/bench_stock_conv.err; echo "bench with MIOpen's convolution launches rc=$?"
   URSA_FUSED_BN=0 python3 bench.py --no-parity --no-cpu-baseline --ref-style-steps 0 --multi-chain-sweep "" --detail-out $out/r05_bench_detail_stock_bn.json > $out/r05_bench_line_stock_bn.json 2> $out/bench_stock.err; echo "bench with stock BatchNorm launches rc=$?"
   python3 -m ursabench_amd.time_script --dataset CIFAR10 --model PreResNet20 --save_path $out/r05_time_script_preresnet20 --samples 3 --trials 10 --discard_first \
       --methods SGLD SGHMC cSGLD cSGHMC SWAG MCdropout SGD > $out/time_script.log 2>&1; echo "time_script rc=$?"

@@ -1,12 +1,19 @@
-"""The weight gradient of the benchmark networks' convolutions as gfx950 launches (K7, include/ursa_hip.h).
+"""The convolutions of the benchmark networks' training step as gfx950 launches (K7, K8, K9: include/ursa_hip.h).
 
 `Conv2d` is what `ursabench_amd.models` instantiates where the reference's networks write `nn.Conv2d(...)`
 (URSABench/models/preresnet.py:25-27,62-64,100,130-136). It IS an `nn.Conv2d` (same parameters, state_dict keys,
-initialisation); the forward and the input gradient stay MIOpen's. What changes, for the layer shapes K7 covers, on contiguous
-fp32 NCHW HIP tensors while gradients are recorded: the weight gradient of `loss.backward()` (URSABench/inference/sghmc.py:80)
-is computed by `ursa_conv_wgrad_f32` - two launches straight from the NCHW tensors, exact fp32, fixed summation order -
-instead of MIOpen's sequence for these sizes (two layout transposes, a zero fill, an atomics-based implicit GEMM, a transpose
-back: 92 of the 237 launches of a PreResNet-20 step, profiles/r05_step_timeline.json).
+initialisation). For the layer shapes the library covers - every convolution of the BasicBlock pre-activation ResNets - on
+contiguous fp32 NCHW HIP tensors, WHILE GRADIENTS ARE RECORDED (a training / HMC step):
+
+  forward and input gradient   K8 `ursa_conv3x3_f32` (3x3, stride 1 and 2) / K9 `ursa_conv1x1s2_f32` (1x1 stride 2 shortcuts): one
+                               launch each, direct convolution in exact fp32 on the matrix pipe, instead of MIOpen's Winograd /
+                               implicit-GEMM launches (18.3 us -> 10.3 us per 3x3 layer and direction at the workload's sizes)
+  weight gradient              K7 `ursa_conv_wgrad_f32`: two launches straight from the NCHW tensors, fixed summation order, instead
+                               of MIOpen's sequence for these sizes (two layout transposes, a zero fill, an atomics-based implicit
+                               GEMM, a transpose back: 92 of the 237 launches of a PreResNet-20 step in round 4)
+
+Evaluation-mode forwards (no gradient recorded: the BMA predictive at thousands of rows per batch) stay MIOpen's - its
+Winograd launch is the faster one there (bench.py `bma` leg: 23.7 k vs 21.9 k predictions/s).
 
 `deferred()`: whoever owns the destination of the gradients (the chain engine: its flat arena) can take K7's second launch -
 the fixed-order sum over the K slices - for ALL layers of a backward pass at once: the backward of a covered layer applied
@@ -14,9 +21,10 @@ inside the context runs the first launch only and records (partial sums, weight)
 where the caller says, in one launch. Outside the context each layer's backward returns its weight gradient as autograd expects.
 
 Anything else - other kernel sizes / strides / channel counts, bias, groups, dilation, host tensors, other dtypes or layouts,
-double backward - takes `nn.Conv2d.forward`, the stock path, unchanged. On a HIP tensor the K7 path needs
+double backward - takes `nn.Conv2d.forward`, the stock path, unchanged. On a HIP tensor the covered paths need
 csrc/libursa_hip.so (no silent fallback: a missing library raises). `URSA_FUSED_CONV=0` in the environment, or
-`enabled(False)`, selects the stock path everywhere (A/B runs).
+`enabled(False)`, selects the stock path everywhere; `URSA_FUSED_CONV_FWD=0` / `forward_enabled(False)` keeps K7 and hands
+forward / input gradient back to MIOpen (A/B runs).
 """
 import os
 import threading

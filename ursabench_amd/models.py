@@ -1,8 +1,9 @@
 """The networks the benchmark configurations name (BASELINE.json `configs`), as plain nn.Modules.
 
-Convolution forwards / input gradients and linear layers stay stock PyTorch-ROCm (MIOpen / rocBLAS). Two things these
-modules do differently from the reference's on a HIP device: the weight gradient of the small-channel 3x3 convolutions
-(`fused_conv.Conv2d`, K7: two launches instead of MIOpen's five to six per layer) and `relu(bn(x))`: every BatchNorm of the
+Linear layers stay stock PyTorch-ROCm (rocBLAS), and so do convolutions outside a gradient-recording step. Two things these
+modules do differently from the reference's on a HIP device: the convolutions of a training step (`fused_conv.Conv2d`: K8 / K9
+forward and input gradient, K7 weight gradient - every convolution of the BasicBlock ResNets, instead of MIOpen's launches) and
+`relu(bn(x))`: every BatchNorm of the
 pre-activation networks is followed by a ReLU, and that pair runs as the K6 launches of
 `fused_bn.bn_relu` (2 forward + 2 backward per layer instead of 5-9 MIOpen / ATen launches: the
 BatchNorm + ReLU share of a PreResNet-20 training step was 31 % of its kernel time). Host tensors
