@@ -404,7 +404,7 @@ int ursa_conv_wgrad_reduce_f32(const ursa_conv_pending* items, int32_t n, ursa_s
  *                     [Cin', Cout', 3, 3] weight tensor (Cin / Cout below = Cin' / Cout').
  *
  * Contiguous NCHW fp32, x / y 16-byte aligned; w contiguous. One launch; exact fp32 on v_mfma_f32_16x16x4_f32: each output
- * is a few interleaved fma chains over (channel group, tap) - a direct convolution, no Winograd transform. Shapes covered
+ * is four interleaved fma chains over (channel group, tap), added pairwise - a direct convolution, no Winograd transform. Shapes covered
  * (any N, H = W):   stride 1 (Cin, Cout, H): (3, 16, 32) forward only; (16, 16, 32), (32, 32, 16), (64, 64, 8) both forms
  *                   stride 2 forward: (16, 32, 32), (32, 64, 16);   stride 2 flipped (Cin', Cout', H of dy): (32, 16, 16), (64, 32, 8)
  * ursa_conv3x3_supported() says whether a (shape, flags) is covered (otherwise URSA_EVALUE).

@@ -456,7 +456,7 @@ struct Fw {
     static constexpr int need(int p) { return MODE == 0 ? RP * (p + 1) + 1 : MODE == 1 ? 2 * RP * (p + 1) : RP * (p + 1); }
 };
 
-template <int CIN, int COUT_WG, int W, int R, int PH, int MODE>
+template <int CIN, int COUT_WG, int W, int R, int PH, int MODE, int DBG = 0>   // DBG != 0: knobs-build experiments only (what bounds the launch)
 __global__ __launch_bounds__(kThreads) void k_conv3x3(const float* __restrict__ x, const float* __restrict__ w,
                                                        float* __restrict__ y, int N, int Cout, int ipw, int flip_arg) {
     using C = Fw<CIN, COUT_WG, W, R, PH, MODE>;
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3(const float* __restrict__ 
             };
             constexpr int STEPS = C::TPW * C::KG;
             float a[2][C::NA];
-            constexpr int NACC = MODE == 2 ? 4 : 2;            // MODE 2: one per parity class; else two interleaved chains
+            constexpr int NACC = 4;                            // MODE 2: one per parity class; else four interleaved chains
             f32x4 acc[NACC];
 #pragma unroll
             for (int c = 0; c < NACC; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -610,12 +610,16 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3(const float* __restrict__ 
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
+                    if constexpr (DBG == 2) {                  // no matrix work: one VALU add per step keeps the reads alive
+                        if (tap == 0) acc[0].x += a[s & 1][0];
+                        continue;
+                    }
                     if constexpr (MODE == 2) {
                         const int kh = tap / 3, kw = tap % 3;
                         const int cls = (kh != 1) * 2 + (kw != 1), src = (kh == 0) * 2 + (kw == 0);
                         acc[cls] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s & 1][src], wr[g][8 - tap], acc[cls], 0, 0, 0);   // (wr holds w[..][8 - tap])
                     } else {
-                        acc[(g * 9 + tap) & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s & 1][tap], wr[g][tap], acc[(g * 9 + tap) & 1], 0, 0, 0);
+                        acc[(g * 9 + tap) & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s & 1][tap], wr[g][tap], acc[(g * 9 + tap) & 3], 0, 0, 0);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -630,7 +634,9 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3(const float* __restrict__ 
                         *reinterpret_cast<f32x4*>(o0 + 2 * W) = f32x4{acc[2].x, acc[3].x, acc[2].y, acc[3].y};
                         *reinterpret_cast<f32x4*>(o0 + 2 * W + 4) = f32x4{acc[2].z, acc[3].z, acc[2].w, acc[3].w};
                     } else {
-                        *reinterpret_cast<f32x4*>(yo + band * R * W + t * 16 + 4 * k) = acc[0] + acc[1];
+                        const f32x4 out = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+                        if (DBG != 1 || out.x == 12345.678f)   // DBG 1: no stores
+                            *reinterpret_cast<f32x4*>(yo + band * R * W + t * 16 + 4 * k) = out;
                     }
 #pragma unroll
                     for (int c = 0; c < NACC; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -664,6 +670,16 @@ FwPlan fw_plan_for(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, u
     else if (Cin == 3 && Cout == 16 && W == 32) p = {4, 1, 1, k_conv3x3<3, 16, 32, 8, 4, 0>};
     else if (Cin == 32 && Cout == 32 && W == 16) p = {2, 1, 1, k_conv3x3<32, 32, 16, 8, 4, 0>};
     else if (Cin == 64 && Cout == 64 && W == 8) p = {1, 4, 2, k_conv3x3<64, 16, 8, 8, 1, 0>};
+#ifdef URSA_DEBUG_KNOBS
+    if (const char* e = getenv("URSA_CONV_FWD_DBG")) {        // what bounds the launch: 1 = no stores, 2 = no matrix work (wrong results)
+        if (atoi(e) == 1 && Cin == 16 && Cout == 16 && W == 32) p.fn = k_conv3x3<16, 16, 32, 8, 4, 0, 1>;
+        if (atoi(e) == 2 && Cin == 16 && Cout == 16 && W == 32) p.fn = k_conv3x3<16, 16, 32, 8, 4, 0, 2>;
+        if (atoi(e) == 1 && Cin == 32 && Cout == 32 && W == 16) p.fn = k_conv3x3<32, 32, 16, 8, 4, 0, 1>;
+        if (atoi(e) == 2 && Cin == 32 && Cout == 32 && W == 16) p.fn = k_conv3x3<32, 32, 16, 8, 4, 0, 2>;
+        if (atoi(e) == 3 && Cin == 16 && Cout == 16 && W == 32) p = {8, 1, 1, k_conv3x3<16, 16, 32, 4, 2, 0>};    // 1,024 workgroups of 4 rows
+        if (atoi(e) == 4 && Cin == 16 && Cout == 16 && W == 32) p = {16, 1, 1, k_conv3x3<16, 16, 32, 2, 1, 0>};   // 2,048 workgroups of 2 rows
+    }
+#endif
     return p;
 }
 
