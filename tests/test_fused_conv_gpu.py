@@ -359,3 +359,21 @@ def test_every_convolution_of_the_network_takes_a_hand_written_launch():
         for n in seen:
             delattr(k, n)
     assert seen == dict(conv3x3=19 + 18, conv1x1s2=2 + 2, conv_wgrad=21), seen
+
+
+@pytest.mark.parametrize('cin,cout,hw,n', [(16, 16, 32, 300), (32, 32, 16, 500), (64, 64, 8, 1600)])
+def test_large_batches_take_longer_k_slices_and_stay_exact(cin, cout, hw, n):
+    """Beyond 768 K slices K7 gives a workgroup several images (HMC's 1,024-row chunks): the slice count stays bounded and
+    the result - small integers, exact in fp32 - still equals the oracle bit for bit; K8 at the same batch likewise."""
+    k = _native.default_kernels()
+    per_copy = cout * cin * 9
+    slices = k.conv_wgrad_ws_floats((n, cin, hw, hw), cout, 3, 1) // per_copy
+    assert slices <= 768 and slices < k.conv_wgrad_ws_floats((128, cin, hw, hw), cout, 3, 1) // per_copy * n // 128
+    rng = np.random.default_rng(n)
+    x = rng.integers(-2, 3, (n, cin, hw, hw)).astype(np.float32)
+    dy = rng.integers(-2, 3, (n, cout, hw, hw)).astype(np.float32)
+    w = rng.integers(-2, 3, (cout, cin, 3, 3)).astype(np.float32)
+    dx_, ddy, dw_ = (torch.from_numpy(a).to(DEV) for a in (x, dy, w))
+    assert np.array_equal(_k7(dx_, ddy, cout).cpu().numpy(), oracle_lib.conv_wgrad(x, dy, 3, 1))
+    assert np.array_equal(k.conv3x3(dx_, dw_).cpu().numpy(), oracle_lib.conv3x3(x, w))
+    assert np.array_equal(k.conv3x3(ddy, dw_, flip=True).cpu().numpy(), oracle_lib.conv3x3(dy, w, flip=True))

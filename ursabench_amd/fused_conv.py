@@ -148,17 +148,22 @@ class Conv2d(nn.Conv2d):
                 and self.groups == 1 and self.padding_mode == 'zeros' and st == self.stride[1] and w.dtype == torch.float32
                 and x.is_contiguous() and w.is_contiguous() and x.data_ptr() % 16 == 0):
             return super().forward(x)
-        k = _native.default_kernels()
-        N, cin, H, W = x.shape
-        k8, k9 = _k8 and ks == 3 and st in (1, 2), _k8 and ks == 1 and st == 2
-        fwd = (k8 and k.conv3x3_supported(x.shape, self.out_channels, stride=st)) or (k9 and k.conv1x1s2_supported(x.shape, self.out_channels))
         if not (torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)):
             # no gradient recorded (evaluation, the BMA predictive at 4,096 rows): MIOpen's Winograd launch is the faster one at
             # large batches (bench.py bma leg: 23.7 k vs 21.9 k predictions/s) - K8 is for the training step's sizes
             return super().forward(x)
-        bwd = x.requires_grad and ((k8 and k.conv3x3_supported((N, self.out_channels, H // st, W // st), cin, flip=True, stride=st))
-                                   or (k9 and k.conv1x1s2_supported((N, self.out_channels, H // 2, W // 2), cin, flip=True)))
-        ws = k.conv_wgrad_ws_floats(x.shape, self.out_channels, ks, st) if w.requires_grad else 0
+        key = (tuple(x.shape), x.requires_grad, w.requires_grad, _k8)
+        plan = self.__dict__.get('_ursa_plan')
+        if plan is None or plan[0] != key:                     # what the library covers for this call: asked once per shape
+            k = _native.default_kernels()
+            N, cin, H, W = x.shape
+            k8, k9 = _k8 and ks == 3 and st in (1, 2), _k8 and ks == 1 and st == 2
+            fwd = (k8 and k.conv3x3_supported(x.shape, self.out_channels, stride=st)) or (k9 and k.conv1x1s2_supported(x.shape, self.out_channels))
+            bwd = x.requires_grad and ((k8 and k.conv3x3_supported((N, self.out_channels, H // st, W // st), cin, flip=True, stride=st))
+                                       or (k9 and k.conv1x1s2_supported((N, self.out_channels, H // 2, W // 2), cin, flip=True)))
+            ws = k.conv_wgrad_ws_floats(x.shape, self.out_channels, ks, st) if w.requires_grad else 0
+            plan = self.__dict__['_ursa_plan'] = (key, ws, bool(fwd), bool(bwd))
+        _, ws, fwd, bwd = plan
         if not (fwd or bwd or ws):
             return super().forward(x)
         return _Conv.apply(x, w, st, ws, fwd, bwd)
