@@ -594,6 +594,45 @@ def roofline_block(sampler, large_n, group=None):
     return out, large
 
 
+def roofline_conv_block(dev):
+    """The kernel with the largest share of a training step since the convolutions are hand-written: K8 at the 16-channel 3x3
+    layer (12 of a step's 146 launches; K8 as a whole is 36 % of its kernel time, profiles/r05_step_timeline.json). The very
+    launch the step issues (batch 128, [128, 16, 32, 32] in and out), timed with HIP events on its stream over 128-launch graph
+    replays. Bound: the fp32-input matrix pipe - algorithmic flops 2 * N*H*W * Cin*Cout*9 against 157.3 TFLOP/s."""
+    from ursabench_amd import _native
+    K = _native.default_kernels()
+    stream = torch.cuda.current_stream()
+    # eight input / output buffers taken in turn (128 MB in all: beyond the L2s, inside the Infinity Cache - where a step's
+    # activations live when the next launch reads them); one buffer read 128 times over would sit in L2 and read 8.9 us
+    xs = [torch.randn(BATCH, 16, 32, 32, device=dev) for _ in range(8)]
+    ys = [torch.empty_like(xs[0]) for _ in range(8)]
+    w = torch.randn(16, 16, 3, 3, device=dev) * 0.1
+    turn = [0]
+
+    def fn():
+        turn[0] += 1
+        K.conv3x3(xs[turn[0] % 8], w, ys[turn[0] % 8])
+    batches = sorted(event_time_ms(fn, 1024, stream, graph_batch=128) for _ in range(5))
+    ms = batches[2]
+    flops = 2 * BATCH * 32 * 32 * 16 * 16 * 9
+    nbytes = 4 * (2 * xs[0].numel() + w.numel())
+    ach = flops / (ms * 1e-3) / 1e12
+    prof = rocprof_average('k_conv3x3<16, 16, 32, 8, 4, 0')
+    traffic, tsrc = pmc_bytes('k_conv3x3<16, 16, 32')
+    return {'bound': 'mfma', 'kernel': 'k_conv3x3<16, 16, 32, ...> (K8: forward / input gradient of the 16-channel 3x3 layers, batch 128)',
+            'achieved': round(ach, 2), 'peak': MFMA_FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / MFMA_FP32_PEAK_TFLOPS, 4),
+            'flops_per_launch': flops, 'bytes_per_launch': nbytes, 'traffic': traffic, 'traffic_source': tsrc,
+            'us_per_launch': round(ms * 1e3, 3), 'us_per_launch_batches': [round(b * 1e3, 3) for b in batches],
+            'frac_uses': 'us_per_launch (HIP events, measured live in this run, eight operand buffers in turn); frac_rocprof uses the '
+                         'committed profile of this command, whose calls include the step\'s own launches of this kernel',
+            'us_per_launch_rocprof': None if prof is None else prof['us'],
+            'frac_rocprof': None if prof is None else round(flops / (prof['us'] * 1e-6) / 1e12 / MFMA_FP32_PEAK_TFLOPS, 4),
+            'rocprof_source': None if prof is None else f"{prof['file']}: {prof['calls']} launches of this kernel",
+            'share_of_step': 'K8 36 %, K6 32 %, K7 22 % of a step\'s 1,057 us of kernel time (profiles/r05_step_timeline.json); K1 - '
+                             '`roofline_k1` - is one 3.4 us launch per step',
+            'hbm_frac_for_the_record': round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+
+
 def roofline_kernels_block(dev, large_n):
     """Every hand-written kernel's roofline in the driver's own run, HIP events on the launch stream,
     median of 5 batches: K2 / K3 at the WideResNet-28-10 arena (36,546,980 parameters); K4 in exactly the launch forms
@@ -1116,6 +1155,12 @@ def run_c2(a, job, legs, line):
         r = legs.run('roofline', roofline_block, sampler, a.large_n, group)
         if r is not None:
             line['roofline'], line['roofline_large'] = r
+        from ursabench_amd import fused_conv
+        if fused_conv.enabled() and fused_conv.forward_enabled() and kpg == 1:
+            # the dominant kernel of a step is K8 since round 5: it becomes `roofline`; the update launch's object moves to `roofline_k1`
+            rc = legs.run('roofline_conv', roofline_conv_block, dev)
+            if rc is not None:
+                line['roofline_k1'], line['roofline'] = line.get('roofline'), rc
         line['roofline_bma_kernel'] = legs.run('roofline_bma_kernel', bma_kernel_block, max(1, len(ensemble)), N_TEST, CLASSES)
         if world == 1:
             line['roofline_kernels'] = legs.run('roofline_kernels', roofline_kernels_block, dev, a.large_n)
@@ -1371,8 +1416,11 @@ def compact_line(line, detail_path):
             out[k] = line[k]
     r = line.get('roofline')
     if r:
-        out['roofline'] = _pick(r, ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'bytes_per_launch', 'us_per_launch',
-                                    'us_per_launch_rocprof', 'frac_rocprof', 'rocprof_source', 'chains_per_launch'))
+        keys = ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'bytes_per_launch', 'flops_per_launch', 'us_per_launch',
+                'us_per_launch_rocprof', 'frac_rocprof', 'rocprof_source', 'chains_per_launch')
+        out['roofline'] = _pick(r, keys)
+        if line.get('roofline_k1'):
+            out['roofline_k1'] = _pick(line['roofline_k1'], keys)
     if line.get('roofline_large'):
         out['roofline_large'] = _pick(line['roofline_large'], ('kernel', 'elements', 'frac', 'achieved', 'us_per_launch', 'bytes_per_launch', 'traffic'))
     k6 = line.get('roofline_k6')
@@ -1412,7 +1460,7 @@ def compact_line(line, detail_path):
     out['detail'] = detail_path
     # the bound is part of the contract: shed the optional objects, largest first, until the line fits
     for k in ('roofline_kernels_frac', 'multi_chain_per_gpu', 'roofline_k6', 'reference_style_gpu', 'roofline_bma_kernel', 'engine', 'parity',
-              'rccl', 'roofline_large'):
+              'rccl', 'roofline_large', 'roofline_k1'):
         if len(json.dumps(out)) < COMPACT_LIMIT:
             break
         out.pop(k, None)
