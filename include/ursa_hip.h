@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define URSA_ABI_VERSION 6
+#define URSA_ABI_VERSION 7
 
 typedef void* ursa_stream_t; /* hipStream_t */
 
@@ -403,7 +403,7 @@ int ursa_conv_wgrad_reduce_f32(const ursa_conv_pending* items, int32_t n, ursa_s
  *                     (H = W = dy's size), y = dx [N, Cout', s H, s W] with Cout' = its INPUT channels, w = the layer's own
  *                     [Cin', Cout', 3, 3] weight tensor (Cin / Cout below = Cin' / Cout').
  *
- * Contiguous NCHW fp32, x / y 16-byte aligned; w contiguous. One launch; exact fp32 on v_mfma_f32_16x16x4_f32: each output
+ * Contiguous NCHW fp32, x / y / w 16-byte aligned (URSA_EALIGN otherwise; w is read through 16-byte loads); w contiguous. One launch; exact fp32 on v_mfma_f32_16x16x4_f32: each output
  * is four interleaved fma chains over (channel group, tap), added pairwise - a direct convolution, no Winograd transform. Shapes covered
  * (any N, H = W):   stride 1 (Cin, Cout, H): (3, 16, 32) forward only; (16, 16, 32), (32, 32, 16), (64, 64, 8) both forms
  *                   stride 2 forward: (16, 32, 32), (32, 64, 16);   stride 2 flipped (Cin', Cout', H of dy): (32, 16, 16), (64, 32, 8)
@@ -432,6 +432,69 @@ int ursa_conv3x3_f32(const float* x, const float* w, float* y, int64_t N, int64_
 int ursa_conv1x1s2_supported(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, uint32_t flags);
 int ursa_conv1x1s2_f32(const float* x, const float* w, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W,
                        uint32_t flags, ursa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K10  the pre-activation unit of the BasicBlock ResNets, one launch each way      URSABench/models/preresnet.py:33-52
+ *      (`out = bn1(x); relu; conv1; bn2; relu; conv2; out += residual`) and the backward of those ops in `loss.backward()`
+ *      (URSABench/inference/sghmc.py:80).
+ *
+ * ursa_preact_conv3x3_f32 is K8's launch (same arithmetic, same shapes) with up to two things folded in, chosen by flags
+ * (| URSA_CONV_FLIP / URSA_CONV_STRIDE2 as in K8):
+ *   URSA_PREACT_BN     the tensor convolved is relu(bn(x)) in training mode: x's batch statistics arrive as per-channel partial
+ *                      sums in double (in_partial [Cin][in_nl][2] = (sum x, sum x^2), in_nl <= 16: the out_partial of the
+ *                      launch that produced x); every workgroup merges them (K6's tree: the doubles K6's own merge gives) and
+ *                      finishes as K6 does - mean_c = (float)(s1/n), invstd_c = (float)(1/sqrt(s2/n - mean^2 + eps)), alpha_c =
+ *                      invstd_c * gamma_c, beta'_c = fmaf(-mean_c, alpha_c, beta_c), staged value = max(fmaf(x, alpha_c,
+ *                      beta'_c), 0) (NaN stays), padding stays zero - so relu(bn(x)) is never stored. One workgroup also writes
+ *                      bn_save [4][Cin] = mean, invstd, alpha, beta' (what the backward launches take) and, if given, updates
+ *                      running_mean / running_var exactly as ursa_bn_relu_fwd_f32 does.
+ *   URSA_PREACT_STATS  (forward forms; required there) out_partial [Cout][nl][2] receives per-channel (sum, sum of squares)
+ *                      of what is stored to y, in double, as nl <= 16 partial sums: the in_partial of the next unit / of
+ *                      ursa_bn_apply_f32. With URSA_PREACT_ADD what is stored (and summed) is y + aux (`out += residual`;
+ *                      aux: y's shape) - one fp32 add per element, as torch's.
+ *   URSA_PREACT_BNBWD  (with URSA_CONV_FLIP; required there) the launch is the input gradient of the convolution AND the
+ *                      first half of the backward of the BatchNorm + ReLU in front of it: aux = that BatchNorm's input (the
+ *                      result's shape), aux_bn_save = its bn_save; stored to y: g = fmaf(aux, alpha_c, beta'_c) > 0 ? dh : 0
+ *                      (the forward's gate recomputed from its saved scalars, as K6's backward); out_partial [Cout'][nl][2] =
+ *                      (sum g, sum g * (aux - mean_c)) in double. ursa_bn_bwd_dx_f32 finishes: dx, dgamma, dbeta.
+ * Sums are deterministic: every workgroup's per-channel sums go to its own slot of `scratch`, workgroups count themselves out
+ * on one of <= 16 line counters, and the LAST one of a line adds the line's slots in ascending order (a fixed order whatever
+ * the arrival order; nobody waits for a workgroup that is not running). `scratch` (ursa_preact_geometry()[1] bytes, 128-byte
+ * aligned) must be ZERO before its first launch and is zero again when a launch has drained: zero it once, then reuse it for
+ * the same layer and direction (never for two launches that may overlap). A poll that runs out (never in a correct run) raises
+ * the error word in scratch (uint32 at byte offset ursa_preact_geometry()[3]) and makes the sums NaN.
+ * Shapes (any N, H = W): forward stride 1 (Cin, Cout, H): (3, 16, 32) without BN / ADD (the stem); (16, 16, 32), (32, 32, 16),
+ * (64, 64, 8) with BN, with or without ADD; forward stride 2: (16, 32, 32), (32, 64, 16) with BN; flipped (+ BNBWD): the five
+ * input-gradient forms K8 covers. ursa_preact_geometry: out[0] = nl, out[1] = scratch bytes, out[2] = workgroups per channel,
+ * out[3] = byte offset of the error word in scratch; URSA_EVALUE = not covered.
+ * ursa_preact_wgrad_partial_f32: K7's first launch with x = max(fmaf(x, alpha, beta'), 0) taken while the tile is staged
+ * (bn_save of the BatchNorm in front of the layer); same scratch size, same second launch (ursa_conv_wgrad_reduce_f32).
+ * ursa_bn_apply_f32 / ursa_bn_bwd_dx_f32: K6's second launches alone, fed by such partial sums (nl <= 64): the BatchNorm that
+ * ends the network, and the `dx` half of every BatchNorm backward. g is already gated. save: [4][C] as bn_save.
+ * Traffic per unit and direction: the convolution's own (x + y + w) + 4 B x elements of aux; K6's 12 / 20 B per element are gone.
+ */
+#define URSA_PREACT_BN      0x10u
+#define URSA_PREACT_STATS   0x20u
+#define URSA_PREACT_ADD     0x40u
+#define URSA_PREACT_BNBWD   0x80u
+#define URSA_PREACT_ALLFLAGS 0xF3u
+int ursa_preact_geometry(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, uint32_t flags, int64_t* out /* [4] */);
+int ursa_preact_conv3x3_f32(const float* x, const float* w, float* y,
+                            const double* in_partial, int32_t in_nl, const float* gamma, const float* beta,
+                            float* running_mean /* or NULL */, float* running_var /* or NULL */, float* bn_save /* [4][Cin] */,
+                            float eps, float momentum,
+                            const float* aux /* ADD: addend; BNBWD: the BatchNorm input */, const float* aux_bn_save /* BNBWD */,
+                            double* out_partial, void* scratch, int64_t scratch_bytes,
+                            int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, uint32_t flags, ursa_stream_t stream);
+int ursa_preact_wgrad_partial_f32(const float* x, const float* bn_save, const float* dy, float* ws, int64_t ws_floats,
+                                  int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, int32_t stride, ursa_stream_t stream);
+int ursa_bn_apply_f32(const float* x, float* y, const double* partial, int32_t nl, const float* gamma, const float* beta,
+                      float* running_mean /* or NULL */, float* running_var /* or NULL */, float* save /* [4][C] */,
+                      int64_t N, int64_t C, int64_t HW, float eps, float momentum, uint32_t flags /* URSA_BN_RELU */,
+                      ursa_stream_t stream);
+int ursa_bn_bwd_dx_f32(const float* x, const float* g, const float* dz /* or NULL */, float* dx, const float* gamma,
+                       const float* save /* [4][C] */, const double* partial, int32_t nl, float* dgamma, float* dbeta,
+                       int64_t N, int64_t C, int64_t HW, ursa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------ */
 int ursa_abi_version(void);

@@ -555,3 +555,92 @@ int oracle_conv1x1s2_f32(const float* x, const float* w, float* y, int64_t N, in
     }
     return 0;
 }
+
+/* ---------------------------------------------------------------------------------------
+ * K10  the pre-activation unit, restated as the composition of the restatements above     URSABench/models/preresnet.py:33-52
+ *      (`out = self.bn1(x); out = self.relu(out); out = self.conv1(out)` ... `out += residual`) and the backward of those ops.
+ *
+ * forward:  h = bn ? relu(batch_norm(x)) : x  (oracle_bn_relu_fwd_f32: torch's CPU rounding, running statistics updated);
+ *           y = conv3x3(h, w, stride) (oracle_conv3x3_f32) ; addend: y = y + addend (one fp32 add, torch's `out += residual`);
+ *           sums[c] = (sum y, sum y^2) per output channel in double - the statistics the next BatchNorm starts from;
+ *           save [4][Cin] = mean, invstd, alpha = invstd * gamma, beta' = fmaf(-mean, alpha, beta)  (bn only).
+ * h: scratch of x's size (bn only).
+ */
+int oracle_preact_fwd_f32(const float* x, const float* w, const float* addend, float* y, float* h, const float* gamma,
+                          const float* beta, float* running_mean, float* running_var, float* save, double* sums, int64_t N,
+                          int64_t Cin, int64_t Cout, int64_t H, int64_t W, int64_t stride, float eps, float momentum, int bn)
+{
+    const float* in = x;
+    if (bn) {
+        oracle_bn_relu_fwd_f32(x, h, gamma, beta, running_mean, running_var, save, save + Cin, N, Cin, H * W, eps, momentum, 1);
+        for (int64_t c = 0; c < Cin; ++c) {
+            save[2 * Cin + c] = save[Cin + c] * gamma[c];
+            save[3 * Cin + c] = fmaf(-save[c], save[2 * Cin + c], beta[c]);
+        }
+        in = h;
+    }
+    oracle_conv3x3_f32(in, w, y, N, Cin, Cout, H, W, 0, stride);
+    const int64_t OHW = (H / stride) * (W / stride);
+    for (int64_t c = 0; c < Cout; ++c) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int64_t n = 0; n < N; ++n)
+            for (int64_t j = 0; j < OHW; ++j) {
+                const int64_t o = (n * Cout + c) * OHW + j;
+                if (addend) y[o] = y[o] + addend[o];
+                const double d = (double)y[o];
+                s1 += d;
+                s2 += d * d;
+            }
+        sums[2 * c] = s1;
+        sums[2 * c + 1] = s2;
+    }
+    return 0;
+}
+
+/* backward, first half: dh = conv3x3_flip(dy, w, stride) (the layer's input gradient); g = fmaf(xin, alpha, beta') > 0 ? dh : 0
+ * with the forward's saved scalars (threshold_backward on the forward's own gate); sums[c] = (sum g, sum g * (xin - mean)) in
+ * double: the two sums of native_batch_norm_backward. dy: [N, Cd, H, W]; xin, g: [N, Cx, H*stride, W*stride]; save: [4][Cx]. */
+int oracle_preact_bwd_f32(const float* dy, const float* w, const float* xin, const float* save, float* g, double* sums,
+                          int64_t N, int64_t Cd, int64_t Cx, int64_t H, int64_t W, int64_t stride)
+{
+    oracle_conv3x3_f32(dy, w, g, N, Cd, Cx, H, W, 1, stride);
+    const int64_t HW = H * stride * W * stride;
+    for (int64_t c = 0; c < Cx; ++c) {
+        const float mean = save[c], alpha = save[2 * Cx + c], shift = save[3 * Cx + c];
+        double sum = 0.0, dotp = 0.0;
+        for (int64_t n = 0; n < N; ++n)
+            for (int64_t j = 0; j < HW; ++j) {
+                const int64_t o = (n * Cx + c) * HW + j;
+                const float ge = fmaf(xin[o], alpha, shift) > 0.0f ? g[o] : 0.0f;
+                g[o] = ge;
+                sum += (double)ge;
+                dotp += (double)ge * ((double)xin[o] - (double)mean);
+            }
+        sums[2 * c] = sum;
+        sums[2 * c + 1] = dotp;
+    }
+    return 0;
+}
+
+/* backward, second half (native_batch_norm_backward's dx, torch's CPU association, as oracle_bn_relu_bwd_f32 above) from the
+ * gated gradient and its sums; dz (or NULL) = the gradient reaching x on its other path, added last. */
+int oracle_bn_bwd_dx_f32(const float* x, const float* g, const float* dz, float* dx, const float* gamma, const float* save,
+                         const double* sums, float* dgamma, float* dbeta, int64_t N, int64_t C, int64_t HW)
+{
+    const double n = (double)N * (double)HW;
+    for (int64_t c = 0; c < C; ++c) {
+        const float mean = save[c], invstd = save[C + c], w = gamma[c];
+        const double sum = sums[2 * c], dotp = sums[2 * c + 1];
+        const float gm = (float)(sum / n);
+        const float k = (float)(dotp * (double)invstd * (double)invstd / n);
+        for (int64_t i = 0; i < N; ++i)
+            for (int64_t j = 0; j < HW; ++j) {
+                const int64_t o = (i * C + c) * HW + j;
+                const float r = (((g[o] - gm) - (x[o] - mean) * k) * invstd) * w;
+                dx[o] = dz ? dz[o] + r : r;
+            }
+        dbeta[c] = (float)sum;
+        dgamma[c] = (float)(dotp * (double)invstd);
+    }
+    return 0;
+}

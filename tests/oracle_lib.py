@@ -186,3 +186,47 @@ def conv1x1s2(x, w, flip=False):
     rc = _L.oracle_conv1x1s2_f32(_p(x), _p(np.ascontiguousarray(w.reshape(w.shape[0], w.shape[1]))), _p(y), N, Cin, Cout, H, W, int(flip))
     assert rc == 0
     return y
+
+
+_L.oracle_preact_fwd_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _f, _f, _i32]
+_L.oracle_preact_bwd_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64]
+_L.oracle_bn_bwd_dx_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64]
+
+
+def preact_fwd(x, w, *, bn=None, addend=None, stride=1, eps=1e-5, momentum=0.1, running=None):
+    """K10 forward: y = conv3x3(relu(bn(x)), w, stride) (+ addend). bn = (gamma, beta) or None (the stem); running = (mean, var)
+    updated in place. Returns (y, sums float64 [Cout, 2] = (sum y, sum y^2), save [4, Cin] | None)."""
+    N, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    y = np.empty((N, Cout, H // stride, W // stride), np.float32)
+    sums = np.empty((Cout, 2), np.float64)
+    save = np.empty((4, Cin), np.float32) if bn is not None else None
+    h = np.empty_like(x) if bn is not None else None
+    gamma, beta = bn if bn is not None else (None, None)
+    rm, rv = running if running is not None else (None, None)
+    rc = _L.oracle_preact_fwd_f32(_p(x), _p(w), _p(addend), _p(y), _p(h), _p(gamma), _p(beta), _p(rm), _p(rv), _p(save), sums.ctypes.data,
+                                  N, Cin, Cout, H, W, stride, eps, momentum, int(bn is not None))
+    assert rc == 0
+    return y, sums, save
+
+
+def preact_bwd(dy, w, xin, save, *, stride=1):
+    """K10 backward, first half: (g, sums float64 [Cx, 2]) - the gated input gradient and (sum g, sum g * (xin - mean))."""
+    N, Cd, H, W = dy.shape
+    Cx = xin.shape[1]
+    assert xin.shape == (N, Cx, H * stride, W * stride) and w.shape == (Cd, Cx, 3, 3) and save.shape == (4, Cx)
+    g = np.empty_like(xin)
+    sums = np.empty((Cx, 2), np.float64)
+    rc = _L.oracle_preact_bwd_f32(_p(dy), _p(w), _p(xin), _p(save), _p(g), sums.ctypes.data, N, Cd, Cx, H, W, stride)
+    assert rc == 0
+    return g, sums
+
+
+def bn_bwd_dx(x, g, gamma, save, sums, dz=None):
+    """K10 backward, second half: (dx, dgamma, dbeta) from the gated gradient and its sums."""
+    N, C, HW = _bn_dims(x)
+    dx, dg, db = np.empty_like(x), np.empty(C, np.float32), np.empty(C, np.float32)
+    rc = _L.oracle_bn_bwd_dx_f32(_p(x), _p(g), _p(dz), _p(dx), _p(gamma), _p(save), np.ascontiguousarray(sums).ctypes.data, _p(dg), _p(db),
+                                 N, C, HW)
+    assert rc == 0
+    return dx, dg, db

@@ -249,6 +249,18 @@ def test_k8_is_bit_reproducible_and_checks_its_operands():
         k.conv3x3(torch.randn(2, 16, 32, 32, device=DEV), torch.randn(32, 16, 3, 3, device=DEV))
     with pytest.raises(ValueError, match='should be'):
         k.conv3x3(x, w, torch.empty(128, 32, 16, 8, device=DEV))
+    # a weight view at storage offset 1 (4-byte aligned only): K8 reads w through 16-byte loads, so the library refuses it
+    # (URSA_EALIGN) and the module takes the stock launch for it - same values to rounding
+    w_odd = torch.empty(w.numel() + 1, device=DEV)[1:].view_as(w).copy_(w)
+    assert w_odd.data_ptr() % 16 == 4 and w_odd.is_contiguous()
+    with pytest.raises(ValueError, match='ursa error -3'):
+        k.conv3x3(x, w_odd)
+    conv = fused_conv.Conv2d(32, 32, 3, 1, 1, bias=False).to(DEV)
+    conv.weight = nn.Parameter(w_odd)
+    xg = x.clone().requires_grad_()
+    y = conv(xg)
+    assert conv.__dict__.get('_ursa_plan') is None, 'an odd-offset weight must not reach K8'
+    assert torch.allclose(y, k.conv3x3(x, w), rtol=1e-4, atol=1e-4)
 
 
 def test_network_forward_and_gradients_k8_vs_stock_vs_cpu():
@@ -337,10 +349,14 @@ def test_k8_stride2_equals_the_oracle(cin, cout, hw, n):
                           oracle_lib.conv3x3(di, wi, flip=True, stride=2))
 
 
-def test_every_convolution_of_the_network_takes_a_hand_written_launch():
-    """PreResNet-20 training step with gradients recorded: no MIOpen convolution launch is left."""
+@pytest.mark.parametrize('k10', [False, True])
+def test_every_convolution_of_the_network_takes_a_hand_written_launch(k10):
+    """PreResNet-20 training step with gradients recorded: no MIOpen convolution launch is left - with the K6 / K8 launches
+    (fused_block off: 19 + 18 K8, 21 K7) and with K10's (19 + 18 fused launches; the 18 weight gradients behind a BatchNorm by the
+    staging form, the stem's and the two 1x1 shortcuts' by the plain one)."""
+    from ursabench_amd import fused_block
     k = _native.default_kernels()
-    seen = dict(conv3x3=0, conv1x1s2=0, conv_wgrad=0)
+    seen = dict(conv3x3=0, conv1x1s2=0, conv_wgrad=0, conv_wgrad_partial=0, preact_conv3x3=0, preact_wgrad_partial=0)
     origs = {n: getattr(k, n) for n in seen}
 
     def wrap(name):
@@ -350,15 +366,20 @@ def test_every_convolution_of_the_network_takes_a_hand_written_launch():
         return f
     for n in seen:
         setattr(k, n, wrap(n))
+    old = fused_block.enabled(k10)
     try:
         torch.manual_seed(0)
         net = models.PreResNet(10, 20).to(DEV).train()
         x, y = torch.randn(16, 3, 32, 32, device=DEV), torch.randint(0, 10, (16,), device=DEV)
         _grads(net, x, y)
     finally:
+        fused_block.enabled(old)
         for n in seen:
             delattr(k, n)
-    assert seen == dict(conv3x3=19 + 18, conv1x1s2=2 + 2, conv_wgrad=21), seen
+    if k10:
+        assert seen == dict(conv3x3=0, conv1x1s2=2 + 2, conv_wgrad=2, conv_wgrad_partial=1, preact_conv3x3=19 + 18, preact_wgrad_partial=18), seen
+    else:
+        assert seen == dict(conv3x3=19 + 18, conv1x1s2=2 + 2, conv_wgrad=21, conv_wgrad_partial=0, preact_conv3x3=0, preact_wgrad_partial=0), seen
 
 
 @pytest.mark.parametrize('cin,cout,hw,n', [(16, 16, 32, 300), (32, 32, 16, 500), (64, 64, 8, 1600)])

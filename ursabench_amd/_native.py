@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libursa_hip.so')
 KNOBS_LIB_PATH = os.path.join(_HERE, 'csrc', 'libursa_hip_knobs.so')   # -DURSA_DEBUG_KNOBS build: tests / tools only
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # flags (mirror include/ursa_hip.h)
 STEP_NOISE, STEP_FIRST, STEP_ZERO_GRAD, STEP_WD, STEP_SGD, STEP_ADVANCE = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
@@ -27,6 +27,7 @@ LEAP_KICK, LEAP_DRIFT = 0x1, 0x2
 REDUCE_WS_FLOATS = 2048
 BN_RELU, BN_TWO_LAUNCH, BN_HELD = 0x1, 0x2, 0x4
 CONV_FLIP, CONV_STRIDE2 = 0x1, 0x2
+PREACT_BN, PREACT_STATS, PREACT_ADD, PREACT_BNBWD = 0x10, 0x20, 0x40, 0x80
 
 
 def bn_ws_floats(channels):
@@ -40,6 +41,7 @@ BMA_MAX_CLASSES = 1024
 
 _vp, _i64, _i32, _u64, _u32, _f = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_uint64,
                                    ctypes.c_uint32, ctypes.c_float)
+_i64p = ctypes.POINTER(ctypes.c_int64)
 
 #: every symbol include/ursa_hip.h declares, with its ctypes signature
 SIGNATURES = {
@@ -71,6 +73,12 @@ SIGNATURES = {
     'ursa_conv3x3_f32': (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _u32, _vp]),
     'ursa_conv1x1s2_supported': (ctypes.c_int, [_i64, _i64, _i64, _i64, _i64, _u32]),
     'ursa_conv1x1s2_f32': (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _u32, _vp]),
+    'ursa_preact_geometry': (ctypes.c_int, [_i64, _i64, _i64, _i64, _i64, _u32, _i64p]),
+    'ursa_preact_conv3x3_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _i64,
+                                               _i64, _i64, _i64, _i64, _i64, _u32, _vp]),
+    'ursa_preact_wgrad_partial_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp]),
+    'ursa_bn_apply_f32': (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f, _f, _u32, _vp]),
+    'ursa_bn_bwd_dx_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i64, _i64, _i64, _vp]),
 }
 
 
@@ -560,6 +568,122 @@ class HipKernels:
                                              CONV_FLIP if flip else 0, _stream(dev))
         _check(self.lib, rc, 'ursa_conv1x1s2_f32')
         return y
+
+
+    # K10 -----------------------------------------------------------------------------
+    def preact_geometry(self, x_shape, cout, *, flip=False, stride=1, bn=False, add=False):
+        """(nl, scratch bytes, workgroups per channel, byte offset of the error word) of the K10 launch over an input of `x_shape` ([N, Cin, H, W]) to `cout`
+        channels, or None when the library does not cover it. Forward forms leave the statistics of their output (bn: the
+        BatchNorm + ReLU in front of the convolution folded in; add: `out += residual` folded in); flip: the input gradient
+        with the BatchNorm backward's sums (x_shape = the output gradient's shape, cout = the layer's input channels)."""
+        n, cin, h, w = (int(v) for v in x_shape)
+        out = (ctypes.c_int64 * 4)()
+        rc = self.lib.ursa_preact_geometry(n, cin, int(cout), h, w, self._preact_flags(flip, stride, bn, add), out)
+        if rc == -5:
+            return None
+        _check(self.lib, rc, 'ursa_preact_geometry')
+        return int(out[0]), int(out[1]), int(out[2]), int(out[3])
+
+    def _preact_flags(self, flip, stride, bn, add):
+        fl = self._conv_flags(flip, stride)
+        if flip:
+            return fl | PREACT_BNBWD
+        return fl | PREACT_STATS | (PREACT_BN if bn else 0) | (PREACT_ADD if add else 0)
+
+    @staticmethod
+    def _f64ptr(t, name, n, dev):
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.device == dev and t.dtype == torch.float64 and t.is_contiguous()
+                and t.numel() == n):
+            raise ValueError(f'{name} must be a contiguous float64 tensor of {n} elements on {dev}')
+        return t.data_ptr()
+
+    @staticmethod
+    def _scratch_ptr(t, need, dev):
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.device == dev and t.dtype == torch.uint8 and t.is_contiguous()
+                and t.numel() >= need and t.data_ptr() % 128 == 0):
+            raise ValueError(f'scratch must be a contiguous 128-byte aligned uint8 tensor of >= {need} bytes on {dev} (zeroed once)')
+        return t.data_ptr()
+
+    def preact_conv3x3(self, x, w, y, out_partial, scratch, *, stride=1, flip=False, bn=None, add=None, bwd=None):
+        """One K10 launch (include/ursa_hip.h). bn = (in_partial [Cin, in_nl, 2] float64, gamma, beta, running_mean | None,
+        running_var | None, bn_save [4, Cin], eps, momentum): convolve relu(bn(x)); add = the tensor added to the result before it is
+        stored and summed; bwd = (bn_input, bn_save [4, C]) with flip=True: the gated input gradient and the BatchNorm backward's
+        sums. out_partial: float64 [Cout, nl, 2]; scratch: uint8, zeroed once, private to this layer and direction."""
+        if x.dim() != 4 or w.dim() != 4 or tuple(w.shape[2:]) != (3, 3) or w.shape[0 if flip else 1] != x.shape[1]:
+            raise ValueError(f'not a 3x3 convolution: x {tuple(x.shape)}, w {tuple(w.shape)}, flip={flip}')
+        if flip != (bwd is not None) or (flip and (bn is not None or add is not None)):
+            raise ValueError('flip goes with bwd and excludes bn / add')
+        N, Cin, H, W = x.shape
+        Cout = w.shape[1 if flip else 0]
+        dev = x.device
+        shape = (N, Cout, H * stride, W * stride) if flip else (N, Cout, H // stride, W // stride)
+        if tuple(y.shape) != shape:
+            raise ValueError(f'y {tuple(y.shape)} should be {shape}')
+        geo = self.preact_geometry(x.shape, Cout, flip=flip, stride=stride, bn=bn is not None, add=add is not None)
+        if geo is None:
+            raise ValueError(f'K10 does not cover x {tuple(x.shape)} -> {Cout} channels (flip={flip}, stride={stride}, bn={bn is not None}, add={add is not None})')
+        nl, sbytes = geo[:2]
+        ny = y.numel()
+        if bn is not None:
+            ip, gamma, beta, rm, rv, save, eps, mom = bn
+            if ip.dim() != 3 or ip.shape[0] != Cin or ip.shape[2] != 2:
+                raise ValueError(f'in_partial {tuple(ip.shape)} should be [{Cin}, nl, 2]')
+            bnargs = (self._f64ptr(ip, 'in_partial', ip.numel(), dev), int(ip.shape[1]), _ptr(gamma, 'gamma', Cin, dev), _ptr(beta, 'beta', Cin, dev),
+                      _ptr(rm, 'running_mean', Cin, dev, optional=True), _ptr(rv, 'running_var', Cin, dev, optional=True),
+                      _ptr(save, 'bn_save', 4 * Cin, dev), float(eps), float(mom))
+        else:
+            bnargs = (None, 0, None, None, None, None, None, 0.0, 0.0)
+        aux = aux_save = None
+        if add is not None:
+            aux = _ptr(add, 'addend', ny, dev)
+        if bwd is not None:
+            aux, aux_save = _ptr(bwd[0], 'bn input', ny, dev), _ptr(bwd[1], 'bn_save', 4 * Cout, dev)
+        with torch.cuda.device(dev):
+            rc = self.lib.ursa_preact_conv3x3_f32(_ptr(x, 'x'), _ptr(w, 'w', None, dev), _ptr(y, 'y', None, dev), *bnargs, aux, aux_save,
+                                                  self._f64ptr(out_partial, 'out_partial', Cout * nl * 2, dev),
+                                                  self._scratch_ptr(scratch, sbytes, dev), scratch.numel(), N, Cin, Cout, H, W,
+                                                  self._preact_flags(flip, stride, bn is not None, add is not None), _stream(dev))
+        _check(self.lib, rc, 'ursa_preact_conv3x3_f32')
+        return y
+
+    def preact_wgrad_partial(self, x, bn_save, dy, dw_shape, ws, stride=1):
+        """K7's first launch with the x operand = relu(bn(x)) rebuilt from bn_save while staged; returns conv_wgrad_reduce's record."""
+        N, Cin, Cout, H, W, ksize = self._conv_dims(x, dy, dw_shape, stride)
+        if ksize != 3:
+            raise ValueError('the fused form is for the 3x3 layers')
+        dev = x.device
+        with torch.cuda.device(dev):
+            rc = self.lib.ursa_preact_wgrad_partial_f32(_ptr(x, 'x'), _ptr(bn_save, 'bn_save', 4 * Cin, dev), _ptr(dy, 'dy', None, dev),
+                                                        _ptr(ws, 'ws', None, dev), ws.numel(), N, Cin, Cout, H, W, int(stride), _stream(dev))
+        _check(self.lib, rc, 'ursa_preact_wgrad_partial_f32')
+        return (ws, N, Cin, Cout, H, W, ksize, int(stride))
+
+    def bn_apply(self, x, y, partial, gamma, beta, running_mean, running_var, save, *, eps, momentum, relu=True):
+        """K6's normalise launch alone, statistics from a convolution launch's partial sums (float64 [C, nl, 2])."""
+        N, C, HW = self._bn_dims(x)
+        dev = x.device
+        if partial.dim() != 3 or partial.shape[0] != C or partial.shape[2] != 2:
+            raise ValueError(f'partial {tuple(partial.shape)} should be [{C}, nl, 2]')
+        with torch.cuda.device(dev):
+            rc = self.lib.ursa_bn_apply_f32(_ptr(x, 'x'), _ptr(y, 'y', x.numel(), dev), self._f64ptr(partial, 'partial', partial.numel(), dev),
+                                            int(partial.shape[1]), _ptr(gamma, 'gamma', C, dev), _ptr(beta, 'beta', C, dev),
+                                            _ptr(running_mean, 'running_mean', C, dev, optional=True),
+                                            _ptr(running_var, 'running_var', C, dev, optional=True), _ptr(save, 'save', 4 * C, dev),
+                                            N, C, HW, float(eps), float(momentum), BN_RELU if relu else 0, _stream(dev))
+        _check(self.lib, rc, 'ursa_bn_apply_f32')
+
+    def bn_bwd_dx(self, x, g, dx, gamma, save, partial, dgamma, dbeta, *, dz=None):
+        """K6's dx launch alone: g is the gated output gradient, partial (float64 [C, nl, 2]) its sums from the K10 launch."""
+        N, C, HW = self._bn_dims(x)
+        dev, n = x.device, x.numel()
+        if partial.dim() != 3 or partial.shape[0] != C or partial.shape[2] != 2:
+            raise ValueError(f'partial {tuple(partial.shape)} should be [{C}, nl, 2]')
+        with torch.cuda.device(dev):
+            rc = self.lib.ursa_bn_bwd_dx_f32(_ptr(x, 'x'), _ptr(g, 'g', n, dev), _ptr(dz, 'dz', n, dev, optional=True), _ptr(dx, 'dx', n, dev),
+                                             _ptr(gamma, 'gamma', C, dev), _ptr(save, 'save', 4 * C, dev),
+                                             self._f64ptr(partial, 'partial', partial.numel(), dev), int(partial.shape[1]),
+                                             _ptr(dgamma, 'dgamma', C, dev), _ptr(dbeta, 'dbeta', C, dev), N, C, HW, _stream(dev))
+        _check(self.lib, rc, 'ursa_bn_bwd_dx_f32')
 
 
 def knobs_kernels():

@@ -1732,4 +1732,58 @@ int ursa_bn_relu_bwd_gated_f32(const float* x, const float* dy, const float* dz,
     return bn_bwd_impl(x, dy, dz, dx, nullptr, gamma, beta, save_mean, save_invstd, gate, dgamma, dbeta, ws, N, C, HW, flags, &gt, stream);
 }
 
+// ---- K10's ends of a chain of fused units: K6's SECOND launches alone, fed by partial sums that a convolution launch left
+//      (ursa_preact_conv3x3_f32: `partial` = its out_partial, [C][nl] pairs of doubles, nl <= 16) ------------------------------
+// forward: merge + normalise (+ ReLU) + running statistics; save: [4][C] = mean, invstd, alpha, beta' (K10's bn_save layout)
+int ursa_bn_apply_f32(const float* x, float* y, const double* partial, int32_t nl, const float* gamma, const float* beta,
+                      float* running_mean, float* running_var, float* save, int64_t N, int64_t C, int64_t HW, float eps,
+                      float momentum, uint32_t flags, ursa_stream_t stream)
+{
+    if (flags & ~URSA_BN_RELU) return URSA_EFLAGS;
+    if (N <= 0 || C <= 0 || HW <= 0) return URSA_ESIZE;
+    if (!x || !y || !partial || !gamma || !beta || !save) return URSA_ENULL;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return URSA_ENULL;
+    if (nl < 1 || nl > kBnMaxSplit) return URSA_ESIZE;
+    if (!bn_aligned4(x) || !bn_aligned4(y) || !bn_aligned4(save) || !bn_aligned16(partial)) return URSA_EALIGN;
+    if (N * HW < 2) return URSA_EVALUE;
+    BnPlan p;
+    const int rc = bn_plan(N, C, HW, bn_aligned16(x) && bn_aligned16(y), &p);
+    if (rc) return rc;
+    p.g.gate_out = save + 2 * C;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid = p.g.cfirst ? dim3(p.g.C, p.S) : dim3(p.S, p.g.C), block(kBnBlock);
+    const double2* part = reinterpret_cast<const double2*>(partial);
+#define URSA_BN_APPLY(V, R) hipLaunchKernelGGL((k_bn_fwd_apply<V, R>), grid, block, 0, st, x, y, part, (int)nl, gamma, beta, running_mean, \
+                                               running_var, save, save + C, eps, momentum, p.g)
+    if (p.V == 4) { if (flags & URSA_BN_RELU) URSA_BN_APPLY(4, true); else URSA_BN_APPLY(4, false); }
+    else          { if (flags & URSA_BN_RELU) URSA_BN_APPLY(1, true); else URSA_BN_APPLY(1, false); }
+#undef URSA_BN_APPLY
+    return bn_launch_status();
+}
+
+// backward: dx = (((g - gm) - (x - mean) * k) * invstd) * gamma (+ dz), dgamma, dbeta from the merged sums; g = the ALREADY
+// gated output gradient (ursa_preact_conv3x3_f32 with URSA_PREACT_BNBWD stored it), so no gate is recomputed here
+int ursa_bn_bwd_dx_f32(const float* x, const float* g, const float* dz, float* dx, const float* gamma, const float* save,
+                       const double* partial, int32_t nl, float* dgamma, float* dbeta, int64_t N, int64_t C, int64_t HW,
+                       ursa_stream_t stream)
+{
+    if (N <= 0 || C <= 0 || HW <= 0) return URSA_ESIZE;
+    if (!x || !g || !dx || !gamma || !save || !partial || !dgamma || !dbeta) return URSA_ENULL;
+    if (nl < 1 || nl > kBnMaxSplit) return URSA_ESIZE;
+    if (!bn_aligned4(x) || !bn_aligned4(g) || !bn_aligned4(dz) || !bn_aligned4(dx) || !bn_aligned4(save) || !bn_aligned16(partial)) return URSA_EALIGN;
+    BnPlan p;
+    const int rc = bn_plan(N, C, HW, bn_aligned16(x) && bn_aligned16(g) && bn_aligned16(dz) && bn_aligned16(dx), &p);
+    if (rc) return rc;
+    p.g.gate_in = save + 2 * C;                                  // (not read without RELU; keeps beta out of the launch)
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid = p.g.cfirst ? dim3(p.g.C, p.S) : dim3(p.S, p.g.C), block(kBnBlock);
+    const double2* part = reinterpret_cast<const double2*>(partial);
+#define URSA_BN_DX(V, RES) hipLaunchKernelGGL((k_bn_bwd_dx<V, false, RES>), grid, block, 0, st, x, g, dz, dx, gamma, (const float*)nullptr, save, \
+                                              save + C, part, (int)nl, dgamma, dbeta, p.g, BnGates{})
+    if (p.V == 4) { if (dz) URSA_BN_DX(4, true); else URSA_BN_DX(4, false); }
+    else          { if (dz) URSA_BN_DX(1, true); else URSA_BN_DX(1, false); }
+#undef URSA_BN_DX
+    return bn_launch_status();
+}
+
 }  // extern "C"

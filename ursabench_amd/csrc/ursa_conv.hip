@@ -34,6 +34,140 @@ constexpr int kThreads = 256;
 constexpr int pitch64p4(int n) { return ((n - 4 + 63) / 64) * 64 + 4; }
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// K10 (fused pre-activation unit, below): what K8 / K7 are told when the BatchNorm + ReLU that precedes a convolution
+// (URSABench/models/preresnet.py:40-42,45-47) is applied while the input tile is staged, and the statistics the NEXT
+// BatchNorm needs - or the two sums its backward needs - are taken from the accumulators before they are stored.
+typedef unsigned long long u64;
+typedef u64 __attribute__((address_space(1))) gu64;
+typedef unsigned int __attribute__((address_space(1))) gu32;
+constexpr int kLines = 16;                  // most partial sums per channel a consumer merges (one 16-lane DPP row)
+constexpr u64 kSlotXor = 0xFFF8DEADBEEF0001ull;   // a NaN payload no sum of floats has: a published word is never zero
+constexpr unsigned kPollLimit = 1u << 20;
+
+struct Fuse {
+    // PRO: y = conv(relu(bn(x))): the batch statistics of x arrive as per-line partial sums (sum x, sum x^2 in double)
+    const double2* in_partial;              // [CIN][in_nl]
+    const float* gamma;                     // [CIN]
+    const float* beta;
+    float* running_mean;                    // or null
+    float* running_var;
+    float* save;                            // [4][CIN]: mean, invstd, alpha = invstd * gamma, beta' = fma(-mean, alpha, beta)
+    double in_count;                        // N * H * W of x
+    float eps, momentum;
+    int in_nl;
+    // EPI
+    int nl;                                 // lines = partial sums per output channel this launch leaves in out_partial
+    int line_sz;                            // workgroups (grid.x indices) per line
+    const float* aux;                       // EPI 2: the addend (shape of y); EPI 3: the BatchNorm input at y's positions
+    const float* bsave;                     // EPI 3: [4][Cout] of that BatchNorm (mean, invstd, alpha, beta')
+    u64* slots;                             // [Cout][grid.x][2]: zero at launch, zero again when the launch has drained
+    double2* out_partial;                   // [Cout][nl]
+    unsigned int* tickets;                  // [grid.y][kLines][32]: one counter per 128-byte line, zero at launch and afterwards
+    unsigned int* err;                      // sticky: a bounded poll ran out (never in a correct run); the sums are NaN then
+};
+
+// sum of a double over the 16 lanes of a DPP row, the same bits in all 16, fixed tree (the first four steps of K6's
+// bn_wave_sum: merging <= 16 partial sums here gives the doubles K6's own merge gives for the same 16 numbers)
+__device__ __forceinline__ double row_sum16(double v)
+{
+#define URSA_ROW_DPP64(CTRL) do { \
+        const long long b_ = __builtin_bit_cast(long long, v); \
+        const int lo_ = __builtin_amdgcn_update_dpp(0, (int)(b_ & 0xffffffffll), CTRL, 0xF, 0xF, true); \
+        const int hi_ = __builtin_amdgcn_update_dpp(0, (int)(b_ >> 32), CTRL, 0xF, 0xF, true); \
+        v += __builtin_bit_cast(double, ((long long)hi_ << 32) | (unsigned int)lo_); } while (0)
+    URSA_ROW_DPP64(0xB1);
+    URSA_ROW_DPP64(0x4E);
+    URSA_ROW_DPP64(0x141);
+    URSA_ROW_DPP64(0x140);
+#undef URSA_ROW_DPP64
+    return v;
+}
+
+__device__ __forceinline__ float relu_nan(float v) { return v < 0.f ? 0.f : v; }   // NaN stays NaN (K6's bn_relu_fwd)
+__device__ __forceinline__ f32x4 bn_relu4(const f32x4& v, float scale, float shift)
+{
+    return f32x4{relu_nan(fmaf(v.x, scale, shift)), relu_nan(fmaf(v.y, scale, shift)), relu_nan(fmaf(v.z, scale, shift)),
+                 relu_nan(fmaf(v.w, scale, shift))};
+}
+
+// End of a launch that leaves per-channel sums (EPI): every thread holds (s1, s2) of ITS output channel (channel
+// co_base + 16 * (wave % MT) + (lane & 15)); the workgroup's sums go to its slot, a ticket on its line's counter tells the
+// last workgroup of the line that all of them are there, and that one adds the line's slots in ascending order and stores
+// the line's partial sum. No atomics on the data, no spinning on workgroups that may not be running: a fixed summation
+// order whatever the arrival order. The words travel as agent-scope atomic stores / loads (they bypass the non-coherent
+// per-XCD L2 lines) XORed with a NaN payload, so a zero word means "not there yet"; the ticket is taken after
+// s_waitcnt vmcnt(0), and the reader still polls (bounded) - belt and braces.
+template <int COUT_WG, int MT, int WPC>
+__device__ __forceinline__ void publish_sums(const Fuse& f, double s1, double s2, float* smem, int co_base, int Cout)
+{
+    const int tid = threadIdx.x;
+    __shared__ int fin;
+    __syncthreads();                                           // every wave is done with the tile: reuse it
+    double2* red = reinterpret_cast<double2*>(smem);
+    red[tid] = make_double2(s1, s2);
+    __syncthreads();
+    const int S = gridDim.x, tile = blockIdx.x, line = tile / f.line_sz;
+    if (tid < 64) {
+        if (tid < COUT_WG) {
+            const int cc = tid >> 4, jj = tid & 15;
+            double a = 0.0, b = 0.0;
+#pragma unroll
+            for (int ws = 0; ws < WPC; ++ws)
+#pragma unroll
+                for (int kq = 0; kq < 4; ++kq) {
+                    const double2 v = red[(cc + MT * ws) * 64 + kq * 16 + jj];
+                    a += v.x;
+                    b += v.y;
+                }
+            gu64* sl = (gu64*)(f.slots + ((size_t)(co_base + tid) * S + tile) * 2);
+            __hip_atomic_store(sl, __builtin_bit_cast(u64, a) ^ kSlotXor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sl + 1, __builtin_bit_cast(u64, b) ^ kSlotXor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) {
+            const int first = line * f.line_sz;
+            const int quota = S - first < f.line_sz ? S - first : f.line_sz;
+            gu32* tp = (gu32*)(f.tickets + ((size_t)blockIdx.y * kLines + line) * 32);
+            const unsigned t = __hip_atomic_fetch_add(tp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            fin = t == (unsigned)quota - 1u;
+            if (fin) __hip_atomic_store(tp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
+        }
+    }
+    __syncthreads();
+    if (!fin) return;
+    const int first = line * f.line_sz;
+    const int cnt = S - first < f.line_sz ? S - first : f.line_sz;
+    for (int e = tid; e < COUT_WG * 16; e += kThreads) {       // (channel, lane of its row): COUT_WG * 16 is a multiple of 256
+        const int c = e >> 4, i = e & 15;
+        double a = 0.0, b = 0.0;
+        bool bad = false;
+        for (int t = i; t < cnt; t += 16) {                   // this lane's slots, ascending
+            gu64* sl = (gu64*)(f.slots + ((size_t)(co_base + c) * S + first + t) * 2);
+            u64 wa, wb;
+            unsigned spins = 0;
+            for (;;) {
+                wa = __hip_atomic_load(sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                wb = __hip_atomic_load(sl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (wa != 0 && wb != 0) break;
+                if (++spins > kPollLimit) { bad = true; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            a += __builtin_bit_cast(double, wa ^ kSlotXor);
+            b += __builtin_bit_cast(double, wb ^ kSlotXor);
+            __hip_atomic_store(sl, (u64)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sl + 1, (u64)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (bad) {
+            a = b = __builtin_nan("");
+            __hip_atomic_store((gu32*)f.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        a = row_sum16(a);
+        b = row_sum16(b);
+        if (i == 0) f.out_partial[(size_t)(co_base + c) * f.nl + line] = make_double2(a, b);
+    }
+}
+
 // CIN: input channels (all staged; padded to a multiple of 16 by one zero plane); COUT_WG: output channels one workgroup takes
 // (grid.y covers the rest); WO: output width = height; R: output rows per band (grid.x = bands x image groups); STRIDE 1 / 2;
 // TAPS 9 (3x3, pad 1) or 1 (the centre tap alone: 1x1, pad 0, at STRIDE 2); PH: phases per tile (see the kernel).
@@ -63,10 +197,15 @@ struct Wg {
     static_assert(SMEM * 4 <= 64 * 1024, "static LDS");
 };
 
-template <int CIN, int COUT_WG, int WO, int R, int STRIDE, int TAPS, int PH>
+// XBN: the x operand is relu(fma(x, alpha[ci], beta'[ci])) - the BatchNorm + ReLU that stands in front of the layer (K10),
+// applied as the tile is staged from the scale / shift the forward saved (xbn: [4][CIN], rows 2 and 3), so the normalised
+// activation is never stored; the padding stays zero.
+template <int CIN, int COUT_WG, int WO, int R, int STRIDE, int TAPS, int PH, bool XBN = false>
 __global__ __launch_bounds__(kThreads) void k_conv_wgrad(const float* __restrict__ x, const float* __restrict__ dy,
-                                                          float* __restrict__ partial, int N, int Cout, int ipw) {
+                                                          float* __restrict__ partial, int N, int Cout, int ipw,
+                                                          const float* __restrict__ xbn) {
     using C = Wg<CIN, COUT_WG, WO, R, STRIDE, TAPS, PH>;
+    static_assert(!XBN || kThreads % (CIN * (C::WI / 4)) == 0, "XBN: a thread stages one channel");
     __shared__ __attribute__((aligned(16))) float smem[C::SMEM];
     float* xs = smem;
     float* ds = smem + C::XS;
@@ -89,6 +228,12 @@ __global__ __launch_bounds__(kThreads) void k_conv_wgrad(const float* __restrict
     const int cot = pair / C::CT, cit = pair % C::CT;
     const int c = lane & 15, g = lane >> 4;
     const int xplane = (cit * 16 + c < CIN) ? cit * 16 + c : CIN;      // padded channels read the zero plane
+    float xb_scale = 0.f, xb_shift = 0.f;                      // XBN: this thread's staged channel is the same for every chunk
+    if constexpr (XBN) {
+        const int ci_t = (tid / (C::WI / 4)) % CIN;
+        xb_scale = xbn[2 * CIN + ci_t];
+        xb_shift = xbn[3 * CIN + ci_t];
+    }
 
     // One image's tiles in PH phases of RP output rows. Every thread's global loads are issued together, in the order the
     // phases need them (row-major chunks of 256 float4: x rows first needed by phase p, then dy rows of phase p); phase p stages
@@ -146,7 +291,8 @@ __global__ __launch_bounds__(kThreads) void k_conv_wgrad(const float* __restrict
             const int ih = band * R * STRIDE - 1 + r;
             const bool in = ih >= 0 && ih < C::WI;
             if (XV % kThreads == 0 || idx < XV)
-                *reinterpret_cast<f32x4*>(xs + ci * C::XPLANE + r * C::WP + 4 + 4 * c4) = in ? vx[k] : f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(xs + ci * C::XPLANE + r * C::WP + 4 + 4 * c4) =
+                    in ? (XBN ? bn_relu4(vx[k], xb_scale, xb_shift) : vx[k]) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int k = 0; k < ND; ++k) {
@@ -292,30 +438,32 @@ struct Plan {
     int ipw;          // images per workgroup
     int taps;
     int64_t E;        // floats of one partial copy
-    void (*fn)(const float*, const float*, float*, int, int, int);
+    void (*fn)(const float*, const float*, float*, int, int, int, const float*);
 };
 
 // Which shapes K7 takes: every convolution of the CIFAR pre-activation ResNets with BasicBlocks
 // (URSABench/models/preresnet.py:25-27,100,130-136): the three stages' 3x3 / stride 1 layers, the stem (3 -> 16), the two
 // 3x3 / stride 2 layers that open stages 2 and 3 and their 1x1 / stride 2 shortcuts. Anything else -> slices = 0, and the
 // caller keeps MIOpen's weight gradient.
-Plan plan_for(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, int ksize, int stride) {
+// xbn: the K10 form (x operand normalised + rectified while staged): the 3x3 layers that follow a BatchNorm (all but the stem)
+Plan plan_for(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, int ksize, int stride, bool xbn = false) {
     Plan p = {0, 0, 0, 0, 0, nullptr};
     if (N < 1 || N > (1 << 20) || H != W) return p;
     int bands = 0;
     const bool k3 = ksize == 3, k1 = ksize == 1;
+    if (xbn && (!k3 || Cin == 3)) return p;
     if (k3 && stride == 1 && Cin == 16 && Cout == 16 && W == 32) {
-        p.ipw = 1, bands = 4, p.gy = 1, p.fn = k_conv_wgrad<16, 16, 32, 8, 1, 9, 4>;
+        p.ipw = 1, bands = 4, p.gy = 1, p.fn = xbn ? k_conv_wgrad<16, 16, 32, 8, 1, 9, 4, true> : k_conv_wgrad<16, 16, 32, 8, 1, 9, 4>;
     } else if (k3 && stride == 1 && Cin == 32 && Cout == 32 && W == 16) {
-        p.ipw = 1, bands = 2, p.gy = 1, p.fn = k_conv_wgrad<32, 32, 16, 8, 1, 9, 4>;
+        p.ipw = 1, bands = 2, p.gy = 1, p.fn = xbn ? k_conv_wgrad<32, 32, 16, 8, 1, 9, 4, true> : k_conv_wgrad<32, 32, 16, 8, 1, 9, 4>;
     } else if (k3 && stride == 1 && Cin == 64 && Cout == 64 && W == 8) {
-        p.ipw = 2, bands = 1, p.gy = 4, p.fn = k_conv_wgrad<64, 16, 8, 8, 1, 9, 4>;
+        p.ipw = 2, bands = 1, p.gy = 4, p.fn = xbn ? k_conv_wgrad<64, 16, 8, 8, 1, 9, 4, true> : k_conv_wgrad<64, 16, 8, 8, 1, 9, 4>;
     } else if (k3 && stride == 1 && Cin == 3 && Cout == 16 && W == 32) {
         p.ipw = 1, bands = 4, p.gy = 1, p.fn = k_conv_wgrad<3, 16, 32, 8, 1, 9, 4>;
     } else if (k3 && stride == 2 && Cin == 16 && Cout == 32 && W == 32) {
-        p.ipw = 1, bands = 2, p.gy = 1, p.fn = k_conv_wgrad<16, 32, 16, 8, 2, 9, 4>;
+        p.ipw = 1, bands = 2, p.gy = 1, p.fn = xbn ? k_conv_wgrad<16, 32, 16, 8, 2, 9, 4, true> : k_conv_wgrad<16, 32, 16, 8, 2, 9, 4>;
     } else if (k3 && stride == 2 && Cin == 32 && Cout == 64 && W == 16) {
-        p.ipw = 2, bands = 2, p.gy = 2, p.fn = k_conv_wgrad<32, 32, 8, 4, 2, 9, 2>;
+        p.ipw = 2, bands = 2, p.gy = 2, p.fn = xbn ? k_conv_wgrad<32, 32, 8, 4, 2, 9, 2, true> : k_conv_wgrad<32, 32, 8, 4, 2, 9, 2>;
     } else if (k1 && stride == 2 && Cin == 16 && Cout == 32 && W == 32) {
         p.ipw = 2, bands = 2, p.gy = 1, p.fn = k_conv_wgrad<16, 32, 16, 8, 2, 1, 4>;
     } else if (k1 && stride == 2 && Cin == 32 && Cout == 64 && W == 16) {
@@ -354,18 +502,32 @@ extern "C" int64_t ursa_conv_wgrad_ws_floats(int64_t N, int64_t Cin, int64_t Cou
     return p.slices ? (int64_t)p.slices * p.E : 0;
 }
 
+static int wgrad_partial_impl(const float* x, const float* xbn, const float* dy, float* ws, int64_t ws_floats, int64_t N, int64_t Cin,
+                              int64_t Cout, int64_t H, int64_t W, int32_t ksize, int32_t stride, ursa_stream_t stream) {
+    if (!x || !dy || !ws) return URSA_ENULL;
+    if (int rc = check_shape(N, Cin, Cout, H, W)) return rc;
+    if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)ws) & 15 || (uintptr_t)xbn & 3) return URSA_EALIGN;
+    const Plan p = plan_for(N, Cin, Cout, H, W, ksize, stride, xbn != nullptr);
+    if (!p.slices) return URSA_EVALUE;                         // shape not covered: ursa_conv_wgrad_ws_floats() said 0
+    if (ws_floats < (int64_t)p.slices * p.E) return URSA_ESIZE;
+    hipLaunchKernelGGL(p.fn, dim3(p.slices, p.gy), dim3(kThreads), 0, (hipStream_t)stream, x, dy, ws, (int)N, (int)Cout, p.ipw, xbn);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? URSA_OK : (int)e;
+}
+
 extern "C" int ursa_conv_wgrad_partial_f32(const float* x, const float* dy, float* ws, int64_t ws_floats, int64_t N, int64_t Cin,
                                            int64_t Cout, int64_t H, int64_t W, int32_t ksize, int32_t stride,
                                            ursa_stream_t stream) {
-    if (!x || !dy || !ws) return URSA_ENULL;
-    if (int rc = check_shape(N, Cin, Cout, H, W)) return rc;
-    if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)ws) & 15) return URSA_EALIGN;
-    const Plan p = plan_for(N, Cin, Cout, H, W, ksize, stride);
-    if (!p.slices) return URSA_EVALUE;                         // shape not covered: ursa_conv_wgrad_ws_floats() said 0
-    if (ws_floats < (int64_t)p.slices * p.E) return URSA_ESIZE;
-    hipLaunchKernelGGL(p.fn, dim3(p.slices, p.gy), dim3(kThreads), 0, (hipStream_t)stream, x, dy, ws, (int)N, (int)Cout, p.ipw);
-    const hipError_t e = hipGetLastError();
-    return e == hipSuccess ? URSA_OK : (int)e;
+    return wgrad_partial_impl(x, nullptr, dy, ws, ws_floats, N, Cin, Cout, H, W, ksize, stride, stream);
+}
+
+// K10: the same first launch with x = relu(fma(x, alpha, beta')) taken while the tile is staged (bn_save: the [4][Cin] block
+// ursa_preact_conv3x3_f32 saved for the BatchNorm in front of this layer). Same slices, same scratch, same second launch.
+extern "C" int ursa_preact_wgrad_partial_f32(const float* x, const float* bn_save, const float* dy, float* ws, int64_t ws_floats,
+                                             int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, int32_t stride,
+                                             ursa_stream_t stream) {
+    if (!bn_save) return URSA_ENULL;
+    return wgrad_partial_impl(x, bn_save, dy, ws, ws_floats, N, Cin, Cout, H, W, 3, stride, stream);
 }
 
 extern "C" int ursa_conv_wgrad_reduce_f32(const ursa_conv_pending* items, int32_t n, ursa_stream_t stream) {
@@ -456,11 +618,23 @@ struct Fw {
     static constexpr int need(int p) { return MODE == 0 ? RP * (p + 1) + 1 : MODE == 1 ? 2 * RP * (p + 1) : RP * (p + 1); }
 };
 
-template <int CIN, int COUT_WG, int W, int R, int PH, int MODE, int DBG = 0>   // DBG != 0: knobs-build experiments only (what bounds the launch)
+// K10 forms of the same launch (PRO / EPI; `f` is only read when one of them is set):
+//   PRO 1: the staged tensor is relu(bn(x)) with bn's batch statistics merged here from the producer's per-line partial
+//          sums (every workgroup the same 16-lane tree: identical scalars); workgroup (0, 0) also stores mean / invstd / alpha /
+//          beta' for the backward and updates the running statistics. The zero padding stays zero.
+//   EPI 1: per-channel (sum y, sum y^2) of the output in double -> publish_sums: what the NEXT BatchNorm needs.
+//   EPI 2: the same of z = y + addend (`out += residual`, preresnet.py:49-52); z is what is stored.
+//   EPI 3: (input-gradient forms) g = the ReLU gate of the BatchNorm in front of the layer applied to the result
+//          (gate recomputed from that BatchNorm's input `aux` and saved scalars, as K6's backward does), g is what is stored, and
+//          (sum g, sum g * (aux - mean)) in double -> publish_sums: the two sums of native_batch_norm_backward.
+template <int CIN, int COUT_WG, int W, int R, int PH, int MODE, int DBG = 0, int PRO = 0, int EPI = 0>   // DBG != 0: knobs-build experiments only (what bounds the launch)
 __global__ __launch_bounds__(kThreads) void k_conv3x3(const float* __restrict__ x, const float* __restrict__ w,
-                                                       float* __restrict__ y, int N, int Cout, int ipw, int flip_arg) {
+                                                       float* __restrict__ y, int N, int Cout, int ipw, int flip_arg, const Fuse f) {
     using C = Fw<CIN, COUT_WG, W, R, PH, MODE>;
+    static_assert(!PRO || kThreads % (CIN * (C::WIN / 4)) == 0, "PRO: a thread stages one channel");
+    static_assert(!EPI || C::TPW == 1, "EPI: one run per wave and phase");
     __shared__ __attribute__((aligned(16))) float smem[C::SMEM];
+    __shared__ float2 tab[PRO ? CIN : 1];
     float* xs = smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int band = blockIdx.x % C::BANDS, ig = blockIdx.x / C::BANDS;
@@ -497,6 +671,7 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3(const float* __restrict__ 
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+    float pro_scale = 0.f, pro_shift = 0.f;                    // PRO: this thread's staged channel is the same for every chunk
     auto stage = [&](int p) {
 #pragma unroll
         for (int kk = 0; kk < NX; ++kk) {
@@ -506,13 +681,78 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3(const float* __restrict__ 
             const int ih = row0 + r;
             const bool in = ih >= 0 && ih < C::WIN;
             if (XV % kThreads == 0 || idx < XV)
-                *reinterpret_cast<f32x4*>(xs + ci * C::XPLANE + r * C::WP + 4 + 4 * c4) = in ? vx[kk] : f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(xs + ci * C::XPLANE + r * C::WP + 4 + 4 * c4) =
+                    in ? (PRO ? bn_relu4(vx[kk], pro_scale, pro_shift) : vx[kk]) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    // EPI 2 / 3: the second operand of the epilogue (addend / BatchNorm input) at this lane's output positions, loaded with the
+    // image's rows: NAUX float4 per image (MODE 2 stores a 2 x 8 block per run: four of them)
+    constexpr int NAUX = (EPI >= 2) ? PH * (MODE == 2 ? 4 : 1) : 1;
+    f32x4 av[NAUX];
+    auto aux_off = [&](int n, int p) -> size_t {               // offset of this lane's first output float4 of phase p, image n
+        const int t = p * C::TP + wsub;
+        const size_t img = ((size_t)n * Cout + co_base + cot * 16 + j) * (MODE == 2 ? 4 * W * W : W * W);
+        if constexpr (MODE == 2) {
+            const int lin0 = t * 16 + 4 * k, prow = band * R + lin0 / W, pcol = lin0 % W;
+            return img + (size_t)(2 * prow) * (2 * W) + 2 * pcol;
+        } else {
+            return img + band * R * W + t * 16 + 4 * k;
+        }
+    };
+    auto issue_aux = [&](int n) {
+        if constexpr (EPI >= 2) {
+#pragma unroll
+            for (int p = 0; p < PH; ++p) {
+                const float* a = f.aux + aux_off(n, p);
+                if constexpr (MODE == 2) {
+                    av[4 * p] = *reinterpret_cast<const f32x4*>(a);
+                    av[4 * p + 1] = *reinterpret_cast<const f32x4*>(a + 4);
+                    av[4 * p + 2] = *reinterpret_cast<const f32x4*>(a + 2 * W);
+                    av[4 * p + 3] = *reinterpret_cast<const f32x4*>(a + 2 * W + 4);
+                } else {
+                    av[p] = *reinterpret_cast<const f32x4*>(a);
+                }
+            }
         }
     };
 
     const int n0 = ig * ipw;
     const int n1 = n0 + ipw < N ? n0 + ipw : N;
     if (n0 < n1) issue(n0);                                    // the first image's rows are in flight while the weights are read
+    if (n0 < n1) issue_aux(n0);
+
+    if constexpr (PRO == 1) {
+        // scale / shift of every input channel from the producer's partial sums: lane (channel, part) of a 16-lane row loads one
+        // partial, the row adds them (K6's tree), lane 0 of the row finishes in double - torch's CPU BatchNorm rounding, K6's code
+        for (int e = tid; e < CIN * 16; e += kThreads) {       // CIN * 16 is a multiple of 256: every lane takes part in the DPP sums
+            const int c = e >> 4, i = e & 15;
+            double a = 0.0, b = 0.0;
+            if (i < f.in_nl) { const double2 q = f.in_partial[(size_t)c * f.in_nl + i]; a = q.x; b = q.y; }
+            a = row_sum16(a);
+            b = row_sum16(b);
+            if (i == 0) {
+                const double cnt = f.in_count;
+                const double mean = a / cnt;
+                double var = b / cnt - mean * mean;
+                if (var < 0.0) var = 0.0;
+                const float meanf = (float)mean;
+                const float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
+                const float alpha = invstd * f.gamma[c];
+                const float shift = fmaf(-meanf, alpha, f.beta[c]);
+                tab[c] = make_float2(alpha, shift);
+                if (blockIdx.x == 0 && blockIdx.y == 0) {
+                    f.save[c] = meanf;
+                    f.save[CIN + c] = invstd;
+                    f.save[2 * CIN + c] = alpha;
+                    f.save[3 * CIN + c] = shift;
+                    if (f.running_mean) {      // torch: running = momentum * batch + (1 - momentum) * running, unbiased variance
+                        f.running_mean[c] = f.momentum * meanf + (1.0f - f.momentum) * f.running_mean[c];
+                        f.running_var[c] = f.momentum * (float)(var * (cnt / (cnt - 1.0))) + (1.0f - f.momentum) * f.running_var[c];
+                    }
+                }
+            }
+        }
+    }
 
     // weights: coalesced global reads -> LDS rows [o][channel * 9 + tap] at a pitch of 4 mod 64 floats (lane (o = j, channel k)
     // reads bank 4 j + 9 k + const: 64 distinct banks) -> this lane's Cin/4 * 9 registers
@@ -563,6 +803,37 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3(const float* __restrict__ 
             for (int tap = 0; tap < 9; ++tap) wr[g][tap] = wl[(cot * 16 + j) * C::WPITCH + (g * 4 + k) * 9 + tap];
         __syncthreads();                                       // every wave has its weights: the region becomes the x tile
     }
+    if constexpr (PRO == 1) {
+        const float2 ss = tab[(tid / (C::WIN / 4)) % CIN];
+        pro_scale = ss.x, pro_shift = ss.y;
+    }
+    // EPI: this lane's output channel is the same for the whole launch
+    double s1 = 0.0, s2 = 0.0;
+    float g_scale = 0.f, g_shift = 0.f, g_mean = 0.f;
+    if constexpr (EPI == 3) {
+        const int cj = co_base + cot * 16 + j;
+        g_mean = f.bsave[cj], g_scale = f.bsave[2 * Cout + cj], g_shift = f.bsave[3 * Cout + cj];
+    }
+    const double g_meand = (double)g_mean;
+    // what is stored for an accumulated float4 `v` whose second operand is `a`; the sums of the stored / gated values
+    auto finish4 = [&](f32x4 v, const f32x4& a) -> f32x4 {
+        if constexpr (EPI == 2) v = v + a;                     // z = y + addend, one fp32 add as torch's
+        if constexpr (EPI == 1 || EPI == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const double d = (double)v[e]; s1 += d; s2 = fma(d, d, s2); }
+        }
+        if constexpr (EPI == 3) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool open = fmaf(a[e], g_scale, g_shift) > 0.f;
+                const float ge = open ? v[e] : 0.f;
+                v[e] = ge;
+                s1 += (double)ge;
+                s2 = fma((double)ge, (double)a[e] - g_meand, s2);
+            }
+        }
+        return v;
+    };
     for (int i = tid; i < C::CINP * C::RI; i += kThreads) {    // halo columns (and, for a padded channel count, whole zero planes)
         float* row = xs + (i / C::RI) * C::XPLANE + (i % C::RI) * C::WP;
         row[3] = 0.f;
@@ -626,15 +897,16 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3(const float* __restrict__ 
                 if (g == C::KG - 1) {                          // D: positions 4*k .. 4*k + 3 of the run, output channel j
                     const int t = p * C::TP + wsub + C::WPC * (s / C::KG);
                     float* yo = y + ((size_t)n * Cout + co_base + cot * 16 + j) * (MODE == 2 ? 4 * W * W : W * W);
+                    constexpr int AP = EPI >= 2 ? 1 : 0;        // (EPI: one run per wave and phase, so the phase indexes av)
                     if constexpr (MODE == 2) {
                         const int lin0 = t * 16 + 4 * k, prow = band * R + lin0 / W, pcol = lin0 % W;
                         float* o0 = yo + (size_t)(2 * prow) * (2 * W) + 2 * pcol;
-                        *reinterpret_cast<f32x4*>(o0) = f32x4{acc[0].x, acc[1].x, acc[0].y, acc[1].y};
-                        *reinterpret_cast<f32x4*>(o0 + 4) = f32x4{acc[0].z, acc[1].z, acc[0].w, acc[1].w};
-                        *reinterpret_cast<f32x4*>(o0 + 2 * W) = f32x4{acc[2].x, acc[3].x, acc[2].y, acc[3].y};
-                        *reinterpret_cast<f32x4*>(o0 + 2 * W + 4) = f32x4{acc[2].z, acc[3].z, acc[2].w, acc[3].w};
+                        *reinterpret_cast<f32x4*>(o0) = finish4(f32x4{acc[0].x, acc[1].x, acc[0].y, acc[1].y}, av[AP * 4 * p]);
+                        *reinterpret_cast<f32x4*>(o0 + 4) = finish4(f32x4{acc[0].z, acc[1].z, acc[0].w, acc[1].w}, av[AP * (4 * p + 1)]);
+                        *reinterpret_cast<f32x4*>(o0 + 2 * W) = finish4(f32x4{acc[2].x, acc[3].x, acc[2].y, acc[3].y}, av[AP * (4 * p + 2)]);
+                        *reinterpret_cast<f32x4*>(o0 + 2 * W + 4) = finish4(f32x4{acc[2].z, acc[3].z, acc[2].w, acc[3].w}, av[AP * (4 * p + 3)]);
                     } else {
-                        const f32x4 out = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+                        const f32x4 out = finish4((acc[0] + acc[1]) + (acc[2] + acc[3]), av[AP * p]);
                         if (DBG != 1 || out.x == 12345.678f)   // DBG 1: no stores
                             *reinterpret_cast<f32x4*>(yo + band * R * W + t * 16 + 4 * k) = out;
                     }
@@ -643,12 +915,14 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3(const float* __restrict__ 
                 }
             }
         }
+        if (EPI >= 2 && n + 1 < n1) issue_aux(n + 1);          // after this image's stores: av is free again
     }
+    if constexpr (EPI != 0) publish_sums<COUT_WG, C::MT, C::WPC>(f, s1, s2, smem, co_base, Cout);
 }
 
 struct FwPlan {
     int gx_per_image, gy, ipw;
-    void (*fn)(const float*, const float*, float*, int, int, int, int);
+    void (*fn)(const float*, const float*, float*, int, int, int, int, Fuse);
 };
 
 // the 3x3 layers of the CIFAR pre-activation ResNets: stride 1 - the stem and the three stages' equal-width layers (forward and,
@@ -694,12 +968,125 @@ extern "C" int ursa_conv3x3_f32(const float* x, const float* w, float* y, int64_
     if (flags & ~(URSA_CONV_FLIP | URSA_CONV_STRIDE2)) return URSA_EFLAGS;
     if (!x || !w || !y) return URSA_ENULL;
     if (N < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return URSA_ESIZE;
-    if (((uintptr_t)x | (uintptr_t)y) & 15 || (uintptr_t)w & 3) return URSA_EALIGN;
+    if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)w) & 15) return URSA_EALIGN;      // w is read through float4 loads too
     const FwPlan p = fw_plan_for(N, Cin, Cout, H, W, flags);
     if (!p.fn) return URSA_EVALUE;
     const int groups = (int)((N + p.ipw - 1) / p.ipw);
     hipLaunchKernelGGL(p.fn, dim3(groups * p.gx_per_image, p.gy), dim3(kThreads), 0, (hipStream_t)stream, x, w, y, (int)N, (int)Cout,
-                       p.ipw, (int)(flags & URSA_CONV_FLIP));
+                       p.ipw, (int)(flags & URSA_CONV_FLIP), Fuse{});
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? URSA_OK : (int)e;
+}
+
+// =====================================================================================================================
+// K10: the pre-activation unit `conv(relu(bn(x)))` (+ `out += residual`) of the BasicBlock ResNets as ONE launch each way
+// (URSABench/models/preresnet.py:33-52: bn1 -> relu -> conv1 -> bn2 -> relu -> conv2 -> += residual). K8's launch with the
+// BatchNorm that precedes the convolution applied while its tile is staged (PRO) and the per-channel sums the next BatchNorm -
+// or this one's backward - needs taken from the accumulators (EPI): the normalised activation is never stored, the separate
+// statistics / normalise / reduce launches of K6 (64 of a PreResNet-20 step's 146 launches) disappear.
+namespace {
+
+FwPlan fuse_plan_for(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, uint32_t flags) {
+    FwPlan p = {0, 0, 0, nullptr};
+    if (N < 1 || N > (1 << 20) || H != W) return p;
+    const bool flip = flags & URSA_CONV_FLIP, s2 = flags & URSA_CONV_STRIDE2, bn = flags & URSA_PREACT_BN;
+    const bool stats = flags & URSA_PREACT_STATS, add = flags & URSA_PREACT_ADD, bwd = flags & URSA_PREACT_BNBWD;
+    if (flip) {                                                // input gradient + the sums of the BatchNorm backward in front of the layer
+        if (!bwd || bn || stats || add) return p;
+        if (s2) {
+            if (Cin == 32 && Cout == 16 && W == 16) p = {2, 1, 1, k_conv3x3<32, 16, 16, 8, 2, 2, 0, 0, 3>};
+            else if (Cin == 64 && Cout == 32 && W == 8) p = {1, 2, 1, k_conv3x3<64, 16, 8, 8, 1, 2, 0, 0, 3>};
+        } else if (Cin == Cout) {
+            if (Cin == 16 && W == 32) p = {4, 1, 1, k_conv3x3<16, 16, 32, 8, 4, 0, 0, 0, 3>};
+            else if (Cin == 32 && W == 16) p = {2, 1, 1, k_conv3x3<32, 32, 16, 8, 4, 0, 0, 0, 3>};
+            else if (Cin == 64 && W == 8) p = {1, 4, 2, k_conv3x3<64, 16, 8, 8, 1, 0, 0, 0, 3>};
+        }
+        return p;
+    }
+    if (bwd || !stats) return p;                               // forward forms always leave the next BatchNorm's sums
+    if (s2) {
+        if (!bn || add) return p;
+        if (Cin == 16 && Cout == 32 && W == 32) p = {2, 1, 1, k_conv3x3<16, 32, 16, 8, 4, 1, 0, 1, 1>};
+        else if (Cin == 32 && Cout == 64 && W == 16) p = {1, 2, 1, k_conv3x3<32, 32, 8, 8, 2, 1, 0, 1, 1>};
+        return p;
+    }
+    if (Cin == 3 && Cout == 16 && W == 32) {                   // the stem: no BatchNorm in front, no residual
+        if (!bn && !add) p = {4, 1, 1, k_conv3x3<3, 16, 32, 8, 4, 0, 0, 0, 1>};
+        return p;
+    }
+    if (!bn) return p;
+    if (Cin == 16 && Cout == 16 && W == 32) {
+        if (add) p = {4, 1, 1, k_conv3x3<16, 16, 32, 8, 4, 0, 0, 1, 2>};
+        else p = {4, 1, 1, k_conv3x3<16, 16, 32, 8, 4, 0, 0, 1, 1>};
+    } else if (Cin == 32 && Cout == 32 && W == 16) {
+        if (add) p = {2, 1, 1, k_conv3x3<32, 32, 16, 8, 4, 0, 0, 1, 2>};
+        else p = {2, 1, 1, k_conv3x3<32, 32, 16, 8, 4, 0, 0, 1, 1>};
+    } else if (Cin == 64 && Cout == 64 && W == 8) {
+        if (add) p = {1, 4, 2, k_conv3x3<64, 16, 8, 8, 1, 0, 0, 1, 2>};
+        else p = {1, 4, 2, k_conv3x3<64, 16, 8, 8, 1, 0, 0, 1, 1>};
+    }
+    return p;
+}
+
+struct FuseGeom {
+    int S, line_sz, nl;
+    int64_t tickets_bytes, scratch_bytes;
+};
+
+FuseGeom fuse_geom(const FwPlan& p, int64_t N, int64_t Cout) {
+    FuseGeom g;
+    g.S = (int)((N + p.ipw - 1) / p.ipw) * p.gx_per_image;
+    g.line_sz = (g.S + kLines - 1) / kLines;
+    g.nl = (g.S + g.line_sz - 1) / g.line_sz;
+    g.tickets_bytes = (int64_t)p.gy * kLines * 128;
+    g.scratch_bytes = g.tickets_bytes + 128 + Cout * (int64_t)g.S * 16;
+    return g;
+}
+
+}  // namespace
+
+extern "C" int ursa_preact_geometry(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, uint32_t flags, int64_t* out) {
+    if (!out) return URSA_ENULL;
+    if (flags & ~URSA_PREACT_ALLFLAGS) return URSA_EFLAGS;
+    const FwPlan p = fuse_plan_for(N, Cin, Cout, H, W, flags);
+    if (!p.fn) return URSA_EVALUE;
+    const FuseGeom g = fuse_geom(p, N, Cout);
+    out[0] = g.nl, out[1] = g.scratch_bytes, out[2] = g.S, out[3] = g.tickets_bytes;
+    return URSA_OK;
+}
+
+extern "C" int ursa_preact_conv3x3_f32(const float* x, const float* w, float* y, const double* in_partial, int32_t in_nl,
+                                       const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                       float* bn_save, float eps, float momentum, const float* aux, const float* aux_bn_save,
+                                       double* out_partial, void* scratch, int64_t scratch_bytes, int64_t N, int64_t Cin,
+                                       int64_t Cout, int64_t H, int64_t W, uint32_t flags, ursa_stream_t stream) {
+    if (flags & ~URSA_PREACT_ALLFLAGS) return URSA_EFLAGS;
+    if (!x || !w || !y || !out_partial || !scratch) return URSA_ENULL;
+    if (N < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return URSA_ESIZE;
+    const bool bn = flags & URSA_PREACT_BN, add = flags & URSA_PREACT_ADD, bwd = flags & URSA_PREACT_BNBWD;
+    if (bn && (!in_partial || !gamma || !beta || !bn_save || in_nl < 1 || in_nl > kLines)) return in_partial && gamma && beta && bn_save ? URSA_ESIZE : URSA_ENULL;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return URSA_ENULL;
+    if ((add || bwd) && !aux) return URSA_ENULL;
+    if (bwd && !aux_bn_save) return URSA_ENULL;
+    if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)w | (uintptr_t)aux | (uintptr_t)in_partial | (uintptr_t)out_partial) & 15) return URSA_EALIGN;
+    if ((uintptr_t)scratch & 127) return URSA_EALIGN;
+    if (((uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)running_mean | (uintptr_t)running_var | (uintptr_t)bn_save | (uintptr_t)aux_bn_save) & 3) return URSA_EALIGN;
+    const FwPlan p = fuse_plan_for(N, Cin, Cout, H, W, flags);
+    if (!p.fn) return URSA_EVALUE;
+    const FuseGeom g = fuse_geom(p, N, Cout);
+    if (scratch_bytes < g.scratch_bytes) return URSA_ESIZE;
+    if (bn && N * H * W < 2) return URSA_EVALUE;               // torch: "Expected more than 1 value per channel"
+    Fuse f = {};
+    f.in_partial = reinterpret_cast<const double2*>(in_partial), f.gamma = gamma, f.beta = beta;
+    f.running_mean = running_mean, f.running_var = running_var, f.save = bn_save;
+    f.in_count = (double)(N * H * W), f.eps = eps, f.momentum = momentum, f.in_nl = in_nl;
+    f.nl = g.nl, f.line_sz = g.line_sz, f.aux = aux, f.bsave = aux_bn_save;
+    f.tickets = reinterpret_cast<unsigned int*>(scratch);
+    f.err = reinterpret_cast<unsigned int*>((char*)scratch + g.tickets_bytes);
+    f.slots = reinterpret_cast<u64*>((char*)scratch + g.tickets_bytes + 128);
+    f.out_partial = reinterpret_cast<double2*>(out_partial);
+    hipLaunchKernelGGL(p.fn, dim3(g.S, p.gy), dim3(kThreads), 0, (hipStream_t)stream, x, w, y, (int)N, (int)Cout, p.ipw,
+                       (int)(flags & URSA_CONV_FLIP), f);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? URSA_OK : (int)e;
 }

@@ -146,7 +146,7 @@ class Conv2d(nn.Conv2d):
         if not (_on and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and self.bias is None
                 and self.kernel_size in ((3, 3), (1, 1)) and self.padding == (ks // 2, ks // 2) and self.dilation == (1, 1)
                 and self.groups == 1 and self.padding_mode == 'zeros' and st == self.stride[1] and w.dtype == torch.float32
-                and x.is_contiguous() and w.is_contiguous() and x.data_ptr() % 16 == 0):
+                and x.is_contiguous() and w.is_contiguous() and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0):
             return super().forward(x)
         if not (torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)):
             # no gradient recorded (evaluation, the BMA predictive at 4,096 rows): MIOpen's Winograd launch is the faster one at

@@ -22,6 +22,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import fused_block
 from .fused_bn import add_bn_relu, bn_relu
 from .fused_conv import Conv2d
 
@@ -172,9 +173,16 @@ class PreResNet(nn.Module):
         blocks += [block(self.inplanes, planes) for _ in range(1, reps)]
         return nn.Sequential(*blocks)
 
-    def forward(self, x):
+    def _trunk(self, x):
+        """relu(bn(layer3(layer2(layer1(conv1(x)))))). A training step of a BasicBlock network on a HIP device takes the K10
+        launches (`fused_block`: one launch per bn -> relu -> conv unit); everything else the K6 / K8 launches or the stock ops."""
+        if self.depth < 44 and fused_block.eligible(self, x):
+            return fused_block.trunk(self, x)
         x = self.layer3(self.layer2(self.layer1(self.conv1(x))))     # the last block's pending sum
-        return self.fc(_pool8(add_bn_relu(self.bn, x)[1], self.avgpool))
+        return add_bn_relu(self.bn, x)[1]
+
+    def forward(self, x):
+        return self.fc(_pool8(self._trunk(x), self.avgpool))
 
 
 class PreResNet_dropout(PreResNet):
@@ -187,8 +195,7 @@ class PreResNet_dropout(PreResNet):
         self.dropout = dropout
 
     def forward(self, x):
-        x = self.layer3(self.layer2(self.layer1(self.conv1(x))))
-        return self.fc(F.dropout(_pool8(add_bn_relu(self.bn, x)[1], self.avgpool), p=self.dropout))
+        return self.fc(F.dropout(_pool8(self._trunk(x), self.avgpool), p=self.dropout))
 
 
 # ---- wide ResNet -------------------------------------------------------------------------
