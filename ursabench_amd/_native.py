@@ -608,7 +608,8 @@ class HipKernels:
         """One K10 launch (include/ursa_hip.h). bn = (in_partial [Cin, in_nl, 2] float64, gamma, beta, running_mean | None,
         running_var | None, bn_save [4, Cin], eps, momentum): convolve relu(bn(x)); add = the tensor added to the result before it is
         stored and summed; bwd = (bn_input, bn_save [4, C]) with flip=True: the gated input gradient and the BatchNorm backward's
-        sums. out_partial: float64 [Cout, nl, 2]; scratch: uint8, zeroed once, private to this layer and direction."""
+        sums. out_partial: float64 [Cout, nl, 2]; scratch: uint8, zeroed once, private to this layer (forward forms only: the
+        input-gradient forms need none - pass None)"""
         if x.dim() != 4 or w.dim() != 4 or tuple(w.shape[2:]) != (3, 3) or w.shape[0 if flip else 1] != x.shape[1]:
             raise ValueError(f'not a 3x3 convolution: x {tuple(x.shape)}, w {tuple(w.shape)}, flip={flip}')
         if flip != (bwd is not None) or (flip and (bn is not None or add is not None)):
@@ -641,7 +642,8 @@ class HipKernels:
         with torch.cuda.device(dev):
             rc = self.lib.ursa_preact_conv3x3_f32(_ptr(x, 'x'), _ptr(w, 'w', None, dev), _ptr(y, 'y', None, dev), *bnargs, aux, aux_save,
                                                   self._f64ptr(out_partial, 'out_partial', Cout * nl * 2, dev),
-                                                  self._scratch_ptr(scratch, sbytes, dev), scratch.numel(), N, Cin, Cout, H, W,
+                                                  self._scratch_ptr(scratch, sbytes, dev) if sbytes else None, scratch.numel() if sbytes else 0,
+                                                  N, Cin, Cout, H, W,
                                                   self._preact_flags(flip, stride, bn is not None, add is not None), _stream(dev))
         _check(self.lib, rc, 'ursa_preact_conv3x3_f32')
         return y

@@ -462,7 +462,9 @@ __global__ __launch_bounds__(kBnBlock) void k_bn_bwd_reduce(const float* __restr
 //      dbeta = sum ; dgamma = dotp * invstd ; gm = sum / n ; k = dotp * invstd^2 / n
 //      dx = ((dy' - gm) - (x - mean) * k) * invstd * gamma     (RES: + dz, the gradient that reaches the residual sum
 //      z = x on its other path: the accumulation autograd would run as a separate add launch)
-template <int V, bool RELU, bool RES, bool GATED = false>
+// BIGS: S > 64 partial sums per channel (K10: one per workgroup of the convolution launch that left them): every thread adds
+// its partials in ascending order (t, t + 256, ...), then the workgroup's fixed tree - every workgroup of the channel the same.
+template <int V, bool RELU, bool RES, bool GATED = false, bool BIGS = false>
 __global__ __launch_bounds__(kBnBlock) void k_bn_bwd_dx(const float* __restrict__ x, const float* __restrict__ dy,
                                                         const float* __restrict__ dz, float* __restrict__ dx, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const float* __restrict__ save_mean,
@@ -490,7 +492,18 @@ __global__ __launch_bounds__(kBnBlock) void k_bn_bwd_dx(const float* __restrict_
         const int64_t iu = i0 + u * kBnBlock;
         if (iu < hi) { o0[u] = bn_off(g, c, iu); a0[u] = xv[o0[u]]; b0[u] = dv[o0[u]]; if (RES) r0[u] = rv[o0[u]]; }
     }
-    if (threadIdx.x < 64) {
+    if constexpr (BIGS) {
+        __shared__ double shd[2 * kBnBlock / 64];
+        double a = 0.0, b = 0.0;
+        for (int t = threadIdx.x; t < S; t += kBnBlock) { const double2 p = partial[(int64_t)c * S + t]; a += p.x; b += p.y; }
+        bn_block_sum2(a, b, shd);
+        if (threadIdx.x == 0) {
+            const double n = (double)g.per_ch * V, iv = (double)invstd;
+            sh[0] = (float)(a / n);
+            sh[1] = (float)(b * iv * iv / n);
+            if (bn_split(g) == 0) { dbeta[c] = (float)a; dgamma[c] = (float)(b * iv); }
+        }
+    } else if (threadIdx.x < 64) {
         double a = 0.0, b = 0.0;
         if ((int)threadIdx.x < S) { const double2 p = partial[(int64_t)c * S + threadIdx.x]; a = p.x; b = p.y; }
         a = bn_wave_sum(a);
@@ -1769,7 +1782,7 @@ int ursa_bn_bwd_dx_f32(const float* x, const float* g, const float* dz, float* d
 {
     if (N <= 0 || C <= 0 || HW <= 0) return URSA_ESIZE;
     if (!x || !g || !dx || !gamma || !save || !partial || !dgamma || !dbeta) return URSA_ENULL;
-    if (nl < 1 || nl > kBnMaxSplit) return URSA_ESIZE;
+    if (nl < 1 || nl > 65536) return URSA_ESIZE;
     if (!bn_aligned4(x) || !bn_aligned4(g) || !bn_aligned4(dz) || !bn_aligned4(dx) || !bn_aligned4(save) || !bn_aligned16(partial)) return URSA_EALIGN;
     BnPlan p;
     const int rc = bn_plan(N, C, HW, bn_aligned16(x) && bn_aligned16(g) && bn_aligned16(dz) && bn_aligned16(dx), &p);
@@ -1778,8 +1791,11 @@ int ursa_bn_bwd_dx_f32(const float* x, const float* g, const float* dz, float* d
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid = p.g.cfirst ? dim3(p.g.C, p.S) : dim3(p.S, p.g.C), block(kBnBlock);
     const double2* part = reinterpret_cast<const double2*>(partial);
-#define URSA_BN_DX(V, RES) hipLaunchKernelGGL((k_bn_bwd_dx<V, false, RES>), grid, block, 0, st, x, g, dz, dx, gamma, (const float*)nullptr, save, \
-                                              save + C, part, (int)nl, dgamma, dbeta, p.g, BnGates{})
+#define URSA_BN_DX(V, RES) do { \
+    if (nl > kBnMaxSplit) hipLaunchKernelGGL((k_bn_bwd_dx<V, false, RES, false, true>), grid, block, 0, st, x, g, dz, dx, gamma, (const float*)nullptr, \
+                                             save, save + C, part, (int)nl, dgamma, dbeta, p.g, BnGates{}); \
+    else hipLaunchKernelGGL((k_bn_bwd_dx<V, false, RES>), grid, block, 0, st, x, g, dz, dx, gamma, (const float*)nullptr, save, \
+                            save + C, part, (int)nl, dgamma, dbeta, p.g, BnGates{}); } while (0)
     if (p.V == 4) { if (dz) URSA_BN_DX(4, true); else URSA_BN_DX(4, false); }
     else          { if (dz) URSA_BN_DX(1, true); else URSA_BN_DX(1, false); }
 #undef URSA_BN_DX

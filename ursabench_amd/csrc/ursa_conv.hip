@@ -92,57 +92,104 @@ __device__ __forceinline__ f32x4 bn_relu4(const f32x4& v, float scale, float shi
 }
 
 // End of a launch that leaves per-channel sums (EPI): every thread holds (s1, s2) of ITS output channel (channel
-// co_base + 16 * (wave % MT) + (lane & 15)); the workgroup's sums go to its slot, a ticket on its line's counter tells the
-// last workgroup of the line that all of them are there, and that one adds the line's slots in ascending order and stores
-// the line's partial sum. No atomics on the data, no spinning on workgroups that may not be running: a fixed summation
-// order whatever the arrival order. The words travel as agent-scope atomic stores / loads (they bypass the non-coherent
-// per-XCD L2 lines) XORed with a NaN payload, so a zero word means "not there yet"; the ticket is taken after
-// s_waitcnt vmcnt(0), and the reader still polls (bounded) - belt and braces.
+// co_base + 16 * (wave % MT) + (lane & 15)). The workgroups of one grid.y row are cut into <= 16 "lines" of line_sz consecutive
+// grid.x indices; a line's sums are added in ascending grid.x order by ONE of its workgroups and stored as the line's partial
+// sum: a fixed summation order whatever the arrival order, no atomics on the data.
+//   * Who adds: the workgroup of the line that STARTED last. Every workgroup takes a ticket on its line's counter when it
+//     starts (take_ticket: one relaxed agent-scope fetch-add whose result is first needed here, a whole launch later - its
+//     round trip hides behind the convolution); the one that drew the last ticket knows every other workgroup of the line is
+//     running, and a running workgroup of this launch never waits for anything - so waiting for THEIR sums cannot starve,
+//     whatever else shares the device (other streams, graph branches), and needs no assumption about dispatch order.
+//   * How the sums travel: the other workgroups store theirs to their slot with agent-scope atomic stores (they bypass the
+//     non-coherent per-XCD L2 lines) as bits XOR a NaN payload, so a zero word means "not there yet", and exit. The adder
+//     polls the line's slots (agent-scope loads; bounded: a poll that runs out raises *err and makes the sums NaN - never in a
+//     correct run), adds them by position with its own sums (which never leave the workgroup), stores the partial sum, zeroes
+//     the slots and re-arms the counter: the scratch is zero again when the launch has drained.
+// One memory round trip (the poll) is what the launch pays at its end.
+__device__ __forceinline__ unsigned take_ticket(const Fuse& f)
+{
+    unsigned t = 0;
+    if (threadIdx.x == 0) {
+        const int line = blockIdx.x / f.line_sz;
+        gu32* tp = (gu32*)(f.tickets + ((size_t)blockIdx.y * kLines + line) * 32);
+        t = __hip_atomic_fetch_add(tp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return t;
+}
+
+// EPI 3 (the input-gradient forms): no hand-over inside the launch at all. The launch that follows is per channel (K6's dx
+// launch), so every workgroup simply stores its sums at out_partial[channel][grid.x index] and that launch adds a channel's
+// S partial sums itself, in ascending order (k_bn_bwd_dx<.., BIGS>): nothing waits at the end of the convolution.
 template <int COUT_WG, int MT, int WPC>
-__device__ __forceinline__ void publish_sums(const Fuse& f, double s1, double s2, float* smem, int co_base, int Cout)
+__device__ __forceinline__ void store_sums(const Fuse& f, double s1, double s2, float* smem, int co_base)
 {
     const int tid = threadIdx.x;
-    __shared__ int fin;
     __syncthreads();                                           // every wave is done with the tile: reuse it
     double2* red = reinterpret_cast<double2*>(smem);
     red[tid] = make_double2(s1, s2);
     __syncthreads();
+    if (tid < COUT_WG) {
+        const int cc = tid >> 4, jj = tid & 15;
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int ws = 0; ws < WPC; ++ws)
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) {
+                const double2 v = red[(cc + MT * ws) * 64 + kq * 16 + jj];
+                a += v.x;
+                b += v.y;
+            }
+        f.out_partial[(size_t)(co_base + tid) * gridDim.x + blockIdx.x] = make_double2(a, b);
+    }
+}
+
+template <int COUT_WG, int MT, int WPC>
+__device__ __forceinline__ void publish_sums(const Fuse& f, unsigned ticket, double s1, double s2, float* smem, int co_base, int Cout)
+{
+    const int tid = threadIdx.x;
+    __shared__ int adder;
+    __shared__ double2 own[COUT_WG];
     const int S = gridDim.x, tile = blockIdx.x, line = tile / f.line_sz;
-    if (tid < 64) {
-        if (tid < COUT_WG) {
-            const int cc = tid >> 4, jj = tid & 15;
-            double a = 0.0, b = 0.0;
+    const int first = line * f.line_sz;
+    const int cnt = S - first < f.line_sz ? S - first : f.line_sz;
+    __syncthreads();                                           // every wave is done with the tile: reuse it
+    double2* red = reinterpret_cast<double2*>(smem);
+    red[tid] = make_double2(s1, s2);
+    if (tid == 0) adder = ticket == (unsigned)cnt - 1u;
+    __syncthreads();
+    const bool is_adder = adder != 0;
+    if (tid < COUT_WG) {
+        const int cc = tid >> 4, jj = tid & 15;
+        double a = 0.0, b = 0.0;
 #pragma unroll
-            for (int ws = 0; ws < WPC; ++ws)
+        for (int ws = 0; ws < WPC; ++ws)
 #pragma unroll
-                for (int kq = 0; kq < 4; ++kq) {
-                    const double2 v = red[(cc + MT * ws) * 64 + kq * 16 + jj];
-                    a += v.x;
-                    b += v.y;
-                }
+            for (int kq = 0; kq < 4; ++kq) {
+                const double2 v = red[(cc + MT * ws) * 64 + kq * 16 + jj];
+                a += v.x;
+                b += v.y;
+            }
+        if (is_adder) {
+            own[tid] = make_double2(a, b);
+        } else {
             gu64* sl = (gu64*)(f.slots + ((size_t)(co_base + tid) * S + tile) * 2);
             __hip_atomic_store(sl, __builtin_bit_cast(u64, a) ^ kSlotXor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(sl + 1, __builtin_bit_cast(u64, b) ^ kSlotXor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (tid == 0) {
-            const int first = line * f.line_sz;
-            const int quota = S - first < f.line_sz ? S - first : f.line_sz;
-            gu32* tp = (gu32*)(f.tickets + ((size_t)blockIdx.y * kLines + line) * 32);
-            const unsigned t = __hip_atomic_fetch_add(tp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            fin = t == (unsigned)quota - 1u;
-            if (fin) __hip_atomic_store(tp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
-        }
     }
+    if (!is_adder) return;
     __syncthreads();
-    if (!fin) return;
-    const int first = line * f.line_sz;
-    const int cnt = S - first < f.line_sz ? S - first : f.line_sz;
+    const int mine = tile - first;                             // this workgroup's position in the line
     for (int e = tid; e < COUT_WG * 16; e += kThreads) {       // (channel, lane of its row): COUT_WG * 16 is a multiple of 256
         const int c = e >> 4, i = e & 15;
         double a = 0.0, b = 0.0;
         bool bad = false;
-        for (int t = i; t < cnt; t += 16) {                   // this lane's slots, ascending
+        for (int t = i; t < cnt; t += 16) {                   // this lane's positions, ascending
+            if (t == mine) {
+                a += own[c].x;
+                b += own[c].y;
+                continue;
+            }
             gu64* sl = (gu64*)(f.slots + ((size_t)(co_base + c) * S + first + t) * 2);
             u64 wa, wb;
             unsigned spins = 0;
@@ -151,7 +198,7 @@ __device__ __forceinline__ void publish_sums(const Fuse& f, double s1, double s2
                 wb = __hip_atomic_load(sl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (wa != 0 && wb != 0) break;
                 if (++spins > kPollLimit) { bad = true; break; }
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(1);
             }
             a += __builtin_bit_cast(double, wa ^ kSlotXor);
             b += __builtin_bit_cast(double, wb ^ kSlotXor);
@@ -166,6 +213,8 @@ __device__ __forceinline__ void publish_sums(const Fuse& f, double s1, double s2
         b = row_sum16(b);
         if (i == 0) f.out_partial[(size_t)(co_base + c) * f.nl + line] = make_double2(a, b);
     }
+    if (tid == 0)                                              // every workgroup of the line has counted itself: re-armed for the next launch
+        __hip_atomic_store((gu32*)(f.tickets + ((size_t)blockIdx.y * kLines + line) * 32), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // CIN: input channels (all staged; padded to a multiple of 16 by one zero plane); COUT_WG: output channels one workgroup takes
@@ -720,20 +769,30 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3(const float* __restrict__ 
     const int n1 = n0 + ipw < N ? n0 + ipw : N;
     if (n0 < n1) issue(n0);                                    // the first image's rows are in flight while the weights are read
     if (n0 < n1) issue_aux(n0);
+    unsigned ticket = 0;
+    if constexpr (EPI == 1 || EPI == 2) ticket = take_ticket(f);   // "this workgroup runs": needed at the very end (publish_sums)
 
+    __shared__ double2 dsum[PRO ? CIN : 1];
     if constexpr (PRO == 1) {
-        // scale / shift of every input channel from the producer's partial sums: lane (channel, part) of a 16-lane row loads one
-        // partial, the row adds them (K6's tree), lane 0 of the row finishes in double - torch's CPU BatchNorm rounding, K6's code
+        // per-channel sums of x from the producer's partial sums: lane (channel, part) of a 16-lane row loads one partial, the row
+        // adds them (K6's tree). The scalars are finished below, between the two barriers of the weight staging, by one thread
+        // per channel.
         for (int e = tid; e < CIN * 16; e += kThreads) {       // CIN * 16 is a multiple of 256: every lane takes part in the DPP sums
             const int c = e >> 4, i = e & 15;
             double a = 0.0, b = 0.0;
             if (i < f.in_nl) { const double2 q = f.in_partial[(size_t)c * f.in_nl + i]; a = q.x; b = q.y; }
             a = row_sum16(a);
             b = row_sum16(b);
-            if (i == 0) {
+            if (i == 0) dsum[c] = make_double2(a, b);
+        }
+    }
+    auto pro_finish = [&]() {                                  // after a barrier: torch's CPU BatchNorm rounding, K6's code
+        if constexpr (PRO == 1) {
+            if (tid < CIN) {
+                const int c = tid;
                 const double cnt = f.in_count;
-                const double mean = a / cnt;
-                double var = b / cnt - mean * mean;
+                const double mean = dsum[c].x / cnt;
+                double var = dsum[c].y / cnt - mean * mean;
                 if (var < 0.0) var = 0.0;
                 const float meanf = (float)mean;
                 const float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
@@ -752,7 +811,7 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3(const float* __restrict__ 
                 }
             }
         }
-    }
+    };
 
     // weights: coalesced global reads -> LDS rows [o][channel * 9 + tap] at a pitch of 4 mod 64 floats (lane (o = j, channel k)
     // reads bank 4 j + 9 k + const: 64 distinct banks) -> this lane's Cin/4 * 9 registers
@@ -797,6 +856,7 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3(const float* __restrict__ 
                 wl[(idx / ROW) * C::WPITCH + idx % ROW] = w[(size_t)co_base * ROW + idx];
         }
         __syncthreads();
+        pro_finish();
 #pragma unroll
         for (int g = 0; g < C::KG; ++g)
 #pragma unroll
@@ -917,7 +977,15 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3(const float* __restrict__ 
         }
         if (EPI >= 2 && n + 1 < n1) issue_aux(n + 1);          // after this image's stores: av is free again
     }
-    if constexpr (EPI != 0) publish_sums<COUT_WG, C::MT, C::WPC>(f, s1, s2, smem, co_base, Cout);
+    if constexpr (EPI != 0 && DBG == 3) {                      // knobs: no hand-over at all (what the accumulation alone costs)
+        if (s1 + s2 == 12345.678) y[0] = 0.f;
+    } else if constexpr (EPI != 0 && DBG == 4) {               // knobs: slots stored, nobody adds (what the final poll costs)
+        publish_sums<COUT_WG, C::MT, C::WPC>(f, 0xffffffffu, s1, s2, smem, co_base, Cout);
+    } else if constexpr (EPI == 3) {
+        store_sums<COUT_WG, C::MT, C::WPC>(f, s1, s2, smem, co_base);
+    } else if constexpr (EPI != 0) {
+        publish_sums<COUT_WG, C::MT, C::WPC>(f, ticket, s1, s2, smem, co_base, Cout);
+    }
 }
 
 struct FwPlan {
@@ -1018,6 +1086,14 @@ FwPlan fuse_plan_for(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W,
     if (Cin == 16 && Cout == 16 && W == 32) {
         if (add) p = {4, 1, 1, k_conv3x3<16, 16, 32, 8, 4, 0, 0, 1, 2>};
         else p = {4, 1, 1, k_conv3x3<16, 16, 32, 8, 4, 0, 0, 1, 1>};
+#ifdef URSA_DEBUG_KNOBS
+        if (const char* e = getenv("URSA_K10_DBG")) {            // what the fused launch pays for: 1 = prologue only (no sums), 2 = sums only (x taken as is)
+            if (atoi(e) == 1) p.fn = k_conv3x3<16, 16, 32, 8, 4, 0, 0, 1, 0>;
+            if (atoi(e) == 2) p.fn = k_conv3x3<16, 16, 32, 8, 4, 0, 0, 0, 1>;
+            if (atoi(e) == 3) p.fn = k_conv3x3<16, 16, 32, 8, 4, 0, 3, 0, 1>;   // sums accumulated, not handed over
+            if (atoi(e) == 4) p.fn = k_conv3x3<16, 16, 32, 8, 4, 0, 4, 0, 1>;   // slots stored, no final add (leaves the scratch dirty)
+        }
+#endif
     } else if (Cin == 32 && Cout == 32 && W == 16) {
         if (add) p = {2, 1, 1, k_conv3x3<32, 32, 16, 8, 4, 0, 0, 1, 2>};
         else p = {2, 1, 1, k_conv3x3<32, 32, 16, 8, 4, 0, 0, 1, 1>};
@@ -1033,9 +1109,13 @@ struct FuseGeom {
     int64_t tickets_bytes, scratch_bytes;
 };
 
-FuseGeom fuse_geom(const FwPlan& p, int64_t N, int64_t Cout) {
+FuseGeom fuse_geom(const FwPlan& p, int64_t N, int64_t Cout, bool flip) {
     FuseGeom g;
     g.S = (int)((N + p.ipw - 1) / p.ipw) * p.gx_per_image;
+    if (flip) {                                                // one partial sum per workgroup, added by the dx launch: no scratch
+        g.line_sz = 1, g.nl = g.S, g.tickets_bytes = 0, g.scratch_bytes = 0;
+        return g;
+    }
     g.line_sz = (g.S + kLines - 1) / kLines;
     g.nl = (g.S + g.line_sz - 1) / g.line_sz;
     g.tickets_bytes = (int64_t)p.gy * kLines * 128;
@@ -1050,7 +1130,7 @@ extern "C" int ursa_preact_geometry(int64_t N, int64_t Cin, int64_t Cout, int64_
     if (flags & ~URSA_PREACT_ALLFLAGS) return URSA_EFLAGS;
     const FwPlan p = fuse_plan_for(N, Cin, Cout, H, W, flags);
     if (!p.fn) return URSA_EVALUE;
-    const FuseGeom g = fuse_geom(p, N, Cout);
+    const FuseGeom g = fuse_geom(p, N, Cout, flags & URSA_CONV_FLIP);
     out[0] = g.nl, out[1] = g.scratch_bytes, out[2] = g.S, out[3] = g.tickets_bytes;
     return URSA_OK;
 }
@@ -1061,7 +1141,7 @@ extern "C" int ursa_preact_conv3x3_f32(const float* x, const float* w, float* y,
                                        double* out_partial, void* scratch, int64_t scratch_bytes, int64_t N, int64_t Cin,
                                        int64_t Cout, int64_t H, int64_t W, uint32_t flags, ursa_stream_t stream) {
     if (flags & ~URSA_PREACT_ALLFLAGS) return URSA_EFLAGS;
-    if (!x || !w || !y || !out_partial || !scratch) return URSA_ENULL;
+    if (!x || !w || !y || !out_partial) return URSA_ENULL;
     if (N < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return URSA_ESIZE;
     const bool bn = flags & URSA_PREACT_BN, add = flags & URSA_PREACT_ADD, bwd = flags & URSA_PREACT_BNBWD;
     if (bn && (!in_partial || !gamma || !beta || !bn_save || in_nl < 1 || in_nl > kLines)) return in_partial && gamma && beta && bn_save ? URSA_ESIZE : URSA_ENULL;
@@ -1073,7 +1153,8 @@ extern "C" int ursa_preact_conv3x3_f32(const float* x, const float* w, float* y,
     if (((uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)running_mean | (uintptr_t)running_var | (uintptr_t)bn_save | (uintptr_t)aux_bn_save) & 3) return URSA_EALIGN;
     const FwPlan p = fuse_plan_for(N, Cin, Cout, H, W, flags);
     if (!p.fn) return URSA_EVALUE;
-    const FuseGeom g = fuse_geom(p, N, Cout);
+    const FuseGeom g = fuse_geom(p, N, Cout, flags & URSA_CONV_FLIP);
+    if (g.scratch_bytes && !scratch) return URSA_ENULL;
     if (scratch_bytes < g.scratch_bytes) return URSA_ESIZE;
     if (bn && N * H * W < 2) return URSA_EVALUE;               // torch: "Expected more than 1 value per channel"
     Fuse f = {};

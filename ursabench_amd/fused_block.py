@@ -168,7 +168,7 @@ class _Unit(torch.autograd.Function):
         geo = K.preact_geometry(dy.shape, Cin, flip=True, stride=s)
         g = torch.empty_like(x)
         pb = torch.empty(Cin, geo[0], 2, dtype=torch.float64, device=dev)
-        K.preact_conv3x3(dy, w, g, pb, _scratch_for(ctx.conv, 'b', geo, dev), stride=s, flip=True, bwd=(x, save))
+        K.preact_conv3x3(dy, w, g, pb, None, stride=s, flip=True, bwd=(x, save))
         dx = torch.empty_like(x)
         dgb = x.new_empty(2, Cin)
         K.bn_bwd_dx(x, g, dx, gamma, save, pb, dgb[0], dgb[1], dz=None if dxa is None else _aligned(dxa))
