@@ -382,3 +382,24 @@ def test_network_inside_a_replayed_graph_equals_eager():
         for p, gb, (k, _) in zip(params, gbuf, net.named_parameters()):
             assert torch.equal(gb, want[k]), k
     fused_block.check(DEV)
+
+
+def test_side_branch_of_the_weight_gradients_changes_no_bit():
+    """The engine runs K7's first launches on a side stream beside the backward pass (fused_conv.Sink; inside the captured step:
+    a parallel branch of the hipGraph). Same launches, same operands, only their place in time differs: a chain sampled with and
+    without the side branch ends on identical parameters - eager steps, the captured step and its replays."""
+    import ursabench_amd.inference as inference
+    from ursabench_amd.data import synthetic
+    finals = []
+    for side in (True, False):
+        torch.manual_seed(11)
+        train = synthetic(128 * 6 + 40, (3, 32, 32), 10, seed=5, device=DEV, batch_size=128)      # 6 full batches + a ragged one
+        s = inference.SGHMC({'lr': 0.1, 'prior_std': 0.5, 'num_samples': 2, 'alpha': 0.5, 'burn_in_epochs': 0},
+                            models.PreResNet(10, 20).to(DEV), train, device=DEV)
+        s.engine.wgrad_side = side
+        ens = s.sample()
+        assert s.engine.stats['graph_replays'] > 0
+        finals.append(torch.cat([p.detach().reshape(-1) for p in ens[-1].parameters()]).clone())
+    assert torch.isfinite(finals[0]).all()
+    assert torch.equal(finals[0], finals[1])
+    fused_block.check(DEV)

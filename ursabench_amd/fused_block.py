@@ -88,14 +88,15 @@ def _aligned(t):
 def _wgrad(ctx_sink, K, x, bn_save, dy, w, ws_floats, stride):
     """Weight gradient by K7 (x operand rebuilt from bn_save while staged when given): into the engine's sink (deferred second
     launch) or returned."""
-    ws = x.new_empty(ws_floats)
-    rec = (K.preact_wgrad_partial(x, bn_save, dy, w.shape, ws, stride) if bn_save is not None
-           else K.conv_wgrad_partial(x, dy, w.shape, ws, stride))
+    def first():
+        ws = x.new_empty(ws_floats)
+        return (K.preact_wgrad_partial(x, bn_save, dy, w.shape, ws, stride) if bn_save is not None
+                else K.conv_wgrad_partial(x, dy, w.shape, ws, stride))
     if ctx_sink is not None:
-        ctx_sink.append((rec, w))
+        ctx_sink.append((ctx_sink.launch(first, x, dy, bn_save), w))     # (beside the backward pass if the sink has a side stream)
         return None
     dw = torch.empty_like(w)
-    K.conv_wgrad_reduce([(rec, dw)])
+    K.conv_wgrad_reduce([(first(), dw)])
     return dw
 
 

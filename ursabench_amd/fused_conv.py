@@ -61,15 +61,52 @@ def forward_enabled(flag=None):
 _tls = threading.local()          # deferred(): the sink of the thread that runs the forward
 
 
+class Sink(list):
+    """What `deferred()` hands out: the list of (record of the first K7 launch, weight parameter), plus - when the caller gave a
+    side stream - what it takes to run those launches BESIDE the rest of the backward pass: nothing in a backward pass depends
+    on a weight gradient, so the K7 launches form a branch of their own (inside a captured step: a parallel branch of the
+    hipGraph) that only the flush joins. `keep` holds the operands the side launches read until the join: autograd drops its
+    reference to a gradient tensor as soon as the node returns, and the block could otherwise be handed to a later allocation
+    of the main stream while the side launch still reads it."""
+
+    def __init__(self, side=None):
+        super().__init__()
+        self.side, self.keep, self.forked = side, [], False
+
+    def launch(self, fn, *operands):
+        """fn() enqueues one first-K7 launch and returns its record: on the side stream (after everything enqueued so far on
+        the current one) if there is one, else in place. `operands`: the tensors it reads."""
+        if self.side is None:
+            return fn()
+        cur = torch.cuda.current_stream(self.side.device)
+        self.side.wait_stream(cur)
+        with torch.cuda.stream(self.side):
+            rec = fn()
+        self.keep.append(operands)
+        self.forked = True
+        return rec
+
+    def join(self):
+        """The current stream waits for the side launches (before `flush`); the held operands are released."""
+        if self.forked:
+            torch.cuda.current_stream(self.side.device).wait_stream(self.side)
+            self.forked = False
+        self.keep.clear()
+
+
 class deferred:
     """Context around a FORWARD pass: the backward of every covered layer applied inside leaves (record of the first K7
     launch, weight parameter) in the returned list instead of returning a weight gradient - the weight's `.grad` stays None -
     and the caller hands the list to `flush()` once `backward()` has returned. The decision is taken in the forward (this
-    thread) and travels in the autograd context: the backward runs on autograd's device thread."""
+    thread) and travels in the autograd context: the backward runs on autograd's device thread. `side`: a stream the first
+    launches may run on beside the backward pass (`Sink`); the caller then calls `join()` on the list before `flush()`."""
+
+    def __init__(self, side=None):
+        self.side = side
 
     def __enter__(self):
         self.old = getattr(_tls, 'sink', None)
-        _tls.sink = sink = []
+        _tls.sink = sink = Sink(self.side)
         return sink
 
     def __exit__(self, *exc):
@@ -124,10 +161,10 @@ class _Conv(torch.autograd.Function):
         if need_dx and ctx.k8_bwd:
             dx, need_dx = (k.conv3x3(dy, w, flip=True, stride=s) if w.shape[2] == 3 else k.conv1x1s2(dy, w, flip=True)), False
         if need_dw and ctx.ws_floats:
-            ws = x.new_empty(ctx.ws_floats)
             if ctx.sink is not None:
-                ctx.sink.append((k.conv_wgrad_partial(x, dy, w.shape, ws, s), ctx.weight))
+                ctx.sink.append((ctx.sink.launch(lambda: k.conv_wgrad_partial(x, dy, w.shape, x.new_empty(ctx.ws_floats), s), x, dy), ctx.weight))
             else:
+                ws = x.new_empty(ctx.ws_floats)
                 dw = torch.empty_like(w)
                 k.conv_wgrad(x, dy, dw, ws, s)
             need_dw = False

@@ -78,7 +78,7 @@ class ChainGroup:
             return s.engine.forward_backward(x, y)
         from .. import fused_bn
         with fused_bn.several_streams():
-            return s.engine.forward_backward(x, y)
+            return s.engine.forward_backward(x, y, wgrad_side=False)
 
     def _round_eager(self, x, y):
         keeps = [self._forward_backward(s, x, y) for s in self.samplers]

@@ -41,6 +41,11 @@ class ChainEngine:
         self._static = None
         self._eps_static = None
         self._eager_full_steps = 0
+        # K7's first launches on a side stream beside the backward pass (fused_conv.Sink). OFF: measured SLOWER on this stack - 21
+        # fork / join edges per captured step cost more than the overlap gains (2.90 -> 2.25 samples/s, 223 us of idle time per
+        # step between dependent branches; profiles/r06_side_branch_ab.json). The pairing that works is inside ONE launch
+        # (ursa_preact_bwd_pair_f32). Kept as a switch: it changes no bit (tests/test_fused_block_gpu.py).
+        self.wgrad_side = False
         self.gate_probe = None           # fused_bn.GateProbe: parity runs against the reference CPU path only
         self._graph_probe = None
         self.stats = dict(graph_replays=0, eager_steps=0, captures=0)
@@ -54,10 +59,14 @@ class ChainEngine:
         optimizer.ctl_zero_grad = False
         self.invalidate()
 
-    def forward_backward(self, x, y):
+    def forward_backward(self, x, y, wgrad_side=None):
         """Forward + loss + backward, gradients packed into the arena. Returns what `finish` needs to put back
-        the tensors that received no gradient (None almost always)."""
-        with deferred_bn_counters(self.model), fused_bn.probing(self.gate_probe), fused_conv.deferred() as pend:
+        the tensors that received no gradient (None almost always). wgrad_side=False: keep K7's launches on the current
+        stream (ChainGroup: the device is already shared by the chains' branches)."""
+        side = None
+        if self.wgrad_side and wgrad_side is not False:
+            side = side_streams(self.device, 2)[1]          # ([0]: the stream eager warm-up steps / single-chain groups run on)
+        with deferred_bn_counters(self.model), fused_bn.probing(self.gate_probe), fused_conv.deferred(side) as pend:
             logits = self.model(x)                  # (deferred_bn_counters: 19 one-element counter kernels -> one multi-tensor add)
         loss = self.crit(logits, y)
         # Gradients: with p.grad = None autograd hands over its freshly computed tensors (no kernel);
@@ -67,6 +76,7 @@ class ChainEngine:
         for p in self._params:
             p.grad = None
         loss.backward()
+        pend.join()                                 # the K7 branch meets the main stream again: its partial sums are reduced below
         grads = [p.grad for p in self._params]
         grad_views = self.opt.arena.grad_views
         keep = None
