@@ -488,6 +488,17 @@ int ursa_preact_conv3x3_f32(const float* x, const float* w, float* y,
                             int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, uint32_t flags, ursa_stream_t stream);
 int ursa_preact_wgrad_partial_f32(const float* x, const float* bn_save, const float* dy, float* ws, int64_t ws_floats,
                                   int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, int32_t stride, ursa_stream_t stream);
+/* The two convolutions of a unit's backward pass in ONE launch: ursa_preact_conv3x3_f32(URSA_CONV_FLIP | URSA_PREACT_BNBWD) and
+ * ursa_preact_wgrad_partial_f32 read the same output gradient dy and depend on nothing of each other; here their workgroups
+ * alternate inside one grid (even index: input gradient, odd: weight gradient). The same workgroup programs on the same operands:
+ * g, out_partial and ws hold exactly what the two launches would have left (bit for bit); one launch's fixed cost instead of two,
+ * and on the 16-channel layers the two kinds of workgroups run side by side on a CU.
+ * dy: [N, Cd, H, W]; w: the layer's [Cd, Cx, 3, 3]; x: the input of the BatchNorm in front of the layer, [N, Cx, sH, sW] (s = 2 with
+ * URSA_CONV_STRIDE2); bn_save: that BatchNorm's [4][Cx]; g: [N, Cx, sH, sW]; out_partial: [Cx][nl][2] doubles, nl as
+ * ursa_preact_geometry(N, Cd, Cx, H, W, FLIP | BNBWD | stride) says; ws: ursa_conv_wgrad_ws_floats(N, Cx, Cd, sH, sW, 3, s) floats. */
+int ursa_preact_bwd_pair_f32(const float* dy, const float* w, float* g, const float* x, const float* bn_save, double* out_partial,
+                             float* ws, int64_t ws_floats, int64_t N, int64_t Cd, int64_t Cx, int64_t H, int64_t W,
+                             uint32_t flags /* URSA_CONV_STRIDE2 */, ursa_stream_t stream);
 int ursa_bn_apply_f32(const float* x, float* y, const double* partial, int32_t nl, const float* gamma, const float* beta,
                       float* running_mean /* or NULL */, float* running_var /* or NULL */, float* save /* [4][C] */,
                       int64_t N, int64_t C, int64_t HW, float eps, float momentum, uint32_t flags /* URSA_BN_RELU */,

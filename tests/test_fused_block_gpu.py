@@ -165,6 +165,32 @@ def test_backward_unit_equals_the_unfused_launches(cin, cout, hw, stride, n):
 
 
 @pytest.mark.parametrize('cin,cout,hw,stride', UNITS)
+@pytest.mark.parametrize('n', BATCHES + [300])
+def test_paired_backward_launch_equals_its_two_launches_bit_for_bit(cin, cout, hw, stride, n):
+    """ursa_preact_bwd_pair_f32: the input-gradient and the weight-gradient workgroups of a unit interleaved in one grid - the same
+    programs on the same operands (n = 300: K7 takes several images per workgroup there, so the two roles differ in number)."""
+    x, w, gamma, beta, _, dy = _rand_unit(cin, cout, hw, stride, n, 17 * n + cout)
+    K = _K()
+    _, _, st = _unfused_fwd(x, w, stride, gamma, beta)
+    geo = K.preact_geometry(dy.shape, cin, flip=True, stride=stride)
+    g_ref = torch.empty_like(x)
+    pb_ref = torch.empty(cin, geo[0], 2, dtype=torch.float64, device=DEV)
+    K.preact_conv3x3(dy, w, g_ref, pb_ref, None, stride=stride, flip=True, bwd=(x, st))
+    wsf = K.conv_wgrad_ws_floats(x.shape, cout, 3, stride)
+    ws_ref = torch.zeros(wsf, device=DEV)
+    K.preact_wgrad_partial(x, st, dy, w.shape, ws_ref, stride)
+    g = torch.full_like(x, float('nan'))
+    pb = torch.full_like(pb_ref, float('nan'))
+    ws = torch.zeros(wsf, device=DEV)
+    rec = K.preact_bwd_pair(dy, w, g, x, st, pb, ws, stride)
+    assert torch.equal(g, g_ref) and torch.equal(pb, pb_ref) and torch.equal(ws, ws_ref)
+    dw, dw_ref = torch.empty_like(w), torch.empty_like(w)
+    K.conv_wgrad_reduce([(rec, dw)])
+    K.conv_wgrad_reduce([((ws_ref,) + rec[1:], dw_ref)])
+    assert torch.equal(dw, dw_ref) and torch.isfinite(dw).all()
+
+
+@pytest.mark.parametrize('cin,cout,hw,stride', UNITS)
 def test_integer_inputs_equal_the_oracle_exactly(cin, cout, hw, stride):
     """x = +-1 with every channel balanced: mean 0, variance 1 exactly, eps = 0 -> invstd = 1, alpha = gamma, beta' = beta: with
     integer gamma / beta / w / addend / dy every product and sum is an integer below 2^24, so ANY slip - a tap, a halo column, a
@@ -283,8 +309,10 @@ def _step(net, x, y):
     return logits.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters()}
 
 
+@pytest.mark.parametrize('pair', [True, False])
 @pytest.mark.parametrize('depth,n', [(8, 5), (20, 128), (20, 80), (32, 16)])
-def test_network_fused_equals_the_k6_k8_path_bit_for_bit(depth, n):
+def test_network_fused_equals_the_k6_k8_path_bit_for_bit(depth, n, pair, request):
+    request.addfinalizer(lambda old=fused_block.paired(pair): fused_block.paired(old))
     torch.manual_seed(depth + n)
     net = models.PreResNet(10, depth).to(DEV).train()
     for m in net.modules():                        # non-trivial affine parameters and running statistics

@@ -352,11 +352,11 @@ def test_k8_stride2_equals_the_oracle(cin, cout, hw, n):
 @pytest.mark.parametrize('k10', [False, True])
 def test_every_convolution_of_the_network_takes_a_hand_written_launch(k10):
     """PreResNet-20 training step with gradients recorded: no MIOpen convolution launch is left - with the K6 / K8 launches
-    (fused_block off: 19 + 18 K8, 21 K7) and with K10's (19 + 18 fused launches; the 18 weight gradients behind a BatchNorm by the
-    staging form, the stem's and the two 1x1 shortcuts' by the plain one)."""
+    (fused_block off: 19 + 18 K8, 21 K7) and with K10's (19 fused forward launches, 18 paired backward launches = input gradient +
+    weight gradient of a unit in one grid; the stem's and the two 1x1 shortcuts' weight gradients by K7's plain form)."""
     from ursabench_amd import fused_block
     k = _native.default_kernels()
-    seen = dict(conv3x3=0, conv1x1s2=0, conv_wgrad=0, conv_wgrad_partial=0, preact_conv3x3=0, preact_wgrad_partial=0)
+    seen = dict(conv3x3=0, conv1x1s2=0, conv_wgrad=0, conv_wgrad_partial=0, preact_conv3x3=0, preact_wgrad_partial=0, preact_bwd_pair=0)
     origs = {n: getattr(k, n) for n in seen}
 
     def wrap(name):
@@ -376,10 +376,12 @@ def test_every_convolution_of_the_network_takes_a_hand_written_launch(k10):
         fused_block.enabled(old)
         for n in seen:
             delattr(k, n)
-    if k10:
-        assert seen == dict(conv3x3=0, conv1x1s2=2 + 2, conv_wgrad=2, conv_wgrad_partial=1, preact_conv3x3=19 + 18, preact_wgrad_partial=18), seen
+    if k10:          # the 18 units' input-gradient + weight-gradient launches go out as 18 paired launches
+        assert seen == dict(conv3x3=0, conv1x1s2=2 + 2, conv_wgrad=2, conv_wgrad_partial=1, preact_conv3x3=19, preact_wgrad_partial=0,
+                            preact_bwd_pair=18), seen
     else:
-        assert seen == dict(conv3x3=19 + 18, conv1x1s2=2 + 2, conv_wgrad=21, conv_wgrad_partial=0, preact_conv3x3=0, preact_wgrad_partial=0), seen
+        assert seen == dict(conv3x3=19 + 18, conv1x1s2=2 + 2, conv_wgrad=21, conv_wgrad_partial=0, preact_conv3x3=0, preact_wgrad_partial=0,
+                            preact_bwd_pair=0), seen
 
 
 @pytest.mark.parametrize('cin,cout,hw,n', [(16, 16, 32, 300), (32, 32, 16, 500), (64, 64, 8, 1600)])

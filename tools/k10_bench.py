@@ -94,6 +94,7 @@ for cin, cout, hw, st in UNITS:
     wss = [torch.empty(wsf, device=DEV) for _ in range(SETS)]
     r['k7_partial'] = timed(lambda i: K.conv_wgrad_partial(xs[i % SETS], dys[i % SETS], w.shape, wss[i % SETS], st))
     r['k7_partial_xbn'] = timed(lambda i: K.preact_wgrad_partial(xs[i % SETS], save, dys[i % SETS], w.shape, wss[i % SETS], st))
+    r['bwd_pair'] = timed(lambda i: K.preact_bwd_pair(dys[i % SETS], w, gs[i % SETS], xs[i % SETS], save, pb, wss[i % SETS], st))
     out[f'{cin}x{cout}x{hw}s{st}'] = r
     print(f'{cin}x{cout}x{hw}s{st}', json.dumps(r), flush=True)
 if len(sys.argv) > 1:

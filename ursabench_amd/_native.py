@@ -77,6 +77,7 @@ SIGNATURES = {
     'ursa_preact_conv3x3_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _i64,
                                                _i64, _i64, _i64, _i64, _i64, _u32, _vp]),
     'ursa_preact_wgrad_partial_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp]),
+    'ursa_preact_bwd_pair_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _u32, _vp]),
     'ursa_bn_apply_f32': (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f, _f, _u32, _vp]),
     'ursa_bn_bwd_dx_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i64, _i64, _i64, _vp]),
 }
@@ -659,6 +660,28 @@ class HipKernels:
                                                         _ptr(ws, 'ws', None, dev), ws.numel(), N, Cin, Cout, H, W, int(stride), _stream(dev))
         _check(self.lib, rc, 'ursa_preact_wgrad_partial_f32')
         return (ws, N, Cin, Cout, H, W, ksize, int(stride))
+
+    def preact_bwd_pair(self, dy, w, g, x, bn_save, out_partial, ws, stride=1):
+        """preact_conv3x3(dy, w, g, out_partial, None, flip=True, bwd=(x, bn_save)) and preact_wgrad_partial(x, bn_save, dy, w.shape, ws)
+        in ONE launch (their workgroups interleaved); returns conv_wgrad_reduce's record for the weight gradient."""
+        if dy.dim() != 4 or w.dim() != 4 or tuple(w.shape[2:]) != (3, 3) or w.shape[0] != dy.shape[1]:
+            raise ValueError(f'not a 3x3 convolution: dy {tuple(dy.shape)}, w {tuple(w.shape)}')
+        N, Cd, H, W = dy.shape
+        Cx = w.shape[1]
+        dev = dy.device
+        shape = (N, Cx, H * stride, W * stride)
+        if tuple(x.shape) != shape or tuple(g.shape) != shape:
+            raise ValueError(f'x {tuple(x.shape)} / g {tuple(g.shape)} should be {shape}')
+        geo = self.preact_geometry(dy.shape, Cx, flip=True, stride=stride)
+        if geo is None:
+            raise ValueError(f'K10 does not cover the backward of dy {tuple(dy.shape)} -> {Cx} channels (stride {stride})')
+        with torch.cuda.device(dev):
+            rc = self.lib.ursa_preact_bwd_pair_f32(_ptr(dy, 'dy'), _ptr(w, 'w', None, dev), _ptr(g, 'g', None, dev), _ptr(x, 'x', None, dev),
+                                                   _ptr(bn_save, 'bn_save', 4 * Cx, dev), self._f64ptr(out_partial, 'out_partial', Cx * geo[0] * 2, dev),
+                                                   _ptr(ws, 'ws', None, dev), ws.numel(), N, Cd, Cx, H, W, CONV_STRIDE2 if stride == 2 else 0,
+                                                   _stream(dev))
+        _check(self.lib, rc, 'ursa_preact_bwd_pair_f32')
+        return (ws, N, Cx, Cd, H * stride, W * stride, 3, int(stride))
 
     def bn_apply(self, x, y, partial, gamma, beta, running_mean, running_var, save, *, eps, momentum, relu=True):
         """K6's normalise launch alone, statistics from a convolution launch's partial sums (float64 [C, nl, 2])."""

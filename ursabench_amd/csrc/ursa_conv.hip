@@ -106,12 +106,12 @@ __device__ __forceinline__ f32x4 bn_relu4(const f32x4& v, float scale, float shi
 //     correct run), adds them by position with its own sums (which never leave the workgroup), stores the partial sum, zeroes
 //     the slots and re-arms the counter: the scratch is zero again when the launch has drained.
 // One memory round trip (the poll) is what the launch pays at its end.
-__device__ __forceinline__ unsigned take_ticket(const Fuse& f)
+__device__ __forceinline__ unsigned take_ticket(const Fuse& f, int bx, int by)
 {
     unsigned t = 0;
     if (threadIdx.x == 0) {
-        const int line = blockIdx.x / f.line_sz;
-        gu32* tp = (gu32*)(f.tickets + ((size_t)blockIdx.y * kLines + line) * 32);
+        const int line = bx / f.line_sz;
+        gu32* tp = (gu32*)(f.tickets + ((size_t)by * kLines + line) * 32);
         t = __hip_atomic_fetch_add(tp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     return t;
@@ -121,7 +121,7 @@ __device__ __forceinline__ unsigned take_ticket(const Fuse& f)
 // launch), so every workgroup simply stores its sums at out_partial[channel][grid.x index] and that launch adds a channel's
 // S partial sums itself, in ascending order (k_bn_bwd_dx<.., BIGS>): nothing waits at the end of the convolution.
 template <int COUT_WG, int MT, int WPC>
-__device__ __forceinline__ void store_sums(const Fuse& f, double s1, double s2, float* smem, int co_base)
+__device__ __forceinline__ void store_sums(const Fuse& f, double s1, double s2, float* smem, int co_base, int bx, int gx)
 {
     const int tid = threadIdx.x;
     __syncthreads();                                           // every wave is done with the tile: reuse it
@@ -139,17 +139,18 @@ __device__ __forceinline__ void store_sums(const Fuse& f, double s1, double s2, 
                 a += v.x;
                 b += v.y;
             }
-        f.out_partial[(size_t)(co_base + tid) * gridDim.x + blockIdx.x] = make_double2(a, b);
+        f.out_partial[(size_t)(co_base + tid) * gx + bx] = make_double2(a, b);
     }
 }
 
 template <int COUT_WG, int MT, int WPC>
-__device__ __forceinline__ void publish_sums(const Fuse& f, unsigned ticket, double s1, double s2, float* smem, int co_base, int Cout)
+__device__ __forceinline__ void publish_sums(const Fuse& f, unsigned ticket, double s1, double s2, float* smem, int co_base, int bx, int by,
+                                             int gx)
 {
     const int tid = threadIdx.x;
     __shared__ int adder;
     __shared__ double2 own[COUT_WG];
-    const int S = gridDim.x, tile = blockIdx.x, line = tile / f.line_sz;
+    const int S = gx, tile = bx, line = tile / f.line_sz;
     const int first = line * f.line_sz;
     const int cnt = S - first < f.line_sz ? S - first : f.line_sz;
     __syncthreads();                                           // every wave is done with the tile: reuse it
@@ -214,7 +215,7 @@ __device__ __forceinline__ void publish_sums(const Fuse& f, unsigned ticket, dou
         if (i == 0) f.out_partial[(size_t)(co_base + c) * f.nl + line] = make_double2(a, b);
     }
     if (tid == 0)                                              // every workgroup of the line has counted itself: re-armed for the next launch
-        __hip_atomic_store((gu32*)(f.tickets + ((size_t)blockIdx.y * kLines + line) * 32), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store((gu32*)(f.tickets + ((size_t)by * kLines + line) * 32), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // CIN: input channels (all staged; padded to a multiple of 16 by one zero plane); COUT_WG: output channels one workgroup takes
@@ -249,18 +250,18 @@ struct Wg {
 // XBN: the x operand is relu(fma(x, alpha[ci], beta'[ci])) - the BatchNorm + ReLU that stands in front of the layer (K10),
 // applied as the tile is staged from the scale / shift the forward saved (xbn: [4][CIN], rows 2 and 3), so the normalised
 // activation is never stored; the padding stays zero.
-template <int CIN, int COUT_WG, int WO, int R, int STRIDE, int TAPS, int PH, bool XBN = false>
-__global__ __launch_bounds__(kThreads) void k_conv_wgrad(const float* __restrict__ x, const float* __restrict__ dy,
-                                                          float* __restrict__ partial, int N, int Cout, int ipw,
-                                                          const float* __restrict__ xbn) {
+// (bx, by): the workgroup's place in the launch's logical grid - blockIdx of k_conv_wgrad; a workgroup of the paired backward
+// launch (k_bwd_pair below) plays this role with indices of its own. smem: >= Wg::SMEM floats, 16-byte aligned.
+template <int CIN, int COUT_WG, int WO, int R, int STRIDE, int TAPS, int PH, bool XBN>
+__device__ __forceinline__ void wgrad_body(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial, int N,
+                                           int Cout, int ipw, const float* __restrict__ xbn, float* smem, const int bx, const int by) {
     using C = Wg<CIN, COUT_WG, WO, R, STRIDE, TAPS, PH>;
     static_assert(!XBN || kThreads % (CIN * (C::WI / 4)) == 0, "XBN: a thread stages one channel");
-    __shared__ __attribute__((aligned(16))) float smem[C::SMEM];
     float* xs = smem;
     float* ds = smem + C::XS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int band = blockIdx.x % C::BANDS, ig = blockIdx.x / C::BANDS;
-    const int co_base = blockIdx.y * COUT_WG;
+    const int band = bx % C::BANDS, ig = bx / C::BANDS;
+    const int co_base = by * COUT_WG;
 
     for (int i = tid; i < CIN * C::RI; i += kThreads) {       // halo columns: written once, no load ever touches them
         float* row = xs + (i / C::RI) * C::XPLANE + (i % C::RI) * C::WP;
@@ -406,9 +407,9 @@ __global__ __launch_bounds__(kThreads) void k_conv_wgrad(const float* __restrict
     // partial dW of this K slice, tile order: element ((pair * TAPS + tap) * 4 + reg) * 64 + lane holds
     // dW[co = cot*16 + (lane >> 4)*4 + reg][ci = cit*16 + (lane & 15)][tap]
     const size_t E = (size_t)(Cout / 16) * C::CT * C::TE;
-    float* out = partial + (size_t)blockIdx.x * E;
+    float* out = partial + (size_t)bx * E;
     if constexpr (C::KW == 1) {
-        const int pair_g = (blockIdx.y * C::MT + cot) * C::CT + cit;
+        const int pair_g = (by * C::MT + cot) * C::CT + cit;
 #pragma unroll
         for (int j = 0; j < TAPS; ++j)
 #pragma unroll
@@ -426,10 +427,18 @@ __global__ __launch_bounds__(kThreads) void k_conv_wgrad(const float* __restrict
             float s = red[p * C::TE + rem];                    // waves p, p + PW, p + 2 PW, ...: ascending K part
 #pragma unroll
             for (int kp = 1; kp < C::KW; ++kp) s += red[(p + C::PW * kp) * C::TE + rem];
-            const int pair_g = (blockIdx.y * C::MT + p / C::CT) * C::CT + p % C::CT;
+            const int pair_g = (by * C::MT + p / C::CT) * C::CT + p % C::CT;
             out[(size_t)pair_g * C::TE + rem] = s;
         }
     }
+}
+
+template <int CIN, int COUT_WG, int WO, int R, int STRIDE, int TAPS, int PH, bool XBN = false>
+__global__ __launch_bounds__(kThreads) void k_conv_wgrad(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          float* __restrict__ partial, int N, int Cout, int ipw,
+                                                          const float* __restrict__ xbn) {
+    __shared__ __attribute__((aligned(16))) float smem[Wg<CIN, COUT_WG, WO, R, STRIDE, TAPS, PH>::SMEM];
+    wgrad_body<CIN, COUT_WG, WO, R, STRIDE, TAPS, PH, XBN>(x, dy, partial, N, Cout, ipw, xbn, smem, blockIdx.x, blockIdx.y);
 }
 
 // Second launch, for up to kMaxItems layers at once: dW[co][ci][tap] = sum over the layer's S slices, ascending.
@@ -676,18 +685,19 @@ struct Fw {
 //   EPI 3: (input-gradient forms) g = the ReLU gate of the BatchNorm in front of the layer applied to the result
 //          (gate recomputed from that BatchNorm's input `aux` and saved scalars, as K6's backward does), g is what is stored, and
 //          (sum g, sum g * (aux - mean)) in double -> publish_sums: the two sums of native_batch_norm_backward.
-template <int CIN, int COUT_WG, int W, int R, int PH, int MODE, int DBG = 0, int PRO = 0, int EPI = 0>   // DBG != 0: knobs-build experiments only (what bounds the launch)
-__global__ __launch_bounds__(kThreads) void k_conv3x3(const float* __restrict__ x, const float* __restrict__ w,
-                                                       float* __restrict__ y, int N, int Cout, int ipw, int flip_arg, const Fuse f) {
+// (bx, by, gx): the workgroup's place in the launch's logical grid and that grid's x extent - blockIdx / gridDim.x of k_conv3x3;
+// a workgroup of the paired backward launch (k_bwd_pair) plays this role with indices of its own. smem: >= Fw::SMEM floats.
+template <int CIN, int COUT_WG, int W, int R, int PH, int MODE, int DBG, int PRO, int EPI>   // DBG != 0: knobs-build experiments only (what bounds the launch)
+__device__ __forceinline__ void conv_body(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int N, int Cout,
+                                          int ipw, int flip_arg, const Fuse& f, float* smem, const int bx, const int by, const int gx) {
     using C = Fw<CIN, COUT_WG, W, R, PH, MODE>;
     static_assert(!PRO || kThreads % (CIN * (C::WIN / 4)) == 0, "PRO: a thread stages one channel");
     static_assert(!EPI || C::TPW == 1, "EPI: one run per wave and phase");
-    __shared__ __attribute__((aligned(16))) float smem[C::SMEM];
     __shared__ float2 tab[PRO ? CIN : 1];
     float* xs = smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int band = blockIdx.x % C::BANDS, ig = blockIdx.x / C::BANDS;
-    const int co_base = blockIdx.y * COUT_WG;
+    const int band = bx % C::BANDS, ig = bx / C::BANDS;
+    const int co_base = by * COUT_WG;
     const int j = lane & 15, k = lane >> 4;
     const int cot = wave % C::MT, wsub = wave / C::MT;
     const int flip = MODE == 2 ? 1 : MODE == 1 ? 0 : flip_arg;   // which weight layout is read (MODE 2: the transposed one)
@@ -770,7 +780,7 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3(const float* __restrict__ 
     if (n0 < n1) issue(n0);                                    // the first image's rows are in flight while the weights are read
     if (n0 < n1) issue_aux(n0);
     unsigned ticket = 0;
-    if constexpr (EPI == 1 || EPI == 2) ticket = take_ticket(f);   // "this workgroup runs": needed at the very end (publish_sums)
+    if constexpr (EPI == 1 || EPI == 2) ticket = take_ticket(f, bx, by);   // "this workgroup runs": needed at the very end (publish_sums)
 
     __shared__ double2 dsum[PRO ? CIN : 1];
     if constexpr (PRO == 1) {
@@ -799,7 +809,7 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3(const float* __restrict__ 
                 const float alpha = invstd * f.gamma[c];
                 const float shift = fmaf(-meanf, alpha, f.beta[c]);
                 tab[c] = make_float2(alpha, shift);
-                if (blockIdx.x == 0 && blockIdx.y == 0) {
+                if (bx == 0 && by == 0) {
                     f.save[c] = meanf;
                     f.save[CIN + c] = invstd;
                     f.save[2 * CIN + c] = alpha;
@@ -980,12 +990,42 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3(const float* __restrict__ 
     if constexpr (EPI != 0 && DBG == 3) {                      // knobs: no hand-over at all (what the accumulation alone costs)
         if (s1 + s2 == 12345.678) y[0] = 0.f;
     } else if constexpr (EPI != 0 && DBG == 4) {               // knobs: slots stored, nobody adds (what the final poll costs)
-        publish_sums<COUT_WG, C::MT, C::WPC>(f, 0xffffffffu, s1, s2, smem, co_base, Cout);
+        publish_sums<COUT_WG, C::MT, C::WPC>(f, 0xffffffffu, s1, s2, smem, co_base, bx, by, gx);
     } else if constexpr (EPI == 3) {
-        store_sums<COUT_WG, C::MT, C::WPC>(f, s1, s2, smem, co_base);
+        store_sums<COUT_WG, C::MT, C::WPC>(f, s1, s2, smem, co_base, bx, gx);
     } else if constexpr (EPI != 0) {
-        publish_sums<COUT_WG, C::MT, C::WPC>(f, ticket, s1, s2, smem, co_base, Cout);
+        publish_sums<COUT_WG, C::MT, C::WPC>(f, ticket, s1, s2, smem, co_base, bx, by, gx);
     }
+}
+
+template <int CIN, int COUT_WG, int W, int R, int PH, int MODE, int DBG = 0, int PRO = 0, int EPI = 0>
+__global__ __launch_bounds__(kThreads) void k_conv3x3(const float* __restrict__ x, const float* __restrict__ w,
+                                                       float* __restrict__ y, int N, int Cout, int ipw, int flip_arg, const Fuse f) {
+    __shared__ __attribute__((aligned(16))) float smem[Fw<CIN, COUT_WG, W, R, PH, MODE>::SMEM];
+    conv_body<CIN, COUT_WG, W, R, PH, MODE, DBG, PRO, EPI>(x, w, y, N, Cout, ipw, flip_arg, f, smem, blockIdx.x, blockIdx.y, gridDim.x);
+}
+
+// The two convolutions of a unit's backward pass - the input gradient (conv_body, EPI 3) and the weight gradient (wgrad_body,
+// XBN) - read the same output gradient and depend on nothing of each other: ONE launch whose workgroups alternate between the
+// two roles (even linear index: input gradient, odd: weight gradient; what one role has more of comes last). Both alone are
+// bound by latency and launch cost at two workgroups per CU; side by side on the same CUs they fill each other's gaps:
+// one launch's fixed cost instead of two, and no cross-queue edge as a parallel graph branch would need.
+template <int CIN_A, int COUT_WG_A, int W_A, int R_A, int PH_A, int MODE_A, int CIN_B, int COUT_WG_B, int WO_B, int R_B, int STRIDE_B, int PH_B>
+__global__ __launch_bounds__(kThreads) void k_bwd_pair(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ g,
+                                                        const float* __restrict__ x, float* __restrict__ partial, int N, int Cd, int Cx,
+                                                        int ipw_a, int ipw_b, int gx_a, int gy_a, int gx_b, int gy_b, const Fuse f) {
+    using A = Fw<CIN_A, COUT_WG_A, W_A, R_A, PH_A, MODE_A>;
+    using B = Wg<CIN_B, COUT_WG_B, WO_B, R_B, STRIDE_B, 9, PH_B>;
+    __shared__ __attribute__((aligned(16))) float smem[cmax(A::SMEM, B::SMEM)];
+    const int na = gx_a * gy_a, nb = gx_b * gy_b, m = na < nb ? na : nb;
+    const int id = blockIdx.x;
+    int role, idx;
+    if (id < 2 * m) role = id & 1, idx = id >> 1;
+    else role = na > nb ? 0 : 1, idx = id - m;
+    if (role == 0)      // dx' = gate(conv_flip(dy, w)): staged tensor dy [N, Cd, ..], result g [N, Cx, ..]
+        conv_body<CIN_A, COUT_WG_A, W_A, R_A, PH_A, MODE_A, 0, 0, 3>(dy, w, g, N, Cx, ipw_a, 1, f, smem, idx % gx_a, idx / gx_a, gx_a);
+    else                // dW partial sums: x operand = relu(bn(x)) rebuilt from f.bsave while staged
+        wgrad_body<CIN_B, COUT_WG_B, WO_B, R_B, STRIDE_B, 9, PH_B, true>(x, dy, partial, N, Cd, ipw_b, f.bsave, smem, idx % gx_b, idx / gx_b);
 }
 
 struct FwPlan {
@@ -1168,6 +1208,45 @@ extern "C" int ursa_preact_conv3x3_f32(const float* x, const float* w, float* y,
     f.out_partial = reinterpret_cast<double2*>(out_partial);
     hipLaunchKernelGGL(p.fn, dim3(g.S, p.gy), dim3(kThreads), 0, (hipStream_t)stream, x, w, y, (int)N, (int)Cout, p.ipw,
                        (int)(flags & URSA_CONV_FLIP), f);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? URSA_OK : (int)e;
+}
+
+// The paired backward launch: ursa_preact_conv3x3_f32(FLIP | BNBWD) and ursa_preact_wgrad_partial_f32 of one unit in one launch
+// (k_bwd_pair). Same workgroup programs, same operands, same results bit for bit; grid = the two launches' workgroups interleaved.
+typedef void (*PairFn)(const float*, const float*, float*, const float*, float*, int, int, int, int, int, int, int, int, int, Fuse);
+
+static PairFn pair_fn_for(int64_t Cd, int64_t Cx, int64_t W, bool s2) {
+    // (Cd, W) = channels / size of dy; Cx = channels of the layer's input
+    if (!s2 && Cd == 16 && Cx == 16 && W == 32) return k_bwd_pair<16, 16, 32, 8, 4, 0, 16, 16, 32, 8, 1, 4>;
+    if (!s2 && Cd == 32 && Cx == 32 && W == 16) return k_bwd_pair<32, 32, 16, 8, 4, 0, 32, 32, 16, 8, 1, 4>;
+    if (!s2 && Cd == 64 && Cx == 64 && W == 8) return k_bwd_pair<64, 16, 8, 8, 1, 0, 64, 16, 8, 8, 1, 4>;
+    if (s2 && Cd == 32 && Cx == 16 && W == 16) return k_bwd_pair<32, 16, 16, 8, 2, 2, 16, 32, 16, 8, 2, 4>;
+    if (s2 && Cd == 64 && Cx == 32 && W == 8) return k_bwd_pair<64, 16, 8, 8, 1, 2, 32, 32, 8, 4, 2, 2>;
+    return nullptr;
+}
+
+extern "C" int ursa_preact_bwd_pair_f32(const float* dy, const float* w, float* g, const float* x, const float* bn_save,
+                                        double* out_partial, float* ws, int64_t ws_floats, int64_t N, int64_t Cd, int64_t Cx,
+                                        int64_t H, int64_t W, uint32_t flags, ursa_stream_t stream) {
+    if (flags & ~URSA_CONV_STRIDE2) return URSA_EFLAGS;
+    if (!dy || !w || !g || !x || !bn_save || !out_partial || !ws) return URSA_ENULL;
+    if (N < 1 || Cd < 1 || Cx < 1 || H < 1 || W < 1) return URSA_ESIZE;
+    if (((uintptr_t)dy | (uintptr_t)w | (uintptr_t)g | (uintptr_t)x | (uintptr_t)out_partial | (uintptr_t)ws) & 15 || (uintptr_t)bn_save & 3) return URSA_EALIGN;
+    const bool s2 = flags & URSA_CONV_STRIDE2;
+    const int st = s2 ? 2 : 1;
+    const FwPlan a = fuse_plan_for(N, Cd, Cx, H, W, URSA_CONV_FLIP | URSA_PREACT_BNBWD | (flags & URSA_CONV_STRIDE2));
+    const Plan b = plan_for(N, Cx, Cd, H * st, W * st, 3, st, true);
+    const PairFn fn = pair_fn_for(Cd, Cx, W, s2);
+    if (!a.fn || !b.slices || !fn || H != W) return URSA_EVALUE;
+    if (ws_floats < (int64_t)b.slices * b.E) return URSA_ESIZE;
+    const FuseGeom ga = fuse_geom(a, N, Cx, true);
+    Fuse f = {};
+    f.nl = ga.nl, f.line_sz = ga.line_sz, f.aux = x, f.bsave = bn_save;
+    f.out_partial = reinterpret_cast<double2*>(out_partial);
+    const int na = ga.S * a.gy, nb = b.slices * b.gy;
+    hipLaunchKernelGGL(fn, dim3(na + nb), dim3(kThreads), 0, (hipStream_t)stream, dy, w, g, x, ws, (int)N, (int)Cd, (int)Cx, a.ipw, b.ipw,
+                       ga.S, a.gy, b.slices, b.gy, f);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? URSA_OK : (int)e;
 }

@@ -32,6 +32,16 @@ from torch.autograd.function import once_differentiable
 from . import _native, fused_bn, fused_conv
 
 _on = os.environ.get('URSA_FUSED_BLOCK', '1') != '0'
+_pair = os.environ.get('URSA_BWD_PAIR', '1') != '0'      # a unit's input-gradient and weight-gradient launches as one (A/B: 0)
+
+
+def paired(flag=None):
+    """Query / set whether a unit's two backward convolutions go out as ONE launch (ursa_preact_bwd_pair_f32)."""
+    global _pair
+    old = _pair
+    if flag is not None:
+        _pair = bool(flag)
+    return old
 
 
 def enabled(flag=None):
@@ -164,12 +174,23 @@ class _Unit(torch.autograd.Function):
         if dy is None:                                          # the unit's result unused: only the shortcut path's gradient flows
             return dxa, None, None, None, None, None, None, None, None, None
         dy = _aligned(dy)
-        dw = _wgrad(ctx.sink, K, x, save, dy, ctx.weight, ctx.ws_floats, s) if ctx.needs_input_grad[4] else None
         Cin = x.shape[1]
         geo = K.preact_geometry(dy.shape, Cin, flip=True, stride=s)
         g = torch.empty_like(x)
         pb = torch.empty(Cin, geo[0], 2, dtype=torch.float64, device=dev)
-        K.preact_conv3x3(dy, w, g, pb, None, stride=s, flip=True, bwd=(x, save))
+        dw = None
+        if ctx.needs_input_grad[4] and _pair and (ctx.sink is None or ctx.sink.side is None):
+            # the unit's two backward convolutions in ONE launch (their workgroups interleaved)
+            rec = K.preact_bwd_pair(dy, w, g, x, save, pb, x.new_empty(ctx.ws_floats), s)
+            if ctx.sink is not None:
+                ctx.sink.append((rec, ctx.weight))
+            else:
+                dw = torch.empty_like(w)
+                K.conv_wgrad_reduce([(rec, dw)])
+        else:
+            if ctx.needs_input_grad[4]:
+                dw = _wgrad(ctx.sink, K, x, save, dy, ctx.weight, ctx.ws_floats, s)
+            K.preact_conv3x3(dy, w, g, pb, None, stride=s, flip=True, bwd=(x, save))
         dx = torch.empty_like(x)
         dgb = x.new_empty(2, Cin)
         K.bn_bwd_dx(x, g, dx, gamma, save, pb, dgb[0], dgb[1], dz=None if dxa is None else _aligned(dxa))
