@@ -78,6 +78,7 @@ def parse(argv=None):
                     'gpurun_out/bench_detail_<config>.json. stdout carries ONE compact JSON line (< 8 KB) that names this file')
     ap.add_argument('--full-line', action='store_true', help='print the full record on stdout instead of the compact line (tools/ only)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-full-size-legs', action='store_true', help='c2: skip the bounded full-size C4 / C5 legs (2 SWAG members + BMA; 8 HMC proposals)')
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--force-dist', action='store_true', help='join a process group even when WORLD_SIZE is 1')
     ap.add_argument('--cpu-steps', type=int, default=150, help='minibatch steps of the CPU port to time')
@@ -212,16 +213,30 @@ def pmc_traffic(kernel_key, elements):
     return None, 'none (no committed PMC pass for this kernel and size)'
 
 
-def rocprof_average(kernel_substr, files=('r05_bench_kernel_stats.csv', 'r04_bench_kernel_stats.csv', 'r03_bench_kernel_stats.csv')):
+def _lib_sha256():
+    import hashlib
+    from ursabench_amd import _native
+    try:
+        return hashlib.sha256(open(_native.LIB_PATH, 'rb').read()).hexdigest()
+    except OSError:
+        return None
+
+
+def rocprof_average(kernel_substr, files=('r06_bench_kernel_stats.csv',)):
     """Average duration of a kernel in the committed `rocprofv3 --kernel-trace --stats` summary of THIS command
-    (profiles/rNN_bench_kernel_stats.csv, written by tools/r04_evidence.sh). The profiler cannot run inside the
-    measurement, so this is read from the file and named: a reader recomputes frac_rocprof = bytes / us from it.
-    Returns dict(us, calls, file) or None."""
+    (profiles/r06_bench_kernel_stats.csv, written by tools/r06_evidence.sh). The profiler cannot run inside the
+    measurement, so this is read from the file and named: a reader recomputes frac_rocprof = flops / us from it.
+    Only THIS round's file, and only if it was taken with the very library that is loaded now (profiles/
+    r06_bench_kernel_stats.meta.json records its sha256): a profile of other kernels can never feed a fresh line
+    (VERDICT r5 #8, ADVICE r5). Returns dict(us, calls, file) or None."""
     import csv
     for name in files:
         path = os.path.join(ROOT, 'profiles', name)
-        if not os.path.exists(path):
+        meta = os.path.join(ROOT, 'profiles', name.replace('.csv', '.meta.json'))
+        if not os.path.exists(path) or not os.path.exists(meta):
             continue
+        if json.load(open(meta)).get('libursa_hip_sha256') != _lib_sha256():
+            continue                                          # the kernels changed since the profile was taken
         tot = calls = 0
         for row in csv.DictReader(open(path)):
             if kernel_substr in row['Name']:
@@ -254,7 +269,7 @@ def load_gate_lists():
 
 
 def parity_trial(dev, seed_offset, steps_per_sample=1, samples=3, rows=128, test_rows=128, depth=20, n_noise=N_TRAIN,
-                 given_gates=True):
+                 given_gates=True, timed_path=False):
     """One (rows, seed) of parity_block: the torch-CPU port once (recording its near-zero ReLU gates), then the GPU path
     on the same init / inputs / noise - `natural` (gates as the GPU's own convolutions decide them; differing ones
     counted against the port's lists) and, if `given_gates`, `given` (the port's gates handed to the backward launches)."""
@@ -311,27 +326,33 @@ def parity_trial(dev, seed_offset, steps_per_sample=1, samples=3, rows=128, test
         pred.update_statistics(members, output_performance=False)
         return pred.ensemble_proba, pred.expected_data_uncertainty
 
-    def gpu_run(force, fused=True):
+    def gpu_run(force, fused=True, instrument=True, head=True):
         was = fused_bn.enabled(fused)        # fused=False: MIOpen's BatchNorm + ATen's ReLU / add launches in K6's place (natural gates only)
         try:
-            return _gpu_run(force)
+            return _gpu_run(force, instrument, head)
         finally:
             fused_bn.enabled(was)
 
-    def _gpu_run(force):
+    def _gpu_run(force, instrument=True, head=True):
+        # instrument=False: no GateProbe - the chain then takes the launches that are TIMED (K10's fused units and, with head, K11's
+        # fused head), which the probe's presence turns off (it observes relu(bn(x)), which those launches never store)
         # the product path with the port's noise injected through the kernel's eps input
         train = DeviceLoader(xtr.to(dev), ytr.to(dev), rows)
         s = inference.SGHMC(dict(hyp), copy.deepcopy(net0), train, device=dev, seed=1, use_graph=True)
         s.optimizer.param_groups[0]['num_training_samples'] = n_noise     # the N of optim_sghmc.py:48,64: the workload's 50,000
         idx = s.arena.layout.gather_index(dev)
-        probe = s.engine.gate_probe = fused_bn.GateProbe(n_bn, cap, dev, force=force)
+        probe = fused_bn.GateProbe(n_bn, cap, dev, force=force)
+        if instrument:
+            s.engine.gate_probe = probe
+        s.engine.fused_head = head
+        gates_at = (lambda k: lists[k % total]) if instrument else None
 
         def eps(k):
             e = torch.zeros(s.arena.n, device=dev)
             e[idx] = torch.cat([t.reshape(-1) for t in eps_steps[k % total]]).to(dev)
             return e
         s.eps_provider = eps
-        s.gate_provider = lambda k: lists[k % total]
+        s.gate_provider = gates_at
         # Compare the path that is TIMED: hipGraph replays reading the injected noise (and here the gate lists) from
         # persistent buffers. Capture needs one eager warm-up step (MIOpen's solver search cannot run inside a
         # capture): take it and the capture on this very chain, then put the chain back to its initial state, so
@@ -340,7 +361,7 @@ def parity_trial(dev, seed_offset, steps_per_sample=1, samples=3, rows=128, test
         saved = (a.theta.clone(), None if a.fbuf is None else a.fbuf.clone(), [b.clone() for _, b in a.ibufs])
         s.engine.WARMUP_STEPS = 1
         for _ in range(2):                                                # eager warm-up step, then capture + first replay
-            s.engine.run_epoch(train, True, eps_per_step=eps, gates_per_step=lambda k: lists[0])
+            s.engine.run_epoch(train, True, eps_per_step=eps, gates_per_step=(lambda k: lists[0]) if instrument else None)
         assert s.engine.stats['captures'] == 1 and s.engine.stats['graph_replays'] >= 1, s.engine.stats
         with torch.no_grad():
             a.theta.copy_(saved[0])
@@ -363,12 +384,18 @@ def parity_trial(dev, seed_offset, steps_per_sample=1, samples=3, rows=128, test
         flips = [sum(h['flips']) for h in probe.history]
         outside = [h['n_open_as_reference'] == [c['n_open'] for c in calls] for h, calls in zip(probe.history, gate_steps)]
         # (1) sampler: every posterior sample, GPU member vs the port's member
-        per_sample = []
+        per_sample, probas = [], []
         for k in range(samples):
             pgk, egk = gpu_predictive(ens[k:k + 1])
             pck, eck = cpu_predictive(cpu_members[k:k + 1])
+            probas.append(pgk.clone())
             per_sample.append({'minibatch_steps': (k + 1) * steps_per_sample, 'max_rel_err_proba': rel(pgk, pck),
                                'max_rel_err_entropy': rel(egk, eck)})
+        if not instrument:
+            from ursabench_amd import fused_block
+            assert fused_block.eligible(s.model.train(), xtr[:rows].to(dev)), 'the uninstrumented chain should take the fused units'
+            return {'per_sample': per_sample, 'engine': dict(s.engine.stats), '_proba': probas,
+                    '_theta': [torch.cat([p_.detach().reshape(-1) for p_ in m.parameters()]).clone() for m in ens]}
         # (2) bma: the GPU ensemble, same members evaluated by the CPU loop
         host_members = []
         for m in ens:
@@ -379,16 +406,36 @@ def parity_trial(dev, seed_offset, steps_per_sample=1, samples=3, rows=128, test
         pc, ec = cpu_predictive(host_members)
         return {'gates_given': bool(force), 'gate_flips_per_step': flips, 'no_gate_outside_the_band_differs_per_step': outside,
                 'per_sample': per_sample, 'engine': dict(s.engine.stats),
-                'bma_same_members': {'members': samples, 'max_rel_err_proba': rel(pg, pc), 'max_rel_err_entropy': rel(eg, ec)}}
+                'bma_same_members': {'members': samples, 'max_rel_err_proba': rel(pg, pc), 'max_rel_err_entropy': rel(eg, ec)},
+                '_proba': probas, '_theta': [torch.cat([p_.detach().reshape(-1) for p_ in m.parameters()]).clone() for m in ens]}
 
     out = {'rows': rows, 'seed_offset': seed_offset, 'gates_per_step': int(sum(c['numel'] for c in gate_steps[0])),
            'near_zero_listed_per_step': [int(sum(len(c['idx']) for c in calls)) for calls in gate_steps],
            'natural': gpu_run(False)}
+    if timed_path:
+        # The launches that are TIMED (no probe installed: K10's fused units; + K11's fused head) against the instrumented
+        # natural run above on the same init / inputs / noise. K10 is the same arithmetic in fewer launches: with the stock head
+        # the chain must end on IDENTICAL parameters after every sample (asserted). K11 changes summation trees in the head
+        # (pooling, classifier): its first sample - one minibatch step, no gate can have moved yet - is held to 1e-5 on the
+        # predictive against the instrumented run; later samples are reported (a 1e-8 difference in a weight can flip a ReLU gate).
+        nat = out['natural']
+        k10 = gpu_run(False, instrument=False, head=False)
+        k11 = gpu_run(False, instrument=False, head=True)
+        out['timed_path'] = {
+            'k10_parameters_bit_equal_to_instrumented_per_sample': [bool(torch.equal(a_, b_)) for a_, b_ in zip(k10['_theta'], nat['_theta'])],
+            'k10_per_sample_vs_cpu': k10['per_sample'],
+            'k11_max_rel_err_proba_vs_instrumented_per_sample': [rel(a_, b_) for a_, b_ in zip(k11['_proba'], nat['_proba'])],
+            'k11_per_sample_vs_cpu': k11['per_sample'], 'engine': k11['engine']}
+    for v in out.values():
+        if isinstance(v, dict):
+            v.pop('_proba', None), v.pop('_theta', None)
     if given_gates:
         out['given'] = gpu_run(True)
+        out['given'].pop('_proba', None), out['given'].pop('_theta', None)
         # the same natural run with the STOCK BatchNorm / ReLU launches: differing gates come from the convolutions' last bits, not
         # from the BatchNorm arithmetic, so K6 must not be worse in distribution (VERDICT r4 #5 i)
         out['natural_stock_bn'] = gpu_run(False, fused=False)
+        out['natural_stock_bn'].pop('_proba', None), out['natural_stock_bn'].pop('_theta', None)
     return out
 
 
@@ -429,7 +476,7 @@ def parity_block(dev, steps_per_sample=1, samples=3, rows=128, test_rows=128, de
     plan = [(rows, off, True) for off in seeds] + [(small_rows, off, False) for off in seeds]
     trials, ok_work, ok_equal, ok_bma, n_equal = [], True, True, True, 0
     for r, off, given in plan:
-        t = parity_trial(dev, off, steps_per_sample, samples, r, test_rows, depth, n_noise, given_gates=given)
+        t = parity_trial(dev, off, steps_per_sample, samples, r, test_rows, depth, n_noise, given_gates=given, timed_path=given)
         trials.append(t)
         nat = t['natural']
         for k, ps in enumerate(nat['per_sample']):           # gate-equal prefix of the natural run
@@ -455,6 +502,18 @@ def parity_block(dev, steps_per_sample=1, samples=3, rows=128, test_rows=128, de
     k6_final, st_final = [v['k6_err_per_sample'][-1] for v in side.values()], [v['stock_err_per_sample'][-1] for v in side.values()]
     k6_first, st_first = [v['k6_err_per_sample'][0] for v in side.values()], [v['stock_err_per_sample'][0] for v in side.values()]
     ok_stock = bool(paired) and med(k6_final) <= 3 * med(st_final) + PARITY_RTOL and med(k6_first) <= 3 * med(st_first) + PARITY_RTOL
+    # the launches that are timed (K10 units, K11 head: no probe installed) against the instrumented runs above, same seeds
+    tp = [t['timed_path'] for t in trials if 'timed_path' in t]
+    ok_k10 = bool(tp) and all(all(t_['k10_parameters_bit_equal_to_instrumented_per_sample']) for t_ in tp)
+    ok_k11 = bool(tp) and all(t_['k11_max_rel_err_proba_vs_instrumented_per_sample'][0] <= PARITY_RTOL for t_ in tp)
+    timed = {'what': 'the chain WITHOUT the parity instrument - the launches bench.py times: K10 fused units (+ K11 fused head) - against the '
+                     'instrumented natural run of the same seed: K10 with the stock head ends every sample on bit-identical parameters '
+                     '(asserted); K11 first sample (one step: no gate can have moved) within 1e-5 on the predictive (asserted), later '
+                     'samples reported',
+             'pass_k10_bit_equal': ok_k10, 'pass_k11_first_sample': ok_k11,
+             'k11_worst_first_sample': max((t_['k11_max_rel_err_proba_vs_instrumented_per_sample'][0] for t_ in tp), default=None),
+             'k11_worst_any_sample_reported': max((max(t_['k11_max_rel_err_proba_vs_instrumented_per_sample']) for t_ in tp), default=None),
+             'k11_worst_vs_cpu_reported': max((ps['max_rel_err_proba'] for t_ in tp for ps in t_['k11_per_sample_vs_cpu']), default=None)}
     out = {'what': f'PreResNet-{depth} SGHMC at the workload hyper-parameters, identical init / inputs / injected noise, predictive '
                    f'on {test_rows} test rows after each of {samples} samples of {steps_per_sample} minibatch step(s); GPU path (every '
                    'compared step a hipGraph replay reading the injected noise) vs torch-CPU port of the reference path; '
@@ -468,8 +527,8 @@ def parity_block(dev, steps_per_sample=1, samples=3, rows=128, test_rows=128, de
                                               'median_stock_bn': med(st_first) if paired else None,
                                               'median_final_k6': med(k6_final) if paired else None,
                                               'median_final_stock_bn': med(st_final) if paired else None},
-           'pass_k6_not_worse_than_stock': ok_stock,
-           'trials': trials, 'pass': bool(ok_work and ok_equal and ok_bma and ok_stock)}
+           'pass_k6_not_worse_than_stock': ok_stock, 'timed_path': timed,
+           'trials': trials, 'pass': bool(ok_work and ok_equal and ok_bma and ok_stock and ok_k10 and ok_k11)}
     if not out['pass']:
         raise AssertionError(f'parity: predictive probabilities beyond {PARITY_RTOL} relative: {json.dumps(out)}')
     return out
@@ -595,42 +654,83 @@ def roofline_block(sampler, large_n, group=None):
 
 
 def roofline_conv_block(dev):
-    """The kernel with the largest share of a training step since the convolutions are hand-written: K8 at the 16-channel 3x3
-    layer (12 of a step's 146 launches; K8 as a whole is 36 % of its kernel time, profiles/r05_step_timeline.json). The very
-    launch the step issues (batch 128, [128, 16, 32, 32] in and out), timed with HIP events on its stream over 128-launch graph
-    replays. Bound: the fp32-input matrix pipe - algorithmic flops 2 * N*H*W * Cin*Cout*9 against 157.3 TFLOP/s."""
-    from ursabench_amd import _native
+    """The kernels with the largest share of a training step: the convolution launches of the 16-channel 3x3 layers, in the forms
+    the step issues them since round 6 (profiles/r06_step_timeline.json):
+      pair     k_bwd_pair<16,16,32,..>: a unit's input gradient (+ BatchNorm-backward sums) and weight gradient (x operand
+               normalised while staged) in ONE launch - 6 of a step's launches, the largest single kernel of the step;
+      forward  k_conv3x3<16,16,32,..,PRO,EPI>: conv(relu(bn(x))) with the statistics of the result (K10's forward form);
+      k8       the plain convolution launch (K8), for reference: what rounds 5 reported.
+    Each is the very launch the step issues (batch 128, [128, 16, 32, 32] tensors), timed with HIP events on its stream over
+    128-launch graph replays on eight operand sets taken in turn. Bound: the fp32-input matrix pipe (v_mfma_f32_16x16x4_f32) -
+    algorithmic flops 2 * N*H*W * Cin*Cout*9 per convolution (the pair holds two) against 157.3 TFLOP/s. `roofline` = the pair
+    (the dominant kernel); the other two ride along as `forward` / `k8`."""
+    from ursabench_amd import _native, fused_block
     K = _native.default_kernels()
     stream = torch.cuda.current_stream()
-    # eight input / output buffers taken in turn (128 MB in all: beyond the L2s, inside the Infinity Cache - where a step's
-    # activations live when the next launch reads them); one buffer read 128 times over would sit in L2 and read 8.9 us
+    # eight operand sets taken in turn (beyond the L2s, inside the Infinity Cache - where a step's activations live when the next
+    # launch reads them); one buffer read 128 times over would sit in L2
     xs = [torch.randn(BATCH, 16, 32, 32, device=dev) for _ in range(8)]
     ys = [torch.empty_like(xs[0]) for _ in range(8)]
+    dys = [torch.randn(BATCH, 16, 32, 32, device=dev) for _ in range(8)]
     w = torch.randn(16, 16, 3, 3, device=dev) * 0.1
+    gamma, beta = torch.rand(16, device=dev) + 0.5, torch.randn(16, device=dev) * 0.1
+    xd = xs[0].double()
+    ip = torch.stack([xd.sum((0, 2, 3)), (xd * xd).sum((0, 2, 3))], -1)[:, None, :].contiguous()
+    save = torch.empty(4, 16, device=dev)
+    geo = K.preact_geometry(xs[0].shape, 16, bn=True)
+    sc = torch.zeros(geo[1], dtype=torch.uint8, device=dev)
+    part = torch.empty(16, geo[0], 2, dtype=torch.float64, device=dev)
+    geob = K.preact_geometry(dys[0].shape, 16, flip=True)
+    pb = torch.empty(16, geob[0], 2, dtype=torch.float64, device=dev)
+    wss = [torch.empty(K.conv_wgrad_ws_floats(xs[0].shape, 16, 3, 1), device=dev) for _ in range(8)]
+    bn = (ip, gamma, beta, None, None, save, 1e-5, 0.0)
+    K.preact_conv3x3(xs[0], w, ys[0], part, sc, bn=bn)                      # fills `save`
     turn = [0]
 
-    def fn():
+    def nxt():
         turn[0] += 1
-        K.conv3x3(xs[turn[0] % 8], w, ys[turn[0] % 8])
-    batches = sorted(event_time_ms(fn, 1024, stream, graph_batch=128) for _ in range(5))
-    ms = batches[2]
+        return turn[0] % 8
     flops = 2 * BATCH * 32 * 32 * 16 * 16 * 9
-    nbytes = 4 * (2 * xs[0].numel() + w.numel())
-    ach = flops / (ms * 1e-3) / 1e12
-    prof = rocprof_average('k_conv3x3<16, 16, 32, 8, 4, 0')
-    traffic, tsrc = pmc_bytes('k_conv3x3<16, 16, 32')
-    return {'bound': 'mfma', 'kernel': 'k_conv3x3<16, 16, 32, ...> (K8: forward / input gradient of the 16-channel 3x3 layers, batch 128)',
-            'achieved': round(ach, 2), 'peak': MFMA_FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / MFMA_FP32_PEAK_TFLOPS, 4),
-            'flops_per_launch': flops, 'bytes_per_launch': nbytes, 'traffic': traffic, 'traffic_source': tsrc,
-            'us_per_launch': round(ms * 1e3, 3), 'us_per_launch_batches': [round(b * 1e3, 3) for b in batches],
-            'frac_uses': 'us_per_launch (HIP events, measured live in this run, eight operand buffers in turn); frac_rocprof uses the '
-                         'committed profile of this command, whose calls include the step\'s own launches of this kernel',
-            'us_per_launch_rocprof': None if prof is None else prof['us'],
-            'frac_rocprof': None if prof is None else round(flops / (prof['us'] * 1e-6) / 1e12 / MFMA_FP32_PEAK_TFLOPS, 4),
-            'rocprof_source': None if prof is None else f"{prof['file']}: {prof['calls']} launches of this kernel",
-            'share_of_step': 'K8 36 %, K6 32 %, K7 22 % of a step\'s 1,057 us of kernel time (profiles/r05_step_timeline.json); K1 - '
-                             '`roofline_k1` - is one 3.4 us launch per step',
-            'hbm_frac_for_the_record': round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+
+    def timed(fn, n_conv, substr, what):
+        batches = sorted(event_time_ms(fn, 1024, stream, graph_batch=128) for _ in range(5))
+        ms = batches[2]
+        ach = n_conv * flops / (ms * 1e-3) / 1e12
+        prof = rocprof_average(substr)
+        return {'kernel': what, 'achieved': round(ach, 2), 'frac': round(ach / MFMA_FP32_PEAK_TFLOPS, 4), 'flops_per_launch': n_conv * flops,
+                'us_per_launch': round(ms * 1e3, 3), 'us_per_launch_batches': [round(b_ * 1e3, 3) for b_ in batches],
+                'us_per_launch_rocprof': None if prof is None else prof['us'],
+                'frac_rocprof': None if prof is None else round(n_conv * flops / (prof['us'] * 1e-6) / 1e12 / MFMA_FP32_PEAK_TFLOPS, 4),
+                'rocprof_source': None if prof is None else f"{prof['file']}: {prof['calls']} launches of this kernel"}
+
+    def f_pair():
+        i = nxt()
+        K.preact_bwd_pair(dys[i], w, ys[i], xs[i], save, pb, wss[i], 1)
+
+    def f_fwd():
+        i = nxt()
+        K.preact_conv3x3(xs[i], w, ys[i], part, sc, bn=bn)
+
+    def f_k8():
+        i = nxt()
+        K.conv3x3(xs[i], w, ys[i])
+    pair = timed(f_pair, 2, 'k_bwd_pair<16, 16, 32', 'k_bwd_pair<16, 16, 32, ..> (K10: input gradient + weight gradient of a 16-channel unit in one launch, batch 128)')
+    fwd = timed(f_fwd, 1, 'k_conv3x3<16, 16, 32, 8, 4, 0, 0, 1, 1>', 'k_conv3x3<16, 16, 32, .., PRO 1, EPI 1> (K10: conv(relu(bn(x))) + statistics of the result)')
+    k8 = timed(f_k8, 1, 'k_conv3x3<16, 16, 32, 8, 4, 0, 0, 0, 0>', 'k_conv3x3<16, 16, 32, ..> (K8: the plain launch; rounds 5\'s `roofline`)')
+    main = pair if fused_block.paired() and fused_block.enabled() else fwd
+    nbytes = 4 * (4 * xs[0].numel() + 2 * w.numel()) if main is pair else 4 * (2 * xs[0].numel() + w.numel())
+    traffic, tsrc = pmc_bytes('k_bwd_pair<16, 16, 32' if main is pair else 'k_conv3x3<16, 16, 32, 8, 4, 0, 0, 1, 1>', names=('r06_pmc.json',))
+    out = {'bound': 'mfma', 'peak': MFMA_FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s', **main, 'bytes_per_launch': nbytes, 'traffic': traffic,
+           'traffic_source': tsrc,
+           'frac_uses': 'us_per_launch (HIP events, measured live in this run, eight operand sets in turn); frac_rocprof uses the committed '
+                        'profile of this command (only if taken with the loaded library: profiles/r06_bench_kernel_stats.meta.json)',
+           'forward': fwd, 'k8': k8,
+           'share_of_step': 'profiles/r06_step_timeline.json: the paired backward launches ~40 % of a step\'s kernel time, the fused forward '
+                            'launches ~30 %, K6\'s dx launches ~11 %; K1 - `roofline_k1` - is one launch per step',
+           'why_not_higher': 'at batch 128 a 16-channel layer is 604 MFLOP = 3.84 us of matrix-pipe time per CU (2 workgroups per CU, all 256 '
+                             'CUs busy): launch (2.8 us) + first tile\'s loads + drain bound the plain launch at ~8.6 us; DESIGN.md §11',
+           'hbm_frac_for_the_record': round(nbytes / (main['us_per_launch'] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)}
+    return out
 
 
 def roofline_kernels_block(dev, large_n):
@@ -1033,6 +1133,11 @@ def _bn_relu_path(job):
         return 'torch ops (host tensors)'
     if not fused_bn.enabled():
         return 'stock MIOpen / ATen launches (URSA_FUSED_BN=0)'
+    from ursabench_amd import fused_block
+    if fused_block.enabled() and not fused_bn._two_launch:
+        return ('training step: folded into the convolution launches (K10, ursabench_amd/fused_block.py: normalise + ReLU while the tile is '
+                'staged, statistics / backward sums from the accumulators; `dx` by K6\'s second launch); the head by K11; evaluation and '
+                'other networks: K6 launches (ursabench_amd/fused_bn.py)')
     return ('K6 launches (ursabench_amd/fused_bn.py: relu(bn(x)) and the residual sums around it)'
             + (', two-launch form only (URSA_BN_TWO_LAUNCH=1)' if fused_bn._two_launch else ''))
 
@@ -1045,7 +1150,11 @@ def _conv_path(job):
         return 'stock MIOpen launches (URSA_FUSED_CONV=0)'
     if not fused_conv.forward_enabled():
         return 'K7 weight gradients; forward / input gradient MIOpen (URSA_FUSED_CONV_FWD=0)'
-    return 'K8 forward / input gradient of the stride-1 3x3 layers + K7 weight gradients (ursabench_amd/fused_conv.py); other launches MIOpen'
+    from ursabench_amd import fused_block
+    k10 = ('; inside a training step of the BasicBlock ResNets each bn -> relu -> conv unit is ONE K10 launch forward and its input + weight '
+           'gradients ONE paired launch backward (ursabench_amd/fused_block.py)') if fused_block.enabled() else ''
+    return ('K8: 3x3 forward / input gradient at stride 1 and 2; K9: the 1x1 stride-2 shortcuts; K7: every weight gradient '
+            '(ursabench_amd/fused_conv.py)' + k10 + '; evaluation forwards (no gradient recorded) stay MIOpen')
 
 
 def base_line(a, job, metric, unit, workload):
@@ -1161,6 +1270,10 @@ def run_c2(a, job, legs, line):
             rc = legs.run('roofline_conv', roofline_conv_block, dev)
             if rc is not None:
                 line['roofline_k1'], line['roofline'] = line.get('roofline'), rc
+                # SURVEY.md 8(d)'s own roofline (HBM, every kernel of the path) stays visible inside the parsed object
+                if line.get('roofline_large'):
+                    rc['hbm_k1_large_frac'] = line['roofline_large'].get('frac')
+                    rc['hbm_k1_large_gbps'] = line['roofline_large'].get('achieved')
         line['roofline_bma_kernel'] = legs.run('roofline_bma_kernel', bma_kernel_block, max(1, len(ensemble)), N_TEST, CLASSES)
         if world == 1:
             line['roofline_kernels'] = legs.run('roofline_kernels', roofline_kernels_block, dev, a.large_n)
@@ -1174,6 +1287,11 @@ def run_c2(a, job, legs, line):
             line['sanity_c4_c5'] = legs.run('sanity_c4_c5', sanity_block, a, job)
         if world == 1 and not a.no_cpu_baseline:
             line['cpu_baseline'] = legs.run('cpu_baseline', cpu_baseline_block, a.cpu_steps)
+        if world == 1 and kpg == 1 and not a.no_full_size_legs:
+            ensemble.clear()                                      # the C2 member bank is done with
+            torch.cuda.empty_cache()
+            line['c5'] = legs.run('c5', full_size_legs_block, a, job, 'c5')
+            line['c4'] = legs.run('c4', full_size_legs_block, a, job, 'c4')
 
 
 def roofline_k6_object(rk):
@@ -1232,6 +1350,42 @@ def sanity_block(a, job):
     return out
 
 
+def full_size_legs_block(a, job, which):
+    """BASELINE configs[3] / [4] at FULL size but bounded length, under the default command (the driver only ever
+    runs `bench.py --gpus 1 ...`, so full-size C4 / C5 figures existed only as builder-run files). Same code as `--config c4` /
+    `--config c5`, same shapes; what is bounded is the count:
+      c4  WideResNet-28-10 / 100 classes (36.5 M parameters), SWAG: 2 members formed (K3 draw + the reference's full bn_update pass
+          over the 50,000 training images, 391 train-mode batches of 128 - the two members' passes share one sweep, as
+          SWAG.sample does for an ensemble) from SEEDED moments (no SGD trajectory: the draw / refresh / evaluation cost does
+          not depend on the moments' values), then the BMA predictive of those 2 members over the 10,000-row test set.
+      c5  PreResNet-164 / 100 classes (1.7 M parameters), HMC: 4 chains, full-batch potential over 1,024 rows, L = 3 leapfrog
+          steps, 2 proposals per chain timed (after the capture rounds).
+    A figure over 2 members / 8 proposals is a short sample of the same steady state the full runs measure (profiles/)."""
+    import copy
+    cfgs = {'c4': (run_c4, dict(steps=2, warmup=0, c4_train=N_TRAIN, c4_epochs=0, c4_weak=False)),
+            'c5': (run_c5, dict(steps=2, warmup=0, c5_batch=1024, c5_chains=4, c5_L=3))}
+    fn, over = cfgs[which]
+    a2 = copy.copy(a)
+    for k, v in over.items():
+        setattr(a2, k, v)
+    sub_legs, sub = Legs(), {'config': {}}
+    t0 = time.perf_counter()
+    fn(a2, job, sub_legs, sub)
+    out = {'seconds': round(time.perf_counter() - t0, 1), 'overrides': over, 'errors': sub_legs.errors, 'leg_seconds': sub_legs.seconds}
+    if which == 'c4':
+        out.update({'members_per_s': sub.get('value'), 'members_timed': 2, 'bma_preds_per_s': sub.get('bma_preds_per_s'),
+                    'bma_members': sub.get('bma_members'), 'bma_member_forwards_per_s': sub.get('bma_member_forwards_per_s'),
+                    'moments': sub.get('moments'), 'params': (sub.get('config') or {}).get('params'), 'roofline_k3': sub.get('roofline')})
+    else:
+        out.update({'proposals_per_s': sub.get('value'), 'proposals_timed': 8, 'leapfrog_steps_per_s': sub.get('leapfrog_steps_per_s'),
+                    'acceptance': sub.get('acceptance_rate_rank0'), 'chains': 4, 'full_batch': 1024, 'L': 3,
+                    'params': (sub.get('config') or {}).get('params'), 'roofline_k4': sub.get('roofline')})
+    torch.cuda.empty_cache()
+    if sub_legs.errors:
+        raise RuntimeError(f'{which}: {json.dumps(sub_legs.errors)[:1200]}')
+    return out
+
+
 def run_c4(a, job, legs, line):
     """BASELINE configs[3]: WideResNet-28-10 / CIFAR-100-shaped, SWAG (as published: reference_quirks=False), 30-member
     BMA. Rank 0 runs the SGD trajectory (`--c4-epochs` epochs over the full 50,000 images; the draw/eval cost
@@ -1273,6 +1427,18 @@ def run_c4(a, job, legs, line):
 
     def trajectory():
         t0 = time.perf_counter()
+        if a.c4_epochs <= 0:
+            # bounded leg of the default command: no SGD trajectory - seeded moments around the initial weights (SURVEY.md 8(d):
+            # "or seeded random mean/sq - the eval cost does not depend on their values"): mean = theta_0, sq = mean^2 + (0.01 eps)^2
+            g = torch.Generator(device=dev).manual_seed(1234)
+            with torch.no_grad():
+                s._mean.copy_(s.arena.theta)
+                s._sq.copy_(s._mean * s._mean + (0.01 * torch.randn(s._mean.shape, generator=g, device=dev)) ** 2)
+            s.num_models_collected += 1
+            s.adopt_moments()
+            line['trajectory_seconds'] = round(time.perf_counter() - t0, 2)
+            line['moments'] = 'seeded (no trajectory): mean = initial weights, variance = (0.01 eps)^2'
+            return
         if rank == 0:
             s.run_trajectory()
         from ursabench_amd.distributed import share_swag_moments
@@ -1417,8 +1583,11 @@ def compact_line(line, detail_path):
     r = line.get('roofline')
     if r:
         keys = ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'bytes_per_launch', 'flops_per_launch', 'us_per_launch',
-                'us_per_launch_rocprof', 'frac_rocprof', 'rocprof_source', 'chains_per_launch')
+                'us_per_launch_rocprof', 'frac_rocprof', 'rocprof_source', 'chains_per_launch', 'hbm_k1_large_frac', 'hbm_k1_large_gbps')
         out['roofline'] = _pick(r, keys)
+        for sub in ('forward', 'k8'):
+            if r.get(sub):
+                out['roofline'][sub] = _pick(r[sub], ('kernel', 'frac', 'us_per_launch', 'frac_rocprof'))
         if line.get('roofline_k1'):
             out['roofline_k1'] = _pick(line['roofline_k1'], keys)
     if line.get('roofline_large'):
@@ -1445,6 +1614,9 @@ def compact_line(line, detail_path):
         out['parity'] = _pick(par, ('rtol', 'seeds', 'rows_workload', 'rows_small', 'pass', 'pass_workload_rows', 'pass_gate_equal',
                                     'gate_equal_samples_asserted', 'pass_bma_same_members', 'worst_max_rel_err_proba_gates_given',
                                     'worst_max_rel_err_proba_natural_reported', 'pass_k6_not_worse_than_stock', 'natural_first_step_k6_vs_stock'))
+        if par.get('timed_path'):
+            out['parity']['timed_path'] = _pick(par['timed_path'], ('pass_k10_bit_equal', 'pass_k11_first_sample', 'k11_worst_first_sample',
+                                                                    'k11_worst_any_sample_reported', 'k11_worst_vs_cpu_reported'))
         geg = par.get('given_equal_gradients')
         if geg:
             out['parity']['given_equal_gradients'] = _pick(geg, ('minibatch_steps', 'steps_bit_identical_theta_and_momentum', 'pass'))
@@ -1453,6 +1625,10 @@ def compact_line(line, detail_path):
         out['multi_chain_per_gpu'] = {'best': mc.get('best'), 'samples_per_s_by_chains': {str(r_['chains_per_gpu']): r_['value'] for r_ in mc.get('sweep', [])}}
     if line.get('reference_style_gpu'):
         out['reference_style_gpu'] = _pick(line['reference_style_gpu'], ('value', 'unit', 'ms_per_minibatch_step'))
+    if line.get('c4'):
+        out['c4'] = _pick(line['c4'], ('members_per_s', 'members_timed', 'bma_preds_per_s', 'bma_members', 'params', 'seconds'))
+    if line.get('c5'):
+        out['c5'] = _pick(line['c5'], ('proposals_per_s', 'proposals_timed', 'acceptance', 'chains', 'full_batch', 'L', 'params', 'seconds'))
     rc = line.get('rccl')
     if rc:
         out['rccl'] = _pick(rc, ('backend', 'world', 'ranks_seen', 'distinct_devices', 'all_reduce_bytes', 'all_reduce_us'))

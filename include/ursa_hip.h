@@ -507,6 +507,37 @@ int ursa_bn_bwd_dx_f32(const float* x, const float* g, const float* dz /* or NUL
                        const float* save /* [4][C] */, const double* partial, int32_t nl, float* dgamma, float* dbeta,
                        int64_t N, int64_t C, int64_t HW, ursa_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * K11  the head of a training step      URSABench/models/preresnet.py:146-150 (`x = self.bn(x); x = self.relu(x); x = self.avgpool(x);
+ *      x = x.view(x.size(0), -1); x = self.fc(x)`), the samplers' loss nn.CrossEntropyLoss() (URSABench/inference/sghmc.py:38-40,
+ *      76-77) and the backward of all of it in `loss.backward()` (sghmc.py:80): stock PyTorch-ROCm runs ~13 launches of ~5 us on
+ *      128 x 64 x 8 x 8 numbers; here three.
+ *   ursa_bn_relu_pool_f32      pooled[n][c] = mean over the 8 x 8 map of max(fmaf(z, alpha_c, beta'_c), 0): training-mode BatchNorm (its
+ *                              statistics from `partial`, the out_partial of the K10 launch that produced z; scalars, `save` [4][C] and
+ *                              running statistics exactly as ursa_bn_apply_f32) + ReLU + AvgPool2d(8) without storing the activation.
+ *                              HW must be 64 (URSA_EVALUE otherwise: the caller keeps ursa_bn_apply_f32 + its own pooling). fp32 sums
+ *                              in a fixed tree; the division by 64 is exact.
+ *   ursa_fc_ce_f32             ONE workgroup: logits = pooled W^T + b, loss = mean cross entropy over the rows whose target is not
+ *                              ignore_index, and the gradients dW [K][C], db [K], dpooled [N][C] of that loss (grad_output 1). logits
+ *                              may be NULL. fma chains in ascending index order; expf / logf of the device library (<= 1 ulp).
+ *                              Covered: N <= 256, K <= 16, K*C <= 2048, N*C <= 8192 (ursa_fc_ce_supported). A target outside [0, K)
+ *                              other than ignore_index makes the loss and the gradients NaN (torch: device-side assert).
+ *   ursa_bn_relu_pool_bwd_f32  the backward of ursa_bn_relu_pool_f32: dz, dgamma, dbeta from dpooled (the gradient of every position of
+ *                              map (n, c) is dpooled[n][c] / 64 where the forward's gate was open; then K6's backward arithmetic,
+ *                              one workgroup per channel, the channel in registers: N <= 128, HW = 64).
+ * Results are within fp32 rounding of the stock sequence (different summation trees), not bit-equal to it; oracle twins:
+ * oracle_bn_relu_pool_f32, oracle_fc_ce_f32, oracle_bn_relu_pool_bwd_f32 (sums in double, rounded once).
+ */
+int ursa_bn_relu_pool_f32(const float* z, const double* partial, int32_t nl, const float* gamma, const float* beta,
+                          float* running_mean /* or NULL */, float* running_var /* or NULL */, float* save /* [4][C] */,
+                          float* pooled /* [N][C] */, int64_t N, int64_t C, int64_t HW, float eps, float momentum, ursa_stream_t stream);
+int ursa_fc_ce_supported(int64_t N, int64_t C, int64_t K);
+int ursa_fc_ce_f32(const float* pooled, const float* W, const float* b /* or NULL */, const int64_t* target, float* loss /* [1] */,
+                   float* logits /* [N][K] or NULL */, float* dW, float* db /* iff b */, float* dpooled, int64_t N, int64_t C, int64_t K,
+                   int64_t ignore_index, ursa_stream_t stream);
+int ursa_bn_relu_pool_bwd_f32(const float* z, const float* dpooled, const float* gamma, const float* save /* [4][C] */, float* dz,
+                              float* dgamma, float* dbeta, int64_t N, int64_t C, int64_t HW, ursa_stream_t stream);
+
 /* ------------------------------------------------------------------------------------ */
 int ursa_abi_version(void);
 const char* ursa_strerror(int code);

@@ -22,6 +22,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <stdlib.h>
 
 #define STEP_NOISE     0x1u
 #define STEP_FIRST     0x2u
@@ -643,4 +644,82 @@ int oracle_bn_bwd_dx_f32(const float* x, const float* g, const float* dz, float*
         dgamma[c] = (float)(dotp * (double)invstd);
     }
     return 0;
+}
+
+/* ---------------------------------------------------------------------------------------
+ * K11  the head of a training step, restated      URSABench/models/preresnet.py:146-150 (bn -> relu -> AvgPool2d(8) -> fc) and
+ *      nn.CrossEntropyLoss() (URSABench/inference/sghmc.py:38-40,76-77), with the backward of `loss.backward()` (sghmc.py:80).
+ *      Sums in double, rounded once (as K7 / K8's restatements: the device's fp32 trees are compared to rounding).
+ */
+/* pooled[n][c] = mean over HW of relu(batch_norm(z)) (oracle_bn_relu_fwd_f32's rounding for the normalised value); h: scratch */
+int oracle_bn_relu_pool_f32(const float* z, float* h, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                            float* save, float* pooled, int64_t N, int64_t C, int64_t HW, float eps, float momentum)
+{
+    oracle_bn_relu_fwd_f32(z, h, gamma, beta, running_mean, running_var, save, save + C, N, C, HW, eps, momentum, 1);
+    for (int64_t c = 0; c < C; ++c) {
+        save[2 * C + c] = save[C + c] * gamma[c];
+        save[3 * C + c] = fmaf(-save[c], save[2 * C + c], beta[c]);
+    }
+    for (int64_t n = 0; n < N; ++n)
+        for (int64_t c = 0; c < C; ++c) {
+            double s = 0.0;
+            for (int64_t j = 0; j < HW; ++j) s += (double)h[(n * C + c) * HW + j];
+            pooled[n * C + c] = (float)(s / (double)HW);
+        }
+    return 0;
+}
+
+/* logits = p W^T + b; loss = mean CE over rows with target != ignore_index; gradients of the loss (grad_output 1) */
+int oracle_fc_ce_f32(const float* p, const float* W, const float* b, const int64_t* target, float* loss, float* logits, float* dW,
+                     float* db, float* dp, int64_t N, int64_t C, int64_t K, int64_t ignore_index)
+{
+    double* dl = (double*)malloc(sizeof(double) * (size_t)(N * K));
+    double tot = 0.0;
+    int64_t cnt = 0;
+    for (int64_t n = 0; n < N; ++n) {
+        double l[1024], m = -INFINITY, s = 0.0;
+        for (int64_t k = 0; k < K; ++k) {
+            double acc = b ? (double)b[k] : 0.0;
+            for (int64_t c = 0; c < C; ++c) acc += (double)p[n * C + c] * (double)W[k * C + c];
+            l[k] = (double)(float)acc;                  /* the logits are fp32 numbers */
+            if (logits) logits[n * K + k] = (float)acc;
+            if (l[k] > m) m = l[k];
+        }
+        for (int64_t k = 0; k < K; ++k) s += exp(l[k] - m);
+        const double lse = m + log(s);
+        const int valid = target[n] != ignore_index;
+        if (valid) { tot += lse - l[target[n]]; ++cnt; }
+        for (int64_t k = 0; k < K; ++k) dl[n * K + k] = valid ? exp(l[k] - lse) - (k == target[n] ? 1.0 : 0.0) : 0.0;
+    }
+    loss[0] = (float)(tot / (double)cnt);
+    for (int64_t i = 0; i < N * K; ++i) dl[i] /= (double)cnt;
+    for (int64_t k = 0; k < K; ++k) {
+        double sb = 0.0;
+        for (int64_t n = 0; n < N; ++n) sb += dl[n * K + k];
+        if (db) db[k] = (float)sb;
+        for (int64_t c = 0; c < C; ++c) {
+            double acc = 0.0;
+            for (int64_t n = 0; n < N; ++n) acc += dl[n * K + k] * (double)p[n * C + c];
+            dW[k * C + c] = (float)acc;
+        }
+    }
+    for (int64_t n = 0; n < N; ++n)
+        for (int64_t c = 0; c < C; ++c) {
+            double acc = 0.0;
+            for (int64_t k = 0; k < K; ++k) acc += dl[n * K + k] * (double)W[k * C + c];
+            dp[n * C + c] = (float)acc;
+        }
+    free(dl);
+    return 0;
+}
+
+/* backward of oracle_bn_relu_pool_f32: dy[n][c][j] = dpooled[n][c] / HW, then oracle_bn_relu_bwd_f32 (gate from the saved scalars);
+ * dy: scratch of z's size */
+int oracle_bn_relu_pool_bwd_f32(const float* z, const float* dpooled, float* dy, const float* gamma, const float* beta, const float* save,
+                                float* dz, float* dgamma, float* dbeta, int64_t N, int64_t C, int64_t HW)
+{
+    for (int64_t n = 0; n < N; ++n)
+        for (int64_t c = 0; c < C; ++c)
+            for (int64_t j = 0; j < HW; ++j) dy[(n * C + c) * HW + j] = dpooled[n * C + c] / (float)HW;
+    return oracle_bn_relu_bwd_f32(z, dy, dz, gamma, beta, save, save + C, dgamma, dbeta, N, C, HW, 1);
 }

@@ -230,3 +230,39 @@ def bn_bwd_dx(x, g, gamma, save, sums, dz=None):
                                  N, C, HW)
     assert rc == 0
     return dx, dg, db
+
+
+_L.oracle_bn_relu_pool_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f, _f]
+_L.oracle_fc_ce_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64]
+_L.oracle_bn_relu_pool_bwd_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64]
+
+
+def bn_relu_pool(z, gamma, beta, *, eps=1e-5, momentum=0.1, running=None):
+    """K11: (pooled [N, C], save [4, C]) = mean over the map of relu(batch_norm(z)), training mode."""
+    N, C, HW = _bn_dims(z)
+    h, save, pooled = np.empty_like(z), np.empty((4, C), np.float32), np.empty((N, C), np.float32)
+    rm, rv = running if running is not None else (None, None)
+    rc = _L.oracle_bn_relu_pool_f32(_p(z), _p(h), _p(gamma), _p(beta), _p(rm), _p(rv), _p(save), _p(pooled), N, C, HW, eps, momentum)
+    assert rc == 0
+    return pooled, save
+
+
+def fc_ce(p, W, b, target, ignore_index=-100):
+    """K11: (loss, logits, dW, db, dp) of mean cross entropy over fc(p)."""
+    N, C = p.shape
+    K = W.shape[0]
+    t = np.ascontiguousarray(target, np.int64)
+    loss, logits = np.empty(1, np.float32), np.empty((N, K), np.float32)
+    dW, db, dp = np.empty_like(W), (None if b is None else np.empty_like(b)), np.empty_like(p)
+    rc = _L.oracle_fc_ce_f32(_p(p), _p(W), _p(b), t.ctypes.data, _p(loss), _p(logits), _p(dW), _p(db), _p(dp), N, C, K, ignore_index)
+    assert rc == 0
+    return float(loss[0]), logits, dW, db, dp
+
+
+def bn_relu_pool_bwd(z, dpooled, gamma, beta, save):
+    """K11: (dz, dgamma, dbeta) of bn_relu_pool for the pooled gradient."""
+    N, C, HW = _bn_dims(z)
+    dy, dz, dg, db = np.empty_like(z), np.empty_like(z), np.empty(C, np.float32), np.empty(C, np.float32)
+    rc = _L.oracle_bn_relu_pool_bwd_f32(_p(z), _p(dpooled), _p(dy), _p(gamma), _p(beta), _p(np.ascontiguousarray(save)), _p(dz), _p(dg), _p(db), N, C, HW)
+    assert rc == 0
+    return dz, dg, db

@@ -17,7 +17,7 @@ k1 = [i for i, r in enumerate(rows) if is_k1(r[2])]
 steps = []
 for a, b in zip(k1, k1[1:]):
     n = b - a
-    if 80 <= n <= 400 and not is_k1(rows[a + 1][2]):        # a forward/backward lies between them (round 5: ~125 dispatches)
+    if 40 <= n <= 400 and not is_k1(rows[a + 1][2]):        # a forward/backward lies between them (round 5: ~146 dispatches, round 6: ~75)
         steps.append((a + 1, b + 1))                          # dispatches after K1 a up to and including K1 b
 if not steps:
     sys.exit('no training steps found in the trace')

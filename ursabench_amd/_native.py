@@ -78,6 +78,10 @@ SIGNATURES = {
                                                _i64, _i64, _i64, _i64, _i64, _u32, _vp]),
     'ursa_preact_wgrad_partial_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp]),
     'ursa_preact_bwd_pair_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _u32, _vp]),
+    'ursa_bn_relu_pool_f32': (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f, _f, _vp]),
+    'ursa_fc_ce_supported': (ctypes.c_int, [_i64, _i64, _i64]),
+    'ursa_fc_ce_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
+    'ursa_bn_relu_pool_bwd_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     'ursa_bn_apply_f32': (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f, _f, _u32, _vp]),
     'ursa_bn_bwd_dx_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i64, _i64, _i64, _vp]),
 }
@@ -709,6 +713,47 @@ class HipKernels:
                                              self._f64ptr(partial, 'partial', partial.numel(), dev), int(partial.shape[1]),
                                              _ptr(dgamma, 'dgamma', C, dev), _ptr(dbeta, 'dbeta', C, dev), N, C, HW, _stream(dev))
         _check(self.lib, rc, 'ursa_bn_bwd_dx_f32')
+
+
+    # K11 -----------------------------------------------------------------------------
+    def head_supported(self, z_shape, num_classes):
+        """Whether the three K11 launches cover a final activation of `z_shape` ([N, C, 8, 8]) and `num_classes` outputs."""
+        n, c, h, w = (int(v) for v in z_shape)
+        return h == 8 and w == 8 and n <= 128 and bool(self.lib.ursa_fc_ce_supported(n, c, int(num_classes)))
+
+    def bn_relu_pool(self, z, partial, gamma, beta, running_mean, running_var, save, pooled, *, eps, momentum):
+        N, C, HW = self._bn_dims(z)
+        dev = z.device
+        with torch.cuda.device(dev):
+            rc = self.lib.ursa_bn_relu_pool_f32(_ptr(z, 'z'), self._f64ptr(partial, 'partial', partial.numel(), dev), int(partial.shape[1]),
+                                                _ptr(gamma, 'gamma', C, dev), _ptr(beta, 'beta', C, dev),
+                                                _ptr(running_mean, 'running_mean', C, dev, optional=True),
+                                                _ptr(running_var, 'running_var', C, dev, optional=True), _ptr(save, 'save', 4 * C, dev),
+                                                _ptr(pooled, 'pooled', N * C, dev), N, C, HW, float(eps), float(momentum), _stream(dev))
+        _check(self.lib, rc, 'ursa_bn_relu_pool_f32')
+
+    def fc_ce(self, pooled, W, b, target, loss, dW, db, dpooled, *, logits=None, ignore_index=-100):
+        N, C = pooled.shape
+        K = W.shape[0]
+        dev = pooled.device
+        if not (isinstance(target, torch.Tensor) and target.is_cuda and target.device == dev and target.dtype == torch.int64
+                and target.is_contiguous() and target.numel() == N):
+            raise ValueError(f'target must be a contiguous int64 tensor of {N} labels on {dev}')
+        with torch.cuda.device(dev):
+            rc = self.lib.ursa_fc_ce_f32(_ptr(pooled, 'pooled'), _ptr(W, 'W', K * C, dev), _ptr(b, 'b', K, dev, optional=True), target.data_ptr(),
+                                         _ptr(loss, 'loss', 1, dev), _ptr(logits, 'logits', N * K, dev, optional=True), _ptr(dW, 'dW', K * C, dev),
+                                         _ptr(db, 'db', K, dev, optional=True), _ptr(dpooled, 'dpooled', N * C, dev), N, C, K, int(ignore_index),
+                                         _stream(dev))
+        _check(self.lib, rc, 'ursa_fc_ce_f32')
+
+    def bn_relu_pool_bwd(self, z, dpooled, gamma, save, dz, dgamma, dbeta):
+        N, C, HW = self._bn_dims(z)
+        dev = z.device
+        with torch.cuda.device(dev):
+            rc = self.lib.ursa_bn_relu_pool_bwd_f32(_ptr(z, 'z'), _ptr(dpooled, 'dpooled', N * C, dev), _ptr(gamma, 'gamma', C, dev),
+                                                    _ptr(save, 'save', 4 * C, dev), _ptr(dz, 'dz', z.numel(), dev), _ptr(dgamma, 'dgamma', C, dev),
+                                                    _ptr(dbeta, 'dbeta', C, dev), N, C, HW, _stream(dev))
+        _check(self.lib, rc, 'ursa_bn_relu_pool_bwd_f32')
 
 
 def knobs_kernels():

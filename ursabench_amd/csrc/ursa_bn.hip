@@ -1803,3 +1803,150 @@ int ursa_bn_bwd_dx_f32(const float* x, const float* g, const float* dz, float* d
 }
 
 }  // extern "C"
+
+// =====================================================================================================================
+// K11, the BatchNorm ends of the network's head (URSABench/models/preresnet.py:146-148: `x = self.bn(x); x = self.relu(x);
+// x = self.avgpool(x)` on the final 8 x 8 map, and their backward): the rectified activation is only ever averaged, so it is
+// neither stored (forward) nor is its gradient (backward: d relu(bn(z)) = dpooled / 64, the same number for a whole map).
+namespace {
+
+__device__ __forceinline__ float row_sum16f(float v)
+{
+    v += bn_dpp<0xB1>(v);
+    v += bn_dpp<0x4E>(v);
+    v += bn_dpp<0x141>(v);
+    v += bn_dpp<0x140>(v);
+    return v;
+}
+
+// forward: pooled[n][c] = (sum over the 64 positions of max(fmaf(z, alpha_c, beta'_c), 0)) / 64. grid (C, ceil(N / 16)); a 16-lane row
+// owns one (n, c) map: lane i its float4 i; fp32 sums: ((x + y) + (z + w)) per lane, then the row's DPP tree. Statistics merged
+// from the producer's partial sums exactly as k_bn_fwd_apply does (same scalars, same running statistics).
+__global__ __launch_bounds__(kBnBlock) void k_bn_relu_pool64(const float4* __restrict__ z, const double2* __restrict__ partial, int S,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                             float* __restrict__ save, float* __restrict__ pooled, int N, int C, float eps,
+                                                             float momentum)
+{
+    __shared__ float sh[2];
+    const int c = blockIdx.x, r = threadIdx.x >> 4, i = threadIdx.x & 15, n = blockIdx.y * 16 + r;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n < N) v = z[((int64_t)n * C + c) * 16 + i];           // before the merge: its dependent chain runs under the load
+    if (threadIdx.x < 64) {
+        double mean, var;
+        const double cnt = (double)N * 64.0;
+        bn_merge(partial, c, S, cnt, mean, var);
+        if (threadIdx.x == 0) {
+            const float meanf = (float)mean;
+            const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+            const float alpha = invstd * gamma[c];
+            sh[0] = alpha;
+            sh[1] = fmaf(-meanf, alpha, beta[c]);
+            if (blockIdx.y == 0) {
+                save[c] = meanf;
+                save[C + c] = invstd;
+                save[2 * C + c] = alpha;
+                save[3 * C + c] = sh[1];
+                if (running_mean) {
+                    running_mean[c] = momentum * meanf + (1.0f - momentum) * running_mean[c];
+                    running_var[c] = momentum * (float)(var * (cnt / (cnt - 1.0))) + (1.0f - momentum) * running_var[c];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const float scale = sh[0], shift = sh[1];
+    const float a = bn_relu_fwd(fmaf(v.x, scale, shift)), b = bn_relu_fwd(fmaf(v.y, scale, shift));
+    const float d = bn_relu_fwd(fmaf(v.z, scale, shift)), e = bn_relu_fwd(fmaf(v.w, scale, shift));
+    const float s = row_sum16f((a + b) + (d + e));
+    if (i == 0 && n < N) pooled[(int64_t)n * C + c] = s * (1.0f / 64.0f);
+}
+
+// backward: the gradient of every position of map (n, c) is dpooled[n][c] / 64 where the ReLU was open (gate from the forward's
+// saved scalars, as K6's backward). One workgroup per channel holds the channel (N <= 128 maps of 16 float4: 8 per thread) in
+// registers: sums in double, the workgroup's fixed tree, then dz from registers - K6's one-pass backward with dy never stored.
+constexpr int kPoolEpt = 8;
+__global__ __launch_bounds__(kBnBlock) void k_bn_relu_pool64_bwd(const float4* __restrict__ z, const float* __restrict__ dpooled,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ save,
+                                                                 float4* __restrict__ dz, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                 int N, int C)
+{
+    __shared__ double shd[2 * kBnBlock / 64];
+    const int c = blockIdx.x;
+    const float mean = save[c], invstd = save[C + c], scale = save[2 * C + c], shift = save[3 * C + c], w = gamma[c];
+    const double meand = (double)mean;
+    float4 x[kPoolEpt], g[kPoolEpt];
+    const int total = N * 16;
+#pragma unroll
+    for (int k = 0; k < kPoolEpt; ++k) {
+        const int e = threadIdx.x + k * kBnBlock;
+        if (e < total) {
+            const int n = e >> 4;
+            x[k] = z[((int64_t)n * C + c) * 16 + (e & 15)];
+            const float d = dpooled[(int64_t)n * C + c] * (1.0f / 64.0f);
+            g[k] = make_float4(d, d, d, d);
+        }
+    }
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < kPoolEpt; ++k) {
+        if (threadIdx.x + k * kBnBlock < total) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float xe = comp(x[k], q);
+                const float ge = fmaf(xe, scale, shift) > 0.f ? comp(g[k], q) : 0.f;
+                setc(g[k], q, ge);
+                s1 += (double)ge;
+                s2 = fma((double)ge, (double)xe - meand, s2);
+            }
+        }
+    }
+    bn_block_sum2(s1, s2, shd);
+    const double cnt = (double)N * 64.0, iv = (double)invstd;
+    const float gm = (float)(s1 / cnt), kk = (float)(s2 * iv * iv / cnt);
+    if (threadIdx.x == 0) { dbeta[c] = (float)s1; dgamma[c] = (float)(s2 * iv); }
+#pragma unroll
+    for (int k = 0; k < kPoolEpt; ++k) {
+        const int e = threadIdx.x + k * kBnBlock;
+        if (e < total) {
+            float4 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) setc(o, q, (((comp(g[k], q) - gm) - (comp(x[k], q) - mean) * kk) * invstd) * w);
+            dz[((int64_t)(e >> 4) * C + c) * 16 + (e & 15)] = o;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ursa_bn_relu_pool_f32(const float* z, const double* partial, int32_t nl, const float* gamma, const float* beta, float* running_mean,
+                          float* running_var, float* save, float* pooled, int64_t N, int64_t C, int64_t HW, float eps, float momentum,
+                          ursa_stream_t stream)
+{
+    if (N <= 0 || C <= 0 || HW <= 0) return URSA_ESIZE;
+    if (!z || !partial || !gamma || !beta || !save || !pooled) return URSA_ENULL;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return URSA_ENULL;
+    if (HW != 64 || C > 65535 || N > (1 << 20)) return URSA_EVALUE;           // the 8 x 8 map the CIFAR networks end with
+    if (nl < 1 || nl > kBnMaxSplit) return URSA_ESIZE;
+    if (!bn_aligned16(z) || !bn_aligned16(partial) || !bn_aligned4(save) || !bn_aligned4(pooled)) return URSA_EALIGN;
+    hipLaunchKernelGGL(k_bn_relu_pool64, dim3((unsigned)C, (unsigned)((N + 15) / 16)), dim3(kBnBlock), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(z), reinterpret_cast<const double2*>(partial), (int)nl, gamma, beta, running_mean,
+                       running_var, save, pooled, (int)N, (int)C, eps, momentum);
+    return bn_launch_status();
+}
+
+int ursa_bn_relu_pool_bwd_f32(const float* z, const float* dpooled, const float* gamma, const float* save, float* dz, float* dgamma,
+                              float* dbeta, int64_t N, int64_t C, int64_t HW, ursa_stream_t stream)
+{
+    if (N <= 0 || C <= 0 || HW <= 0) return URSA_ESIZE;
+    if (!z || !dpooled || !gamma || !save || !dz || !dgamma || !dbeta) return URSA_ENULL;
+    if (HW != 64 || C > 65535 || N * 16 > (int64_t)kBnBlock * kPoolEpt) return URSA_EVALUE;   // a channel in one workgroup's registers: N <= 128
+    if (!bn_aligned16(z) || !bn_aligned16(dz) || !bn_aligned4(dpooled) || !bn_aligned4(save)) return URSA_EALIGN;
+    hipLaunchKernelGGL(k_bn_relu_pool64_bwd, dim3((unsigned)C), dim3(kBnBlock), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(z), dpooled,
+                       gamma, save, reinterpret_cast<float4*>(dz), dgamma, dbeta, (int)N, (int)C);
+    return bn_launch_status();
+}
+
+}  // extern "C"

@@ -115,6 +115,7 @@ class _Stem(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, owner, ws_floats):
+        ctx.set_materialize_grads(False)                        # (or autograd fills a float64 zero "gradient" for the partial sums)
         K = _native.default_kernels()
         geo = K.preact_geometry(x.shape, w.shape[0])
         y = x.new_empty(x.shape[0], w.shape[0], x.shape[2], x.shape[3])
@@ -129,7 +130,7 @@ class _Stem(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, dy, _):
         x, w = ctx.saved_tensors
-        if not ctx.needs_input_grad[1]:
+        if dy is None or not ctx.needs_input_grad[1]:
             return None, None, None, None
         dw = _wgrad(ctx.sink, _native.default_kernels(), x, None, _aligned(dy), ctx.weight, ctx.ws_floats, 1)
         return None, dw, None, None
@@ -228,6 +229,55 @@ class _FinalBN(torch.autograd.Function):
         return dx, None, dgb[0], dgb[1], None
 
 
+_ones = {}
+
+
+def one(device):
+    """The persistent 1.0 the engine hands to `loss.backward()` for a loss that came from `trunk_loss`: `_Head.backward`
+    recognises it by address and skips the multiplication by grad_output (and autograd's ones_like fill launch is gone too)."""
+    device = torch.device(device)
+    t = _ones.get(device)
+    if t is None:
+        t = _ones[device] = torch.ones((), device=device)
+    return t
+
+
+class _Head(torch.autograd.Function):
+    """loss = cross_entropy(fc(avgpool(relu(bn(z)))), target) (URSABench/models/preresnet.py:146-150 + the samplers' CrossEntropyLoss)
+    as K11's launches: BatchNorm + ReLU + pooling in one (the activation is not stored), the classifier, the loss AND their gradients
+    in one workgroup, and in the backward one launch that turns the pooled gradient into dz / dgamma / dbeta."""
+
+    @staticmethod
+    def forward(ctx, z, pz, gamma, beta, W, b, target, bn, ignore_index):
+        K = _native.default_kernels()
+        N, C = z.shape[0], z.shape[1]
+        save, pooled = z.new_empty(4, C), z.new_empty(N, C)
+        track = bn.training and bn.track_running_stats and bn.running_mean is not None
+        if track and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        rm, rv = (bn.running_mean, bn.running_var) if track else (None, None)
+        K.bn_relu_pool(z, pz, gamma, beta, rm, rv, save, pooled, eps=bn.eps, momentum=bn.momentum if track else 0.0)
+        loss = z.new_empty(1)
+        dW, db, dp = torch.empty_like(W), (None if b is None else torch.empty_like(b)), torch.empty_like(pooled)
+        K.fc_ce(pooled, W, b, target, loss, dW, db, dp, ignore_index=ignore_index)
+        ctx.save_for_backward(z, gamma, save, dW, dp, *(() if db is None else (db,)))
+        return loss.view(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gl):
+        z, gamma, save, dW, dp, *rest = ctx.saved_tensors
+        db = rest[0] if rest else None
+        K = _native.default_kernels()
+        C = z.shape[1]
+        if gl.data_ptr() != one(z.device).data_ptr():            # a caller's own grad_output: scale (three small launches)
+            dW, dp = dW * gl, dp * gl
+            db = None if db is None else db * gl
+        dz, dgb = torch.empty_like(z), z.new_empty(2, C)
+        K.bn_relu_pool_bwd(z, dp, gamma, save, dz, dgb[0], dgb[1])
+        return dz, None, dgb[0], dgb[1], dW, db, None, None, None
+
+
 def _bn_ok(bn, dev):
     return (type(bn) is nn.BatchNorm2d and bn.training and bn.affine and bn.momentum is not None and bn.weight.dtype == torch.float32
             and bn.weight.device == dev and bn.weight.is_contiguous() and bn.bias.is_contiguous())
@@ -292,9 +342,24 @@ def eligible(model, x):
     return plan is not None and all(b.training for b in plan[1])
 
 
-def trunk(model, x):
-    """conv1 -> layer1..3 -> bn -> relu of a BasicBlock PreResNet (URSABench/models/preresnet.py:138-146) as K10 launches; returns
-    relu(bn(z)) of the last residual sum. Call only when `eligible(model, x)`."""
+def head_eligible(model, x, target, crit):
+    """Whether `trunk_loss` applies: `trunk` does, the criterion is a plain mean nn.CrossEntropyLoss and K11 covers the head."""
+    if not (type(crit) is nn.CrossEntropyLoss and crit.weight is None and crit.reduction == 'mean' and crit.label_smoothing == 0.0):
+        return False
+    fc = model.fc
+    if not (type(fc) is nn.Linear and fc.weight.dtype == torch.float32 and fc.weight.is_contiguous()
+            and (fc.bias is None or fc.bias.is_contiguous())):
+        return False
+    if not (isinstance(target, torch.Tensor) and target.is_cuda and target.dtype == torch.int64 and target.dim() == 1
+            and target.is_contiguous() and target.shape[0] == x.shape[0]):
+        return False
+    if not eligible(model, x):
+        return False
+    return _native.default_kernels().head_supported((x.shape[0], model.bn.num_features, x.shape[2] // 4, x.shape[3] // 4), fc.out_features)
+
+
+def _units(model, x):
+    """conv1 -> layer1..3 as K10 launches: the last residual sum and the partial sums of its statistics."""
     ws = iter(_plan(model, x)[0])
     y, p = _Stem.apply(x, model.conv1.weight, model.conv1, next(ws))
     for stage in (model.layer1, model.layer2, model.layer3):
@@ -303,4 +368,18 @@ def trunk(model, x):
             y1, p1, za = _Unit.apply(y, p, blk.bn1.weight, blk.bn1.bias, blk.conv1.weight, None, blk.bn1, blk.conv1, st, next(ws))
             sc = za if blk.downsample is None else blk.downsample(za)
             y, p, _ = _Unit.apply(y1, p1, blk.bn2.weight, blk.bn2.bias, blk.conv2.weight, sc, blk.bn2, blk.conv2, 1, next(ws))
+    return y, p
+
+
+def trunk_loss(model, x, target, crit):
+    """The whole training forward as K10 + K11 launches: the scalar loss crit(model(x), target). Call only when
+    `head_eligible(model, x, target, crit)`; hand `one(x.device)` to its `.backward()`."""
+    y, p = _units(model, x)
+    return _Head.apply(y, p, model.bn.weight, model.bn.bias, model.fc.weight, model.fc.bias, target, model.bn, crit.ignore_index)
+
+
+def trunk(model, x):
+    """conv1 -> layer1..3 -> bn -> relu of a BasicBlock PreResNet (URSABench/models/preresnet.py:138-146) as K10 launches; returns
+    relu(bn(z)) of the last residual sum. Call only when `eligible(model, x)`."""
+    y, p = _units(model, x)
     return _FinalBN.apply(y, p, model.bn.weight, model.bn.bias, model.bn)

@@ -16,7 +16,7 @@ path that is timed — is the path the reference comparisons execute.
 """
 import torch
 
-from .. import fused_bn, fused_conv
+from .. import fused_block, fused_bn, fused_conv
 from .._capture import capture, side_streams
 from ..util import deferred_bn_counters
 
@@ -46,6 +46,7 @@ class ChainEngine:
         # step between dependent branches; profiles/r06_side_branch_ab.json). The pairing that works is inside ONE launch
         # (ursa_preact_bwd_pair_f32). Kept as a switch: it changes no bit (tests/test_fused_block_gpu.py).
         self.wgrad_side = False
+        self.fused_head = True           # take model.forward_loss (K11) where it applies
         self.gate_probe = None           # fused_bn.GateProbe: parity runs against the reference CPU path only
         self._graph_probe = None
         self.stats = dict(graph_replays=0, eager_steps=0, captures=0)
@@ -67,15 +68,22 @@ class ChainEngine:
         if self.wgrad_side and wgrad_side is not False:
             side = side_streams(self.device, 2)[1]          # ([0]: the stream eager warm-up steps / single-chain groups run on)
         with deferred_bn_counters(self.model), fused_bn.probing(self.gate_probe), fused_conv.deferred(side) as pend:
-            logits = self.model(x)                  # (deferred_bn_counters: 19 one-element counter kernels -> one multi-tensor add)
-        loss = self.crit(logits, y)
+            # (deferred_bn_counters: 19 one-element counter kernels -> one multi-tensor add)
+            fl = getattr(self.model, 'forward_loss', None)
+            loss = fl(x, y, self.crit) if fl is not None and self.fused_head else None      # K10 + K11: the loss without the logits
+            fused_loss = loss is not None
+            if not fused_loss:
+                loss = self.crit(self.model(x), y)
         # Gradients: with p.grad = None autograd hands over its freshly computed tensors (no kernel);
         # ONE multi-tensor copy then packs them into the flat arena. Leaving the arena views in
         # p.grad instead makes autograd run one `grad += new` kernel per parameter tensor (61 launches
         # and a fused re-zeroing for PreResNet-20: +0.11 ms per step, tools/exp/step_variants.py).
         for p in self._params:
             p.grad = None
-        loss.backward()
+        if fused_loss:
+            loss.backward(fused_block.one(self.device))     # a persistent 1.0: no ones_like fill, no scaling in the head's backward
+        else:
+            loss.backward()
         pend.join()                                 # the K7 branch meets the main stream again: its partial sums are reduced below
         grads = [p.grad for p in self._params]
         grad_views = self.opt.arena.grad_views

@@ -184,6 +184,14 @@ class PreResNet(nn.Module):
     def forward(self, x):
         return self.fc(_pool8(self._trunk(x), self.avgpool))
 
+    def forward_loss(self, x, target, crit):
+        """crit(self(x), target) for a training step whose loss is a plain mean cross entropy, with the head - the last BatchNorm, ReLU,
+        pooling, classifier, loss and their gradients - as three launches (`fused_block.trunk_loss`, K11) instead of ~13; None when
+        that does not apply (the caller then evaluates crit(self(x), target) itself). The chain engine asks."""
+        if type(self) is PreResNet and self.depth < 44 and fused_block.head_eligible(self, x, target, crit):
+            return fused_block.trunk_loss(self, x, target, crit)
+        return None
+
 
 class PreResNet_dropout(PreResNet):
     """Not in the reference (it ships MLP_, ResNet_ and WideResNet_dropout only): the benchmark's PreResNet with
