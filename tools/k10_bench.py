@@ -18,6 +18,8 @@ N, REP, SETS = 128, 24, 6
 UNITS = [(16, 16, 32, 1), (32, 32, 16, 1), (64, 64, 8, 1), (16, 32, 32, 2), (32, 64, 16, 2)]
 if os.environ.get('URSA_K10_DBG'):
     UNITS = UNITS[:1]                      # the knob's variants exist for the first shape only
+if os.environ.get('URSA_K10_UNITS'):
+    UNITS = UNITS[:int(os.environ['URSA_K10_UNITS'])]
 
 
 def timed(fn):
@@ -97,6 +99,18 @@ for cin, cout, hw, st in UNITS:
     r['bwd_pair'] = timed(lambda i: K.preact_bwd_pair(dys[i % SETS], w, gs[i % SETS], xs[i % SETS], save, pb, wss[i % SETS], st))
     out[f'{cin}x{cout}x{hw}s{st}'] = r
     print(f'{cin}x{cout}x{hw}s{st}', json.dumps(r), flush=True)
+# K7's second launch for the 21 convolutions of a PreResNet-20 step at once (what the engine's flush issues)
+LAYERS = [(3, 16, 32, 3, 1)] + [(16, 16, 32, 3, 1)] * 6 + [(16, 32, 32, 3, 2), (16, 32, 32, 1, 2)] + [(32, 32, 16, 3, 1)] * 5 + \
+         [(32, 64, 16, 3, 2), (32, 64, 16, 1, 2)] + [(64, 64, 8, 3, 1)] * 5
+pend, tot = [], 0
+for cin, cout, hw, ks, st in LAYERS:
+    x, dy = torch.randn(N, cin, hw, hw, device=DEV), torch.randn(N, cout, hw // st, hw // st, device=DEV)
+    ws = torch.empty(K.conv_wgrad_ws_floats(x.shape, cout, ks, st), device=DEV)
+    tot += ws.numel() * 4
+    pend.append((K.conv_wgrad_partial(x, dy, (cout, cin, ks, ks), ws, st), torch.empty(cout, cin, ks, ks, device=DEV)))
+r = {'reduce_21_layers': timed(lambda i: K.conv_wgrad_reduce(pend)), 'partial_sum_bytes': tot}
+out['reduce_step'] = r
+print('reduce_step', json.dumps(r), flush=True)
 if len(sys.argv) > 1:
     json.dump(dict(what='us per launch inside hipGraph replays, batch 128 (tools/k10_bench.py)', dbg=os.environ.get('URSA_K10_DBG'), units=out),
               open(sys.argv[1], 'w'), indent=1)

@@ -98,14 +98,40 @@ if not K6_ONLY:
         K.conv3x3(cx, cw, cy)
         K.conv3x3(cdy, cw, cy, flip=True)
         K.conv_wgrad(cx, cdy, cdw, cws, 1)
-    manifest.append(dict(pattern='k_conv3x3<16, 16, 32', label='K8 forward / input gradient 128x16x32x32', blocks=512, wg=256,
+    manifest.append(dict(pattern='k_conv3x3<16, 16, 32, 8, 4, 0, 0, 0, 0>', label='K8 forward / input gradient 128x16x32x32', blocks=512, wg=256,
                          algorithmic_bytes_per_launch=4 * (2 * cx.numel() + cw.numel()), flops_per_launch=2 * 128 * 1024 * 16 * 16 * 9))
     manifest.append(dict(pattern='k_conv_wgrad<16, 16, 32', label='K7 first launch 128x16x32x32', blocks=512, wg=256,
                          algorithmic_bytes_per_launch=4 * (2 * cx.numel() + cw.numel()), form_bytes=4 * (2 * cx.numel() + cws.numel()),
                          flops_per_launch=2 * 128 * 1024 * 16 * 16 * 9))
     manifest.append(dict(pattern='k_conv_wgrad_reduce', label='K7 second launch (512 slices of 2,304 floats)', blocks=36, wg=256,
                          algorithmic_bytes_per_launch=4 * (cws.numel() + cw.numel())))
-    del cx, cdy, cy, cws
+    # K10 at the same layer: the fused forward unit (BatchNorm + ReLU while staged, statistics of the result), the paired backward
+    # launch (input gradient + BatchNorm-backward sums, weight gradient with the staged transform), K6's dx launch fed by them
+    gam, bet = torch.rand(16, device='cuda') + 0.5, torch.randn(16, device='cuda') * 0.1
+    xd = cx.double()
+    ip = torch.stack([xd.sum((0, 2, 3)), (xd * xd).sum((0, 2, 3))], -1)[:, None, :].contiguous()
+    save = torch.empty(4, 16, device='cuda')
+    geo = K.preact_geometry(cx.shape, 16, bn=True)
+    sc = torch.zeros(geo[1], dtype=torch.uint8, device='cuda')
+    part = torch.empty(16, geo[0], 2, dtype=torch.float64, device='cuda')
+    pb = torch.empty(16, K.preact_geometry(cdy.shape, 16, flip=True)[0], 2, dtype=torch.float64, device='cuda')
+    cws2 = torch.empty(K.conv_wgrad_ws_floats(cx.shape, 16, 3, 1), device='cuda')
+    g_, dx_, dgb = torch.empty_like(cx), torch.empty_like(cx), torch.empty(2, 16, device='cuda')
+    for _ in range(10):
+        K.preact_conv3x3(cx, cw, cy, part, sc, bn=(ip, gam, bet, None, None, save, 1e-5, 0.0))
+        K.preact_conv3x3(cx, cw, cy, part, sc, bn=(ip, gam, bet, None, None, save, 1e-5, 0.0), add=cdy)
+        K.preact_bwd_pair(cdy, cw, g_, cx, save, pb, cws2, 1)
+        K.bn_bwd_dx(cx, g_, dx_, gam, save, pb, dgb[0], dgb[1], dz=cdy)
+    fl = 2 * 128 * 1024 * 16 * 16 * 9
+    manifest.append(dict(pattern='k_conv3x3<16, 16, 32, 8, 4, 0, 0, 1, 1>', label='K10 forward unit conv(relu(bn(x))) + statistics, 128x16x32x32', blocks=512, wg=256,
+                         algorithmic_bytes_per_launch=4 * (2 * cx.numel() + cw.numel()), flops_per_launch=fl))
+    manifest.append(dict(pattern='k_conv3x3<16, 16, 32, 8, 4, 0, 0, 1, 2>', label='K10 forward unit with the residual add, 128x16x32x32', blocks=512, wg=256,
+                         algorithmic_bytes_per_launch=4 * (3 * cx.numel() + cw.numel()), flops_per_launch=fl))
+    manifest.append(dict(pattern='k_bwd_pair<16, 16, 32', label='K10 paired backward launch (input gradient + weight gradient), 128x16x32x32', blocks=512 + cws2.numel() // 2304, wg=256,
+                         algorithmic_bytes_per_launch=4 * (4 * cx.numel() + 2 * cw.numel()), form_bytes=4 * (4 * cx.numel() + cws2.numel()), flops_per_launch=2 * fl))
+    manifest.append(dict(pattern='k_bn_bwd_dx<4, false, true, false, true>', label='K6 dx launch fed by K10 partial sums (+ shortcut gradient), 128x16x32x32', blocks=1024, wg=256,
+                         algorithmic_bytes_per_launch=4 * 4 * cx.numel()))
+    del cx, cdy, cy, cws, cws2, g_, dx_
 # K6 relu(bn(x)): the two-launch form on a 268 MB activation (PreResNet-164's first stage at the HMC batch: beyond the
 # Infinity Cache) and the one-pass form on an 84 MB one (WideResNet-28-10's last stage at 4x the batch)
 for shape, one in K6_SHAPES:

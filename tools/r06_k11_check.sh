@@ -27,3 +27,8 @@ rm -rf /tmp/tl && timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv
     --no-cpu-baseline --no-parity --ref-style-steps 0 --multi-chain-sweep "" --detail-out /tmp/tl_detail.json > /tmp/tl.log 2>&1; rc=$?
 echo "trace rc=$rc" | tee -a "$R/$out/rc.txt"
 cd "$R" && python3 tools/step_timeline.py /tmp/tl "$out/step_timeline.json" | tee "$out/step_timeline.txt"
+timeout -k 10 300 python3 tools/k10_bench.py "$out/k10_bench.json" 2>/dev/null | tee "$out/k10_bench.txt"
+for ipw in 2 4; do
+  echo "URSA_CONV_IPW=$ipw (knobs build: images per K7 workgroup)" | tee -a "$out/k10_bench.txt"
+  URSA_K10_KNOBS=1 URSA_CONV_IPW=$ipw timeout -k 10 300 python3 tools/k10_bench.py "$out/k10_bench_ipw$ipw.json" 2>/dev/null | tee -a "$out/k10_bench.txt"
+done

@@ -511,7 +511,11 @@ Plan plan_for(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, int ks
     const bool k3 = ksize == 3, k1 = ksize == 1;
     if (xbn && (!k3 || Cin == 3)) return p;
     if (k3 && stride == 1 && Cin == 16 && Cout == 16 && W == 32) {
-        p.ipw = 1, bands = 4, p.gy = 1, p.fn = xbn ? k_conv_wgrad<16, 16, 32, 8, 1, 9, 4, true> : k_conv_wgrad<16, 16, 32, 8, 1, 9, 4>;
+        // two images per workgroup: 256 K slices at batch 128 = one per CU; alone the launch takes what 512 slices take
+        // (9.1 us), beside the input-gradient workgroups of the paired launch 21.8 -> 19.8 us, and half the partial sums for
+        // the second launch to read (tools/k10_bench.py with URSA_CONV_IPW, profiles/r06_k7_ipw_ab.json; 32 channels and the
+        // stride-2 layers lose with two: 9.1 -> 13.2, 7.1 -> 9.8 us)
+        p.ipw = 2, bands = 4, p.gy = 1, p.fn = xbn ? k_conv_wgrad<16, 16, 32, 8, 1, 9, 4, true> : k_conv_wgrad<16, 16, 32, 8, 1, 9, 4>;
     } else if (k3 && stride == 1 && Cin == 32 && Cout == 32 && W == 16) {
         p.ipw = 1, bands = 2, p.gy = 1, p.fn = xbn ? k_conv_wgrad<32, 32, 16, 8, 1, 9, 4, true> : k_conv_wgrad<32, 32, 16, 8, 1, 9, 4>;
     } else if (k3 && stride == 1 && Cin == 64 && Cout == 64 && W == 8) {

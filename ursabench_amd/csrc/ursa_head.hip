@@ -7,7 +7,7 @@
 //   logits[n][k] = b[k] + sum_c p[n][c] W[k][c]                                  (fma chain over c, ascending)
 //   lse_n = m_n + log(sum_k exp(logits[n][k] - m_n)),  m_n = max_k logits[n][k]
 //   loss = (sum over rows with target != ignore_index of (lse_n - logits[n][target_n])) / count       (rows summed in a fixed tree)
-//   dlogits[n][k] = (exp(logits[n][k] - lse_n) - [k == target_n]) / count  (0 for ignored rows)
+//   dlogits[n][k] = (exp(logits[n][k] - m_n) / sum_n - [k == target_n]) / count  (0 for ignored rows)
 //   dW[k][c] = sum_n dlogits[n][k] p[n][c] ; db[k] = sum_n dlogits[n][k] ; dp[n][c] = sum_k dlogits[n][k] W[k][c]   (fma chains, ascending)
 // A target outside [0, K) that is not ignore_index makes the loss NaN (torch raises a device-side assert there).
 #include <hip/hip_runtime.h>
@@ -34,6 +34,7 @@ __global__ __launch_bounds__(kHeadThreads) void k_fc_ce(const float* __restrict_
     __shared__ float ws[kHeadMaxKC];                     // [K][C]
     __shared__ float ls[kHeadMaxN * kHeadMaxK];          // logits, then dlogits: [K][N]
     __shared__ float red[kHeadThreads / 64][3];
+    __shared__ float rowmax[kHeadMaxN], rowtgt[kHeadMaxN];
     __shared__ float sh_inv;
     const int tid = threadIdx.x, P = C + 1;
     for (int i = tid; i < N * C; i += kHeadThreads) ps[(i / C) * P + i % C] = p[i];
@@ -49,22 +50,37 @@ __global__ __launch_bounds__(kHeadThreads) void k_fc_ce(const float* __restrict_
         if (logits_out) logits_out[n * K + k] = acc;
     }
     __syncthreads();
-    // one thread per row: log-sum-exp, the row's loss, dlogits before the 1 / count factor (rows that do not count: zeros)
+    // log-sum-exp with the exponentials spread over all threads: per row the maximum and the target's logit (one thread per row), per
+    // (class, row) e = exp(logit - max) (one thread each), per row the sum, its logarithm and the row's loss; dlogits = e / sum - onehot
+    // before the 1 / count factor (rows that do not count: zeros)
+    for (int n = tid; n < N; n += kHeadThreads) {
+        const int64_t t = target[n];
+        float m = ls[n];
+        for (int k = 1; k < K; ++k) m = fmaxf(m, ls[k * N + n]);
+        rowmax[n] = m;
+        const bool ok = t != ignore_index && t >= 0 && t < K;
+        rowtgt[n] = ok ? ls[(int)t * N + n] : 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < K * N; i += kHeadThreads) ls[i] = expf(ls[i] - rowmax[i % N]);
+    __syncthreads();
     float my_loss = 0.f, my_cnt = 0.f, my_bad = 0.f;
     for (int n = tid; n < N; n += kHeadThreads) {
         const int64_t t = target[n];
         const bool valid = t != ignore_index;
         const bool bad = valid && (t < 0 || t >= K);
-        const bool counts = valid && !bad;
-        float m = ls[n];
-        for (int k = 1; k < K; ++k) m = fmaxf(m, ls[k * N + n]);
         float s = 0.f;
-        for (int k = 0; k < K; ++k) s += expf(ls[k * N + n] - m);
-        const float lse = m + logf(s);
-        if (counts) my_loss += lse - ls[(int)t * N + n];
+        for (int k = 0; k < K; ++k) s += ls[k * N + n];
+        if (valid && !bad) my_loss += (rowmax[n] + logf(s)) - rowtgt[n];
         my_cnt += valid ? 1.f : 0.f;
         my_bad += bad ? 1.f : 0.f;
-        for (int k = 0; k < K; ++k) ls[k * N + n] = counts ? expf(ls[k * N + n] - lse) - (k == (int)t ? 1.f : 0.f) : 0.f;
+        rowmax[n] = (valid && !bad) ? 1.0f / s : 0.f;          // (reused: the row's 1 / sum, 0 for rows that do not count)
+    }
+    __syncthreads();
+    for (int i = tid; i < K * N; i += kHeadThreads) {
+        const int k = i / N, n = i % N;
+        const float r = rowmax[n];
+        ls[i] = r != 0.f ? ls[i] * r - ((int64_t)k == target[n] ? 1.f : 0.f) : 0.f;
     }
     // rows are summed in a fixed order: the wave's shuffle tree, then the waves in ascending order
 #pragma unroll

@@ -23,6 +23,7 @@ network takes the K6 / K8 launches, which these are pinned equal to. `URSA_FUSED
 On a HIP tensor the path needs csrc/libursa_hip.so (no silent fallback: a missing library raises).
 """
 import os
+import threading
 import weakref
 
 import torch
@@ -42,6 +43,25 @@ def paired(flag=None):
     if flag is not None:
         _pair = bool(flag)
     return old
+
+
+_tls = threading.local()
+
+
+class separate_launches:
+    """Context around a FORWARD pass: the units applied inside keep their input-gradient and weight-gradient launches apart,
+    whatever `paired()` says. For callers whose steps share the device with other work (ChainGroup's parallel branches: smaller
+    launches interleave better there - 8 chains per GPU 4.95 vs 4.79 samples/s - while a lone chain gains from one launch fewer
+    per unit, 3.01 vs 2.95). The decision is taken in the forward and travels to the backward in its autograd context."""
+
+    def __enter__(self):
+        self.old = getattr(_tls, 'separate', False)
+        _tls.separate = True
+        return self
+
+    def __exit__(self, *exc):
+        _tls.separate = self.old
+        return False
 
 
 def enabled(flag=None):
@@ -161,6 +181,7 @@ class _Unit(torch.autograd.Function):
         ctx.save_for_backward(x, gamma, w, save)
         ctx.stride, ctx.ws_floats, ctx.conv, ctx.weight = stride, ws_floats, conv, w
         ctx.sink = getattr(fused_conv._tls, 'sink', None)
+        ctx.pair = _pair and not getattr(_tls, 'separate', False)
         ctx.has_shortcut = shortcut is not None
         ctx.mark_non_differentiable(part)
         return y, part, x
@@ -180,7 +201,7 @@ class _Unit(torch.autograd.Function):
         g = torch.empty_like(x)
         pb = torch.empty(Cin, geo[0], 2, dtype=torch.float64, device=dev)
         dw = None
-        if ctx.needs_input_grad[4] and _pair and (ctx.sink is None or ctx.sink.side is None):
+        if ctx.needs_input_grad[4] and ctx.pair and (ctx.sink is None or ctx.sink.side is None):
             # the unit's two backward convolutions in ONE launch (their workgroups interleaved)
             rec = K.preact_bwd_pair(dy, w, g, x, save, pb, x.new_empty(ctx.ws_floats), s)
             if ctx.sink is not None:

@@ -76,8 +76,8 @@ class ChainGroup:
         is for one such launch in flight at a time (csrc/ursa_bn.hip), is not taken inside a group of several chains."""
         if len(self.samplers) == 1:
             return s.engine.forward_backward(x, y)
-        from .. import fused_bn
-        with fused_bn.several_streams():
+        from .. import fused_bn, fused_block
+        with fused_bn.several_streams(), fused_block.separate_launches():
             return s.engine.forward_backward(x, y, wgrad_side=False)
 
     def _round_eager(self, x, y):
