@@ -80,6 +80,8 @@ def parse(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-full-size-legs', action='store_true', help='c2: skip the bounded full-size C4 / C5 legs (2 SWAG members + BMA; 8 HMC proposals)')
     ap.add_argument('--no-parity', action='store_true')
+    ap.add_argument('--parity-full-sample', action='store_true', help='c2 (opt-in, ~1 min): ONE whole posterior sample - 391 minibatch steps at the '
+                    'workload batch - against the CPU port with the port\'s near-zero gates given at every step (detail file: parity_full_sample)')
     ap.add_argument('--force-dist', action='store_true', help='join a process group even when WORLD_SIZE is 1')
     ap.add_argument('--cpu-steps', type=int, default=150, help='minibatch steps of the CPU port to time')
     ap.add_argument('--ref-style-steps', type=int, default=150, help='eager reference-style GPU steps to time (0: skip)')
@@ -440,6 +442,7 @@ def parity_trial(dev, seed_offset, steps_per_sample=1, samples=3, rows=128, test
 
 
 PARITY_SEEDS = (0, 10, 20)       # fixed list: every trial runs, every trial is in the line, nothing is selected
+PARITY_EXTRA_NATURAL_SEEDS = (30, 40, 50, 60, 70)   # natural gates only, workload rows
 
 
 def parity_block(dev, steps_per_sample=1, samples=3, rows=128, test_rows=128, depth=20, n_noise=N_TRAIN, small_rows=32,
@@ -473,12 +476,23 @@ def parity_block(dev, steps_per_sample=1, samples=3, rows=128, test_rows=128, de
                            K6's place, same seeds: K6's median error (first sample, last sample) <= 3 x the stock launches' + 1e-5
                            (the criterion of tests/test_gate_parity_gpu.py on G16); both sets side by side in the detail file.
     Natural errors after a differing gate are reported per sample, never asserted, never hidden."""
-    plan = [(rows, off, True) for off in seeds] + [(small_rows, off, False) for off in seeds]
+    # (round 6, VERDICT r5 #7 ii) five more seeds at the workload's rows, natural gates only: eight 128-row seeds in all, each held
+    # to 1e-5 on its gate-equal prefix, with the step of its first differing gate in the line
+    plan = ([(rows, off, True) for off in seeds] + [(small_rows, off, False) for off in seeds]
+            + [(rows, off, False) for off in PARITY_EXTRA_NATURAL_SEEDS])
     trials, ok_work, ok_equal, ok_bma, n_equal = [], True, True, True, 0
+    first_flip = {}
     for r, off, given in plan:
-        t = parity_trial(dev, off, steps_per_sample, samples, r, test_rows, depth, n_noise, given_gates=given, timed_path=given)
+        t0_trial = time.perf_counter()
+        # (the timed-path legs on the first seed only: two more chains per seed, and what they assert is deterministic)
+        t = parity_trial(dev, off, steps_per_sample, samples, r, test_rows, depth, n_noise, given_gates=given,
+                         timed_path=given and off == seeds[0])
+        t['seconds'] = round(time.perf_counter() - t0_trial, 2)
         trials.append(t)
         nat = t['natural']
+        ff = next((k_ for k_, (fl_, eq_) in enumerate(zip(nat['gate_flips_per_step'], nat['no_gate_outside_the_band_differs_per_step']))
+                   if fl_ or not eq_), None)
+        first_flip[f'{r}x{off}'] = ff                         # minibatch step (0-based) of the first differing gate; None: none in the run
         for k, ps in enumerate(nat['per_sample']):           # gate-equal prefix of the natural run
             upto = (k + 1) * steps_per_sample
             if sum(nat['gate_flips_per_step'][:upto]) or not all(nat['no_gate_outside_the_band_differs_per_step'][:upto]):
@@ -520,6 +534,8 @@ def parity_block(dev, steps_per_sample=1, samples=3, rows=128, test_rows=128, de
                    'fixed trial list, every trial asserted: gates given at the workload batch; natural runs on their gate-equal prefix',
            'rtol': PARITY_RTOL, 'seeds': list(seeds), 'rows_workload': rows, 'rows_small': small_rows,
            'pass_workload_rows': bool(ok_work), 'pass_gate_equal': bool(ok_equal), 'gate_equal_samples_asserted': n_equal,
+           'first_differing_gate_step_by_rows_x_seed': first_flip,
+           'natural_seeds_at_workload_rows': len(seeds) + len(PARITY_EXTRA_NATURAL_SEEDS),
            'pass_bma_same_members': bool(ok_bma),
            'worst_max_rel_err_proba_gates_given': worst('given'), 'worst_max_rel_err_proba_natural_reported': worst('natural'),
            'natural_k6_vs_stock_bn_rows_workload': side,
@@ -1192,6 +1208,24 @@ def run_c2(a, job, legs, line):
         line['parity'] = legs.run('parity', parity_block, dev)
         if line['parity'] is not None:
             line['parity']['given_equal_gradients'] = legs.run('given_equal_gradients', given_equal_gradients_block, dev, train)
+    if rank == 0 and a.parity_full_sample and not job.cpu:
+        def full_sample():
+            # VERDICT r5 #7 iii: the legs above compare 3 minibatch steps; this one a whole sample of the workload (391 steps of 128
+            # rows, 50,048 synthetic rows, the workload's hyper-parameters), every step a hipGraph replay with the port's gates given
+            t = parity_trial(dev, 0, steps_per_sample=len(train), samples=1, rows=batch, test_rows=128, depth=depth, given_gates=True)
+            gv = t['given']
+            out = {'minibatch_steps': len(train), 'rows': batch,
+                   'given_max_rel_err_proba': gv['per_sample'][0]['max_rel_err_proba'], 'given_max_rel_err_entropy': gv['per_sample'][0]['max_rel_err_entropy'],
+                   'given_no_gate_outside_the_band_differs': bool(all(gv['no_gate_outside_the_band_differs_per_step'])),
+                   'given_steps_with_a_gate_outside_the_band': int(sum(not v for v in gv['no_gate_outside_the_band_differs_per_step'])),
+                   'near_zero_gates_listed_per_step_mean': float(sum(t['near_zero_listed_per_step']) / len(t['near_zero_listed_per_step'])),
+                   'natural_max_rel_err_proba_reported': t['natural']['per_sample'][0]['max_rel_err_proba'],
+                   'natural_differing_gates_total': int(sum(t['natural']['gate_flips_per_step'])),
+                   'stock_bn_natural_max_rel_err_proba_reported': t['natural_stock_bn']['per_sample'][0]['max_rel_err_proba'],
+                   'rtol': PARITY_RTOL, 'engine': gv['engine']}
+            out['pass'] = bool(out['given_max_rel_err_proba'] <= PARITY_RTOL)
+            return out
+        line['parity_full_sample'] = legs.run('parity_full_sample', full_sample)
     hyp = dict(HYP, num_samples=a.steps + a.warmup)
 
     def make_chain(c):
@@ -1587,7 +1621,7 @@ def compact_line(line, detail_path):
         out['roofline'] = _pick(r, keys)
         for sub in ('forward', 'k8'):
             if r.get(sub):
-                out['roofline'][sub] = _pick(r[sub], ('kernel', 'frac', 'us_per_launch', 'frac_rocprof'))
+                out['roofline'][sub] = _pick(r[sub], ('frac', 'us_per_launch', 'frac_rocprof'))
         if line.get('roofline_k1'):
             out['roofline_k1'] = _pick(line['roofline_k1'], keys)
     if line.get('roofline_large'):
@@ -1612,7 +1646,7 @@ def compact_line(line, detail_path):
     par = line.get('parity')
     if par:
         out['parity'] = _pick(par, ('rtol', 'seeds', 'rows_workload', 'rows_small', 'pass', 'pass_workload_rows', 'pass_gate_equal',
-                                    'gate_equal_samples_asserted', 'pass_bma_same_members', 'worst_max_rel_err_proba_gates_given',
+                                    'gate_equal_samples_asserted', 'first_differing_gate_step_by_rows_x_seed', 'pass_bma_same_members', 'worst_max_rel_err_proba_gates_given',
                                     'worst_max_rel_err_proba_natural_reported', 'pass_k6_not_worse_than_stock', 'natural_first_step_k6_vs_stock'))
         if par.get('timed_path'):
             out['parity']['timed_path'] = _pick(par['timed_path'], ('pass_k10_bit_equal', 'pass_k11_first_sample', 'k11_worst_first_sample',

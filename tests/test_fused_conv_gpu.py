@@ -295,6 +295,36 @@ def test_network_forward_and_gradients_k8_vs_stock_vs_cpu():
     assert worse <= len(g8) // 4, worse                           # ... and no systematic loss against the stock launches
 
 
+def test_network_gradients_with_the_references_gates_given_hold_1e5_of_scale():
+    """The loose cap above exists because a ReLU gate that differs between the devices moves single elements by O(dy). With the
+    CPU run's near-zero gates GIVEN to the backward launches (the parity instrument: tests/gate_lists.py records them on the
+    host, fused_bn.GateProbe hands them to ursa_bn_relu_bwd_gated_f32) both devices differentiate the same piecewise-linear
+    function, and what is left is rounding: EVERY gradient tensor of the PreResNet-20 step at the workload batch within 1e-5 of
+    its scale of the CPU path's, K7 / K8 / K9 convolutions and K6 BatchNorm launches throughout (VERDICT r5 #7 i)."""
+    import gate_lists as GL
+    from ursabench_amd import fused_bn
+    torch.manual_seed(5)
+    net = models.PreResNet(10, 20).to(DEV).train()
+    x, y = torch.randn(128, 3, 32, 32, device=DEV), torch.randint(0, 10, (128,), device=DEV)
+    host = copy.deepcopy(net).cpu()
+    log = GL.NearZeroGates(host)
+    gc = _grads(host, x.cpu(), y.cpu())
+    calls = log.take()
+    log.remove()
+    probe = fused_bn.GateProbe(len(calls), max(len(c['idx']) for c in calls) + 1, DEV, force=True)
+    probe.load([(c['idx'], c['open']) for c in calls])
+    with fused_bn.probing(probe):
+        g8 = _grads(net, x, y)
+    rec = probe.collect()
+    assert rec['n_open_as_reference'] == [c['n_open'] for c in calls], 'a gate OUTSIDE the 1e-4 band differs'
+    worst = {}
+    for k in g8:
+        scale = float(gc[k].abs().max()) + 1e-12
+        worst[k] = float((g8[k].cpu() - gc[k]).abs().max()) / scale
+    bad = {k: v for k, v in worst.items() if v > 1e-5}
+    assert not bad, (bad, max(worst.values()))
+
+
 # ---- K9: the 1x1 / stride 2 shortcuts -------------------------------------------------------------------------------------
 @pytest.mark.parametrize('cin,cout,hw', [(16, 32, 32), (32, 64, 16)])
 @pytest.mark.parametrize('n', [1, 3, 80, 128])
@@ -384,7 +414,7 @@ def test_every_convolution_of_the_network_takes_a_hand_written_launch(k10):
                             preact_bwd_pair=0), seen
 
 
-@pytest.mark.parametrize('cin,cout,hw,n', [(16, 16, 32, 300), (32, 32, 16, 500), (64, 64, 8, 1600)])
+@pytest.mark.parametrize('cin,cout,hw,n', [(16, 16, 32, 400), (32, 32, 16, 500), (64, 64, 8, 1600)])
 def test_large_batches_take_longer_k_slices_and_stay_exact(cin, cout, hw, n):
     """Beyond 768 K slices K7 gives a workgroup several images (HMC's 1,024-row chunks): the slice count stays bounded and
     the result - small integers, exact in fp32 - still equals the oracle bit for bit; K8 at the same batch likewise."""

@@ -12,6 +12,7 @@ b) cp $E/r06_bench_kernel_stats.csv $E/r06_bench_kernel_stats.meta.json $E/r06_p
 c) cp $E/r06_bench_line.json $E/r06_bench_detail.json $E/r06_bench_line_driver_cmd.json $E/r06_bench_detail_driver_cmd.json $E/r06_bench_driver_cmd_wall_time.txt \
       $E/r06_bench_line_k6_k8.json $E/r06_bench_line_unpaired.json profiles/ ;;
 f) cp $E/r06_step_timeline.json profiles/ ;;
+g) cp $E/r06_parity_full_sample.json profiles/ ;;
 esac
 cp $E/r06_sha256_part_$part.txt profiles/r06/
 python3 - <<'PY'

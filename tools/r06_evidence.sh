@@ -43,6 +43,18 @@ c)  # the bench lines: plain, the driver's flags (with wall time), and the A/Bs 
   URSA_FUSED_BLOCK=0 python3 bench.py --no-parity --no-cpu-baseline --ref-style-steps 0 --no-full-size-legs --detail-out "$out/r06_bench_detail_k6_k8.json" > "$out/r06_bench_line_k6_k8.json" 2> "$out/bench_k6k8.err"; echo "bench with the K6 / K8 launches (round 5's step) rc=$?"
   URSA_BWD_PAIR=0 python3 bench.py --no-parity --no-cpu-baseline --ref-style-steps 0 --no-full-size-legs --detail-out "$out/r06_bench_detail_unpaired.json" > "$out/r06_bench_line_unpaired.json" 2> "$out/bench_unpaired.err"; echo "bench with separate backward launches rc=$?"
   ;;
+g)  # one WHOLE posterior sample (391 steps at the workload batch) against the CPU port, the port's gates given at every step
+  python3 bench.py --parity-full-sample --steps 1 --warmup 0 --no-parity --no-cpu-baseline --ref-style-steps 0 --multi-chain-sweep "" --no-full-size-legs \
+      --detail-out "$out/r06_parity_full_sample_detail.json" > "$out/r06_parity_full_sample_line.json" 2> "$out/parity_full.err"; echo "parity full sample rc=$?"
+  python3 - "$out" <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1] + '/r06_parity_full_sample_detail.json'))
+json.dump({'what': 'bench.py --parity-full-sample: one whole posterior sample of the workload (391 minibatch steps, 128 rows each) on the GPU, every step a '
+                   'hipGraph replay, against the torch-CPU port of the reference path on identical init / inputs / noise; predictive on 128 test rows',
+           'parity_full_sample': d.get('parity_full_sample'), 'errors': d.get('errors')}, open(sys.argv[1] + '/r06_parity_full_sample.json', 'w'), indent=1)
+print(json.dumps(d.get('parity_full_sample')))
+PY
+  ;;
 f)  # one minibatch step dispatch by dispatch
   cd /tmp && export TMPDIR=/tmp
   rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-parity --no-cpu-baseline --ref-style-steps 0 --multi-chain-sweep "" --no-full-size-legs --detail-out "$out/tl_detail.json" > "$out/tl_line.json" 2> "$out/tl.err"; echo "trace rc=$?"
