@@ -271,7 +271,7 @@ def load_gate_lists():
 
 
 def parity_trial(dev, seed_offset, steps_per_sample=1, samples=3, rows=128, test_rows=128, depth=20, n_noise=N_TRAIN,
-                 given_gates=True, timed_path=False):
+                 given_gates=True, timed_path=False, stock_bn=True):
     """One (rows, seed) of parity_block: the torch-CPU port once (recording its near-zero ReLU gates), then the GPU path
     on the same init / inputs / noise - `natural` (gates as the GPU's own convolutions decide them; differing ones
     counted against the port's lists) and, if `given_gates`, `given` (the port's gates handed to the backward launches)."""
@@ -306,6 +306,15 @@ def parity_trial(dev, seed_offset, steps_per_sample=1, samples=3, rows=128, test
     torch.manual_seed(777 + seed_offset)
     state, cpu_members, gate_steps = {}, [], []
     batches = [(xtr[i:i + rows], ytr[i:i + rows]) for i in range(0, n_tr, rows)]
+    if steps_per_sample > 50:                                  # a whole sample on the host takes minutes: say so as it goes
+        class _Heartbeat(list):
+            def __iter__(self):
+                for i_, b_ in enumerate(list.__iter__(self)):
+                    if i_ % 20 == 0:
+                        sys.stderr.write(f'[bench] parity: CPU port minibatch step {i_} / {len(self)}\n')
+                        sys.stderr.flush()
+                    yield b_
+        batches = _Heartbeat(batches)
     for lr in lrs:
         port.sghmc_epoch(net_cpu, batches, state, lr=lr, momentum=1 - HYP['alpha'],
                          weight_decay=1 / HYP['prior_std'] ** 2, num_training_samples=n_noise)
@@ -436,8 +445,9 @@ def parity_trial(dev, seed_offset, steps_per_sample=1, samples=3, rows=128, test
         out['given'].pop('_proba', None), out['given'].pop('_theta', None)
         # the same natural run with the STOCK BatchNorm / ReLU launches: differing gates come from the convolutions' last bits, not
         # from the BatchNorm arithmetic, so K6 must not be worse in distribution (VERDICT r4 #5 i)
-        out['natural_stock_bn'] = gpu_run(False, fused=False)
-        out['natural_stock_bn'].pop('_proba', None), out['natural_stock_bn'].pop('_theta', None)
+        if stock_bn:
+            out['natural_stock_bn'] = gpu_run(False, fused=False)
+            out['natural_stock_bn'].pop('_proba', None), out['natural_stock_bn'].pop('_theta', None)
     return out
 
 
@@ -1212,7 +1222,8 @@ def run_c2(a, job, legs, line):
         def full_sample():
             # VERDICT r5 #7 iii: the legs above compare 3 minibatch steps; this one a whole sample of the workload (391 steps of 128
             # rows, 50,048 synthetic rows, the workload's hyper-parameters), every step a hipGraph replay with the port's gates given
-            t = parity_trial(dev, 0, steps_per_sample=len(train), samples=1, rows=batch, test_rows=128, depth=depth, given_gates=True)
+            t = parity_trial(dev, 0, steps_per_sample=len(train), samples=1, rows=batch, test_rows=128, depth=depth, given_gates=True,
+                             stock_bn=False)
             gv = t['given']
             out = {'minibatch_steps': len(train), 'rows': batch,
                    'given_max_rel_err_proba': gv['per_sample'][0]['max_rel_err_proba'], 'given_max_rel_err_entropy': gv['per_sample'][0]['max_rel_err_entropy'],
@@ -1221,7 +1232,6 @@ def run_c2(a, job, legs, line):
                    'near_zero_gates_listed_per_step_mean': float(sum(t['near_zero_listed_per_step']) / len(t['near_zero_listed_per_step'])),
                    'natural_max_rel_err_proba_reported': t['natural']['per_sample'][0]['max_rel_err_proba'],
                    'natural_differing_gates_total': int(sum(t['natural']['gate_flips_per_step'])),
-                   'stock_bn_natural_max_rel_err_proba_reported': t['natural_stock_bn']['per_sample'][0]['max_rel_err_proba'],
                    'rtol': PARITY_RTOL, 'engine': gv['engine']}
             out['pass'] = bool(out['given_max_rel_err_proba'] <= PARITY_RTOL)
             return out

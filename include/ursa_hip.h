@@ -456,20 +456,27 @@ int ursa_conv1x1s2_f32(const float* x, const float* w, float* y, int64_t N, int6
  *                      first half of the backward of the BatchNorm + ReLU in front of it: aux = that BatchNorm's input (the
  *                      result's shape), aux_bn_save = its bn_save; stored to y: g = fmaf(aux, alpha_c, beta'_c) > 0 ? dh : 0
  *                      (the forward's gate recomputed from its saved scalars, as K6's backward); out_partial [Cout'][nl][2] =
- *                      (sum g, sum g * (aux - mean_c)) in double. ursa_bn_bwd_dx_f32 finishes: dx, dgamma, dbeta.
- * Sums are deterministic: every workgroup's per-channel sums go to its own slot of `scratch`, workgroups count themselves out
- * on one of <= 16 line counters, and the LAST one of a line adds the line's slots in ascending order (a fixed order whatever
- * the arrival order; nobody waits for a workgroup that is not running). `scratch` (ursa_preact_geometry()[1] bytes, 128-byte
- * aligned) must be ZERO before its first launch and is zero again when a launch has drained: zero it once, then reuse it for
- * the same layer and direction (never for two launches that may overlap). A poll that runs out (never in a correct run) raises
- * the error word in scratch (uint32 at byte offset ursa_preact_geometry()[3]) and makes the sums NaN.
+ *                      (sum g, sum g * (aux - mean_c)) in double, one pair per workgroup. ursa_bn_bwd_dx_f32 finishes: dx, dgamma, dbeta.
+ * Sums are deterministic (a fixed summation order whatever the arrival order; no atomics on the data):
+ *   forward forms: the grid.x workgroups of a channel are cut into <= 16 lines of consecutive indices; every workgroup takes a
+ *     ticket on its line's counter when it STARTS, stores its sums to its own slot of `scratch` and exits - except the one that
+ *     drew the line's last ticket: it knows every other workgroup of the line is running (a running workgroup of this launch
+ *     never waits for anything, so waiting for THEIR sums cannot starve, whatever else shares the device), polls their slots,
+ *     adds them in ascending order with its own, stores the line's partial sum, zeroes the slots and re-arms the counter.
+ *     `scratch` (ursa_preact_geometry()[1] bytes, 128-byte aligned) must be ZERO before its first launch and is zero again when a
+ *     launch has drained: zero it once, then reuse it for the same layer (never for two launches that may overlap). A poll that
+ *     runs out (never in a correct run) raises the error word in scratch (uint32 at byte offset ursa_preact_geometry()[3]) and
+ *     makes the sums NaN.
+ *   input-gradient forms (BNBWD): no hand-over inside the launch - every workgroup stores its sums at out_partial[channel][its
+ *     grid.x index] (nl = workgroups per channel, up to a few hundred; scratch may be NULL) and ursa_bn_bwd_dx_f32, which is per
+ *     channel anyway, adds its channel's nl partial sums in ascending order.
  * Shapes (any N, H = W): forward stride 1 (Cin, Cout, H): (3, 16, 32) without BN / ADD (the stem); (16, 16, 32), (32, 32, 16),
  * (64, 64, 8) with BN, with or without ADD; forward stride 2: (16, 32, 32), (32, 64, 16) with BN; flipped (+ BNBWD): the five
  * input-gradient forms K8 covers. ursa_preact_geometry: out[0] = nl, out[1] = scratch bytes, out[2] = workgroups per channel,
  * out[3] = byte offset of the error word in scratch; URSA_EVALUE = not covered.
  * ursa_preact_wgrad_partial_f32: K7's first launch with x = max(fmaf(x, alpha, beta'), 0) taken while the tile is staged
  * (bn_save of the BatchNorm in front of the layer); same scratch size, same second launch (ursa_conv_wgrad_reduce_f32).
- * ursa_bn_apply_f32 / ursa_bn_bwd_dx_f32: K6's second launches alone, fed by such partial sums (nl <= 64): the BatchNorm that
+ * ursa_bn_apply_f32 (nl <= 64) / ursa_bn_bwd_dx_f32 (nl <= 65,536): K6's second launches alone, fed by such partial sums: the BatchNorm that
  * ends the network, and the `dx` half of every BatchNorm backward. g is already gated. save: [4][C] as bn_save.
  * Traffic per unit and direction: the convolution's own (x + y + w) + 4 B x elements of aux; K6's 12 / 20 B per element are gone.
  */
@@ -477,7 +484,13 @@ int ursa_conv1x1s2_f32(const float* x, const float* w, float* y, int64_t N, int6
 #define URSA_PREACT_STATS   0x20u
 #define URSA_PREACT_ADD     0x40u
 #define URSA_PREACT_BNBWD   0x80u
-#define URSA_PREACT_ALLFLAGS 0xF3u
+#define URSA_PREACT_EVAL    0x100u  /* with URSA_PREACT_BN [| URSA_PREACT_ADD | URSA_CONV_STRIDE2]: EVALUATION mode - the staged tensor is
+                                       max(fmaf(x, alpha_c, beta'_c), 0) with alpha_c = gamma_c / sqrtf(running_var_c + eps) and beta'_c =
+                                       fmaf(-running_mean_c, alpha_c, beta_c) (ursa_bn_relu_eval_f32's expressions, bit for bit); nothing is
+                                       saved, no sums are taken (out_partial / scratch / in_partial / bn_save may be NULL), the running
+                                       statistics are only read. One launch per bn -> relu -> conv unit of an ensemble member's forward
+                                       (URSABench/tasks/prediction.py:56-58 `model(x)` in eval mode) instead of K6's launch + the convolution */
+#define URSA_PREACT_ALLFLAGS 0x1F3u
 int ursa_preact_geometry(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, uint32_t flags, int64_t* out /* [4] */);
 int ursa_preact_conv3x3_f32(const float* x, const float* w, float* y,
                             const double* in_partial, int32_t in_nl, const float* gamma, const float* beta,

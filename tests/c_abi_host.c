@@ -27,6 +27,14 @@ int oracle_bn_relu_bwd_gated_f32(const float*, const float*, float*, const float
 
 int oracle_conv_wgrad_f32(const float*, const float*, float*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t);
 int oracle_conv3x3_f32(const float*, const float*, float*, int64_t, int64_t, int64_t, int64_t, int64_t, int, int64_t);
+int oracle_preact_fwd_f32(const float*, const float*, const float*, float*, float*, const float*, const float*, float*, float*, float*, double*,
+                          int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, float, float, int);
+int oracle_preact_bwd_f32(const float*, const float*, const float*, const float*, float*, double*, int64_t, int64_t, int64_t, int64_t, int64_t,
+                          int64_t);
+int oracle_bn_bwd_dx_f32(const float*, const float*, const float*, float*, const float*, const float*, const double*, float*, float*, int64_t,
+                         int64_t, int64_t);
+int oracle_fc_ce_f32(const float*, const float*, const float*, const int64_t*, float*, float*, float*, float*, float*, int64_t, int64_t, int64_t,
+                     int64_t);
 
 #define CHECK(x) do { int rc_ = (x); if (rc_) { printf("FAIL %s -> %d (%s)\n", #x, rc_, ursa_strerror(rc_)); return 1; } } while (0)
 
@@ -211,11 +219,125 @@ int main(void)
         if (ursa_conv3x3_f32(dx_, dw_, dy_, N, 5, C, H, H, 0, st) != URSA_EVALUE) { printf("FAIL K8 evalue\n"); return 1; }
         if (ursa_conv_wgrad_f32(dx_, ddy, ddw, dws, 16, N, C, C, H, H, 3, 1, st) != URSA_ESIZE) { printf("FAIL K7 esize\n"); return 1; }
     }
+    /* ABI 7: K10 - one fused unit forward (BatchNorm + ReLU while the tile is staged, convolution, `+= residual`, statistics of the
+     * result) and its backward (paired input-gradient / weight-gradient launch, then K6's dx launch) against the oracle's
+     * restatement on integer-valued data: x = +-1 balanced per channel -> mean 0, variance 1, eps = 0 -> invstd 1, so every
+     * product and sum is an integer and the device must equal the oracle bit for bit, sums included. Then K11's classifier launch. */
+    {
+        const int64_t N = 4, C = 16, H = 32, HW = H * H, tot = N * C * HW, wn = C * C * 9;
+        float *hx = malloc(tot * 4), *hadd = malloc(tot * 4), *hdy = malloc(tot * 4), *hw = malloc(wn * 4), *hg = malloc(C * 4), *hb = malloc(C * 4);
+        float *oy = malloc(tot * 4), *oh = malloc(tot * 4), *og = malloc(tot * 4), *odx = malloc(tot * 4), *got = malloc(tot * 4);
+        float osave[64], gsave[64], odg[16], odb[16], gdg[16], gdb[16];
+        double osums[32], obs[32];
+        unsigned s3 = 7u;
+        for (int64_t c = 0; c < C; ++c)                       /* a balanced +-1 pattern per channel: position parity xor a pseudo-random per-row flip */
+            for (int64_t n = 0; n < N; ++n)
+                for (int64_t j = 0; j < HW; j += 2) {
+                    const float v = frand(&s3) < 0.5f ? 1.0f : -1.0f;
+                    hx[(n * C + c) * HW + j] = v, hx[(n * C + c) * HW + j + 1] = -v;
+                }
+        for (int64_t i = 0; i < tot; ++i) { hadd[i] = floorf(4.99f * frand(&s3)) - 2.0f; hdy[i] = floorf(2.99f * frand(&s3)) - 1.0f; }
+        for (int64_t i = 0; i < wn; ++i) hw[i] = floorf(2.99f * frand(&s3)) - 1.0f;
+        for (int64_t c = 0; c < C; ++c) { hg[c] = 1.0f + floorf(2.99f * frand(&s3)); hb[c] = floorf(2.99f * frand(&s3)) - 1.0f; }
+        oracle_preact_fwd_f32(hx, hw, hadd, oy, oh, hg, hb, NULL, NULL, osave, osums, N, C, C, H, H, 1, 0.0f, 0.0f, 1);
+        oracle_preact_bwd_f32(hdy, hw, hx, osave, og, obs, N, C, C, H, H, 1);
+        oracle_bn_bwd_dx_f32(hx, og, NULL, odx, hg, osave, obs, odg, odb, N, C, HW);
+        int64_t geo[4], geob[4];
+        if (ursa_preact_geometry(N, C, C, H, H, URSA_PREACT_BN | URSA_PREACT_STATS | URSA_PREACT_ADD, geo) != URSA_OK ||
+            ursa_preact_geometry(N, C, C, H, H, URSA_CONV_FLIP | URSA_PREACT_BNBWD, geob) != URSA_OK) { printf("FAIL K10 does not cover the 16-channel unit\n"); return 1; }
+        double hin[32];                                        /* the producer's partial sums of x: one line per channel, (sum, sum of squares) = (0, n) */
+        for (int64_t c = 0; c < C; ++c) { hin[2 * c] = 0.0; hin[2 * c + 1] = (double)(N * HW); }
+        float *dx_, *dadd, *ddy, *dw_, *dy_, *dgm, *dbt, *dsave, *dg_, *ddx, *ddgb, *dws;
+        double *din, *dpart, *dpb;
+        void* dscr;
+        const int64_t wsf = ursa_conv_wgrad_ws_floats(N, C, C, H, H, 3, 1);
+        CHECK(hipMalloc((void**)&dx_, tot * 4)); CHECK(hipMalloc((void**)&dadd, tot * 4)); CHECK(hipMalloc((void**)&ddy, tot * 4));
+        CHECK(hipMalloc((void**)&dy_, tot * 4)); CHECK(hipMalloc((void**)&dg_, tot * 4)); CHECK(hipMalloc((void**)&ddx, tot * 4));
+        CHECK(hipMalloc((void**)&dw_, wn * 4)); CHECK(hipMalloc((void**)&dgm, C * 4)); CHECK(hipMalloc((void**)&dbt, C * 4));
+        CHECK(hipMalloc((void**)&dsave, 4 * C * 4)); CHECK(hipMalloc((void**)&ddgb, 2 * C * 4)); CHECK(hipMalloc((void**)&dws, wsf * 4));
+        CHECK(hipMalloc((void**)&din, sizeof hin)); CHECK(hipMalloc((void**)&dpart, C * geo[0] * 16)); CHECK(hipMalloc((void**)&dpb, C * geob[0] * 16));
+        CHECK(hipMalloc(&dscr, geo[1])); CHECK(hipMemset(dscr, 0, geo[1]));
+        CHECK(hipMemcpy(dx_, hx, tot * 4, hipMemcpyHostToDevice)); CHECK(hipMemcpy(dadd, hadd, tot * 4, hipMemcpyHostToDevice));
+        CHECK(hipMemcpy(ddy, hdy, tot * 4, hipMemcpyHostToDevice)); CHECK(hipMemcpy(dw_, hw, wn * 4, hipMemcpyHostToDevice));
+        CHECK(hipMemcpy(dgm, hg, C * 4, hipMemcpyHostToDevice)); CHECK(hipMemcpy(dbt, hb, C * 4, hipMemcpyHostToDevice));
+        CHECK(hipMemcpy(din, hin, sizeof hin, hipMemcpyHostToDevice));
+        CHECK(ursa_preact_conv3x3_f32(dx_, dw_, dy_, din, 1, dgm, dbt, NULL, NULL, dsave, 0.0f, 0.0f, dadd, NULL, dpart, dscr, geo[1], N, C, C, H, H,
+                                      URSA_PREACT_BN | URSA_PREACT_STATS | URSA_PREACT_ADD, st));
+        CHECK(hipStreamSynchronize(st));
+        CHECK(hipMemcpy(got, dy_, tot * 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(gsave, dsave, 4 * C * 4, hipMemcpyDeviceToHost));
+        if (memcmp(gsave, osave, 4 * C * 4)) { printf("FAIL K10 saved BatchNorm scalars differ from the oracle\n"); return 1; }
+        if (memcmp(got, oy, tot * 4)) { printf("FAIL K10 forward unit differs from the oracle\n"); return 1; }
+        {
+            double* hp = malloc(C * geo[0] * 16);
+            CHECK(hipMemcpy(hp, dpart, C * geo[0] * 16, hipMemcpyDeviceToHost));
+            for (int64_t c = 0; c < C; ++c) {
+                double a = 0.0, b = 0.0;
+                for (int64_t l = 0; l < geo[0]; ++l) { a += hp[(c * geo[0] + l) * 2]; b += hp[(c * geo[0] + l) * 2 + 1]; }
+                if (a != osums[2 * c] || b != osums[2 * c + 1]) { printf("FAIL K10 statistics of the result differ from the oracle\n"); return 1; }
+            }
+            unsigned char* hs = malloc(geo[1]);
+            CHECK(hipMemcpy(hs, dscr, geo[1], hipMemcpyDeviceToHost));
+            for (int64_t i = 0; i < geo[1]; ++i) if (hs[i]) { printf("FAIL K10 scratch not zero after the launch\n"); return 1; }
+        }
+        CHECK(ursa_preact_bwd_pair_f32(ddy, dw_, dg_, dx_, dsave, dpb, dws, wsf, N, C, C, H, H, 0, st));
+        CHECK(ursa_bn_bwd_dx_f32(dx_, dg_, NULL, ddx, dgm, dsave, dpb, (int32_t)geob[0], ddgb, ddgb + C, N, C, HW, st));
+        CHECK(hipStreamSynchronize(st));
+        CHECK(hipMemcpy(got, dg_, tot * 4, hipMemcpyDeviceToHost));
+        if (memcmp(got, og, tot * 4)) { printf("FAIL K10 gated input gradient differs from the oracle\n"); return 1; }
+        CHECK(hipMemcpy(got, ddx, tot * 4, hipMemcpyDeviceToHost));
+        CHECK(hipMemcpy(gdg, ddgb, C * 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(gdb, ddgb + C, C * 4, hipMemcpyDeviceToHost));
+        if (memcmp(gdg, odg, C * 4) || memcmp(gdb, odb, C * 4) || memcmp(got, odx, tot * 4)) { printf("FAIL K10 dx / dgamma / dbeta differ from the oracle\n"); return 1; }
+        {   /* the weight gradient the paired launch left in ws: x operand = relu(bn(x)) = the oracle's h */
+            float *wantw = malloc(wn * 4), *gotw = malloc(wn * 4), *ddw;
+            CHECK(hipMalloc((void**)&ddw, wn * 4));
+            const ursa_conv_pending pw = {dws, ddw, N, C, C, H, H, 3, 1};
+            CHECK(ursa_conv_wgrad_reduce_f32(&pw, 1, st));
+            CHECK(hipStreamSynchronize(st));
+            CHECK(hipMemcpy(gotw, ddw, wn * 4, hipMemcpyDeviceToHost));
+            oracle_conv_wgrad_f32(oh, hdy, wantw, N, C, C, H, H, 3, 1);
+            if (memcmp(gotw, wantw, wn * 4)) { printf("FAIL K10 weight gradient (paired launch) differs from the oracle\n"); return 1; }
+        }
+        if (ursa_preact_geometry(N, 5, C, H, H, URSA_PREACT_BN | URSA_PREACT_STATS, geo) != URSA_EVALUE) { printf("FAIL K10 evalue\n"); return 1; }
+        if (ursa_preact_conv3x3_f32(dx_, dw_, dy_, din, 1, dgm, dbt, NULL, NULL, dsave, 0.0f, 0.0f, dadd, NULL, dpart, dscr, 64, N, C, C, H, H,
+                                    URSA_PREACT_BN | URSA_PREACT_STATS | URSA_PREACT_ADD, st) != URSA_ESIZE) { printf("FAIL K10 esize\n"); return 1; }
+        /* K11: classifier + mean cross entropy + their gradients in one launch, against the oracle (double sums) to rounding */
+        {
+            const int64_t Nn = 32, Cc = 64, Kk = 10;
+            float *hp = malloc(Nn * Cc * 4), *hW = malloc(Kk * Cc * 4), hbias[10], oloss, gloss, *odW = malloc(Kk * Cc * 4), odbias[10], *odp = malloc(Nn * Cc * 4);
+            float *gdW = malloc(Kk * Cc * 4), *gdp = malloc(Nn * Cc * 4), *ologits = malloc(Nn * Kk * 4);
+            int64_t ht[32];
+            for (int64_t i = 0; i < Nn * Cc; ++i) hp[i] = 2.0f * frand(&s3);
+            for (int64_t i = 0; i < Kk * Cc; ++i) hW[i] = 0.6f * frand(&s3) - 0.3f;
+            for (int64_t k = 0; k < Kk; ++k) hbias[k] = 0.2f * frand(&s3) - 0.1f;
+            for (int64_t n = 0; n < Nn; ++n) ht[n] = (int64_t)(9.99f * frand(&s3));
+            ht[3] = -100;
+            oracle_fc_ce_f32(hp, hW, hbias, ht, &oloss, ologits, odW, odbias, odp, Nn, Cc, Kk, -100);
+            float *dp_, *dW_, *dbias, *dloss, *ddW, *ddb, *ddp;
+            int64_t* dt;
+            CHECK(hipMalloc((void**)&dp_, Nn * Cc * 4)); CHECK(hipMalloc((void**)&dW_, Kk * Cc * 4)); CHECK(hipMalloc((void**)&dbias, Kk * 4));
+            CHECK(hipMalloc((void**)&dloss, 4)); CHECK(hipMalloc((void**)&ddW, Kk * Cc * 4)); CHECK(hipMalloc((void**)&ddb, Kk * 4));
+            CHECK(hipMalloc((void**)&ddp, Nn * Cc * 4)); CHECK(hipMalloc((void**)&dt, Nn * 8));
+            CHECK(hipMemcpy(dp_, hp, Nn * Cc * 4, hipMemcpyHostToDevice)); CHECK(hipMemcpy(dW_, hW, Kk * Cc * 4, hipMemcpyHostToDevice));
+            CHECK(hipMemcpy(dbias, hbias, Kk * 4, hipMemcpyHostToDevice)); CHECK(hipMemcpy(dt, ht, Nn * 8, hipMemcpyHostToDevice));
+            CHECK(ursa_fc_ce_f32(dp_, dW_, dbias, dt, dloss, NULL, ddW, ddb, ddp, Nn, Cc, Kk, -100, st));
+            CHECK(hipStreamSynchronize(st));
+            CHECK(hipMemcpy(&gloss, dloss, 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(gdW, ddW, Kk * Cc * 4, hipMemcpyDeviceToHost));
+            CHECK(hipMemcpy(gdp, ddp, Nn * Cc * 4, hipMemcpyDeviceToHost));
+            float wmax = 0.f, pmax = 0.f, werr = 0.f, perr = 0.f;
+            for (int64_t i = 0; i < Kk * Cc; ++i) { wmax = fmaxf(wmax, fabsf(odW[i])); werr = fmaxf(werr, fabsf(gdW[i] - odW[i])); }
+            for (int64_t i = 0; i < Nn * Cc; ++i) { pmax = fmaxf(pmax, fabsf(odp[i])); perr = fmaxf(perr, fabsf(gdp[i] - odp[i])); }
+            if (fabsf(gloss - oloss) > 2e-6f * fabsf(oloss) || werr > 5e-6f * wmax || perr > 5e-6f * pmax) {
+                printf("FAIL K11 classifier launch: loss %g vs %g, dW err %g of %g, dp err %g of %g\n", gloss, oloss, werr, wmax, perr, pmax); return 1; }
+            if (ursa_fc_ce_f32(dp_, dW_, dbias, dt, dloss, NULL, ddW, ddb, ddp, Nn, Cc, 100, -100, st) != URSA_EVALUE) { printf("FAIL K11 evalue\n"); return 1; }
+        }
+    }
     /* argument errors come back as codes, not crashes */
     if (ursa_sgmcmc_step_f32(NULL, NULL, NULL, NULL, NULL, 8, 0, 0, 0, 0, 1, 0, 0, 0, st) != URSA_ENULL) { printf("FAIL enull\n"); return 1; }
     if (ursa_bma_accumulate_f32(dz, dp, de, NULL, NULL, S, B, 5000, omg, goc, 0, st) != URSA_EVALUE) { printf("FAIL evalue\n"); return 1; }
     if (ursa_sgmcmc_step_multi_f32(dth, dgr, dmo, NULL, NULL, 64, 2, 62, NULL, st) != URSA_ESIZE) { printf("FAIL esize (stride < n)\n"); return 1; }
     printf("C-ABI host OK: K1 bit-equal to the oracle over 3 steps (n=%lld), 2 chains in one self-advancing launch bit-equal, "
-           "generator self-test clean, K5 max relative error %.2e, K6 forward + backward + gated backward bit-equal, K7 / K8 bit-equal on integer inputs\n", (long long)n, worst);
+           "generator self-test clean, K5 max relative error %.2e, "
+           "K6 forward + backward + gated backward bit-equal, K7 / K8 bit-equal on integer inputs, "
+           "K10 fused unit (forward, paired backward, dx) bit-equal on integer inputs, K11 classifier launch within rounding\n", (long long)n, worst);
     return 0;
 }

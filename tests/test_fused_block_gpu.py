@@ -431,3 +431,57 @@ def test_side_branch_of_the_weight_gradients_changes_no_bit():
     assert torch.isfinite(finals[0]).all()
     assert torch.equal(finals[0], finals[1])
     fused_block.check(DEV)
+
+
+# ---- evaluation mode: an ensemble member's forward -------------------------------------------------------------------------
+@pytest.mark.parametrize('cin,cout,hw,stride', UNITS)
+@pytest.mark.parametrize('n', [1, 5, 128, 1000])
+def test_evaluation_unit_equals_k6_eval_then_k8_bit_for_bit(cin, cout, hw, stride, n):
+    """ursa_preact_conv3x3_f32(URSA_PREACT_EVAL): the running-statistics transform + ReLU while the tile is staged, then K8's
+    convolution (+ the residual add): the same floats as ursa_bn_relu_eval_f32 followed by ursa_conv3x3_f32 (and torch's add)."""
+    x, w, gamma, beta, add, _ = _rand_unit(cin, cout, hw, stride, n, 13 * n + cin)
+    rm, rv = torch.randn(cin, device=DEV) * 0.3, torch.rand(cin, device=DEV) + 0.4
+    K = _K()
+    assert K.preact_eval_supported(x.shape, cout, stride=stride)
+    h = torch.empty_like(x)
+    K.bn_relu_eval(x, h, gamma, beta, rm, rv, eps=1e-5, relu=True)
+    want = K.conv3x3(h, w, stride=stride)
+    y = torch.full_like(want, float('nan'))
+    K.preact_eval(x, w, y, gamma, beta, rm, rv, eps=1e-5, stride=stride)
+    assert torch.equal(y, want)
+    if stride == 1:
+        assert K.preact_eval_supported(x.shape, cout, add=True)
+        K.preact_eval(x, w, y, gamma, beta, rm, rv, eps=1e-5, add=add)
+        assert torch.equal(y, want + add)
+    else:
+        assert not K.preact_eval_supported(x.shape, cout, stride=2, add=True)
+
+
+@pytest.mark.parametrize('depth,n', [(8, 7), (20, 128), (20, 1024)])
+def test_network_evaluation_forward_fused_vs_the_k6_miopen_path(depth, n):
+    """models.PreResNet in eval mode under no_grad: the fused units against K6's evaluation launches + MIOpen's convolutions (the
+    path of rounds 2-5): the same function up to the convolutions' summation order (1e-5 of the logits' scale); and the path is
+    not taken where it must not be (gradients recorded, training mode)."""
+    torch.manual_seed(depth + n)
+    net = models.PreResNet(10, depth).to(DEV)
+    for m in net.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.2)
+            m.running_mean.normal_(0, 0.3)
+            m.running_var.uniform_(0.5, 1.5)
+    net.eval()
+    x = torch.randn(n, 3, 32, 32, device=DEV)
+    with torch.no_grad():
+        assert fused_block.eval_eligible(net, x)
+        got = net(x)
+        old = fused_block.eval_fused(False)
+        try:
+            assert not fused_block.eval_eligible(net, x)
+            want = net(x)
+        finally:
+            fused_block.eval_fused(old)
+    assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    assert not fused_block.eval_eligible(net, x), 'gradients recorded: the stock evaluation path (autograd through MIOpen / ATen)'
+    with torch.no_grad():
+        assert not fused_block.eval_eligible(net.train(), x)

@@ -27,7 +27,7 @@ LEAP_KICK, LEAP_DRIFT = 0x1, 0x2
 REDUCE_WS_FLOATS = 2048
 BN_RELU, BN_TWO_LAUNCH, BN_HELD = 0x1, 0x2, 0x4
 CONV_FLIP, CONV_STRIDE2 = 0x1, 0x2
-PREACT_BN, PREACT_STATS, PREACT_ADD, PREACT_BNBWD = 0x10, 0x20, 0x40, 0x80
+PREACT_BN, PREACT_STATS, PREACT_ADD, PREACT_BNBWD, PREACT_EVAL = 0x10, 0x20, 0x40, 0x80, 0x100
 
 
 def bn_ws_floats(channels):
@@ -651,6 +651,34 @@ class HipKernels:
                                                   N, Cin, Cout, H, W,
                                                   self._preact_flags(flip, stride, bn is not None, add is not None), _stream(dev))
         _check(self.lib, rc, 'ursa_preact_conv3x3_f32')
+        return y
+
+    def preact_eval_supported(self, x_shape, cout, stride=1, add=False):
+        """Whether the evaluation-mode unit conv(relu(bn_eval(x))) [+ addend] of an input of `x_shape` to `cout` channels is covered."""
+        n, cin, h, w = (int(v) for v in x_shape)
+        out = (ctypes.c_int64 * 4)()
+        fl = self._conv_flags(False, stride) | PREACT_BN | PREACT_EVAL | (PREACT_ADD if add else 0)
+        return self.lib.ursa_preact_geometry(n, cin, int(cout), h, w, fl, out) == 0
+
+    def preact_eval(self, x, w, y, gamma, beta, running_mean, running_var, *, eps, stride=1, add=None):
+        """y = conv2d(relu(batch_norm_eval(x)), w, stride, padding=1) [+ add] in ONE launch (ursa_preact_conv3x3_f32 with
+        URSA_PREACT_EVAL): K6's evaluation expressions applied while the tile is staged, K8's convolution."""
+        if x.dim() != 4 or w.dim() != 4 or tuple(w.shape[2:]) != (3, 3) or w.shape[1] != x.shape[1]:
+            raise ValueError(f'not a 3x3 convolution: x {tuple(x.shape)}, w {tuple(w.shape)}')
+        N, Cin, H, W = x.shape
+        Cout = w.shape[0]
+        dev = x.device
+        shape = (N, Cout, H // stride, W // stride)
+        if tuple(y.shape) != shape:
+            raise ValueError(f'y {tuple(y.shape)} should be {shape}')
+        fl = self._conv_flags(False, stride) | PREACT_BN | PREACT_EVAL | (PREACT_ADD if add is not None else 0)
+        with torch.cuda.device(dev):
+            rc = self.lib.ursa_preact_conv3x3_f32(_ptr(x, 'x'), _ptr(w, 'w', None, dev), _ptr(y, 'y', None, dev), None, 0,
+                                                  _ptr(gamma, 'gamma', Cin, dev), _ptr(beta, 'beta', Cin, dev),
+                                                  _ptr(running_mean, 'running_mean', Cin, dev), _ptr(running_var, 'running_var', Cin, dev),
+                                                  None, float(eps), 0.0, _ptr(add, 'addend', y.numel(), dev, optional=True), None, None, None, 0,
+                                                  N, Cin, Cout, H, W, fl, _stream(dev))
+        _check(self.lib, rc, 'ursa_preact_conv3x3_f32 (evaluation)')
         return y
 
     def preact_wgrad_partial(self, x, bn_save, dy, dw_shape, ws, stride=1):

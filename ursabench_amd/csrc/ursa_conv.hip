@@ -684,6 +684,9 @@ struct Fw {
 //   PRO 1: the staged tensor is relu(bn(x)) with bn's batch statistics merged here from the producer's per-line partial
 //          sums (every workgroup the same 16-lane tree: identical scalars); workgroup (0, 0) also stores mean / invstd / alpha /
 //          beta' for the backward and updates the running statistics. The zero padding stays zero.
+//   PRO 2: the same staging transform in EVALUATION mode: scale / shift from the running statistics (K6's k_bn_eval expressions:
+//          invstd = 1 / sqrtf(running_var + eps), alpha = invstd * gamma, beta' = fmaf(-running_mean, alpha, beta)); nothing saved.
+//   EPI 4: y + addend stored (`out += residual`), no sums (evaluation).
 //   EPI 1: per-channel (sum y, sum y^2) of the output in double -> publish_sums: what the NEXT BatchNorm needs.
 //   EPI 2: the same of z = y + addend (`out += residual`, preresnet.py:49-52); z is what is stored.
 //   EPI 3: (input-gradient forms) g = the ReLU gate of the BatchNorm in front of the layer applied to the result
@@ -801,6 +804,13 @@ __device__ __forceinline__ void conv_body(const float* __restrict__ x, const flo
         }
     }
     auto pro_finish = [&]() {                                  // after a barrier: torch's CPU BatchNorm rounding, K6's code
+        if constexpr (PRO == 2) {
+            if (tid < CIN) {
+                const float invstd = 1.0f / sqrtf(f.running_var[tid] + f.eps);
+                const float alpha = invstd * f.gamma[tid];
+                tab[tid] = make_float2(alpha, fmaf(-f.running_mean[tid], alpha, f.beta[tid]));
+            }
+        }
         if constexpr (PRO == 1) {
             if (tid < CIN) {
                 const int c = tid;
@@ -877,7 +887,7 @@ __device__ __forceinline__ void conv_body(const float* __restrict__ x, const flo
             for (int tap = 0; tap < 9; ++tap) wr[g][tap] = wl[(cot * 16 + j) * C::WPITCH + (g * 4 + k) * 9 + tap];
         __syncthreads();                                       // every wave has its weights: the region becomes the x tile
     }
-    if constexpr (PRO == 1) {
+    if constexpr (PRO != 0) {
         const float2 ss = tab[(tid / (C::WIN / 4)) % CIN];
         pro_scale = ss.x, pro_shift = ss.y;
     }
@@ -891,7 +901,7 @@ __device__ __forceinline__ void conv_body(const float* __restrict__ x, const flo
     const double g_meand = (double)g_mean;
     // what is stored for an accumulated float4 `v` whose second operand is `a`; the sums of the stored / gated values
     auto finish4 = [&](f32x4 v, const f32x4& a) -> f32x4 {
-        if constexpr (EPI == 2) v = v + a;                     // z = y + addend, one fp32 add as torch's
+        if constexpr (EPI == 2 || EPI == 4) v = v + a;         // z = y + addend, one fp32 add as torch's
         if constexpr (EPI == 1 || EPI == 2) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const double d = (double)v[e]; s1 += d; s2 = fma(d, d, s2); }
@@ -991,13 +1001,13 @@ __device__ __forceinline__ void conv_body(const float* __restrict__ x, const flo
         }
         if (EPI >= 2 && n + 1 < n1) issue_aux(n + 1);          // after this image's stores: av is free again
     }
-    if constexpr (EPI != 0 && DBG == 3) {                      // knobs: no hand-over at all (what the accumulation alone costs)
+    if constexpr ((EPI == 1 || EPI == 2) && DBG == 3) {                      // knobs: no hand-over at all (what the accumulation alone costs)
         if (s1 + s2 == 12345.678) y[0] = 0.f;
-    } else if constexpr (EPI != 0 && DBG == 4) {               // knobs: slots stored, nobody adds (what the final poll costs)
+    } else if constexpr ((EPI == 1 || EPI == 2) && DBG == 4) {               // knobs: slots stored, nobody adds (what the final poll costs)
         publish_sums<COUT_WG, C::MT, C::WPC>(f, 0xffffffffu, s1, s2, smem, co_base, bx, by, gx);
     } else if constexpr (EPI == 3) {
         store_sums<COUT_WG, C::MT, C::WPC>(f, s1, s2, smem, co_base, bx, gx);
-    } else if constexpr (EPI != 0) {
+    } else if constexpr (EPI == 1 || EPI == 2) {
         publish_sums<COUT_WG, C::MT, C::WPC>(f, ticket, s1, s2, smem, co_base, bx, by, gx);
     }
 }
@@ -1115,6 +1125,26 @@ FwPlan fuse_plan_for(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W,
         }
         return p;
     }
+    if (flags & URSA_PREACT_EVAL) {                            // evaluation: running statistics in the prologue, optional residual add, no sums
+        if (bwd || stats || !bn) return p;
+        if (s2) {
+            if (add) return p;
+            if (Cin == 16 && Cout == 32 && W == 32) p = {2, 1, 1, k_conv3x3<16, 32, 16, 8, 4, 1, 0, 2, 0>};
+            else if (Cin == 32 && Cout == 64 && W == 16) p = {1, 2, 1, k_conv3x3<32, 32, 8, 8, 2, 1, 0, 2, 0>};
+            return p;
+        }
+        if (Cin == 16 && Cout == 16 && W == 32) {
+            if (add) p = {4, 1, 1, k_conv3x3<16, 16, 32, 8, 4, 0, 0, 2, 4>};
+            else p = {4, 1, 1, k_conv3x3<16, 16, 32, 8, 4, 0, 0, 2, 0>};
+        } else if (Cin == 32 && Cout == 32 && W == 16) {
+            if (add) p = {2, 1, 1, k_conv3x3<32, 32, 16, 8, 4, 0, 0, 2, 4>};
+            else p = {2, 1, 1, k_conv3x3<32, 32, 16, 8, 4, 0, 0, 2, 0>};
+        } else if (Cin == 64 && Cout == 64 && W == 8) {
+            if (add) p = {1, 4, 2, k_conv3x3<64, 16, 8, 8, 1, 0, 0, 2, 4>};
+            else p = {1, 4, 2, k_conv3x3<64, 16, 8, 8, 1, 0, 0, 2, 0>};
+        }
+        return p;
+    }
     if (bwd || !stats) return p;                               // forward forms always leave the next BatchNorm's sums
     if (s2) {
         if (!bn || add) return p;
@@ -1174,6 +1204,10 @@ extern "C" int ursa_preact_geometry(int64_t N, int64_t Cin, int64_t Cout, int64_
     if (flags & ~URSA_PREACT_ALLFLAGS) return URSA_EFLAGS;
     const FwPlan p = fuse_plan_for(N, Cin, Cout, H, W, flags);
     if (!p.fn) return URSA_EVALUE;
+    if (flags & URSA_PREACT_EVAL) {                            // covered; nothing to size
+        out[0] = 0, out[1] = 0, out[2] = (int64_t)((N + p.ipw - 1) / p.ipw) * p.gx_per_image, out[3] = 0;
+        return URSA_OK;
+    }
     const FuseGeom g = fuse_geom(p, N, Cout, flags & URSA_CONV_FLIP);
     out[0] = g.nl, out[1] = g.scratch_bytes, out[2] = g.S, out[3] = g.tickets_bytes;
     return URSA_OK;
@@ -1185,6 +1219,22 @@ extern "C" int ursa_preact_conv3x3_f32(const float* x, const float* w, float* y,
                                        double* out_partial, void* scratch, int64_t scratch_bytes, int64_t N, int64_t Cin,
                                        int64_t Cout, int64_t H, int64_t W, uint32_t flags, ursa_stream_t stream) {
     if (flags & ~URSA_PREACT_ALLFLAGS) return URSA_EFLAGS;
+    if (flags & URSA_PREACT_EVAL) {                            // evaluation form: no sums, no scratch, nothing saved
+        if (!x || !w || !y || !gamma || !beta || !running_mean || !running_var) return URSA_ENULL;
+        if ((flags & URSA_PREACT_ADD) && !aux) return URSA_ENULL;
+        if (N < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return URSA_ESIZE;
+        if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)w | (uintptr_t)aux) & 15) return URSA_EALIGN;
+        if (((uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)running_mean | (uintptr_t)running_var) & 3) return URSA_EALIGN;
+        const FwPlan pe = fuse_plan_for(N, Cin, Cout, H, W, flags);
+        if (!pe.fn) return URSA_EVALUE;
+        Fuse fe = {};
+        fe.gamma = gamma, fe.beta = beta, fe.running_mean = running_mean, fe.running_var = running_var, fe.eps = eps, fe.aux = aux;
+        const int groups = (int)((N + pe.ipw - 1) / pe.ipw);
+        hipLaunchKernelGGL(pe.fn, dim3(groups * pe.gx_per_image, pe.gy), dim3(kThreads), 0, (hipStream_t)stream, x, w, y, (int)N, (int)Cout,
+                           pe.ipw, 0, fe);
+        const hipError_t ee = hipGetLastError();
+        return ee == hipSuccess ? URSA_OK : (int)ee;
+    }
     if (!x || !w || !y || !out_partial) return URSA_ENULL;
     if (N < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return URSA_ESIZE;
     const bool bn = flags & URSA_PREACT_BN, add = flags & URSA_PREACT_ADD, bwd = flags & URSA_PREACT_BNBWD;

@@ -34,6 +34,16 @@ from . import _native, fused_bn, fused_conv
 
 _on = os.environ.get('URSA_FUSED_BLOCK', '1') != '0'
 _pair = os.environ.get('URSA_BWD_PAIR', '1') != '0'      # a unit's input-gradient and weight-gradient launches as one (A/B: 0)
+_eval = os.environ.get('URSA_FUSED_EVAL', '1') != '0'    # evaluation forwards: one launch per bn -> relu -> conv unit (A/B: 0)
+
+
+def eval_fused(flag=None):
+    """Query / set whether evaluation-mode forwards of the BasicBlock networks take the fused units (`eval_trunk`)."""
+    global _eval
+    old = _eval
+    if flag is not None:
+        _eval = bool(flag)
+    return old
 
 
 def paired(flag=None):
@@ -397,6 +407,68 @@ def trunk_loss(model, x, target, crit):
     `head_eligible(model, x, target, crit)`; hand `one(x.device)` to its `.backward()`."""
     y, p = _units(model, x)
     return _Head.apply(y, p, model.bn.weight, model.bn.bias, model.fc.weight, model.fc.bias, target, model.bn, crit.ignore_index)
+
+
+def _eval_plan(model, x):
+    key = ('eval', tuple(x.shape), x.device)
+    cached = model.__dict__.get('_ursa_block_eval_plan')
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    K = _native.default_kernels()
+    N, _, H, W = x.shape
+    ok = x.shape[1] == 3 and _conv_ok(model.conv1, 3, 16, 1) and K.conv3x3_supported(x.shape, 16)
+    shape = (N, 16, H, W)
+    if ok:
+        for stage in (model.layer1, model.layer2, model.layer3):
+            for blk in stage:
+                st, planes = blk.conv1.stride[0], blk.conv1.out_channels
+                cin = shape[1]
+                mid = (N, planes, shape[2] // st, shape[3] // st)
+                ok = (ok and _conv_ok(blk.conv1, cin, planes, st) and _conv_ok(blk.conv2, planes, planes, 1)
+                      and (blk.downsample is not None) == (st != 1 or cin != planes)
+                      and (blk.downsample is None or K.conv1x1s2_supported(shape, planes))
+                      and K.preact_eval_supported(shape, planes, stride=st) and K.preact_eval_supported(mid, planes, add=True))
+                shape = mid
+            if not ok:
+                break
+    plan = bool(ok and shape[1] == model.bn.num_features)
+    model.__dict__['_ursa_block_eval_plan'] = (key, plan)
+    return plan
+
+
+def eval_eligible(model, x):
+    """Whether `eval_trunk(model, x)` applies: an evaluation-mode forward (running statistics everywhere) with no gradient recorded,
+    contiguous fp32 NCHW on a HIP device, every layer covered. An ensemble member's forward in the BMA predictive."""
+    if not (_on and _eval and fused_conv._on and fused_bn._on):
+        return False
+    if not ((not model.training) and isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+            and x.is_contiguous() and x.data_ptr() % 16 == 0 and not torch.is_autocast_enabled()):
+        return False
+    if torch.is_grad_enabled() and (x.requires_grad or model.conv1.weight.requires_grad):
+        return False
+    bns = [m for m in model.modules() if isinstance(m, nn.BatchNorm2d)]
+    if any(b.training or b.running_mean is None or not b.affine or type(b) is not nn.BatchNorm2d for b in bns):
+        return False
+    return _eval_plan(model, x)
+
+
+def eval_trunk(model, x):
+    """conv1 -> layer1..3 of a BasicBlock PreResNet in evaluation mode: one launch per bn -> relu -> conv unit (the BatchNorm's
+    running-statistics transform applied while the convolution stages its tile, `out += residual` in the epilogue) instead of
+    K6's evaluation launch + a convolution launch each; returns the last residual sum (the caller applies the final bn / relu)."""
+    K = _native.default_kernels()
+    y = K.conv3x3(x, model.conv1.weight)
+    for stage in (model.layer1, model.layer2, model.layer3):
+        for blk in stage:
+            st = blk.conv1.stride[0]
+            N, _, H, W = y.shape
+            planes = blk.conv1.out_channels
+            b1, b2 = blk.bn1, blk.bn2
+            y1 = K.preact_eval(y, blk.conv1.weight, y.new_empty(N, planes, H // st, W // st), b1.weight, b1.bias, b1.running_mean, b1.running_var,
+                               eps=b1.eps, stride=st)
+            sc = y if blk.downsample is None else K.conv1x1s2(y, blk.downsample[0].weight)
+            y = K.preact_eval(y1, blk.conv2.weight, torch.empty_like(y1), b2.weight, b2.bias, b2.running_mean, b2.running_var, eps=b2.eps, add=sc)
+    return y
 
 
 def trunk(model, x):

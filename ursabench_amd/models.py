@@ -178,6 +178,8 @@ class PreResNet(nn.Module):
         launches (`fused_block`: one launch per bn -> relu -> conv unit); everything else the K6 / K8 launches or the stock ops."""
         if self.depth < 44 and fused_block.eligible(self, x):
             return fused_block.trunk(self, x)
+        if self.depth < 44 and fused_block.eval_eligible(self, x):       # an ensemble member's forward: no gradient, running statistics
+            return bn_relu(self.bn, fused_block.eval_trunk(self, x))
         x = self.layer3(self.layer2(self.layer1(self.conv1(x))))     # the last block's pending sum
         return add_bn_relu(self.bn, x)[1]
 
