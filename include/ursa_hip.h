@@ -370,6 +370,8 @@ int ursa_bn_relu_bwd_gated_f32(const float* x, const float* dy, const float* dz 
  * Shapes covered (any N; H = W): every convolution of the CIFAR pre-activation ResNets with BasicBlocks -
  *     3x3 stride 1: (Cin, Cout, H) in {(3, 16, 32), (16, 16, 32), (32, 32, 16), (64, 64, 8)}
  *     3x3 stride 2: (16, 32, 32), (32, 64, 16)            1x1 stride 2: (16, 32, 32), (32, 64, 16)
+ *     1x1 stride 1 (K12, the Bottleneck networks): (64, 16, 32) (16, 64, 32) (128, 32, 16) (32, 128, 16) (256, 64, 8) (64, 256, 8)
+ *                                                  (64, 32, 32) (128, 64, 16)
  * ursa_conv_wgrad_ws_floats() returns the scratch `ws` must hold for a shape, 0 when the shape is not covered (the caller
  * then keeps the stock weight gradient; the launches return URSA_EVALUE).
  *   ursa_conv_wgrad_f32          both launches.
@@ -432,6 +434,26 @@ int ursa_conv3x3_f32(const float* x, const float* w, float* y, int64_t N, int64_
 int ursa_conv1x1s2_supported(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, uint32_t flags);
 int ursa_conv1x1s2_f32(const float* x, const float* w, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W,
                        uint32_t flags, ursa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K12  the 1x1 / stride 1 convolutions of the Bottleneck pre-activation ResNets (`self.conv1`, `self.conv3`, the stride-1
+ *      `downsample`: URSABench/models/preresnet.py:56,62,76-87,130-136), forward and input gradient; no bias, no padding.
+ *
+ *     y[n][o][p] = sum_i w[o][i] x[n][i][p]                                   x: [N, Cin, H, W] -> y: [N, Cout, H, W]
+ *     URSA_CONV_FLIP:   the input gradient: x = dy [N, Cin', H, W] (Cin' = the layer's OUTPUT channels), y = dx [N, Cout', H, W]
+ *                       (Cout' = the layer's INPUT channels), w = the layer's own [Cin', Cout'] tensor.
+ * A GEMM on the NCHW planes as they lie (per image Y = W X): exact fp32 on v_mfma_f32_16x16x4_f32, fma chains over the input
+ * channels in ascending groups of four; nothing is transposed (MIOpen runs these layers as NCHW->NHWC transposes + an implicit /
+ * rocBLAS GEMM + a transpose back). Shapes covered (any N, H = W; (Cin, Cout, H) of the launch, either direction):
+ *     (64, 16, 32) (16, 64, 32) (128, 32, 16) (32, 128, 16) (256, 64, 8) (64, 256, 8) (16, 16, 32) (64, 32, 32) (32, 64, 32)
+ *     (128, 64, 16) (64, 128, 16)          - every 1x1 / stride 1 layer of PreResNet-164 and its input gradient.
+ * Weight gradients of these layers: ursa_conv_wgrad_* with ksize 1, stride 1 (K7's two launches; the first is K12's GEMM over
+ * batch x positions, its partial sums in K7's tile order) - covered: every such layer except (16, 16, 32).
+ * Algorithmic HBM traffic: 4 B x (elements of x + elements of y + Cout*Cin).
+ */
+int ursa_conv1x1_supported(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, uint32_t flags);
+int ursa_conv1x1_f32(const float* x, const float* w, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W,
+                     uint32_t flags, ursa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * K10  the pre-activation unit of the BasicBlock ResNets, one launch each way      URSABench/models/preresnet.py:33-52

@@ -723,3 +723,22 @@ int oracle_bn_relu_pool_bwd_f32(const float* z, const float* dpooled, float* dy,
             for (int64_t j = 0; j < HW; ++j) dy[(n * C + c) * HW + j] = dpooled[n * C + c] / (float)HW;
     return oracle_bn_relu_bwd_f32(z, dy, dz, gamma, beta, save, save + C, dgamma, dbeta, N, C, HW, 1);
 }
+
+/* ---------------------------------------------------------------------------------------
+ * K12  1x1 / stride 1 convolution, no bias (`self.conv1` / `self.conv3` of the Bottleneck blocks, URSABench/models/preresnet.py:
+ *      56,62,76-87) and, with flip, its input gradient. Sums in double, rounded once (as K7 / K8 / K9's restatements).
+ *      forward: x [N, Cin, HW] -> y [N, Cout, HW], w [Cout, Cin]; flip: x = dy [N, Cin, HW] -> y = dx [N, Cout, HW], w = the
+ *      layer's [Cin, Cout] tensor. (The weight gradient: oracle_conv_wgrad_f32 with ksize 1, stride 1.)
+ */
+int oracle_conv1x1_f32(const float* x, const float* w, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t HW, int flip)
+{
+    for (int64_t n = 0; n < N; ++n)
+        for (int64_t o = 0; o < Cout; ++o)
+            for (int64_t p = 0; p < HW; ++p) {
+                double acc = 0.0;
+                for (int64_t i = 0; i < Cin; ++i)
+                    acc += (double)(flip ? w[i * Cout + o] : w[o * Cin + i]) * (double)x[(n * Cin + i) * HW + p];
+                y[(n * Cout + o) * HW + p] = (float)acc;
+            }
+    return 0;
+}

@@ -266,3 +266,17 @@ def bn_relu_pool_bwd(z, dpooled, gamma, beta, save):
     rc = _L.oracle_bn_relu_pool_bwd_f32(_p(z), _p(dpooled), _p(dy), _p(gamma), _p(beta), _p(np.ascontiguousarray(save)), _p(dz), _p(dg), _p(db), N, C, HW)
     assert rc == 0
     return dz, dg, db
+
+
+_L.oracle_conv1x1_f32.argtypes = [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32]
+
+
+def conv1x1(x, w, flip=False):
+    """K12: y = conv2d(x, w) for w [Cout, Cin, 1, 1]; flip: the input gradient for the output gradient `x`."""
+    N, Cin, H, W = x.shape
+    Cout = w.shape[1 if flip else 0]
+    assert w.shape[0 if flip else 1] == Cin and w.shape[2:] == (1, 1)
+    y = np.empty((N, Cout, H, W), np.float32)
+    rc = _L.oracle_conv1x1_f32(_p(x), _p(np.ascontiguousarray(w.reshape(w.shape[0], w.shape[1]))), _p(y), N, Cin, Cout, H * W, int(flip))
+    assert rc == 0
+    return y

@@ -430,3 +430,74 @@ def test_large_batches_take_longer_k_slices_and_stay_exact(cin, cout, hw, n):
     assert np.array_equal(_k7(dx_, ddy, cout).cpu().numpy(), oracle_lib.conv_wgrad(x, dy, 3, 1))
     assert np.array_equal(k.conv3x3(dx_, dw_).cpu().numpy(), oracle_lib.conv3x3(x, w))
     assert np.array_equal(k.conv3x3(ddy, dw_, flip=True).cpu().numpy(), oracle_lib.conv3x3(dy, w, flip=True))
+
+
+# ---- K12: the 1x1 / stride 1 layers of the Bottleneck networks -------------------------------------------------------------
+K12_SHAPES = [(64, 16, 32), (16, 64, 32), (128, 32, 16), (32, 128, 16), (256, 64, 8), (64, 256, 8), (16, 16, 32), (64, 32, 32), (128, 64, 16)]
+
+
+@pytest.mark.parametrize('cin,cout,hw', K12_SHAPES)
+@pytest.mark.parametrize('n', [1, 3, 80])
+def test_k12_equals_the_oracle(cin, cout, hw, n):
+    """Forward, input gradient and weight gradient of a 1x1 / stride 1 layer: random data against the oracle's double sums
+    (fp32 fma chains over <= 256 products / over N*H*W products in ordered slices), small integers bit for bit."""
+    rng = np.random.default_rng(17 * n + cin + cout)
+    k = _native.default_kernels()
+    x = rng.standard_normal((n, cin, hw, hw), dtype=np.float32)
+    w = (rng.standard_normal((cout, cin, 1, 1)) * (1.0 / cin) ** 0.5).astype(np.float32)
+    dy = rng.standard_normal((n, cout, hw, hw), dtype=np.float32)
+    tx, tw, tdy = (torch.from_numpy(a).to(DEV) for a in (x, w, dy))
+    assert k.conv1x1_supported(tx.shape, cout) and k.conv1x1_supported(tdy.shape, cin, flip=True)
+    y = torch.full((n, cout, hw, hw), float('nan'), device=DEV)
+    k.conv1x1(tx, tw, y)
+    want = oracle_lib.conv1x1(x, w)
+    assert np.abs(y.cpu().numpy() - want).max() <= 2e-6 * np.abs(want).max()
+    dx = torch.full((n, cin, hw, hw), float('nan'), device=DEV)
+    k.conv1x1(tdy, tw, dx, flip=True)
+    want = oracle_lib.conv1x1(dy, w, flip=True)
+    assert np.abs(dx.cpu().numpy() - want).max() <= 2e-6 * np.abs(want).max()
+    wsf = k.conv_wgrad_ws_floats(tx.shape, cout, 1, 1)
+    if (cin, cout) != (16, 16):
+        assert wsf > 0
+        dw = torch.full((cout, cin, 1, 1), float('nan'), device=DEV)
+        k.conv_wgrad(tx, tdy, dw, torch.empty(wsf, device=DEV), 1)
+        want = oracle_lib.conv_wgrad(x, dy, 1, 1)
+        assert np.abs(dw.cpu().numpy() - want).max() <= RTOL_OF_MAX * np.abs(want).max()
+    else:
+        assert wsf == 0                                     # one 16 x 16 tile: left to the stock launch
+    # integers: exact, bit for bit
+    xi = rng.integers(-3, 4, x.shape).astype(np.float32)
+    wi = rng.integers(-2, 3, w.shape).astype(np.float32)
+    di = rng.integers(-2, 3, dy.shape).astype(np.float32)
+    txi, twi, tdi = (torch.from_numpy(a).to(DEV) for a in (xi, wi, di))
+    assert np.array_equal(k.conv1x1(txi, twi).cpu().numpy(), oracle_lib.conv1x1(xi, wi))
+    assert np.array_equal(k.conv1x1(tdi, twi, flip=True).cpu().numpy(), oracle_lib.conv1x1(di, wi, flip=True))
+    if wsf:
+        dwi = torch.empty(cout, cin, 1, 1, device=DEV)
+        k.conv_wgrad(txi, tdi, dwi, torch.empty(wsf, device=DEV), 1)
+        assert np.array_equal(dwi.cpu().numpy(), oracle_lib.conv_wgrad(xi, di, 1, 1))
+
+
+@pytest.mark.parametrize('cin,cout,hw', [(16, 64, 32), (256, 64, 8)])
+def test_k12_at_the_hmc_batch_against_torch_and_in_the_module(cin, cout, hw):
+    """1,024 rows (several images per workgroup, 256 K slices): against torch's own convolution on the device, through
+    fused_conv.Conv2d with autograd; bit-reproducible."""
+    torch.manual_seed(cin)
+    conv = fused_conv.Conv2d(cin, cout, 1, bias=False).to(DEV)
+    x = torch.randn(1024, cin, hw, hw, device=DEV, requires_grad=True)
+    dy = torch.randn(1024, cout, hw, hw, device=DEV)
+    y = conv(x)
+    assert conv.__dict__['_ursa_plan'][2] and conv.__dict__['_ursa_plan'][3] and conv.__dict__['_ursa_plan'][1] > 0
+    y.backward(dy)
+    gx, gw = x.grad.clone(), conv.weight.grad.clone()
+    xr = x.detach().clone().requires_grad_()
+    wr = conv.weight.detach().clone().requires_grad_()
+    yr = torch.nn.functional.conv2d(xr, wr)
+    yr.backward(dy)
+    assert torch.allclose(y, yr, rtol=1e-4, atol=1e-5 * float(yr.abs().max()))
+    assert torch.allclose(gx, xr.grad, rtol=1e-4, atol=1e-5 * float(xr.grad.abs().max()))
+    assert float((gw - wr.grad).abs().max()) <= 2e-5 * float(wr.grad.abs().max())
+    x.grad = None
+    conv.weight.grad = None
+    conv(x).backward(dy)
+    assert torch.equal(x.grad, gx) and torch.equal(conv.weight.grad, gw)

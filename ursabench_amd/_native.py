@@ -73,6 +73,8 @@ SIGNATURES = {
     'ursa_conv3x3_f32': (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _u32, _vp]),
     'ursa_conv1x1s2_supported': (ctypes.c_int, [_i64, _i64, _i64, _i64, _i64, _u32]),
     'ursa_conv1x1s2_f32': (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _u32, _vp]),
+    'ursa_conv1x1_supported': (ctypes.c_int, [_i64, _i64, _i64, _i64, _i64, _u32]),
+    'ursa_conv1x1_f32': (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _u32, _vp]),
     'ursa_preact_geometry': (ctypes.c_int, [_i64, _i64, _i64, _i64, _i64, _u32, _i64p]),
     'ursa_preact_conv3x3_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _i64,
                                                _i64, _i64, _i64, _i64, _i64, _u32, _vp]),
@@ -574,6 +576,32 @@ class HipKernels:
         _check(self.lib, rc, 'ursa_conv1x1s2_f32')
         return y
 
+
+    # K12 -----------------------------------------------------------------------------
+    def conv1x1_supported(self, x_shape, cout, flip=False):
+        """Whether K12 takes the 1x1 / stride 1 convolution of an input of `x_shape` to `cout` channels (flip: `x_shape` is the
+        output gradient's shape and `cout` the layer's input channels)."""
+        n, cin, h, w = (int(v) for v in x_shape)
+        return bool(self.lib.ursa_conv1x1_supported(n, cin, int(cout), h, w, CONV_FLIP if flip else 0))
+
+    def conv1x1(self, x, w, y=None, flip=False):
+        """y = conv2d(x, w) for a 1x1 weight [Cout, Cin, 1, 1]; flip=True: the input gradient of that layer - `x` is dy
+        [N, Cout, H, W], the result dx [N, Cin, H, W]."""
+        if x.dim() != 4 or w.dim() != 4 or tuple(w.shape[2:]) != (1, 1) or w.shape[0 if flip else 1] != x.shape[1]:
+            raise ValueError(f'not a 1x1 convolution: x {tuple(x.shape)}, w {tuple(w.shape)}, flip={flip}')
+        N, Cin, H, W = x.shape
+        Cout = w.shape[1 if flip else 0]
+        dev = x.device
+        shape = (N, Cout, H, W)
+        if y is None:
+            y = x.new_empty(shape)
+        elif tuple(y.shape) != shape:
+            raise ValueError(f'y {tuple(y.shape)} should be {shape}')
+        with torch.cuda.device(dev):
+            rc = self.lib.ursa_conv1x1_f32(_ptr(x, 'x'), _ptr(w, 'w', None, dev), _ptr(y, 'y', None, dev), N, Cin, Cout, H, W,
+                                           CONV_FLIP if flip else 0, _stream(dev))
+        _check(self.lib, rc, 'ursa_conv1x1_f32')
+        return y
 
     # K10 -----------------------------------------------------------------------------
     def preact_geometry(self, x_shape, cout, *, flip=False, stride=1, bn=False, add=False):

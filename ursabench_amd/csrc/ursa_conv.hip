@@ -503,6 +503,13 @@ struct Plan {
 // (URSABench/models/preresnet.py:25-27,100,130-136): the three stages' 3x3 / stride 1 layers, the stem (3 -> 16), the two
 // 3x3 / stride 2 layers that open stages 2 and 3 and their 1x1 / stride 2 shortcuts. Anything else -> slices = 0, and the
 // caller keeps MIOpen's weight gradient.
+}  // namespace
+// K12 (ursa_conv1x1.hip): the 1x1 / stride 1 weight gradient's first launch, partial sums in this file's tile order
+extern "C" __attribute__((visibility("hidden"))) int ursa_conv1x1_wgrad_plan(int64_t N, int64_t Cin, int64_t Cout, int64_t H,
+                                                                             void (**fn)(const float*, const float*, float*, int, int, int, const float*),
+                                                                             int* slices, int* ipw, int64_t* E);
+namespace {
+
 // xbn: the K10 form (x operand normalised + rectified while staged): the 3x3 layers that follow a BatchNorm (all but the stem)
 Plan plan_for(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, int ksize, int stride, bool xbn = false) {
     Plan p = {0, 0, 0, 0, 0, nullptr};
@@ -510,6 +517,11 @@ Plan plan_for(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, int ks
     int bands = 0;
     const bool k3 = ksize == 3, k1 = ksize == 1;
     if (xbn && (!k3 || Cin == 3)) return p;
+    if (k1 && stride == 1) {                                   // K12: the Bottleneck networks' 1x1 layers
+        if (!ursa_conv1x1_wgrad_plan(N, Cin, Cout, H, &p.fn, &p.slices, &p.ipw, &p.E)) return Plan{0, 0, 0, 0, 0, nullptr};
+        p.gy = 1, p.taps = 1;
+        return p;
+    }
     if (k3 && stride == 1 && Cin == 16 && Cout == 16 && W == 32) {
         // two images per workgroup: 256 K slices at batch 128 = one per CU; alone the launch takes what 512 slices take
         // (9.1 us), beside the input-gradient workgroups of the paired launch 21.8 -> 19.8 us, and half the partial sums for
@@ -1047,6 +1059,19 @@ struct FwPlan {
     void (*fn)(const float*, const float*, float*, int, int, int, int, Fuse);
 };
 
+// Large batches (an ensemble member's 4,096-row evaluation forward, HMC's 1,024-row chunks): several images per workgroup - the
+// weights are staged once and the next image's rows are loaded under this one's matrix work (the kernel's own prefetch) - as
+// long as >= 2,048 workgroups remain (8 per CU). Measured at 4,096 rows (tools/k10_eval_bench.py, profiles/r06_k10_eval_bench.json):
+// 16 ch 198 -> 173 us (0.62 -> 0.71 of the fp32 matrix peak), 32 ch 188 -> 157 (0.78), 64 ch 259 -> 191, stride 2 118 -> 106 /
+// 128 -> 100. Which image a workgroup takes changes nothing in the arithmetic: the same bits. At the training batch (128): no change.
+inline void widen_for_large_batches(FwPlan& p, int64_t N) {
+    if (!p.fn) return;
+    const int64_t wgs1 = N * p.gx_per_image * p.gy;            // workgroups at one image each
+    int ipw = 1;
+    while (ipw < 16 && wgs1 / (2 * ipw) >= 2048) ipw *= 2;
+    if (ipw > p.ipw) p.ipw = ipw;
+}
+
 // the 3x3 layers of the CIFAR pre-activation ResNets: stride 1 - the stem and the three stages' equal-width layers (forward and,
 // flipped, their input gradient); stride 2 - the two layers that open stages 2 and 3, forward (Cin, Cout, H of x) and input
 // gradient (flipped: Cin = dy's channels, Cout = dx's channels, H = dy's size)
@@ -1059,6 +1084,7 @@ FwPlan fw_plan_for(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, u
         else if (!flip && Cin == 32 && Cout == 64 && W == 16) p = {1, 2, 1, k_conv3x3<32, 32, 8, 8, 2, 1>};
         else if (flip && Cin == 32 && Cout == 16 && W == 16) p = {2, 1, 1, k_conv3x3<32, 16, 16, 8, 2, 2>};
         else if (flip && Cin == 64 && Cout == 32 && W == 8) p = {1, 2, 1, k_conv3x3<64, 16, 8, 8, 1, 2>};
+        widen_for_large_batches(p, N);
         return p;
     }
     if (flip && Cin != Cout) return p;                         // flipped stride 1: the equal-width layers only
@@ -1066,6 +1092,7 @@ FwPlan fw_plan_for(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, u
     else if (Cin == 3 && Cout == 16 && W == 32) p = {4, 1, 1, k_conv3x3<3, 16, 32, 8, 4, 0>};
     else if (Cin == 32 && Cout == 32 && W == 16) p = {2, 1, 1, k_conv3x3<32, 32, 16, 8, 4, 0>};
     else if (Cin == 64 && Cout == 64 && W == 8) p = {1, 4, 2, k_conv3x3<64, 16, 8, 8, 1, 0>};
+    widen_for_large_batches(p, N);
 #ifdef URSA_DEBUG_KNOBS
     if (const char* e = getenv("URSA_CONV_FWD_DBG")) {        // what bounds the launch: 1 = no stores, 2 = no matrix work (wrong results)
         if (atoi(e) == 1 && Cin == 16 && Cout == 16 && W == 32) p.fn = k_conv3x3<16, 16, 32, 8, 4, 0, 1>;
@@ -1131,6 +1158,13 @@ FwPlan fuse_plan_for(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W,
             if (add) return p;
             if (Cin == 16 && Cout == 32 && W == 32) p = {2, 1, 1, k_conv3x3<16, 32, 16, 8, 4, 1, 0, 2, 0>};
             else if (Cin == 32 && Cout == 64 && W == 16) p = {1, 2, 1, k_conv3x3<32, 32, 8, 8, 2, 1, 0, 2, 0>};
+            widen_for_large_batches(p, N);
+#ifdef URSA_DEBUG_KNOBS
+            if (const char* e = getenv("URSA_K8_EVAL_IPW")) {
+                const int v = atoi(e);
+                if (v >= 1 && v <= 64 && p.fn) p.ipw = v;
+            }
+#endif
             return p;
         }
         if (Cin == 16 && Cout == 16 && W == 32) {
@@ -1143,6 +1177,13 @@ FwPlan fuse_plan_for(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W,
             if (add) p = {1, 4, 2, k_conv3x3<64, 16, 8, 8, 1, 0, 0, 2, 4>};
             else p = {1, 4, 2, k_conv3x3<64, 16, 8, 8, 1, 0, 0, 2, 0>};
         }
+        widen_for_large_batches(p, N);
+#ifdef URSA_DEBUG_KNOBS
+        if (const char* e = getenv("URSA_K8_EVAL_IPW")) {         // images per workgroup of the evaluation forms (large batches)
+            const int v = atoi(e);
+            if (v >= 1 && v <= 64 && p.fn) p.ipw = v;
+        }
+#endif
         return p;
     }
     if (bwd || !stats) return p;                               // forward forms always leave the next BatchNorm's sums

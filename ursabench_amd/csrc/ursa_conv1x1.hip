@@ -1,0 +1,251 @@
+// ursa_conv1x1.hip — K12: the 1x1 / stride 1 convolutions of the Bottleneck pre-activation ResNets (PreResNet-164, BASELINE
+// configs[4]), NCHW fp32, gfx950: forward, input gradient and weight gradient.
+//
+// What it replaces: `self.conv1(out)` / `self.conv3(out)` and the stride-1 `downsample` (URSABench/models/preresnet.py:56,62,
+// 76-87,130-136) and their halves of ATen's convolution_backward inside `loss.backward()` / hamiltorch's potential gradient
+// (URSABench/inference/hmc.py:71-75). On this stack MIOpen runs them as NCHW->NHWC transposes + an implicit GEMM or a rocBLAS GEMM
+// + a transpose back: `batched_transpose_32x32_dword` alone was 12.4 % of the C5 configuration's kernel time, the GEMMs 19 %, the
+// weight-gradient implicit GEMMs 7.5 % (profiles/r05_c5_kernel_stats.csv). A 1x1 convolution IS a GEMM on the NCHW planes as they
+// lie - per image Y[Cout x HW] = W[Cout x Cin] X[Cin x HW] - so nothing needs transposing.
+//
+//     y[n][o][p]  = sum_i w[o][i] x[n][i][p]                                  (forward; fma chain over i in groups of 4, ascending)
+//     dx[n][i][p] = sum_o w[o][i] dy[n][o][p]                                 (FLIP: the same kernel reading w transposed)
+//     dw[o][i]    = sum_{n, p} dy[n][o][p] x[n][i][p]                         (weight gradient: K split over workgroups, fixed order)
+//
+// Exact fp32 on v_mfma_f32_16x16x4_f32 (every product rounded once, fma chains). These layers are bound by memory, not by the
+// matrix pipe (16 -> 64 channels: 2,048 flops per 320 bytes): a workgroup walks whole images - weights gathered into registers
+// once, 64-position chunks of x staged through LDS with the next chunk's loads issued before this chunk's matrix work.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ursa_hip.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kThreads = 256;
+constexpr int cmin(int a, int b) { return a < b ? a : b; }
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+// ---- forward / input gradient ---------------------------------------------------------------------------------------------
+// A = x: lane (j = lane & 15: position j of a run of 16, k = lane >> 4: channel 4 g + k) reads ONE float of the staged chunk per
+// MFMA; B = w: every lane keeps its (output channel j of a 16-channel tile, channel k of every group) weights in registers for the
+// whole launch; D: a lane holds four adjacent positions of one output channel: one float4 store.
+// Workgroup = 4 waves; a chunk = 64 positions (4 runs) x CK = min(CI, 64) channels in LDS at a row pitch of 80 floats (16 mod 64:
+// the 16 positions x 4 channel planes of an A read fall into 64 distinct banks). MT = CO / 16 output tiles: MT >= 4: wave w owns
+// tiles w, w + 4, ... and all 4 runs; MT = 2: tile w % 2, runs {w / 2, w / 2 + 2}; MT = 1: run w.
+template <int CI, int CO, int HW, bool FLIP>
+__global__ __launch_bounds__(kThreads) void k_conv1x1(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int N,
+                                                      int ipw)
+{
+    constexpr int CK = cmin(CI, 64), NCK = CI / CK, P = 64, PITCH = 80, NPC = HW / P;
+    constexpr int MT = CO / 16, NT = cmax(1, MT / 4), WPT = cmax(1, 4 / MT), NR = 4 / WPT;   // tiles per wave, waves per tile, runs per wave
+    constexpr int KG = CI / 4, KGC = CK / 4;
+    constexpr int NV = CK * (P / 4) / kThreads;                // float4 a thread stages per chunk
+    static_assert(CI % 16 == 0 && CO % 16 == 0 && HW % P == 0 && CI % CK == 0 && (CK * (P / 4)) % kThreads == 0, "geometry");
+    static_assert(MT == 1 || MT == 2 || MT % 4 == 0, "output tiles per workgroup");
+    __shared__ __attribute__((aligned(16))) float xs[CK * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, k = lane >> 4;
+    const int tile0 = MT >= 4 ? wave : wave % MT, run0 = MT >= 4 ? 0 : wave / MT;
+
+    float wr[NT][KG];                                          // w[o = tile * 16 + j][i = 4 g + k]
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < KG; ++g) {
+            const int o = (tile0 + 4 * t) * 16 + j, i = 4 * g + k;
+            wr[t][g] = FLIP ? w[(size_t)i * CO + o] : w[(size_t)o * CI + i];
+        }
+
+    const int n0 = blockIdx.x * ipw;
+    const int n1 = n0 + ipw < N ? n0 + ipw : N;
+    const int steps = (n1 - n0) * NPC * NCK;                   // (image, position chunk, channel chunk) in this order, channel fastest
+    f32x4 vx[NV];
+    auto load = [&](int s) {                                   // every thread's loads of step s, issued together
+        const int n = n0 + s / (NPC * NCK), pc = (s / NCK) % NPC, cc = s % NCK;
+        const float* src = x + ((size_t)n * CI + cc * CK) * HW + pc * P;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int idx = tid + v * kThreads, c = idx / (P / 4), q = idx % (P / 4);
+            vx[v] = *reinterpret_cast<const f32x4*>(src + (size_t)c * HW + 4 * q);
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int idx = tid + v * kThreads, c = idx / (P / 4), q = idx % (P / 4);
+            *reinterpret_cast<f32x4*>(xs + c * PITCH + 4 * q) = vx[v];
+        }
+    };
+    f32x4 acc[NT][NR];
+    if (steps > 0) load(0);
+    for (int ip = 0; ip < (n1 - n0) * NPC; ++ip) {             // (image, position chunk); the channel chunks unrolled: wr's index static
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < NR; ++r) acc[t][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int cc = 0; cc < NCK; ++cc) {
+            const int s = ip * NCK + cc;
+            if (s > 0) __syncthreads();                        // the previous chunk's reads are done
+            stage();
+            __syncthreads();
+            if (s + 1 < steps) load(s + 1);                    // the next chunk's rows are in flight under this chunk's matrix work
+#pragma unroll
+            for (int g = 0; g < KGC; ++g) {
+                float a[NR];
+#pragma unroll
+                for (int r = 0; r < NR; ++r) a[r] = xs[(4 * g + k) * PITCH + (run0 + WPT * r) * 16 + j];
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int r = 0; r < NR; ++r)
+                        acc[t][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], wr[t][cc * KGC + g], acc[t][r], 0, 0, 0);
+            }
+        }
+        const int n = n0 + ip / NPC, pc = ip % NPC;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                float* dst = y + ((size_t)n * CO + (tile0 + 4 * t) * 16 + j) * HW + pc * P + (run0 + WPT * r) * 16 + 4 * k;
+                *reinterpret_cast<f32x4*>(dst) = acc[t][r];
+            }
+    }
+}
+
+// ---- weight gradient, first launch: partial dW of a K slice (ipw images), in K7's tile order (ursa_conv.hip) so that K7's
+// second launch (k_conv_wgrad_reduce) sums the slices in ascending order and writes dW[o][i] --------------------------------
+// GEMM with M = Cout, N = Cin, K = positions: lane (c = lane & 15, g = lane >> 4) reads ONE float4 of dy (its output channel c of a
+// tile, positions 16 t + 4 g .. + 3) and ONE float4 of x (its input channel c of a tile): four MFMAs. Chunks of 32 positions of
+// all CO + CI channel rows in LDS at a row pitch of 36 floats (36 c mod 64 runs through the 16 multiples of 4: the 16 rows' float4
+// reads of one g fall into 64 distinct banks). Waves: WCO = min(4, CO / 16) across output tiles, the rest across input tiles.
+template <int CI, int CO, int HW>
+__global__ __launch_bounds__(kThreads) void k_conv1x1_wgrad(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial,
+                                                            int N, int Cout_unused, int ipw, const float* __restrict__ xbn_unused)
+{
+    constexpr int MTO = CO / 16, CTI = CI / 16, WCO = cmin(4, MTO), WCI = 4 / WCO;
+    constexpr int TO = MTO / WCO, TI = CTI / WCI;              // output / input tiles per wave
+    constexpr int PK = 32, PITCH = 36, NPC = HW / PK;
+    constexpr int TOT = (CO + CI) * (PK / 4), NV = (TOT + kThreads - 1) / kThreads;
+    static_assert(MTO % WCO == 0 && CTI % WCI == 0 && CTI >= WCI && HW % PK == 0, "geometry");
+    static_assert((CO + CI) * PITCH * 4 <= 64 * 1024, "static LDS");
+    __shared__ __attribute__((aligned(16))) float sm[(CO + CI) * PITCH];     // rows [0, CO): dy, rows [CO, CO + CI): x
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int wo = wave % WCO, wi = wave / WCO;
+    const int n0 = blockIdx.x * ipw;
+    const int n1 = n0 + ipw < N ? n0 + ipw : N;
+    const int steps = (n1 - n0) * NPC;
+    f32x4 v[NV];
+    auto load = [&](int s) {
+        const int n = n0 + s / NPC, pc = s % NPC;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            int idx = tid + u * kThreads;
+            if (TOT % kThreads != 0) idx = idx < TOT ? idx : TOT - 1;      // a tail index re-loads the last element (not staged)
+            const int row = idx / (PK / 4), q = idx % (PK / 4);
+            const float* src = row < CO ? dy + ((size_t)n * CO + row) * HW : x + ((size_t)n * CI + (row - CO)) * HW;
+            v[u] = *reinterpret_cast<const f32x4*>(src + pc * PK + 4 * q);
+        }
+    };
+    f32x4 acc[TO][TI];
+#pragma unroll
+    for (int a = 0; a < TO; ++a)
+#pragma unroll
+        for (int b = 0; b < TI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (steps > 0) load(0);
+    for (int s = 0; s < steps; ++s) {
+        if (s > 0) __syncthreads();
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int idx = tid + u * kThreads, row = idx / (PK / 4), q = idx % (PK / 4);
+            if (TOT % kThreads == 0 || idx < TOT) *reinterpret_cast<f32x4*>(sm + row * PITCH + 4 * q) = v[u];
+        }
+        __syncthreads();
+        if (s + 1 < steps) load(s + 1);
+#pragma unroll
+        for (int t = 0; t < PK / 16; ++t) {
+            f32x4 a[TO], b[TI];
+#pragma unroll
+            for (int p = 0; p < TO; ++p) a[p] = *reinterpret_cast<const f32x4*>(sm + ((wo * TO + p) * 16 + c) * PITCH + 16 * t + 4 * g);
+#pragma unroll
+            for (int p = 0; p < TI; ++p) b[p] = *reinterpret_cast<const f32x4*>(sm + (CO + (wi * TI + p) * 16 + c) * PITCH + 16 * t + 4 * g);
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                for (int p = 0; p < TO; ++p)
+#pragma unroll
+                    for (int q = 0; q < TI; ++q) acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p][tt], b[q][tt], acc[p][q], 0, 0, 0);
+        }
+    }
+    // element (pair * 4 + reg) * 64 + lane holds dW[co = cot * 16 + (lane >> 4) * 4 + reg][ci = cit * 16 + (lane & 15)], pair = cot * CTI + cit
+    float* out = partial + (size_t)blockIdx.x * ((size_t)MTO * CTI * 256);
+#pragma unroll
+    for (int p = 0; p < TO; ++p)
+#pragma unroll
+        for (int q = 0; q < TI; ++q) {
+            const int pair = (wo * TO + p) * CTI + wi * TI + q;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(size_t)pair * 256 + r * 64 + lane] = acc[p][q][r];
+        }
+}
+
+typedef void (*FwFn)(const float*, const float*, float*, int, int);
+
+// (CI, CO, H) of the launch: forward = the layer's (Cin, Cout); FLIP = (the layer's Cout, Cin). The bottleneck stages of
+// PreResNet-164: 16 <-> 64 at 32 x 32, 32 <-> 128 at 16 x 16, 64 <-> 256 at 8 x 8, and each stage's first block (16 -> 16, 64 -> 32,
+// 128 -> 64; the 16 -> 64 stride-1 shortcut is the first shape again).
+FwFn fw_for(int64_t CI, int64_t CO, int64_t H, bool flip) {
+#define URSA_1X1(ci, co, h) if (CI == ci && CO == co && H == h) return flip ? (FwFn)k_conv1x1<ci, co, h * h, true> : (FwFn)k_conv1x1<ci, co, h * h, false>;
+    URSA_1X1(64, 16, 32) URSA_1X1(16, 64, 32) URSA_1X1(128, 32, 16) URSA_1X1(32, 128, 16) URSA_1X1(256, 64, 8) URSA_1X1(64, 256, 8)
+    URSA_1X1(16, 16, 32) URSA_1X1(64, 32, 32) URSA_1X1(32, 64, 32) URSA_1X1(128, 64, 16) URSA_1X1(64, 128, 16)
+#undef URSA_1X1
+    return nullptr;
+}
+
+}  // namespace
+
+// images per workgroup: as many as leave >= 1,024 workgroups (4 per CU)
+static int ipw_for(int64_t N) {
+    int ipw = 1;
+    while (ipw < 8 && N / (2 * ipw) >= 1024) ipw *= 2;
+    return ipw;
+}
+
+extern "C" int ursa_conv1x1_supported(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, uint32_t flags) {
+    if (flags & ~URSA_CONV_FLIP) return 0;
+    return N >= 1 && N <= (1 << 20) && H == W && fw_for(Cin, Cout, H, flags & URSA_CONV_FLIP) != nullptr;
+}
+
+extern "C" int ursa_conv1x1_f32(const float* x, const float* w, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W,
+                                uint32_t flags, ursa_stream_t stream) {
+    if (flags & ~URSA_CONV_FLIP) return URSA_EFLAGS;
+    if (!x || !w || !y) return URSA_ENULL;
+    if (N < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return URSA_ESIZE;
+    if (((uintptr_t)x | (uintptr_t)y) & 15 || (uintptr_t)w & 3) return URSA_EALIGN;
+    if (N > (1 << 20) || H != W) return URSA_EVALUE;
+    const FwFn fn = fw_for(Cin, Cout, H, flags & URSA_CONV_FLIP);
+    if (!fn) return URSA_EVALUE;
+    const int ipw = ipw_for(N);
+    hipLaunchKernelGGL(fn, dim3((unsigned)((N + ipw - 1) / ipw)), dim3(kThreads), 0, (hipStream_t)stream, x, w, y, (int)N, ipw);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? URSA_OK : (int)e;
+}
+
+// what ursa_conv.hip's plan_for() asks for a 1x1 / stride 1 weight gradient: the launch, its K slices and the floats of one slice
+extern "C" __attribute__((visibility("hidden"))) int ursa_conv1x1_wgrad_plan(int64_t N, int64_t Cin, int64_t Cout, int64_t H, void (**fn)(const float*, const float*, float*, int, int, int, const float*),
+                                       int* slices, int* ipw, int64_t* E) {
+    typedef void (*WgFn)(const float*, const float*, float*, int, int, int, const float*);
+    WgFn f = nullptr;
+#define URSA_1X1W(ci, co, h) if (Cin == ci && Cout == co && H == h) f = k_conv1x1_wgrad<ci, co, h * h>;
+    URSA_1X1W(64, 16, 32) URSA_1X1W(16, 64, 32) URSA_1X1W(128, 32, 16) URSA_1X1W(32, 128, 16) URSA_1X1W(256, 64, 8) URSA_1X1W(64, 256, 8)
+    URSA_1X1W(64, 32, 32) URSA_1X1W(128, 64, 16)
+#undef URSA_1X1W
+    if (!f || N < 1) return 0;
+    int w = 1;
+    while (N / (2 * w) >= 256) w *= 2;                          // 256 ... 511 K slices: one or two per CU, the partial sums stay small
+    *fn = f, *ipw = w, *slices = (int)((N + w - 1) / w), *E = (Cout / 16) * (Cin / 16) * 256;
+    return 1;
+}

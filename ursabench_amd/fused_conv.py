@@ -5,7 +5,8 @@
 initialisation). For the layer shapes the library covers - every convolution of the BasicBlock pre-activation ResNets - on
 contiguous fp32 NCHW HIP tensors, WHILE GRADIENTS ARE RECORDED (a training / HMC step):
 
-  forward and input gradient   K8 `ursa_conv3x3_f32` (3x3, stride 1 and 2) / K9 `ursa_conv1x1s2_f32` (1x1 stride 2 shortcuts): one
+  forward and input gradient   K8 `ursa_conv3x3_f32` (3x3, stride 1 and 2) / K9 `ursa_conv1x1s2_f32` (1x1 stride 2 shortcuts) / K12
+                               `ursa_conv1x1_f32` (the 1x1 stride 1 layers of the Bottleneck networks: a GEMM on the NCHW planes): one
                                launch each, direct convolution in exact fp32 on the matrix pipe, instead of MIOpen's Winograd /
                                implicit-GEMM launches (18.3 us -> 10.3 us per 3x3 layer and direction at the workload's sizes)
   weight gradient              K7 `ursa_conv_wgrad_f32`: two launches straight from the NCHW tensors, fixed summation order, instead
@@ -38,6 +39,7 @@ from . import _native
 
 _on = os.environ.get('URSA_FUSED_CONV', '1') != '0'
 _k8 = os.environ.get('URSA_FUSED_CONV_FWD', '1') != '0'      # K8 (forward / input gradient) separately, for A/B runs
+_k12 = os.environ.get('URSA_K12', '1') != '0'                # K12 (the 1x1 stride-1 layers of the Bottleneck networks), for A/B runs
 
 
 def enabled(flag=None):
@@ -144,7 +146,9 @@ class _Conv(torch.autograd.Function):
         ctx.stride, ctx.ws_floats, ctx.k8_bwd, ctx.weight, ctx.sink = stride, ws_floats, k8_bwd, w, getattr(_tls, 'sink', None)
         if k8_fwd:
             k = _native.default_kernels()
-            return k.conv3x3(x, w, stride=stride) if w.shape[2] == 3 else k.conv1x1s2(x, w)
+            if w.shape[2] == 3:
+                return k.conv3x3(x, w, stride=stride)
+            return k.conv1x1s2(x, w) if stride == 2 else k.conv1x1(x, w)
         return F.conv2d(x, w, None, stride, w.shape[2] // 2)
 
     @staticmethod
@@ -159,7 +163,11 @@ class _Conv(torch.autograd.Function):
         need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         dx = dw = None
         if need_dx and ctx.k8_bwd:
-            dx, need_dx = (k.conv3x3(dy, w, flip=True, stride=s) if w.shape[2] == 3 else k.conv1x1s2(dy, w, flip=True)), False
+            if w.shape[2] == 3:
+                dx = k.conv3x3(dy, w, flip=True, stride=s)
+            else:
+                dx = k.conv1x1s2(dy, w, flip=True) if s == 2 else k.conv1x1(dy, w, flip=True)
+            need_dx = False
         if need_dw and ctx.ws_floats:
             if ctx.sink is not None:
                 ctx.sink.append((ctx.sink.launch(lambda: k.conv_wgrad_partial(x, dy, w.shape, x.new_empty(ctx.ws_floats), s), x, dy), ctx.weight))
@@ -189,16 +197,18 @@ class Conv2d(nn.Conv2d):
             # no gradient recorded (evaluation, the BMA predictive at 4,096 rows): MIOpen's Winograd launch is the faster one at
             # large batches (bench.py bma leg: 23.7 k vs 21.9 k predictions/s) - K8 is for the training step's sizes
             return super().forward(x)
-        key = (tuple(x.shape), x.requires_grad, w.requires_grad, _k8)
+        key = (tuple(x.shape), x.requires_grad, w.requires_grad, _k8, _k12)
         plan = self.__dict__.get('_ursa_plan')
         if plan is None or plan[0] != key:                     # what the library covers for this call: asked once per shape
             k = _native.default_kernels()
             N, cin, H, W = x.shape
-            k8, k9 = _k8 and ks == 3 and st in (1, 2), _k8 and ks == 1 and st == 2
-            fwd = (k8 and k.conv3x3_supported(x.shape, self.out_channels, stride=st)) or (k9 and k.conv1x1s2_supported(x.shape, self.out_channels))
+            k8, k9, k12 = _k8 and ks == 3 and st in (1, 2), _k8 and ks == 1 and st == 2, _k8 and _k12 and ks == 1 and st == 1
+            fwd = ((k8 and k.conv3x3_supported(x.shape, self.out_channels, stride=st)) or (k9 and k.conv1x1s2_supported(x.shape, self.out_channels))
+                   or (k12 and k.conv1x1_supported(x.shape, self.out_channels)))
             bwd = x.requires_grad and ((k8 and k.conv3x3_supported((N, self.out_channels, H // st, W // st), cin, flip=True, stride=st))
-                                       or (k9 and k.conv1x1s2_supported((N, self.out_channels, H // 2, W // 2), cin, flip=True)))
-            ws = k.conv_wgrad_ws_floats(x.shape, self.out_channels, ks, st) if w.requires_grad else 0
+                                       or (k9 and k.conv1x1s2_supported((N, self.out_channels, H // 2, W // 2), cin, flip=True))
+                                       or (k12 and k.conv1x1_supported((N, self.out_channels, H, W), cin, flip=True)))
+            ws = k.conv_wgrad_ws_floats(x.shape, self.out_channels, ks, st) if w.requires_grad and (_k12 or ks != 1 or st != 1) else 0
             plan = self.__dict__['_ursa_plan'] = (key, ws, bool(fwd), bool(bwd))
         _, ws, fwd, bwd = plan
         if not (fwd or bwd or ws):
