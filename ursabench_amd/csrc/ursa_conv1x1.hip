@@ -36,9 +36,9 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 // tiles w, w + 4, ... and all 4 runs; MT = 2: tile w % 2, runs {w / 2, w / 2 + 2}; MT = 1: run w.
 template <int CI, int CO, int HW, bool FLIP>
 __global__ __launch_bounds__(kThreads) void k_conv1x1(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int N,
-                                                      int ipw)
+                                                      int ipw, int npc)        // npc: position chunks of an image this workgroup walks (grid.y covers the rest)
 {
-    constexpr int CK = cmin(CI, 64), NCK = CI / CK, P = 64, PITCH = 80, NPC = HW / P;
+    constexpr int CK = cmin(CI, 64), NCK = CI / CK, P = 64, PITCH = 80;
     constexpr int MT = CO / 16, NT = cmax(1, MT / 4), WPT = cmax(1, 4 / MT), NR = 4 / WPT;   // tiles per wave, waves per tile, runs per wave
     constexpr int KG = CI / 4, KGC = CK / 4;
     constexpr int NV = CK * (P / 4) / kThreads;                // float4 a thread stages per chunk
@@ -60,10 +60,11 @@ __global__ __launch_bounds__(kThreads) void k_conv1x1(const float* __restrict__ 
 
     const int n0 = blockIdx.x * ipw;
     const int n1 = n0 + ipw < N ? n0 + ipw : N;
-    const int steps = (n1 - n0) * NPC * NCK;                   // (image, position chunk, channel chunk) in this order, channel fastest
+    const int pc0 = blockIdx.y * npc;                          // this workgroup's position chunks of every image: [pc0, pc0 + npc)
+    const int steps = (n1 - n0) * npc * NCK;                   // (image, position chunk, channel chunk) in this order, channel fastest
     f32x4 vx[NV];
     auto load = [&](int s) {                                   // every thread's loads of step s, issued together
-        const int n = n0 + s / (NPC * NCK), pc = (s / NCK) % NPC, cc = s % NCK;
+        const int n = n0 + s / (npc * NCK), pc = pc0 + (s / NCK) % npc, cc = s % NCK;
         const float* src = x + ((size_t)n * CI + cc * CK) * HW + pc * P;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(kThreads) void k_conv1x1(const float* __restrict__ 
     };
     f32x4 acc[NT][NR];
     if (steps > 0) load(0);
-    for (int ip = 0; ip < (n1 - n0) * NPC; ++ip) {             // (image, position chunk); the channel chunks unrolled: wr's index static
+    for (int ip = 0; ip < (n1 - n0) * npc; ++ip) {             // (image, position chunk); the channel chunks unrolled: wr's index static
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(kThreads) void k_conv1x1(const float* __restrict__ 
                         acc[t][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], wr[t][cc * KGC + g], acc[t][r], 0, 0, 0);
             }
         }
-        const int n = n0 + ip / NPC, pc = ip % NPC;
+        const int n = n0 + ip / npc, pc = pc0 + ip % npc;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(kThreads) void k_conv1x1_wgrad(const float* __restr
         }
 }
 
-typedef void (*FwFn)(const float*, const float*, float*, int, int);
+typedef void (*FwFn)(const float*, const float*, float*, int, int, int);
 
 // (CI, CO, H) of the launch: forward = the layer's (Cin, Cout); FLIP = (the layer's Cout, Cin). The bottleneck stages of
 // PreResNet-164: 16 <-> 64 at 32 x 32, 32 <-> 128 at 16 x 16, 64 <-> 256 at 8 x 8, and each stage's first block (16 -> 16, 64 -> 32,
@@ -207,11 +208,17 @@ FwFn fw_for(int64_t CI, int64_t CO, int64_t H, bool flip) {
 
 }  // namespace
 
-// images per workgroup: as many as leave >= 1,024 workgroups (4 per CU)
-static int ipw_for(int64_t N) {
-    int ipw = 1;
-    while (ipw < 8 && N / (2 * ipw) >= 1024) ipw *= 2;
-    return ipw;
+// Launch geometry: a workgroup walks `ipw` images x `npc` of an image's HW / 64 position chunks. One whole image per workgroup
+// is the better walk when the batch alone gives >= 1,024 workgroups (at 1,024 rows a 32 x 32 image cut in four was SLOWER: 86.6 ->
+// 100.4 us, more workgroups re-gathering the weights); small batches cut images until there are 1,024 workgroups; an 8 x 8 image
+// (one chunk) is walked two at a time so that the weights are gathered once per several chunks (38.6 -> 32.5 us). tools/k12_bench.py.
+static void geometry_for(int64_t N, int64_t H, int* ipw, int* npc, int* gy) {
+    const int NPC = (int)(H * H / 64);
+    int split = 1;
+    while (split < NPC && NPC / (2 * split) >= 2 && N * split < 1024) split *= 2;
+    int w = 1;
+    if (NPC < 4) while (w < 8 && N / (2 * w) >= 512) w *= 2;
+    *ipw = w, *npc = NPC / split, *gy = split;
 }
 
 extern "C" int ursa_conv1x1_supported(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, uint32_t flags) {
@@ -228,8 +235,9 @@ extern "C" int ursa_conv1x1_f32(const float* x, const float* w, float* y, int64_
     if (N > (1 << 20) || H != W) return URSA_EVALUE;
     const FwFn fn = fw_for(Cin, Cout, H, flags & URSA_CONV_FLIP);
     if (!fn) return URSA_EVALUE;
-    const int ipw = ipw_for(N);
-    hipLaunchKernelGGL(fn, dim3((unsigned)((N + ipw - 1) / ipw)), dim3(kThreads), 0, (hipStream_t)stream, x, w, y, (int)N, ipw);
+    int ipw, npc, gy;
+    geometry_for(N, H, &ipw, &npc, &gy);
+    hipLaunchKernelGGL(fn, dim3((unsigned)((N + ipw - 1) / ipw), (unsigned)gy), dim3(kThreads), 0, (hipStream_t)stream, x, w, y, (int)N, ipw, npc);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? URSA_OK : (int)e;
 }
@@ -244,8 +252,9 @@ extern "C" __attribute__((visibility("hidden"))) int ursa_conv1x1_wgrad_plan(int
     URSA_1X1W(64, 32, 32) URSA_1X1W(128, 64, 16)
 #undef URSA_1X1W
     if (!f || N < 1) return 0;
+    const int64_t e = (Cout / 16) * (Cin / 16) * 256;
     int w = 1;
-    while (N / (2 * w) >= 256) w *= 2;                          // 256 ... 511 K slices: one or two per CU, the partial sums stay small
-    *fn = f, *ipw = w, *slices = (int)((N + w - 1) / w), *E = (Cout / 16) * (Cin / 16) * 256;
+    while (N / (2 * w) >= 256 && ((N + w - 1) / w) * e * 4 > (16ll << 20)) w *= 2;   // as many K slices as keep the partial sums <= 16 MB (>= 256)
+    *fn = f, *ipw = w, *slices = (int)((N + w - 1) / w), *E = e;
     return 1;
 }
