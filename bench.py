@@ -1497,6 +1497,14 @@ def run_c4(a, job, legs, line):
     def members():
         if a.warmup:
             s.sample(num_samples=a.warmup)                               # MIOpen search / lane warm-up: not part of the ensemble
+        elif not job.cpu:
+            # no warm-up member (the bounded leg of the default command): at least keep MIOpen's first-sight solver search for the
+            # two batch shapes of a refresh pass (128 rows, and the ragged last batch) out of the timed region - one train-mode
+            # forward each on the swag model (its BatchNorm statistics are reset by every member's bn_update anyway)
+            with torch.no_grad():
+                s.swag_model.train()
+                for rows_ in {batch, n_train % batch or batch}:
+                    s.swag_model(train.dataset.x[:rows_])
         ens, dt = job.timed(lambda: s.sample(num_samples=mine) if mine else [])   # SWAG.sample: LANES members per pass over the training set
         ensemble.extend(ens)
         line.update({'value': round(total / dt, 4), 'unit': 'SWAG members/s', 'ms_per_step': round(1e3 * dt / a.steps, 2)})

@@ -1,7 +1,7 @@
 #!/bin/bash
 # K10 per-launch costs (tools/k10_bench.py), with the knobs build's attribution variants, then the unit tests.
 set -u
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$R"
 out=gpurun_out/r06_k10
 mkdir -p "$out"

@@ -3,7 +3,7 @@
 # then the headline config with and without it, and a kernel trace of the step.
 #   /usr/local/graft/bin/gpurun --timeout 1100 -- 'bash tools/r06_k10_check.sh'
 set -u
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$R"
 out=gpurun_out/r06_k10
 mkdir -p "$out"

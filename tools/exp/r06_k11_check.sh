@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 6, K11 (fused head): its tests, the K10 tests again, the headline config, a kernel trace of the step.
 set -u
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$R"
 out=gpurun_out/r06_k11
 mkdir -p "$out"

@@ -1,7 +1,7 @@
 #!/bin/bash
 # K12 (1x1 stride-1 convolutions): its tests, the samplers' HMC tests, the C5 configuration with and without it
 set -u
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$R"
 out=gpurun_out/r06_k12
 mkdir -p "$out"

@@ -1,6 +1,6 @@
 #!/bin/bash
 set -u
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$R"
 out=gpurun_out/r06_k12
 mkdir -p "$out"

@@ -1,7 +1,7 @@
 #!/bin/bash
 # multi-chain sweep with the paired backward launch on / off (and K10 off)
 set -u
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$R"
 out=gpurun_out/r06_k10
 mkdir -p "$out"

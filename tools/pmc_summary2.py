@@ -22,7 +22,7 @@ for key, ctrs in sorted(acc.items()):
     row['launches'] = max(len(v) for v in ctrs.values())
     grid = int(key.split('grid=')[1].split('|')[0])
     wg = int(key.split('wg=')[1])
-    cands = [m for m in manifest if m['pattern'] in key]
+    cands = sorted((m for m in manifest if m['pattern'] in key), key=lambda m_: len(m_['pattern']))   # the most specific pattern wins
     m = None
     for cand in cands:                       # pick the manifest entry whose launch geometry matches
         if 'elements' in cand and abs(grid * 4 - cand['elements']) <= 4 * 512:

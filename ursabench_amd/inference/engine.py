@@ -92,6 +92,10 @@ class ChainEngine:
             # K7: the convolutions' weight gradients are still K-sliced partial sums; ONE launch reduces all of them, in a fixed
             # order, straight into their arena slots (no gradient tensor, no copy for them)
             slot = self._slot
+            stray = [tuple(w.shape) for _, w in pend if id(w) not in slot]
+            if stray:                                   # (re-registered after the engine was built, or left out of the optimizer)
+                raise RuntimeError(f'convolution weights {stray} took K7\'s deferred launch but are not in the optimizer\'s arena: build the '
+                                   f'engine / optimizer after the model\'s parameters are final')
             fused_conv.flush(pend, lambda w: grad_views[slot[id(w)]])
             done = {slot[id(w)] for _, w in pend}
             for i in done:
