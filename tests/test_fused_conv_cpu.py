@@ -74,8 +74,15 @@ def test_plan_covers_the_basic_block_resnets_convolutions_only():
             assert f > 0 and f % ((cout // 16) * ((cin + 15) // 16) * ks * ks * 256) == 0      # whole partial copies, tile order
     for shape, cout, ks, st in (((128, 16, 16, 16), 16, 3, 1), ((128, 160, 32, 32), 160, 3, 1), ((0, 16, 32, 32), 16, 3, 1),
                                 ((128, 16, 32, 16), 16, 3, 1), ((128, 16, 32, 32), 16, 1, 1), ((128, 16, 32, 32), 16, 5, 1),
-                                ((128, 16, 32, 32), 64, 1, 1), ((128, 64, 8, 8), 64, 3, 2)):
+                                ((128, 64, 8, 8), 64, 3, 2), ((128, 64, 16, 16), 16, 1, 1), ((128, 48, 32, 32), 64, 1, 1)):
         assert k.conv_wgrad_ws_floats(shape, cout, ks, st) == 0
+    # K12 (round 6): the 1x1 / stride 1 layers of the Bottleneck networks, K slices bounded by the partial sums' size
+    for n in (1, 128, 1024):
+        for cin, cout, hw in ((64, 16, 32), (16, 64, 32), (128, 32, 16), (32, 128, 16), (256, 64, 8), (64, 256, 8), (64, 32, 32), (128, 64, 16)):
+            f = k.conv_wgrad_ws_floats((n, cin, hw, hw), cout, 1, 1)
+            assert f > 0 and f % ((cout // 16) * (cin // 16) * 256) == 0 and f * 4 <= max(16 << 20, 256 * (cout // 16) * (cin // 16) * 1024)
+            assert k.conv1x1_supported((n, cin, hw, hw), cout) and k.conv1x1_supported((n, cout, hw, hw), cin, flip=True)
+    assert not k.conv1x1_supported((4, 48, 32, 32), 64) and not k.conv1x1_supported((4, 64, 16, 16), 16)
     m = models.PreResNet(10, 20)
     x = torch.zeros(2, 3, 32, 32)
     shapes = []
