@@ -1161,9 +1161,7 @@ def _bn_relu_path(job):
         return 'stock MIOpen / ATen launches (URSA_FUSED_BN=0)'
     from ursabench_amd import fused_block
     if fused_block.enabled() and not fused_bn._two_launch:
-        return ('training step: folded into the convolution launches (K10, ursabench_amd/fused_block.py: normalise + ReLU while the tile is '
-                'staged, statistics / backward sums from the accumulators; `dx` by K6\'s second launch); the head by K11; evaluation and '
-                'other networks: K6 launches (ursabench_amd/fused_bn.py)')
+        return 'K10: folded into the convolution launches (training and evaluation), dx by K6; head K11; other networks K6'
     return ('K6 launches (ursabench_amd/fused_bn.py: relu(bn(x)) and the residual sums around it)'
             + (', two-launch form only (URSA_BN_TWO_LAUNCH=1)' if fused_bn._two_launch else ''))
 
@@ -1177,10 +1175,10 @@ def _conv_path(job):
     if not fused_conv.forward_enabled():
         return 'K7 weight gradients; forward / input gradient MIOpen (URSA_FUSED_CONV_FWD=0)'
     from ursabench_amd import fused_block
-    k10 = ('; inside a training step of the BasicBlock ResNets each bn -> relu -> conv unit is ONE K10 launch forward and its input + weight '
-           'gradients ONE paired launch backward (ursabench_amd/fused_block.py)') if fused_block.enabled() else ''
-    return ('K8: 3x3 forward / input gradient at stride 1 and 2; K9: the 1x1 stride-2 shortcuts; K7: every weight gradient '
-            '(ursabench_amd/fused_conv.py)' + k10 + '; evaluation forwards (no gradient recorded) stay MIOpen')
+    if fused_block.enabled():
+        return ('K10 units (one launch per bn -> relu -> conv forward / evaluation, paired input + weight gradient launch backward) on K8 / K7; '
+                'K9 shortcuts; K12 1x1 layers (Bottleneck networks)')
+    return 'K8 3x3 forward / input gradient, K9 1x1 stride-2 shortcuts, K7 weight gradients, K12 1x1 stride-1 layers; evaluation: K10 units'
 
 
 def base_line(a, job, metric, unit, workload):
@@ -1403,11 +1401,11 @@ def full_size_legs_block(a, job, which):
           SWAG.sample does for an ensemble) from SEEDED moments (no SGD trajectory: the draw / refresh / evaluation cost does
           not depend on the moments' values), then the BMA predictive of those 2 members over the 10,000-row test set.
       c5  PreResNet-164 / 100 classes (1.7 M parameters), HMC: 4 chains, full-batch potential over 1,024 rows, L = 3 leapfrog
-          steps, 2 proposals per chain timed (after the capture rounds).
-    A figure over 2 members / 8 proposals is a short sample of the same steady state the full runs measure (profiles/)."""
+          steps, 4 proposals per chain timed (after the capture rounds).
+    A figure over 2 members / 16 proposals is a short sample of the same steady state the full runs measure (profiles/)."""
     import copy
     cfgs = {'c4': (run_c4, dict(steps=2, warmup=0, c4_train=N_TRAIN, c4_epochs=0, c4_weak=False)),
-            'c5': (run_c5, dict(steps=2, warmup=0, c5_batch=1024, c5_chains=4, c5_L=3))}
+            'c5': (run_c5, dict(steps=4, warmup=0, c5_batch=1024, c5_chains=4, c5_L=3))}
     fn, over = cfgs[which]
     a2 = copy.copy(a)
     for k, v in over.items():
@@ -1421,7 +1419,7 @@ def full_size_legs_block(a, job, which):
                     'bma_members': sub.get('bma_members'), 'bma_member_forwards_per_s': sub.get('bma_member_forwards_per_s'),
                     'moments': sub.get('moments'), 'params': (sub.get('config') or {}).get('params'), 'roofline_k3': sub.get('roofline')})
     else:
-        out.update({'proposals_per_s': sub.get('value'), 'proposals_timed': 8, 'leapfrog_steps_per_s': sub.get('leapfrog_steps_per_s'),
+        out.update({'proposals_per_s': sub.get('value'), 'proposals_timed': 16, 'leapfrog_steps_per_s': sub.get('leapfrog_steps_per_s'),
                     'acceptance': sub.get('acceptance_rate_rank0'), 'chains': 4, 'full_batch': 1024, 'L': 3,
                     'params': (sub.get('config') or {}).get('params'), 'roofline_k4': sub.get('roofline')})
     torch.cuda.empty_cache()
