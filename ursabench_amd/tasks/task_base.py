@@ -190,7 +190,9 @@ class EnsembleAccumulator:
 
     EVAL_ROWS = 1024           # rows per member forward: consecutive loader batches are merged up to this many ...
     MERGE_MAX_PARAMS = 4_000_000   # ... for networks up to this many parameters
-    EVAL_ROWS_SMALL = 4096     # ... and up to this many for networks of at most SMALL_PARAMS parameters (PreResNet-20: 660 k ->
+    EVAL_ROWS_SMALL = 16384    # ... and up to this many for networks of at most SMALL_PARAMS parameters (round 6, with the fused evaluation
+    #                            units: the whole 10,000-row test set in one forward 36.5 k vs 34.7 k BMA-preds/s at 4,096 rows per forward,
+    #                            profiles/r06_bma_lanes_rows_ab.json; rounds 2-5: 4,096 with MIOpen's convolutions - PreResNet-20: 660 k ->
     SMALL_PARAMS = 500_000     # 698 k member-forwards/s at 20 members, tools/exp/bma_probe.py; deeper / wider networks keep
                                # 1,024: their activations per row are what bounds the captured forward's memory)
 
