@@ -175,7 +175,7 @@ def test_conv2d_takes_k7_only_where_covered():
     try:
         for cin, cout, hw, stride, ksz, covered in ((16, 16, 32, 1, 3, True), (3, 16, 32, 1, 3, True), (16, 32, 32, 2, 3, True), (32, 64, 16, 2, 3, True),
                                                     (16, 32, 32, 2, 1, True), (64, 64, 8, 1, 3, True), (16, 16, 16, 1, 3, False),
-                                                    (16, 64, 32, 1, 1, False), (8, 16, 32, 1, 3, False)):
+                                                    (16, 64, 32, 1, 1, True), (16, 32, 32, 1, 1, False), (8, 16, 32, 1, 3, False)):     # (1x1 / stride 1: K12's shapes)
             m = fused_conv.Conv2d(cin, cout, ksz, stride, ksz // 2, bias=False).to(DEV)
             ref = nn.Conv2d(cin, cout, ksz, stride, ksz // 2, bias=False).to(DEV)
             ref.load_state_dict(m.state_dict())

@@ -29,6 +29,18 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kThreads = 256;
+// Registers: left to itself the compiler gives these kernels up to 256 VGPRs PLUS the accumulators' 16 - 38 AGPRs - more than half of
+// a SIMD's 512, i.e. ONE wave per SIMD, one workgroup per CU at a time - although nothing needs that many live values. Asking for two
+// waves per SIMD (`__launch_bounds__(256, 2)`) makes it allocate <= 256 in all (no AGPRs, no scratch except where noted) and two to
+// three workgroups share a CU: the paired backward launch 19.9 / 20.7 / 20.9 -> 17.7 / 17.8 / 17.6 us (its two roles really overlap),
+// the 64-channel evaluation unit 190.6 -> 167.0 us at 4,096 rows; a launch with one workgroup per CU does not change
+// (profiles/r06_minw_ab.json). URSA_MINW=1 (knobs build: make KNOBS_EXTRA=-DURSA_MINW=1) restores the compiler's choice.
+#ifndef URSA_MINW
+#define URSA_MINW 2
+#endif
+// (the strided 64 -> 32 input gradient with BatchNorm-backward sums spills 100 bytes per lane under that cap and is slower alone,
+// 9.1 -> 10.9 us: it keeps the compiler's allocation; inside the paired launch the cap still pays, 16.9 -> 15.9 us)
+constexpr int minw_for(int CIN, int MODE, int EPI) { return (CIN == 64 && MODE == 2 && EPI == 3) ? 1 : URSA_MINW; }
 
 // smallest m >= n with m % 64 == 4: plane pitch that spreads 16 planes' float4 reads over all 64 LDS banks
 constexpr int pitch64p4(int n) { return ((n - 4 + 63) / 64) * 64 + 4; }
@@ -1025,7 +1037,7 @@ __device__ __forceinline__ void conv_body(const float* __restrict__ x, const flo
 }
 
 template <int CIN, int COUT_WG, int W, int R, int PH, int MODE, int DBG = 0, int PRO = 0, int EPI = 0>
-__global__ __launch_bounds__(kThreads) void k_conv3x3(const float* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(kThreads, minw_for(CIN, MODE, EPI)) void k_conv3x3(const float* __restrict__ x, const float* __restrict__ w,
                                                        float* __restrict__ y, int N, int Cout, int ipw, int flip_arg, const Fuse f) {
     __shared__ __attribute__((aligned(16))) float smem[Fw<CIN, COUT_WG, W, R, PH, MODE>::SMEM];
     conv_body<CIN, COUT_WG, W, R, PH, MODE, DBG, PRO, EPI>(x, w, y, N, Cout, ipw, flip_arg, f, smem, blockIdx.x, blockIdx.y, gridDim.x);
@@ -1036,8 +1048,8 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3(const float* __restrict__ 
 // two roles (even linear index: input gradient, odd: weight gradient; what one role has more of comes last). Both alone are
 // bound by latency and launch cost at two workgroups per CU; side by side on the same CUs they fill each other's gaps:
 // one launch's fixed cost instead of two, and no cross-queue edge as a parallel graph branch would need.
-template <int CIN_A, int COUT_WG_A, int W_A, int R_A, int PH_A, int MODE_A, int CIN_B, int COUT_WG_B, int WO_B, int R_B, int STRIDE_B, int PH_B>
-__global__ __launch_bounds__(kThreads) void k_bwd_pair(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ g,
+template <int CIN_A, int COUT_WG_A, int W_A, int R_A, int PH_A, int MODE_A, int CIN_B, int COUT_WG_B, int WO_B, int R_B, int STRIDE_B, int PH_B, int MINW = URSA_MINW>
+__global__ __launch_bounds__(kThreads, MINW) void k_bwd_pair(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ g,
                                                         const float* __restrict__ x, float* __restrict__ partial, int N, int Cd, int Cx,
                                                         int ipw_a, int ipw_b, int gx_a, int gy_a, int gx_b, int gy_b, const Fuse f) {
     using A = Fw<CIN_A, COUT_WG_A, W_A, R_A, PH_A, MODE_A>;
