@@ -1162,6 +1162,12 @@ FwPlan fuse_plan_for(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W,
             else if (Cin == 32 && W == 16) p = {2, 1, 1, k_conv3x3<32, 32, 16, 8, 4, 0, 0, 0, 3>};
             else if (Cin == 64 && W == 8) p = {1, 4, 2, k_conv3x3<64, 16, 8, 8, 1, 0, 0, 0, 3>};
         }
+#ifdef URSA_DEBUG_KNOBS
+        if (const char* e = getenv("URSA_BWD_IPW")) {            // images per workgroup of the input-gradient role
+            const int v = atoi(e);
+            if (v >= 1 && v <= 8 && p.fn) p.ipw = v;
+        }
+#endif
         return p;
     }
     if (flags & URSA_PREACT_EVAL) {                            // evaluation: running statistics in the prologue, optional residual add, no sums
