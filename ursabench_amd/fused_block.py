@@ -56,6 +56,7 @@ def paired(flag=None):
 
 
 _tls = threading.local()
+_GROUP_PAIR = os.environ.get('URSA_GROUP_PAIR', '0') == '1'    # A/B: ChainGroup's chains take the paired launch too
 
 
 class separate_launches:
@@ -66,7 +67,7 @@ class separate_launches:
 
     def __enter__(self):
         self.old = getattr(_tls, 'separate', False)
-        _tls.separate = True
+        _tls.separate = not _GROUP_PAIR
         return self
 
     def __exit__(self, *exc):
