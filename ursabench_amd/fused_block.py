@@ -56,22 +56,38 @@ def paired(flag=None):
 
 
 _tls = threading.local()
-_GROUP_PAIR = os.environ.get('URSA_GROUP_PAIR', '0') == '1'    # A/B: ChainGroup's chains take the paired launch too
+_GROUP_SEPARATE = os.environ.get('URSA_GROUP_PAIR', '1') == '0'    # A/B: ChainGroup's chains keep the two backward launches apart
 
 
 class separate_launches:
     """Context around a FORWARD pass: the units applied inside keep their input-gradient and weight-gradient launches apart,
-    whatever `paired()` says. For callers whose steps share the device with other work (ChainGroup's parallel branches: smaller
-    launches interleave better there - 8 chains per GPU 4.95 vs 4.79 samples/s - while a lone chain gains from one launch fewer
-    per unit, 3.01 vs 2.95). The decision is taken in the forward and travels to the backward in its autograd context."""
+    whatever `paired()` says (the decision is taken in the forward and travels to the backward in its autograd context).
+    ChainGroup used it while the paired kernel held a CU alone (8 chains per GPU: 4.95 vs 4.79 samples/s paired); with the
+    kernels capped at two waves per SIMD the pair wins there too (5.48 vs 5.40, `profiles/r06_group_pair_ab.json`), so nothing
+    enters it by default any more: `URSA_GROUP_PAIR=0` makes ChainGroup do so again (A/B)."""
 
     def __enter__(self):
         self.old = getattr(_tls, 'separate', False)
-        _tls.separate = not _GROUP_PAIR
+        _tls.separate = True
         return self
 
     def __exit__(self, *exc):
         _tls.separate = self.old
+        return False
+
+
+class group_launches:
+    """What ChainGroup wraps each chain's forward in: `separate_launches` under URSA_GROUP_PAIR=0, nothing otherwise."""
+
+    def __enter__(self):
+        self.ctx = separate_launches() if _GROUP_SEPARATE else None
+        if self.ctx is not None:
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
         return False
 
 

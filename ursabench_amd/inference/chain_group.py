@@ -77,7 +77,7 @@ class ChainGroup:
         if len(self.samplers) == 1:
             return s.engine.forward_backward(x, y)
         from .. import fused_bn, fused_block
-        with fused_bn.several_streams(), fused_block.separate_launches():
+        with fused_bn.several_streams(), fused_block.group_launches():
             return s.engine.forward_backward(x, y, wgrad_side=False)
 
     def _round_eager(self, x, y):
