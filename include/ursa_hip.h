@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define URSA_ABI_VERSION 7
+#define URSA_ABI_VERSION 8
 
 typedef void* ursa_stream_t; /* hipStream_t */
 
@@ -454,6 +454,33 @@ int ursa_conv1x1s2_f32(const float* x, const float* w, float* y, int64_t N, int6
 int ursa_conv1x1_supported(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, uint32_t flags);
 int ursa_conv1x1_f32(const float* x, const float* w, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W,
                      uint32_t flags, ursa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K13  `conv1x1(relu(bn(x)))` of the Bottleneck pre-activation unit without storing the normalised activation
+ *      URSABench/models/preresnet.py:70-87 (`out = self.bn1(x); out = self.relu(out); out = self.conv1(out)` and the same around
+ *      bn3 / conv3) and their part of the backward pass inside hamiltorch's potential gradient (URSABench/inference/hmc.py:71-75).
+ *  ursa_bn_stats_f32              K6's first forward launch + the merge of its partial sums, ALONE: batch statistics of x (addend:
+ *                                 of z = x + addend, stored to z_out - the previous block's `out += residual`), the running
+ *                                 statistics update, and save[4][C] = (mean, invstd, scale, shift) with
+ *                                 scale = invstd * gamma, shift = fma(-mean, scale, beta): bit for bit what
+ *                                 ursa_bn_relu_fwd_f32's two-launch form computes; no y. ws: ursa_bn_ws_floats(C) floats.
+ *  ursa_preact_conv1x1_f32        y = conv1x1(relu(fma(x, scale, shift))) - K12's forward launch applying K6's own expression to
+ *                                 the rows of x as it stages them (bn_save: the block above): the bits of ursa_bn_relu_fwd_f32
+ *                                 followed by ursa_conv1x1_f32, with x read once and relu(bn(x)) never written
+ *                                 (at [1024, 64, 32, 32]: 536 MB less traffic per unit). Shapes: ursa_conv1x1_f32's, forward only.
+ *  ursa_preact_wgrad1x1_partial_f32   the first launch of the layer's weight gradient (ursa_conv_wgrad_partial_f32 with ksize 1,
+ *                                 stride 1) recomputing relu(fma(x, scale, shift)) the same way; same scratch, same slices, K7's
+ *                                 second launch unchanged.
+ * The backward of the BatchNorm itself stays ursa_bn_relu_bwd_f32 (it needs x and the saved block only).
+ */
+int ursa_bn_stats_f32(const float* x, const float* addend /* or NULL */, float* z_out /* iff addend */, const float* gamma,
+                      const float* beta, float* running_mean /* or NULL */, float* running_var, float* save /* [4][C] */, float* ws,
+                      int64_t N, int64_t C, int64_t HW, float eps, float momentum, ursa_stream_t stream);
+int ursa_preact_conv1x1_supported(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W);
+int ursa_preact_conv1x1_f32(const float* x, const float* bn_save, const float* w, float* y, int64_t N, int64_t Cin, int64_t Cout,
+                            int64_t H, int64_t W, ursa_stream_t stream);
+int ursa_preact_wgrad1x1_partial_f32(const float* x, const float* bn_save, const float* dy, float* ws, int64_t ws_floats, int64_t N,
+                                     int64_t Cin, int64_t Cout, int64_t H, int64_t W, ursa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * K10  the pre-activation unit of the BasicBlock ResNets, one launch each way      URSABench/models/preresnet.py:33-52

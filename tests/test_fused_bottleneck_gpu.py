@@ -1,0 +1,279 @@
+"""GPU: K13 (ursa_bn_stats_f32, ursa_preact_conv1x1_f32, ursa_preact_wgrad1x1_partial_f32; include/ursa_hip.h) - the Bottleneck
+unit's `conv1x1(relu(bn(x)))` (URSABench/models/preresnet.py:70-87) without storing the normalised activation. Yardsticks:
+  * the launches it replaces - K6's two-launch forward + K12's GEMM, K12's weight gradient on the stored activation - bit for bit;
+  * the oracle (K6's and K12's restatements composed), exactly on integer-valued data, to rounding on random data;
+  * the module path (`fused_bottleneck`) and a whole Bottleneck network against the K6 + K12 path: outputs, every gradient, running
+    statistics, bit for bit.
+"""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import oracle_lib as O
+from ursabench_amd import _native, fused_bn, fused_bottleneck, fused_conv, models
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device('cuda', 0)
+# (Cin, Cout, H = W): the 1x1 / stride 1 layers behind a BatchNorm in PreResNet-164 (preresnet.py:56,62)
+LAYERS = [(64, 16, 32), (16, 64, 32), (128, 32, 16), (32, 128, 16), (256, 64, 8), (64, 256, 8), (64, 32, 32), (128, 64, 16)]
+
+
+def _K():
+    return _native.default_kernels()
+
+
+def _rand(cin, cout, hw, n, seed):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    x = (torch.randn(n, cin, hw, hw, generator=g) * 1.5 + 0.3).to(DEV)
+    b = torch.randn(n, cin, hw, hw, generator=g).to(DEV)
+    w = (torch.randn(cout, cin, 1, 1, generator=g) * 0.2).to(DEV)
+    gamma = (torch.rand(cin, generator=g) + 0.5).to(DEV)
+    beta = (torch.randn(cin, generator=g) * 0.2).to(DEV)
+    dy = torch.randn(n, cout, hw, hw, generator=g).to(DEV)
+    return x, b, w, gamma, beta, dy
+
+
+def _k6_two_launch(x, gamma, beta, addend=None, running=None, eps=1e-5, momentum=0.1):
+    K = _K()
+    C = x.shape[1]
+    y, st = torch.empty_like(x), torch.empty(4, C, device=DEV)
+    z = torch.empty_like(x) if addend is not None else None
+    rm, rv = running if running is not None else (None, None)
+    K.bn_relu_forward(x, y, gamma, beta, rm, rv, st[0], st[1], torch.empty(_native.bn_ws_floats(C), device=DEV), eps=eps, momentum=momentum,
+                      relu=True, addend=addend, z_out=z, two_launch=True, save_gate=st[2:])
+    return y, st, z
+
+
+@pytest.mark.parametrize('cin,cout,hw', LAYERS)
+@pytest.mark.parametrize('n', [1, 3, 40])
+@pytest.mark.parametrize('residual', [False, True])
+def test_launches_equal_k6_plus_k12_bit_for_bit(cin, cout, hw, n, residual):
+    x, b, w, gamma, beta, dy = _rand(cin, cout, hw, n, 7 * n + cin + cout)
+    K = _K()
+    rm0, rv0 = torch.randn(cin, device=DEV), torch.rand(cin, device=DEV) + 0.5
+    run_ref, run = (rm0.clone(), rv0.clone()), (rm0.clone(), rv0.clone())
+    h, st_ref, z_ref = _k6_two_launch(x, gamma, beta, addend=b if residual else None, running=run_ref)
+    y_ref = K.conv1x1(h, w)
+    save = torch.full((4, cin), float('nan'), device=DEV)
+    z = torch.full_like(x, float('nan')) if residual else None
+    K.bn_stats(x, gamma, beta, run[0], run[1], save, torch.empty(_native.bn_ws_floats(cin), device=DEV), eps=1e-5, momentum=0.1,
+               addend=b if residual else None, z_out=z)
+    assert torch.equal(save, st_ref), 'mean / invstd / scale / shift'
+    assert torch.equal(run[0], run_ref[0]) and torch.equal(run[1], run_ref[1]), 'running statistics'
+    xin = x
+    if residual:
+        assert torch.equal(z, z_ref)
+        xin = z
+    y = K.preact_conv1x1(xin, save, w, torch.full_like(y_ref, float('nan')))
+    assert torch.equal(y, y_ref), 'forward'
+    wsf = K.conv_wgrad_ws_floats(x.shape, cout, 1, 1)
+    if wsf:
+        dw_ref, dw = torch.empty_like(w), torch.empty_like(w)
+        K.conv_wgrad_reduce([(K.conv_wgrad_partial(h, dy, w.shape, torch.empty(wsf, device=DEV), 1), dw_ref)])
+        K.conv_wgrad_reduce([(K.preact_wgrad1x1_partial(xin, save, dy, w.shape, torch.empty(wsf, device=DEV)), dw)])
+        assert torch.equal(dw, dw_ref) and torch.isfinite(dw).all(), 'weight gradient with the rows rebuilt while staged'
+
+
+@pytest.mark.parametrize('cin,cout,hw', LAYERS)
+def test_integer_inputs_equal_the_oracle_exactly(cin, cout, hw):
+    """x = +-1 with every channel balanced: mean 0, variance 1 exactly, eps = 0 -> invstd = 1, scale = gamma, shift = beta; integer
+    gamma / beta / w / dy: every product and sum an integer below 2^24, so a wrong channel's scale, a row missed by the transform or
+    one element missing from a sum shows."""
+    n = 4
+    rng = np.random.default_rng(cin + cout)
+    x = np.empty((n, cin, hw, hw), np.float32)
+    for c in range(cin):
+        v = np.repeat(np.array([1.0, -1.0], np.float32), n * hw * hw // 2)
+        rng.shuffle(v)
+        x[:, c] = v.reshape(n, hw, hw)
+    gamma = rng.integers(1, 4, cin).astype(np.float32)
+    beta = rng.integers(-2, 3, cin).astype(np.float32)
+    w = rng.integers(-2, 3, (cout, cin, 1, 1)).astype(np.float32)
+    dy = rng.integers(-2, 3, (n, cout, hw, hw)).astype(np.float32)
+    h, sm, si = O.bn_relu_fwd(x, gamma, beta, eps=0.0, momentum=0.0)
+    assert np.array_equal(sm, np.zeros(cin, np.float32)) and np.array_equal(si, np.ones(cin, np.float32))
+    want_y = O.conv1x1(h, w)
+    K = _K()
+    tx, tw, tg, tb, tdy = (torch.from_numpy(a).to(DEV) for a in (x, w, gamma, beta, dy))
+    save = torch.empty(4, cin, device=DEV)
+    K.bn_stats(tx, tg, tb, None, None, save, torch.empty(_native.bn_ws_floats(cin), device=DEV), eps=0.0, momentum=0.0)
+    assert np.array_equal(save.cpu().numpy(), np.stack([sm, si, gamma, beta]))
+    y = K.preact_conv1x1(tx, save, tw)
+    assert np.array_equal(y.cpu().numpy(), want_y)
+    wsf = K.conv_wgrad_ws_floats(tx.shape, cout, 1, 1)
+    if wsf:
+        dw = torch.empty_like(tw)
+        K.conv_wgrad_reduce([(K.preact_wgrad1x1_partial(tx, save, tdy, tw.shape, torch.empty(wsf, device=DEV)), dw)])
+        assert np.array_equal(dw.cpu().numpy(), O.conv_wgrad(h, dy, 1, 1))
+
+
+@pytest.mark.parametrize('cin,cout,hw', LAYERS[:6])
+def test_random_inputs_against_the_oracle(cin, cout, hw):
+    n = 3
+    x, _, w, gamma, beta, _ = _rand(cin, cout, hw, n, 11 + cin)
+    a = [t.cpu().numpy() for t in (x, w, gamma, beta)]
+    h, sm, si = O.bn_relu_fwd(a[0], a[2], a[3])
+    want = O.conv1x1(h, a[1])
+    K = _K()
+    save = torch.empty(4, cin, device=DEV)
+    K.bn_stats(x, gamma, beta, None, None, save, torch.empty(_native.bn_ws_floats(cin), device=DEV), eps=1e-5, momentum=0.0)
+    assert np.array_equal(save[0].cpu().numpy(), sm) and np.array_equal(save[1].cpu().numpy(), si), 'correctly rounded on both sides'
+    y = K.preact_conv1x1(x, save, w).cpu().numpy()
+    assert np.abs(y - want).max() <= 2e-6 * np.abs(want).max()
+
+
+def _unit(cin, cout):
+    bn = nn.BatchNorm2d(cin).to(DEV)
+    conv = fused_conv.Conv2d(cin, cout, 1, bias=False).to(DEV)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_(0, 0.2)
+    return bn, conv
+
+
+def _run_unit(bn, conv, x, b, dy, dz, fused):
+    old = fused_bottleneck.enabled(fused)
+    old2, fused_bn._two_launch = fused_bn._two_launch, True          # the launches K13 replaces: K6's two-launch form
+    try:
+        xa = x.clone().requires_grad_()
+        xb = None if b is None else b.clone().requires_grad_()
+        arg = xa if xb is None else (xa, xb)
+        took = fused_bottleneck.eligible(bn, conv, *((xa,) if xb is None else (xa, xb)))
+        assert took == fused
+        if took:
+            z, y = fused_bottleneck.bn_relu_conv1x1(bn, conv, arg)
+        else:
+            z, h = fused_bn.add_bn_relu(bn, arg)
+            y = conv(h)
+        loss = (y * dy).sum() + ((z * dz).sum() if xb is not None else 0)
+        grads = torch.autograd.grad(loss, [xa] + ([xb] if xb is not None else []) + [bn.weight, bn.bias, conv.weight])
+        return [y.detach(), z.detach()] + [g.detach() for g in grads] + [bn.running_mean.clone(), bn.running_var.clone(), bn.num_batches_tracked.clone()]
+    finally:
+        fused_bottleneck.enabled(old)
+        fused_bn._two_launch = old2
+
+
+@pytest.mark.parametrize('cin,cout,hw', LAYERS[:6])
+@pytest.mark.parametrize('residual', [False, True])
+def test_module_path_equals_k6_plus_k12_bit_for_bit(cin, cout, hw, residual):
+    n = max(128, -(-fused_bottleneck.MIN_BYTES // (cin * hw * hw * 4)))   # the layer's activation >= fused_bottleneck.MIN_BYTES
+    x, b, _, _, _, dy = _rand(cin, cout, hw, n, 3 + cin)
+    dz = torch.randn_like(x)
+    bn, conv = _unit(cin, cout)
+    bn2, conv2 = copy.deepcopy(bn), copy.deepcopy(conv)
+    got = _run_unit(bn, conv, x, b if residual else None, dy, dz, True)
+    want = _run_unit(bn2, conv2, x, b if residual else None, dy, dz, False)
+    assert len(got) == len(want)
+    for i, (g, r) in enumerate(zip(got, want)):
+        assert torch.equal(g, r), f'output {i}'
+        assert torch.isfinite(g.float()).all()
+
+
+def test_small_activations_and_instrumented_runs_keep_the_k6_launches():
+    bn, conv = _unit(64, 16)
+    x = torch.randn(4, 64, 32, 32, device=DEV, requires_grad=True)          # 1 MB
+    assert not fused_bottleneck.eligible(bn, conv, x)
+    x = torch.randn(128, 64, 32, 32, device=DEV, requires_grad=True)
+    assert fused_bottleneck.eligible(bn, conv, x)
+    with torch.no_grad():
+        assert not fused_bottleneck.eligible(bn, conv, x)
+    bn.eval()
+    assert not fused_bottleneck.eligible(bn, conv, x)
+    bn.train()
+    old = fused_bn.held(True)                                       # whoever opts into the held form keeps K6's launches
+    try:
+        assert not fused_bottleneck.eligible(bn, conv, x)
+    finally:
+        fused_bn.held(old)
+    assert not fused_bottleneck.eligible(bn, nn.Conv2d(64, 16, 1, bias=False).to(DEV), x)
+    assert not fused_bottleneck.eligible(bn, fused_conv.Conv2d(64, 16, 3, 1, 1, bias=False).to(DEV), x)
+
+
+def _grads_of(fn, params):
+    out = fn()
+    return out.detach(), [g.detach() for g in torch.autograd.grad(out, params)]
+
+
+def test_a_chain_of_bottleneck_blocks_equals_the_k6_k12_path_bit_for_bit():
+    """Four stage-1 Bottleneck blocks (64 -> 16 -> 16 -> 64 at 32 x 32, 128 rows: every layer hand-written, so the comparison can be
+    exact) chained through their pending sums: output, every gradient, every running statistic."""
+    torch.manual_seed(3)
+    blocks = nn.ModuleList([models._PreActBottleneck(64, 16) for _ in range(4)]).to(DEV).train()
+    ref = copy.deepcopy(blocks)
+    x = torch.randn(128, 64, 32, 32, device=DEV)
+    t = torch.randn(128, 64, 32, 32, device=DEV)
+
+    def run(bl):
+        h = x.clone().requires_grad_()
+        out = h
+        for b in bl:
+            out = b(out)
+        return ((out[0] + out[1]) * t).sum()
+
+    K = _K()
+    calls = []
+    orig = K.preact_conv1x1
+
+    def spy(*a, **k):
+        calls.append(1)
+        return orig(*a, **k)
+    old2, fused_bn._two_launch = fused_bn._two_launch, True
+    try:
+        K.preact_conv1x1 = spy
+        try:
+            la, ga = _grads_of(lambda: run(blocks), list(blocks.parameters()))
+        finally:
+            del K.preact_conv1x1
+        assert len(calls) == 8, 'both 1x1 layers of every block'
+        old = fused_bottleneck.enabled(False)
+        try:
+            lb, gb = _grads_of(lambda: run(ref), list(ref.parameters()))
+        finally:
+            fused_bottleneck.enabled(old)
+    finally:
+        fused_bn._two_launch = old2
+    assert torch.equal(la, lb)
+    for (name, _), a, b in zip(blocks.named_parameters(), ga, gb):
+        assert torch.equal(a, b) and torch.isfinite(a).all(), name
+    for (name, a), (_, b) in zip(blocks.named_buffers(), ref.named_buffers()):
+        assert torch.equal(a, b), name
+
+
+def test_a_bottleneck_network_agrees_with_the_k6_k12_path():
+    """PreResNet-47 (Bottleneck, 15 blocks) at 128 rows: 20-odd of its 30 `bn -> relu -> conv1x1` units are large enough for K13. Its
+    strided layers are MIOpen's, whose results differ in the last bits from run to run (the K6 + K12 path does not reproduce ITSELF bit
+    for bit on this network), and a last-bit difference flips ReLU gates 47 layers deep: the exact comparison is the chain test
+    above; here the loss to 1e-5 and every gradient to 2 % of its scale - a wiring check (a wrong statistic, a missing shortcut
+    gradient or a skipped weight gradient is far outside that)."""
+    torch.manual_seed(5)
+    net = models.PreResNet(num_classes=10, depth=47).to(DEV).train()
+    ref = copy.deepcopy(net)
+    x = torch.randn(128, 3, 32, 32, device=DEV)
+    y = torch.randint(0, 10, (128,), device=DEV)
+    crit = nn.CrossEntropyLoss()
+    K = _K()
+    calls = []
+    orig = K.preact_conv1x1
+
+    def spy(*a, **k):
+        calls.append(1)
+        return orig(*a, **k)
+    K.preact_conv1x1 = spy
+    try:
+        la, ga = _grads_of(lambda: crit(net(x), y), list(net.parameters()))
+    finally:
+        del K.preact_conv1x1
+    assert len(calls) >= 15, f'K13 took {len(calls)} units'
+    old = fused_bottleneck.enabled(False)
+    try:
+        lb, gb = _grads_of(lambda: crit(ref(x), y), list(ref.parameters()))
+    finally:
+        fused_bottleneck.enabled(old)
+    assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(lb))
+    for (name, _), a, b in zip(net.named_parameters(), ga, gb):
+        assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max()) + 1e-7, name
+    for (name, a), (_, b) in zip(net.named_buffers(), ref.named_buffers()):
+        assert torch.allclose(a.float(), b.float(), rtol=1e-4, atol=1e-5), name

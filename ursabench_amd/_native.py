@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libursa_hip.so')
 KNOBS_LIB_PATH = os.path.join(_HERE, 'csrc', 'libursa_hip_knobs.so')   # -DURSA_DEBUG_KNOBS build: tests / tools only
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # flags (mirror include/ursa_hip.h)
 STEP_NOISE, STEP_FIRST, STEP_ZERO_GRAD, STEP_WD, STEP_SGD, STEP_ADVANCE = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
@@ -75,6 +75,10 @@ SIGNATURES = {
     'ursa_conv1x1s2_f32': (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _u32, _vp]),
     'ursa_conv1x1_supported': (ctypes.c_int, [_i64, _i64, _i64, _i64, _i64, _u32]),
     'ursa_conv1x1_f32': (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _u32, _vp]),
+    'ursa_bn_stats_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f, _f, _vp]),
+    'ursa_preact_conv1x1_supported': (ctypes.c_int, [_i64, _i64, _i64, _i64, _i64]),
+    'ursa_preact_conv1x1_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp]),
+    'ursa_preact_wgrad1x1_partial_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp]),
     'ursa_preact_geometry': (ctypes.c_int, [_i64, _i64, _i64, _i64, _i64, _u32, _i64p]),
     'ursa_preact_conv3x3_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _i64,
                                                _i64, _i64, _i64, _i64, _i64, _u32, _vp]),
@@ -602,6 +606,58 @@ class HipKernels:
                                            CONV_FLIP if flip else 0, _stream(dev))
         _check(self.lib, rc, 'ursa_conv1x1_f32')
         return y
+
+    # K13 -----------------------------------------------------------------------------
+    def bn_stats(self, x, gamma, beta, running_mean, running_var, save, ws, *, eps, momentum, addend=None, z_out=None):
+        """K6's statistics launch + the merge of its partial sums, alone: `save` [4, C] receives (mean, invstd, scale, shift) of the
+        training-mode BatchNorm of x (addend: of z = x + addend, stored to z_out), the running statistics are updated; nothing is
+        normalised - `preact_conv1x1` / `preact_wgrad1x1_partial` apply relu(fma(x, scale, shift)) themselves."""
+        if (addend is None) != (z_out is None):
+            raise ValueError('addend and z_out go together')
+        N, C, HW = self._bn_dims(x)
+        dev, n = x.device, x.numel()
+        if ws.numel() < bn_ws_floats(C):
+            raise ValueError(f'ws must hold {bn_ws_floats(C)} floats')
+        with torch.cuda.device(dev):
+            rc = self.lib.ursa_bn_stats_f32(_ptr(x, 'x'), _ptr(addend, 'addend', n, dev, optional=True), _ptr(z_out, 'z_out', n, dev, optional=True),
+                                            _ptr(gamma, 'gamma', C, dev), _ptr(beta, 'beta', C, dev),
+                                            _ptr(running_mean, 'running_mean', C, dev, optional=True),
+                                            _ptr(running_var, 'running_var', C, dev, optional=True), _ptr(save, 'save', 4 * C, dev),
+                                            _ptr(ws, 'ws', None, dev), N, C, HW, eps, momentum, _stream(dev))
+        _check(self.lib, rc, 'ursa_bn_stats_f32')
+
+    def preact_conv1x1_supported(self, x_shape, cout):
+        N, Cin, H, W = x_shape
+        return bool(self.lib.ursa_preact_conv1x1_supported(N, Cin, cout, H, W))
+
+    def preact_conv1x1(self, x, bn_save, w, y=None):
+        """y = conv2d(relu(fma(x, scale, shift)), w) for a 1x1 weight [Cout, Cin, 1, 1], scale / shift = rows 2, 3 of bn_save [4, Cin]."""
+        if x.dim() != 4 or w.dim() != 4 or tuple(w.shape[2:]) != (1, 1) or w.shape[1] != x.shape[1]:
+            raise ValueError(f'not a 1x1 convolution: x {tuple(x.shape)}, w {tuple(w.shape)}')
+        N, Cin, H, W = x.shape
+        Cout = w.shape[0]
+        dev = x.device
+        if y is None:
+            y = x.new_empty((N, Cout, H, W))
+        elif tuple(y.shape) != (N, Cout, H, W):
+            raise ValueError(f'y {tuple(y.shape)} should be {(N, Cout, H, W)}')
+        with torch.cuda.device(dev):
+            rc = self.lib.ursa_preact_conv1x1_f32(_ptr(x, 'x'), _ptr(bn_save, 'bn_save', 4 * Cin, dev), _ptr(w, 'w', None, dev),
+                                                  _ptr(y, 'y', None, dev), N, Cin, Cout, H, W, _stream(dev))
+        _check(self.lib, rc, 'ursa_preact_conv1x1_f32')
+        return y
+
+    def preact_wgrad1x1_partial(self, x, bn_save, dy, dw_shape, ws):
+        """K12's weight-gradient launch with the x operand = relu(bn(x)) rebuilt from bn_save while staged; returns conv_wgrad_reduce's record."""
+        N, Cin, Cout, H, W, ksize = self._conv_dims(x, dy, dw_shape, 1)
+        if ksize != 1:
+            raise ValueError('this form is for the 1x1 layers')
+        dev = x.device
+        with torch.cuda.device(dev):
+            rc = self.lib.ursa_preact_wgrad1x1_partial_f32(_ptr(x, 'x'), _ptr(bn_save, 'bn_save', 4 * Cin, dev), _ptr(dy, 'dy', None, dev),
+                                                           _ptr(ws, 'ws', None, dev), ws.numel(), N, Cin, Cout, H, W, _stream(dev))
+        _check(self.lib, rc, 'ursa_preact_wgrad1x1_partial_f32')
+        return (ws, N, Cin, Cout, H, W, ksize, 1)
 
     # K10 -----------------------------------------------------------------------------
     def preact_geometry(self, x_shape, cout, *, flip=False, stride=1, bn=False, add=False):

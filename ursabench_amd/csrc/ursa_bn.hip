@@ -280,6 +280,33 @@ __global__ __launch_bounds__(kBnBlock) void k_bn_fwd_apply(const float* __restri
     }
 }
 
+// ---- K13: the statistics launch's partial sums -> the saved [4][C] block, nothing normalised ---------------------------------
+// What k_bn_fwd_apply's prologue computes, alone: one 64-thread workgroup per channel, the same merge (bn_merge), the same scalars
+// and running statistics, so that a consumer which applies y = relu(fma(x, save[2][c], save[3][c])) itself (ursa_preact_conv1x1_f32
+// while it stages x) produces the bits of K6's second launch.
+__global__ __launch_bounds__(64) void k_bn_finalize(const double2* __restrict__ partial, int S, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, float* __restrict__ running_mean,
+                                                    float* __restrict__ running_var, float* __restrict__ save, float eps, float momentum,
+                                                    double n, int C)
+{
+    const int c = blockIdx.x;
+    double mean, var;
+    bn_merge(partial, c, S, n, mean, var);
+    if (threadIdx.x == 0) {
+        const float meanf = (float)mean;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float alpha = invstd * gamma[c];
+        save[c] = meanf;
+        save[C + c] = invstd;
+        save[2 * C + c] = alpha;
+        save[3 * C + c] = fmaf(-meanf, alpha, beta[c]);
+        if (running_mean) {
+            running_mean[c] = momentum * meanf + (1.0f - momentum) * running_mean[c];
+            running_var[c] = momentum * (float)(var * (n / (n - 1.0))) + (1.0f - momentum) * running_var[c];
+        }
+    }
+}
+
 template <bool NT> __device__ __forceinline__ float ev_ld(const float* p) { return NT ? __builtin_nontemporal_load(p) : *p; }
 template <bool NT> __device__ __forceinline__ float4 ev_ld(const float4* p) { return bn_ld<NT>(p); }
 template <bool NT> __device__ __forceinline__ void ev_st(float* p, const float& v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
@@ -1546,6 +1573,36 @@ int ursa_bn_relu_fwd_f32(const float* x, const float* addend, float* z_out, floa
 {
     return bn_fwd_impl(x, addend, z_out, y, nullptr, gamma, beta, running_mean, running_var, save_mean, save_invstd, save_gate, ws, N, C, HW,
                        eps, momentum, flags, stream);
+}
+
+// K13: K6's FIRST forward launch (+ the merge of its partial sums) alone: batch statistics of x (or of z = x + addend, stored to
+// z_out), the [4][C] block (mean, invstd, scale, shift) and the running statistics - exactly the scalars ursa_bn_relu_fwd_f32's
+// two-launch form produces - and no normalised activation: the consumer applies relu(fma(x, scale, shift)) itself.
+int ursa_bn_stats_f32(const float* x, const float* addend, float* z_out, const float* gamma, const float* beta, float* running_mean,
+                      float* running_var, float* save, float* ws, int64_t N, int64_t C, int64_t HW, float eps, float momentum,
+                      ursa_stream_t stream)
+{
+    if (N == 0 || C == 0 || HW == 0) return (N < 0 || C < 0 || HW < 0) ? URSA_ESIZE : URSA_OK;
+    if (N < 0 || C < 0 || HW < 0) return URSA_ESIZE;
+    if (!x || !gamma || !beta || !save || !ws) return URSA_ENULL;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return URSA_ENULL;
+    if ((addend == nullptr) != (z_out == nullptr)) return URSA_ENULL;
+    if (!bn_aligned4(x) || !bn_aligned4(addend) || !bn_aligned4(z_out) || !bn_aligned4(save) || !bn_aligned16(ws)) return URSA_EALIGN;
+    if (N * HW < 2) return URSA_EVALUE;
+    BnPlan p;
+    const int rc = bn_plan(N, C, HW, bn_aligned16(x) && bn_aligned16(addend) && bn_aligned16(z_out), &p);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid = p.g.cfirst ? dim3(p.g.C, p.S) : dim3(p.S, p.g.C), block(kBnBlock);
+    double2* part = reinterpret_cast<double2*>(ws);
+#define URSA_BN_STATS(V) do { \
+    if (addend) hipLaunchKernelGGL((k_bn_stats<V, true>), grid, block, 0, st, x, addend, z_out, part, p.g); \
+    else hipLaunchKernelGGL((k_bn_stats<V, false>), grid, block, 0, st, x, addend, z_out, part, p.g); } while (0)
+    if (p.V == 4) URSA_BN_STATS(4); else URSA_BN_STATS(1);
+#undef URSA_BN_STATS
+    hipLaunchKernelGGL(k_bn_finalize, dim3((unsigned)C), dim3(64), 0, st, part, p.S, gamma, beta, running_mean, running_var, save, eps, momentum,
+                       (double)p.g.per_ch * p.V, (int)C);
+    return bn_launch_status();
 }
 
 #ifdef URSA_DEBUG_KNOBS

@@ -519,7 +519,7 @@ struct Plan {
 // K12 (ursa_conv1x1.hip): the 1x1 / stride 1 weight gradient's first launch, partial sums in this file's tile order
 extern "C" __attribute__((visibility("hidden"))) int ursa_conv1x1_wgrad_plan(int64_t N, int64_t Cin, int64_t Cout, int64_t H,
                                                                              void (**fn)(const float*, const float*, float*, int, int, int, const float*),
-                                                                             int* slices, int* ipw, int64_t* E);
+                                                                             int* slices, int* ipw, int64_t* E, int xbn);
 namespace {
 
 // xbn: the K10 form (x operand normalised + rectified while staged): the 3x3 layers that follow a BatchNorm (all but the stem)
@@ -528,9 +528,9 @@ Plan plan_for(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, int ks
     if (N < 1 || N > (1 << 20) || H != W) return p;
     int bands = 0;
     const bool k3 = ksize == 3, k1 = ksize == 1;
-    if (xbn && (!k3 || Cin == 3)) return p;
-    if (k1 && stride == 1) {                                   // K12: the Bottleneck networks' 1x1 layers
-        if (!ursa_conv1x1_wgrad_plan(N, Cin, Cout, H, &p.fn, &p.slices, &p.ipw, &p.E)) return Plan{0, 0, 0, 0, 0, nullptr};
+    if (xbn && ((!k3 && !(k1 && stride == 1)) || Cin == 3)) return p;
+    if (k1 && stride == 1) {                                   // K12: the Bottleneck networks' 1x1 layers (xbn: K13)
+        if (!ursa_conv1x1_wgrad_plan(N, Cin, Cout, H, &p.fn, &p.slices, &p.ipw, &p.E, xbn)) return Plan{0, 0, 0, 0, 0, nullptr};
         p.gy = 1, p.taps = 1;
         return p;
     }
@@ -614,6 +614,13 @@ extern "C" int ursa_preact_wgrad_partial_f32(const float* x, const float* bn_sav
                                              ursa_stream_t stream) {
     if (!bn_save) return URSA_ENULL;
     return wgrad_partial_impl(x, bn_save, dy, ws, ws_floats, N, Cin, Cout, H, W, 3, stride, stream);
+}
+
+// K13: the same for a 1x1 / stride 1 layer behind a BatchNorm + ReLU (bn_save: what ursa_bn_stats_f32 saved)
+extern "C" int ursa_preact_wgrad1x1_partial_f32(const float* x, const float* bn_save, const float* dy, float* ws, int64_t ws_floats,
+                                                int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, ursa_stream_t stream) {
+    if (!bn_save) return URSA_ENULL;
+    return wgrad_partial_impl(x, bn_save, dy, ws, ws_floats, N, Cin, Cout, H, W, 1, 1, stream);
 }
 
 extern "C" int ursa_conv_wgrad_reduce_f32(const ursa_conv_pending* items, int32_t n, ursa_stream_t stream) {

@@ -34,9 +34,22 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 // Workgroup = 4 waves; a chunk = 64 positions (4 runs) x CK = min(CI, 64) channels in LDS at a row pitch of 80 floats (16 mod 64:
 // the 16 positions x 4 channel planes of an A read fall into 64 distinct banks). MT = CO / 16 output tiles: MT >= 4: wave w owns
 // tiles w, w + 4, ... and all 4 runs; MT = 2: tile w % 2, runs {w / 2, w / 2 + 2}; MT = 1: run w.
-template <int CI, int CO, int HW, bool FLIP>
+//
+// XBN (K13, the Bottleneck networks' `conv(relu(bn(x)))`): x is the BatchNorm's INPUT and `bn` the [4][CI] block K6's statistics
+// launch saved (rows 2, 3: the scale / shift of y = fma(x, scale, shift)); a staged row becomes relu(fma(x, scale, shift)) - K6's
+// own expression, so the result has the bits of K6's second launch followed by this kernel - and the normalised activation is
+// never stored.
+__device__ __forceinline__ float relu_nan(float v) { return v < 0.f ? 0.f : v; }   // NaN stays NaN (K6's bn_relu_fwd)
+__device__ __forceinline__ f32x4 bn_relu4(const f32x4& v, float scale, float shift)
+{
+    return f32x4{relu_nan(fmaf(v.x, scale, shift)), relu_nan(fmaf(v.y, scale, shift)), relu_nan(fmaf(v.z, scale, shift)),
+                 relu_nan(fmaf(v.w, scale, shift))};
+}
+
+template <int CI, int CO, int HW, bool FLIP, bool XBN = false>
 __global__ __launch_bounds__(kThreads) void k_conv1x1(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int N,
-                                                      int ipw, int npc)        // npc: position chunks of an image this workgroup walks (grid.y covers the rest)
+                                                      int ipw, int npc,        // npc: position chunks of an image this workgroup walks (grid.y covers the rest)
+                                                      const float* __restrict__ bn)
 {
     constexpr int CK = cmin(CI, 64), NCK = CI / CK, P = 64, PITCH = 80;
     constexpr int MT = CO / 16, NT = cmax(1, MT / 4), WPT = cmax(1, 4 / MT), NR = 4 / WPT;   // tiles per wave, waves per tile, runs per wave
@@ -44,10 +57,16 @@ __global__ __launch_bounds__(kThreads) void k_conv1x1(const float* __restrict__ 
     constexpr int NV = CK * (P / 4) / kThreads;                // float4 a thread stages per chunk
     static_assert(CI % 16 == 0 && CO % 16 == 0 && HW % P == 0 && CI % CK == 0 && (CK * (P / 4)) % kThreads == 0, "geometry");
     static_assert(MT == 1 || MT == 2 || MT % 4 == 0, "output tiles per workgroup");
+    static_assert(!(XBN && FLIP), "the BatchNorm sits in front of the forward layer");
     __shared__ __attribute__((aligned(16))) float xs[CK * PITCH];
+    __shared__ float tab[XBN ? 2 * CI : 1];                    // scale[CI], shift[CI]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, k = lane >> 4;
     const int tile0 = MT >= 4 ? wave : wave % MT, run0 = MT >= 4 ? 0 : wave / MT;
+    if constexpr (XBN) {
+        for (int i = tid; i < 2 * CI; i += kThreads) tab[i] = bn[2 * CI + i];
+        __syncthreads();
+    }
 
     float wr[NT][KG];                                          // w[o = tile * 16 + j][i = 4 g + k]
 #pragma unroll
@@ -72,10 +91,11 @@ __global__ __launch_bounds__(kThreads) void k_conv1x1(const float* __restrict__ 
             vx[v] = *reinterpret_cast<const f32x4*>(src + (size_t)c * HW + 4 * q);
         }
     };
-    auto stage = [&]() {
+    auto stage = [&](int cc) {
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const int idx = tid + v * kThreads, c = idx / (P / 4), q = idx % (P / 4);
+            if constexpr (XBN) vx[v] = bn_relu4(vx[v], tab[cc * CK + c], tab[CI + cc * CK + c]);
             *reinterpret_cast<f32x4*>(xs + c * PITCH + 4 * q) = vx[v];
         }
     };
@@ -90,7 +110,7 @@ __global__ __launch_bounds__(kThreads) void k_conv1x1(const float* __restrict__ 
         for (int cc = 0; cc < NCK; ++cc) {
             const int s = ip * NCK + cc;
             if (s > 0) __syncthreads();                        // the previous chunk's reads are done
-            stage();
+            stage(cc);
             __syncthreads();
             if (s + 1 < steps) load(s + 1);                    // the next chunk's rows are in flight under this chunk's matrix work
 #pragma unroll
@@ -122,18 +142,24 @@ __global__ __launch_bounds__(kThreads) void k_conv1x1(const float* __restrict__ 
 // tile, positions 16 t + 4 g .. + 3) and ONE float4 of x (its input channel c of a tile): four MFMAs. Chunks of 32 positions of
 // all CO + CI channel rows in LDS at a row pitch of 36 floats (36 c mod 64 runs through the 16 multiples of 4: the 16 rows' float4
 // reads of one g fall into 64 distinct banks). Waves: WCO = min(4, CO / 16) across output tiles, the rest across input tiles.
-template <int CI, int CO, int HW>
+// XBN: x is the BatchNorm's input, `bn` K6's saved [4][CI] block: the staged x rows become relu(fma(x, scale, shift)) (see k_conv1x1).
+template <int CI, int CO, int HW, bool XBN = false>
 __global__ __launch_bounds__(kThreads) void k_conv1x1_wgrad(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial,
-                                                            int N, int Cout_unused, int ipw, const float* __restrict__ xbn_unused)
+                                                            int N, int Cout_unused, int ipw, const float* __restrict__ bn)
 {
     constexpr int MTO = CO / 16, CTI = CI / 16, WCO = cmin(4, MTO), WCI = 4 / WCO;
     constexpr int TO = MTO / WCO, TI = CTI / WCI;              // output / input tiles per wave
     constexpr int PK = 32, PITCH = 36, NPC = HW / PK;
     constexpr int TOT = (CO + CI) * (PK / 4), NV = (TOT + kThreads - 1) / kThreads;
     static_assert(MTO % WCO == 0 && CTI % WCI == 0 && CTI >= WCI && HW % PK == 0, "geometry");
-    static_assert((CO + CI) * PITCH * 4 <= 64 * 1024, "static LDS");
+    static_assert(((CO + CI) * PITCH + (XBN ? 2 * CI : 0)) * 4 <= 64 * 1024, "static LDS");
     __shared__ __attribute__((aligned(16))) float sm[(CO + CI) * PITCH];     // rows [0, CO): dy, rows [CO, CO + CI): x
+    __shared__ float tab[XBN ? 2 * CI : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if constexpr (XBN) {
+        for (int i = tid; i < 2 * CI; i += kThreads) tab[i] = bn[2 * CI + i];
+        __syncthreads();
+    }
     const int c = lane & 15, g = lane >> 4;
     const int wo = wave % WCO, wi = wave / WCO;
     const int n0 = blockIdx.x * ipw;
@@ -162,6 +188,7 @@ __global__ __launch_bounds__(kThreads) void k_conv1x1_wgrad(const float* __restr
 #pragma unroll
         for (int u = 0; u < NV; ++u) {
             const int idx = tid + u * kThreads, row = idx / (PK / 4), q = idx % (PK / 4);
+            if constexpr (XBN) { if (row >= CO && row < CO + CI) v[u] = bn_relu4(v[u], tab[row - CO], tab[CI + row - CO]); }
             if (TOT % kThreads == 0 || idx < TOT) *reinterpret_cast<f32x4*>(sm + row * PITCH + 4 * q) = v[u];
         }
         __syncthreads();
@@ -193,13 +220,14 @@ __global__ __launch_bounds__(kThreads) void k_conv1x1_wgrad(const float* __restr
         }
 }
 
-typedef void (*FwFn)(const float*, const float*, float*, int, int, int);
+typedef void (*FwFn)(const float*, const float*, float*, int, int, int, const float*);
 
 // (CI, CO, H) of the launch: forward = the layer's (Cin, Cout); FLIP = (the layer's Cout, Cin). The bottleneck stages of
 // PreResNet-164: 16 <-> 64 at 32 x 32, 32 <-> 128 at 16 x 16, 64 <-> 256 at 8 x 8, and each stage's first block (16 -> 16, 64 -> 32,
 // 128 -> 64; the 16 -> 64 stride-1 shortcut is the first shape again).
-FwFn fw_for(int64_t CI, int64_t CO, int64_t H, bool flip) {
-#define URSA_1X1(ci, co, h) if (CI == ci && CO == co && H == h) return flip ? (FwFn)k_conv1x1<ci, co, h * h, true> : (FwFn)k_conv1x1<ci, co, h * h, false>;
+FwFn fw_for(int64_t CI, int64_t CO, int64_t H, bool flip, bool xbn = false) {
+#define URSA_1X1(ci, co, h) if (CI == ci && CO == co && H == h) return flip ? (xbn ? nullptr : (FwFn)k_conv1x1<ci, co, h * h, true>) \
+                                : xbn ? (FwFn)k_conv1x1<ci, co, h * h, false, true> : (FwFn)k_conv1x1<ci, co, h * h, false>;
     URSA_1X1(64, 16, 32) URSA_1X1(16, 64, 32) URSA_1X1(128, 32, 16) URSA_1X1(32, 128, 16) URSA_1X1(256, 64, 8) URSA_1X1(64, 256, 8)
     URSA_1X1(16, 16, 32) URSA_1X1(64, 32, 32) URSA_1X1(32, 64, 32) URSA_1X1(128, 64, 16) URSA_1X1(64, 128, 16)
 #undef URSA_1X1
@@ -237,17 +265,39 @@ extern "C" int ursa_conv1x1_f32(const float* x, const float* w, float* y, int64_
     if (!fn) return URSA_EVALUE;
     int ipw, npc, gy;
     geometry_for(N, H, &ipw, &npc, &gy);
-    hipLaunchKernelGGL(fn, dim3((unsigned)((N + ipw - 1) / ipw), (unsigned)gy), dim3(kThreads), 0, (hipStream_t)stream, x, w, y, (int)N, ipw, npc);
+    hipLaunchKernelGGL(fn, dim3((unsigned)((N + ipw - 1) / ipw), (unsigned)gy), dim3(kThreads), 0, (hipStream_t)stream, x, w, y, (int)N, ipw, npc,
+                       (const float*)nullptr);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? URSA_OK : (int)e;
+}
+
+// K13: y = conv1x1(relu(bn(x))) with the BatchNorm's scale / shift taken from `bn_save` (the [4][Cin] block ursa_bn_stats_f32 saved)
+extern "C" int ursa_preact_conv1x1_supported(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W) {
+    return N >= 1 && N <= (1 << 20) && H == W && fw_for(Cin, Cout, H, false, true) != nullptr;
+}
+
+extern "C" int ursa_preact_conv1x1_f32(const float* x, const float* bn_save, const float* w, float* y, int64_t N, int64_t Cin, int64_t Cout,
+                                       int64_t H, int64_t W, ursa_stream_t stream) {
+    if (!x || !bn_save || !w || !y) return URSA_ENULL;
+    if (N < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return URSA_ESIZE;
+    if (((uintptr_t)x | (uintptr_t)y) & 15 || ((uintptr_t)w | (uintptr_t)bn_save) & 3) return URSA_EALIGN;
+    if (N > (1 << 20) || H != W) return URSA_EVALUE;
+    const FwFn fn = fw_for(Cin, Cout, H, false, true);
+    if (!fn) return URSA_EVALUE;
+    int ipw, npc, gy;
+    geometry_for(N, H, &ipw, &npc, &gy);
+    hipLaunchKernelGGL(fn, dim3((unsigned)((N + ipw - 1) / ipw), (unsigned)gy), dim3(kThreads), 0, (hipStream_t)stream, x, w, y, (int)N, ipw, npc,
+                       bn_save);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? URSA_OK : (int)e;
 }
 
 // what ursa_conv.hip's plan_for() asks for a 1x1 / stride 1 weight gradient: the launch, its K slices and the floats of one slice
 extern "C" __attribute__((visibility("hidden"))) int ursa_conv1x1_wgrad_plan(int64_t N, int64_t Cin, int64_t Cout, int64_t H, void (**fn)(const float*, const float*, float*, int, int, int, const float*),
-                                       int* slices, int* ipw, int64_t* E) {
+                                       int* slices, int* ipw, int64_t* E, int xbn) {
     typedef void (*WgFn)(const float*, const float*, float*, int, int, int, const float*);
     WgFn f = nullptr;
-#define URSA_1X1W(ci, co, h) if (Cin == ci && Cout == co && H == h) f = k_conv1x1_wgrad<ci, co, h * h>;
+#define URSA_1X1W(ci, co, h) if (Cin == ci && Cout == co && H == h) f = xbn ? (WgFn)k_conv1x1_wgrad<ci, co, h * h, true> : (WgFn)k_conv1x1_wgrad<ci, co, h * h>;
     URSA_1X1W(64, 16, 32) URSA_1X1W(16, 64, 32) URSA_1X1W(128, 32, 16) URSA_1X1W(32, 128, 16) URSA_1X1W(256, 64, 8) URSA_1X1W(64, 256, 8)
     URSA_1X1W(64, 32, 32) URSA_1X1W(128, 64, 16)
 #undef URSA_1X1W

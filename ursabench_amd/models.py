@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import fused_block
+from . import fused_block, fused_bottleneck
 from .fused_bn import add_bn_relu, bn_relu
 from .fused_conv import Conv2d
 
@@ -116,10 +116,19 @@ class _PreActBottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        x, h = add_bn_relu(self.bn1, x)                 # pending sums in and out, as in _PreActBasic
-        y = self.conv1(h)
+        # pending sums in and out, as in _PreActBasic. K13 (fused_bottleneck): the 1x1 layers apply relu(bn(.)) while they stage
+        # their input - large activations with gradients recorded (the HMC configuration); K6 + K12 otherwise
+        ab = x if isinstance(x, tuple) else (x,)
+        if fused_bottleneck.eligible(self.bn1, self.conv1, *ab):
+            x, y = fused_bottleneck.bn_relu_conv1x1(self.bn1, self.conv1, x)
+        else:
+            x, h = add_bn_relu(self.bn1, x)
+            y = self.conv1(h)
         y = self.conv2(bn_relu(self.bn2, y))
-        y = self.conv3(bn_relu(self.bn3, y))
+        if fused_bottleneck.eligible(self.bn3, self.conv3, y):
+            y = fused_bottleneck.bn_relu_conv1x1(self.bn3, self.conv3, y)[1]
+        else:
+            y = self.conv3(bn_relu(self.bn3, y))
         return y, (x if self.downsample is None else self.downsample(x))
 
 
