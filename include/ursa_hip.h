@@ -463,7 +463,7 @@ int ursa_conv1x1_f32(const float* x, const float* w, float* y, int64_t N, int64_
  *                                 of z = x + addend, stored to z_out - the previous block's `out += residual`), the running
  *                                 statistics update, and save[4][C] = (mean, invstd, scale, shift) with
  *                                 scale = invstd * gamma, shift = fma(-mean, scale, beta): bit for bit what
- *                                 ursa_bn_relu_fwd_f32's two-launch form computes; no y. ws: ursa_bn_ws_floats(C) floats.
+ *                                 ursa_bn_relu_fwd_f32's two-launch form computes; no y. ws: URSA_BN_WS_FLOATS(C) floats.
  *  ursa_preact_conv1x1_f32        y = conv1x1(relu(fma(x, scale, shift))) - K12's forward launch applying K6's own expression to
  *                                 the rows of x as it stages them (bn_save: the block above): the bits of ursa_bn_relu_fwd_f32
  *                                 followed by ursa_conv1x1_f32, with x read once and relu(bn(x)) never written

@@ -26,6 +26,7 @@ int oracle_bn_relu_bwd_gated_f32(const float*, const float*, float*, const float
                                  float*, float*, int64_t, int64_t, int64_t, int, const int32_t*, const uint8_t*, int64_t);
 
 int oracle_conv_wgrad_f32(const float*, const float*, float*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t);
+int oracle_conv1x1_f32(const float*, const float*, float*, int64_t, int64_t, int64_t, int64_t, int);
 int oracle_conv3x3_f32(const float*, const float*, float*, int64_t, int64_t, int64_t, int64_t, int64_t, int, int64_t);
 int oracle_preact_fwd_f32(const float*, const float*, const float*, float*, float*, const float*, const float*, float*, float*, float*, double*,
                           int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, float, float, int);
@@ -300,6 +301,39 @@ int main(void)
         if (ursa_preact_geometry(N, 5, C, H, H, URSA_PREACT_BN | URSA_PREACT_STATS, geo) != URSA_EVALUE) { printf("FAIL K10 evalue\n"); return 1; }
         if (ursa_preact_conv3x3_f32(dx_, dw_, dy_, din, 1, dgm, dbt, NULL, NULL, dsave, 0.0f, 0.0f, dadd, NULL, dpart, dscr, 64, N, C, C, H, H,
                                     URSA_PREACT_BN | URSA_PREACT_STATS | URSA_PREACT_ADD, st) != URSA_ESIZE) { printf("FAIL K10 esize\n"); return 1; }
+        /* ABI 8: K13 - conv1x1(relu(bn(x))), 16 -> 64 channels at 32 x 32, on the same integer-valued x / gamma / beta: the
+         * statistics entry's saved block, the forward and the weight gradient against the oracle's K6 and K12 restatements composed */
+        {
+            const int64_t Co = 64, w1n = Co * C, ytot = N * Co * HW;
+            float *hw1 = malloc(w1n * 4), *hdy1 = malloc(ytot * 4), *oh1 = malloc(tot * 4), *oy1 = malloc(ytot * 4), *gy1 = malloc(ytot * 4);
+            float *odw1 = malloc(w1n * 4), *gdw1 = malloc(w1n * 4), om[16], oi[16], gsv[64];
+            for (int64_t i = 0; i < w1n; ++i) hw1[i] = floorf(4.99f * frand(&s3)) - 2.0f;
+            for (int64_t i = 0; i < ytot; ++i) hdy1[i] = floorf(2.99f * frand(&s3)) - 1.0f;
+            oracle_bn_relu_fwd_f32(hx, oh1, hg, hb, NULL, NULL, om, oi, N, C, HW, 0.0f, 0.0f, 1);
+            oracle_conv1x1_f32(oh1, hw1, oy1, N, C, Co, HW, 0);
+            oracle_conv_wgrad_f32(oh1, hdy1, odw1, N, C, Co, H, H, 1, 1);
+            float *dw1, *dy1, *ddy1, *dsv, *dbws, *dws1, *ddw1;
+            const int64_t wsf1 = ursa_conv_wgrad_ws_floats(N, C, Co, H, H, 1, 1), bws = URSA_BN_WS_FLOATS(C);
+            if (!ursa_preact_conv1x1_supported(N, C, Co, H, H) || wsf1 <= 0) { printf("FAIL K13 does not cover 16 -> 64 at 32 x 32\n"); return 1; }
+            CHECK(hipMalloc((void**)&dw1, w1n * 4)); CHECK(hipMalloc((void**)&dy1, ytot * 4)); CHECK(hipMalloc((void**)&ddy1, ytot * 4));
+            CHECK(hipMalloc((void**)&dsv, 4 * C * 4)); CHECK(hipMalloc((void**)&dbws, bws * 4)); CHECK(hipMalloc((void**)&dws1, wsf1 * 4));
+            CHECK(hipMalloc((void**)&ddw1, w1n * 4));
+            CHECK(hipMemcpy(dw1, hw1, w1n * 4, hipMemcpyHostToDevice)); CHECK(hipMemcpy(ddy1, hdy1, ytot * 4, hipMemcpyHostToDevice));
+            CHECK(ursa_bn_stats_f32(dx_, NULL, NULL, dgm, dbt, NULL, NULL, dsv, dbws, N, C, HW, 0.0f, 0.0f, st));
+            CHECK(ursa_preact_conv1x1_f32(dx_, dsv, dw1, dy1, N, C, Co, H, H, st));
+            CHECK(ursa_preact_wgrad1x1_partial_f32(dx_, dsv, ddy1, dws1, wsf1, N, C, Co, H, H, st));
+            ursa_conv_pending pend = {dws1, ddw1, N, C, Co, H, H, 1, 1};
+            CHECK(ursa_conv_wgrad_reduce_f32(&pend, 1, st));
+            CHECK(hipStreamSynchronize(st));
+            CHECK(hipMemcpy(gsv, dsv, 4 * C * 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(gy1, dy1, ytot * 4, hipMemcpyDeviceToHost));
+            CHECK(hipMemcpy(gdw1, ddw1, w1n * 4, hipMemcpyDeviceToHost));
+            for (int64_t c = 0; c < C; ++c)
+                if (gsv[c] != om[c] || gsv[C + c] != oi[c] || gsv[2 * C + c] != hg[c] || gsv[3 * C + c] != hb[c]) { printf("FAIL K13 saved block differs from the oracle\n"); return 1; }
+            if (memcmp(gy1, oy1, ytot * 4)) { printf("FAIL K13 forward differs from the oracle\n"); return 1; }
+            if (memcmp(gdw1, odw1, w1n * 4)) { printf("FAIL K13 weight gradient differs from the oracle\n"); return 1; }
+            if (ursa_preact_conv1x1_f32(dx_, NULL, dw1, dy1, N, C, Co, H, H, st) != URSA_ENULL) { printf("FAIL K13 enull\n"); return 1; }
+            if (ursa_preact_conv1x1_f32(dx_, dsv, dw1, dy1, N, C, 48, H, H, st) != URSA_EVALUE) { printf("FAIL K13 evalue\n"); return 1; }
+        }
         /* K11: classifier + mean cross entropy + their gradients in one launch, against the oracle (double sums) to rounding */
         {
             const int64_t Nn = 32, Cc = 64, Kk = 10;
@@ -338,6 +372,7 @@ int main(void)
     printf("C-ABI host OK: K1 bit-equal to the oracle over 3 steps (n=%lld), 2 chains in one self-advancing launch bit-equal, "
            "generator self-test clean, K5 max relative error %.2e, "
            "K6 forward + backward + gated backward bit-equal, K7 / K8 bit-equal on integer inputs, "
-           "K10 fused unit (forward, paired backward, dx) bit-equal on integer inputs, K11 classifier launch within rounding\n", (long long)n, worst);
+           "K10 fused unit (forward, paired backward, dx) and K13 (statistics, conv1x1 of relu(bn(x)), weight gradient) bit-equal on integer inputs, "
+           "K11 classifier launch within rounding\n", (long long)n, worst);
     return 0;
 }

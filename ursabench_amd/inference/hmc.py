@@ -26,10 +26,10 @@ import math
 
 import torch
 
-from .. import _native, fused_bn
+from .. import _native, fused_bn, fused_conv
 from .._capture import capture, side_streams
 from ..arena import FlatArena, MemberBank
-from ..util import reset_model
+from ..util import deferred_bn_counters, reset_model
 from .inference_base import _Inference
 
 
@@ -103,13 +103,42 @@ class HMC(_Inference):
             self._ws = torch.zeros(_native.REDUCE_WS_FLOATS, device=dev)
             self._acc = torch.zeros(1, device=dev)
             self._crit = torch.nn.CrossEntropyLoss(reduction='sum')
+            self._slot = {id(p): i for i, p in enumerate(a.params)}
 
     def _eval_potential(self):
         """U(theta) = sum CE + tau/2 ||theta||^2 into self._u and grad log p into self._glogp."""
         a = self.arena
-        a.grad.zero_()
-        nll = self._crit(self.model(self.x), self.y.long().view(-1))
+        params, views = a.params, a.grad_views
+        # As in ChainEngine.forward_backward: the BatchNorm counters bumped by ONE multi-tensor add, K7's second launches for all
+        # convolutions at once, and autograd handing over fresh gradient tensors (p.grad = None) that ONE multi-tensor copy packs
+        # into the arena - with the arena views left in p.grad it runs a `grad += new` kernel per parameter tensor (488 for
+        # PreResNet-164: 4.5 % of the C5 configuration's kernel time, + 1.4 % for the counters, profiles/r06_c5_kernel_stats*.csv).
+        with deferred_bn_counters(self.model), fused_conv.deferred() as pend:
+            nll = self._crit(self.model(self.x), self.y.long().view(-1))
+        for p in params:
+            p.grad = None
         nll.backward()
+        grads = [p.grad for p in params]
+        with torch.no_grad():
+            done = set()
+            if pend:
+                slot = self._slot
+                stray = [tuple(w.shape) for _, w in pend if id(w) not in slot]
+                if stray:
+                    raise RuntimeError(f'convolution weights {stray} took K7\'s deferred launch but are not in the sampler\'s arena')
+                fused_conv.flush(pend, lambda w: views[slot[id(w)]])
+                done = {slot[id(w)] for _, w in pend}
+                for i in done:
+                    if grads[i] is not None:        # the same weight also went through a call K7 does not cover
+                        views[i].add_(grads[i])
+            have = [i for i in range(len(grads)) if i not in done and grads[i] is not None]
+            if have:
+                torch._foreach_copy_([views[i] for i in have], [grads[i] for i in have])
+            for i in range(len(grads)):
+                if i not in done and grads[i] is None:
+                    views[i].zero_()                # a parameter the loss does not reach: gradient 0, as autograd leaves it
+        for p, gv in zip(params, views):
+            p.grad = gv                             # the arena's contract: p.grad is its view
         with torch.no_grad():
             torch.add(a.grad, a.theta, alpha=self.tau, out=self._glogp)
             self._glogp.neg_()
