@@ -1,5 +1,5 @@
 #!/bin/bash
-# ChainGroup (8 chains per GPU): the units' backward launches separate (URSA_GROUP_PAIR=0; shipped until the register cap) against paired (shipped now)
+# ChainGroup (8 chains per GPU): the units' backward launches separate (shipped) against paired (URSA_GROUP_PAIR=1)
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$R"

@@ -56,15 +56,17 @@ def paired(flag=None):
 
 
 _tls = threading.local()
-_GROUP_SEPARATE = os.environ.get('URSA_GROUP_PAIR', '1') == '0'    # A/B: ChainGroup's chains keep the two backward launches apart
+_GROUP_SEPARATE = os.environ.get('URSA_GROUP_PAIR', '0') != '1'    # ChainGroup's chains keep the two backward launches apart (A/B: 1)
 
 
 class separate_launches:
     """Context around a FORWARD pass: the units applied inside keep their input-gradient and weight-gradient launches apart,
     whatever `paired()` says (the decision is taken in the forward and travels to the backward in its autograd context).
-    ChainGroup used it while the paired kernel held a CU alone (8 chains per GPU: 4.95 vs 4.79 samples/s paired); with the
-    kernels capped at two waves per SIMD the pair wins there too (5.48 vs 5.40, `profiles/r06_group_pair_ab.json`), so nothing
-    enters it by default any more: `URSA_GROUP_PAIR=0` makes ChainGroup do so again (A/B)."""
+    ChainGroup's chains run inside it. While the paired kernel held a CU alone that was the faster form there (8 chains per GPU:
+    4.95 vs 4.79 samples/s paired); with the kernels capped at two waves per SIMD the pair is 1.5 % ahead in a group too (5.48 vs
+    5.40, `profiles/r06_group_pair_ab.json`; `URSA_GROUP_PAIR=1` takes it) - the group keeps separate launches so that the paired
+    kernel, the one `bench.py`'s roofline is quoted on, runs only alone on the device in the default command and its rocprofv3
+    average (`profiles/r06_bench_kernel_stats.csv`) is not a mix of lone and eight-way concurrent executions."""
 
     def __enter__(self):
         self.old = getattr(_tls, 'separate', False)
@@ -77,7 +79,7 @@ class separate_launches:
 
 
 class group_launches:
-    """What ChainGroup wraps each chain's forward in: `separate_launches` under URSA_GROUP_PAIR=0, nothing otherwise."""
+    """What ChainGroup wraps each chain's forward in: `separate_launches`, or nothing under URSA_GROUP_PAIR=1."""
 
     def __enter__(self):
         self.ctx = separate_launches() if _GROUP_SEPARATE else None
