@@ -483,6 +483,31 @@ int ursa_preact_wgrad1x1_partial_f32(const float* x, const float* bn_save, const
                                      int64_t Cin, int64_t Cout, int64_t H, int64_t W, ursa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * K14  the backward of `conv1x1(relu(bn(x)))` where the layer narrows (a Bottleneck block's conv1: 64 -> 16, 128 -> 32, 256 -> 64,
+ *      64 -> 32, 128 -> 64): input gradient of the convolution + the BatchNorm's backward without the convolution's input gradient
+ *      dh in memory. K6's backward needs the whole batch's two sums before it can produce any dx, and dh is the widest tensor of
+ *      the unit (4 x dy): instead of writing it once and reading it twice, the memory-bound flipped GEMM runs twice.
+ *      (dy: [N, Cd, H, W]; w: the layer's [Cd, Cx, 1, 1]; x: the BatchNorm's input [N, Cx, H, W]; bn_save: ursa_bn_stats_f32's block)
+ *  ursa_preact_conv1x1_bwd_nl        the workgroups of these launches for a shape = the partial sums per channel; 0 = not covered.
+ *  ursa_preact_conv1x1_bwd_sums_f32  dh = conv^T(dy, w) in registers, the ReLU gate from fma(x, scale, shift) > 0, and per workgroup
+ *                                    (sum g, sum g * (x - mean)) in double -> out_partial [Cx][nl]: K6's first backward launch's sums.
+ *  ursa_bn_bwd_coef_f32              their merge (fixed order) -> coef [3][Cx] = (gm, kk, gamma), dgamma, dbeta - the scalars of
+ *                                    ursa_bn_relu_bwd_f32's second launch.
+ *  ursa_preact_conv1x1_bwd_dx_f32    dh again (same bits), gated, and K6's expression
+ *                                    dx = (((g - gm) - (x - mean) * kk) * invstd) * gamma (+ dz: the gradient reaching the residual
+ *                                    sum on its other path), stored.
+ * Traffic at [1024, 64, 32, 32] <- 16 channels: 335 + 871 MB against 335 (K12) + 536 + 1,072 (K6's two launches).
+ */
+int64_t ursa_preact_conv1x1_bwd_nl(int64_t N, int64_t Cd, int64_t Cx, int64_t H, int64_t W);
+int ursa_preact_conv1x1_bwd_sums_f32(const float* dy, const float* w, const float* x, const float* bn_save, double* out_partial,
+                                     int64_t N, int64_t Cd, int64_t Cx, int64_t H, int64_t W, ursa_stream_t stream);
+int ursa_bn_bwd_coef_f32(const double* partial, int64_t nl, const float* bn_save, const float* gamma, float* coef /* [3][C] */,
+                         float* dgamma, float* dbeta, int64_t n_per_channel, int64_t C, ursa_stream_t stream);
+int ursa_preact_conv1x1_bwd_dx_f32(const float* dy, const float* w, const float* x, const float* bn_save, const float* coef,
+                                   const float* dz /* or NULL */, float* dx, int64_t N, int64_t Cd, int64_t Cx, int64_t H, int64_t W,
+                                   ursa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * K10  the pre-activation unit of the BasicBlock ResNets, one launch each way      URSABench/models/preresnet.py:33-52
  *      (`out = bn1(x); relu; conv1; bn2; relu; conv2; out += residual`) and the backward of those ops in `loss.backward()`
  *      (URSABench/inference/sghmc.py:80).

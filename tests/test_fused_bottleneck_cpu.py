@@ -46,12 +46,33 @@ def test_argument_errors_come_back_as_codes_without_a_device():
     assert lib.ursa_preact_wgrad1x1_partial_f32(one, one, one, one, 1 << 30, 4, 16, 16, 32, 32, None) == EVALUE          # 16 -> 16: not covered
 
 
+def test_k14_coverage_and_argument_errors_without_a_device():
+    K = _native.HipKernels()
+    lib = K.lib
+    for cd, cx, h in [(16, 64, 32), (32, 128, 16), (64, 256, 8), (32, 64, 32), (64, 128, 16)]:
+        assert K.preact_conv1x1_bwd_nl((1024, cd, h, h), cx) >= 512
+    assert K.preact_conv1x1_bwd_nl((1024, 16, 32, 32), 64) == 1024 and K.preact_conv1x1_bwd_nl((8, 16, 32, 32), 64) == 8 * 8     # small batches: an image cut into up to 8 pieces (two chunks each)
+    for cd, cx, h in [(64, 16, 32), (16, 16, 32), (16, 64, 16), (48, 64, 32)]:               # widening / uncovered: K12 + K6
+        assert K.preact_conv1x1_bwd_nl((1024, cd, h, h), cx) == 0
+    one = ctypes.c_void_p(16)
+    assert lib.ursa_preact_conv1x1_bwd_sums_f32(one, one, one, one, None, 4, 16, 64, 32, 32, None) == ENULL
+    assert lib.ursa_preact_conv1x1_bwd_sums_f32(one, one, one, one, one, 4, 64, 16, 32, 32, None) == EVALUE
+    assert lib.ursa_preact_conv1x1_bwd_sums_f32(one, one, one, one, ctypes.c_void_p(8), 4, 16, 64, 32, 32, None) == EALIGN
+    assert lib.ursa_preact_conv1x1_bwd_dx_f32(one, one, one, one, None, None, one, 4, 16, 64, 32, 32, None) == ENULL
+    assert lib.ursa_preact_conv1x1_bwd_dx_f32(one, one, one, one, one, None, one, 0, 16, 64, 32, 32, None) == ESIZE
+    assert lib.ursa_bn_bwd_coef_f32(None, 4, one, one, one, one, one, 4096, 64, None) == ENULL
+    assert lib.ursa_bn_bwd_coef_f32(one, 0, one, one, one, one, one, 4096, 64, None) == ESIZE
+    assert lib.ursa_bn_bwd_coef_f32(ctypes.c_void_p(8), 4, one, one, one, one, one, 4096, 64, None) == EALIGN
+
+
 def test_switch_and_plain_modules():
     old = fused_bottleneck.enabled(False)
     try:
         assert fused_bottleneck.enabled() is False
     finally:
         fused_bottleneck.enabled(old)
+    old = fused_bottleneck.recompute_backward(False)
+    assert fused_bottleneck.recompute_backward(old) is False and fused_bottleneck.recompute_backward() is old
     bn, x = nn.BatchNorm2d(64), torch.randn(64, 64, 32, 32, requires_grad=True)
     assert not fused_bottleneck.eligible(bn, nn.Conv2d(64, 16, 1, bias=False), x)          # not a fused_conv.Conv2d
     assert not fused_bottleneck.eligible(bn, fused_conv.Conv2d(64, 16, 1, bias=True), x)

@@ -79,6 +79,10 @@ SIGNATURES = {
     'ursa_preact_conv1x1_supported': (ctypes.c_int, [_i64, _i64, _i64, _i64, _i64]),
     'ursa_preact_conv1x1_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp]),
     'ursa_preact_wgrad1x1_partial_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp]),
+    'ursa_preact_conv1x1_bwd_nl': (ctypes.c_int64, [_i64, _i64, _i64, _i64, _i64]),
+    'ursa_preact_conv1x1_bwd_sums_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp]),
+    'ursa_bn_bwd_coef_f32': (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
+    'ursa_preact_conv1x1_bwd_dx_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp]),
     'ursa_preact_geometry': (ctypes.c_int, [_i64, _i64, _i64, _i64, _i64, _u32, _i64p]),
     'ursa_preact_conv3x3_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _i64,
                                                _i64, _i64, _i64, _i64, _i64, _u32, _vp]),
@@ -658,6 +662,40 @@ class HipKernels:
                                                            _ptr(ws, 'ws', None, dev), ws.numel(), N, Cin, Cout, H, W, _stream(dev))
         _check(self.lib, rc, 'ursa_preact_wgrad1x1_partial_f32')
         return (ws, N, Cin, Cout, H, W, ksize, 1)
+
+    # K14 -----------------------------------------------------------------------------
+    def preact_conv1x1_bwd_nl(self, dy_shape, cx):
+        """Partial sums per channel the K14 launches leave for an output gradient of `dy_shape` and a layer with `cx` input channels; 0: not covered."""
+        N, Cd, H, W = dy_shape
+        return int(self.lib.ursa_preact_conv1x1_bwd_nl(N, Cd, int(cx), H, W))
+
+    def preact_conv1x1_bwd(self, dy, w, x, bn_save, gamma, dx, dgamma, dbeta, dz=None):
+        """Backward of conv1x1(relu(bn(x))) w.r.t. x (and the BatchNorm's gamma / beta) without storing the convolution's input
+        gradient: sums launch, merge, dx launch. dy [N, Cd, H, W], w [Cd, Cx, 1, 1], x / dx / dz [N, Cx, H, W], bn_save [4, Cx]."""
+        if dy.dim() != 4 or w.dim() != 4 or tuple(w.shape[2:]) != (1, 1) or w.shape[0] != dy.shape[1] or tuple(x.shape) != (dy.shape[0], w.shape[1]) + tuple(dy.shape[2:]):
+            raise ValueError(f'shapes: dy {tuple(dy.shape)}, w {tuple(w.shape)}, x {tuple(x.shape)}')
+        N, Cd, H, W = dy.shape
+        Cx = w.shape[1]
+        dev, n = dy.device, x.numel()
+        nl = self.preact_conv1x1_bwd_nl(dy.shape, Cx)
+        if nl <= 0:
+            raise ValueError(f'K14 does not cover dy {tuple(dy.shape)} -> {Cx} channels')
+        pb = torch.empty(Cx, nl, 2, dtype=torch.float64, device=dev)
+        coef = torch.empty(3, Cx, device=dev)
+        with torch.cuda.device(dev):
+            st = _stream(dev)
+            rc = self.lib.ursa_preact_conv1x1_bwd_sums_f32(_ptr(dy, 'dy'), _ptr(w, 'w', None, dev), _ptr(x, 'x', None, dev),
+                                                           _ptr(bn_save, 'bn_save', 4 * Cx, dev), self._f64ptr(pb, 'partial', 2 * Cx * nl, dev), N, Cd, Cx, H, W, st)
+            _check(self.lib, rc, 'ursa_preact_conv1x1_bwd_sums_f32')
+            rc = self.lib.ursa_bn_bwd_coef_f32(self._f64ptr(pb, 'partial', 2 * Cx * nl, dev), nl, _ptr(bn_save, 'bn_save', 4 * Cx, dev),
+                                               _ptr(gamma, 'gamma', Cx, dev), _ptr(coef, 'coef', 3 * Cx, dev), _ptr(dgamma, 'dgamma', Cx, dev),
+                                               _ptr(dbeta, 'dbeta', Cx, dev), N * H * W, Cx, st)
+            _check(self.lib, rc, 'ursa_bn_bwd_coef_f32')
+            rc = self.lib.ursa_preact_conv1x1_bwd_dx_f32(_ptr(dy, 'dy'), _ptr(w, 'w', None, dev), _ptr(x, 'x', None, dev),
+                                                         _ptr(bn_save, 'bn_save', 4 * Cx, dev), _ptr(coef, 'coef', 3 * Cx, dev),
+                                                         _ptr(dz, 'dz', n, dev, optional=True), _ptr(dx, 'dx', n, dev), N, Cd, Cx, H, W, st)
+            _check(self.lib, rc, 'ursa_preact_conv1x1_bwd_dx_f32')
+        return pb, coef
 
     # K10 -----------------------------------------------------------------------------
     def preact_geometry(self, x_shape, cout, *, flip=False, stride=1, bn=False, add=False):

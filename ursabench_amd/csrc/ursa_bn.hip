@@ -307,6 +307,30 @@ __global__ __launch_bounds__(64) void k_bn_finalize(const double2* __restrict__ 
     }
 }
 
+// ---- K14: a producer's per-workgroup sums of the BatchNorm backward -> the per-channel scalars of K6's dx expression --------
+// What k_bn_bwd_dx<BIGS>'s prologue computes, alone (one workgroup per channel, every thread adds its partials in ascending order,
+// then the workgroup's fixed tree): coef[0][c] = gm = sum / n, coef[1][c] = kk = dotp * invstd^2 / n, coef[2][c] = gamma,
+// dbeta = sum, dgamma = dotp * invstd - for a consumer that applies
+// dx = (((g - gm) - (x - mean) * kk) * invstd) * gamma itself (ursa_preact_conv1x1_bwd_dx_f32).
+__global__ __launch_bounds__(kBnBlock) void k_bn_bwd_coef(const double2* __restrict__ partial, int S, const float* __restrict__ save,
+                                                          const float* __restrict__ gamma, float* __restrict__ coef,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta, double n, int C)
+{
+    __shared__ double shd[2 * kBnBlock / 64];
+    const int c = blockIdx.x;
+    double a = 0.0, b = 0.0;
+    for (int t = threadIdx.x; t < S; t += kBnBlock) { const double2 p = partial[(int64_t)c * S + t]; a += p.x; b += p.y; }
+    bn_block_sum2(a, b, shd);
+    if (threadIdx.x == 0) {
+        const double iv = (double)save[C + c];
+        coef[c] = (float)(a / n);
+        coef[C + c] = (float)(b * iv * iv / n);
+        coef[2 * C + c] = gamma[c];
+        dbeta[c] = (float)a;
+        dgamma[c] = (float)(b * iv);
+    }
+}
+
 template <bool NT> __device__ __forceinline__ float ev_ld(const float* p) { return NT ? __builtin_nontemporal_load(p) : *p; }
 template <bool NT> __device__ __forceinline__ float4 ev_ld(const float4* p) { return bn_ld<NT>(p); }
 template <bool NT> __device__ __forceinline__ void ev_st(float* p, const float& v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
@@ -1602,6 +1626,21 @@ int ursa_bn_stats_f32(const float* x, const float* addend, float* z_out, const f
 #undef URSA_BN_STATS
     hipLaunchKernelGGL(k_bn_finalize, dim3((unsigned)C), dim3(64), 0, st, part, p.S, gamma, beta, running_mean, running_var, save, eps, momentum,
                        (double)p.g.per_ch * p.V, (int)C);
+    return bn_launch_status();
+}
+
+// K14: the merge of a producer's partial sums (partial: [C][nl] pairs of doubles (sum g, sum g * (x - mean)), any nl >= 1) into
+// coef [3][C] = (gm, kk, gamma), dgamma and dbeta; n_per_channel = N * HW of the normalised tensor.
+int ursa_bn_bwd_coef_f32(const double* partial, int64_t nl, const float* bn_save, const float* gamma, float* coef, float* dgamma,
+                         float* dbeta, int64_t n_per_channel, int64_t C, ursa_stream_t stream)
+{
+    if (!partial || !bn_save || !gamma || !coef || !dgamma || !dbeta) return URSA_ENULL;
+    if (nl < 1 || n_per_channel < 1 || C < 1) return URSA_ESIZE;
+    if (!bn_aligned16(partial) || !bn_aligned4(bn_save) || !bn_aligned4(gamma) || !bn_aligned4(coef) || !bn_aligned4(dgamma) || !bn_aligned4(dbeta))
+        return URSA_EALIGN;
+    if (nl > (1 << 24) || C > 65535) return URSA_EVALUE;
+    hipLaunchKernelGGL(k_bn_bwd_coef, dim3((unsigned)C), dim3(kBnBlock), 0, (hipStream_t)stream, reinterpret_cast<const double2*>(partial), (int)nl,
+                       bn_save, gamma, coef, dgamma, dbeta, (double)n_per_channel, (int)C);
     return bn_launch_status();
 }
 

@@ -46,10 +46,27 @@ __device__ __forceinline__ f32x4 bn_relu4(const f32x4& v, float scale, float shi
                  relu_nan(fmaf(v.w, scale, shift))};
 }
 
-template <int CI, int CO, int HW, bool FLIP, bool XBN = false>
-__global__ __launch_bounds__(kThreads) void k_conv1x1(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int N,
+//
+// EPI (K14, FLIP only: the input gradient of a layer with a BatchNorm + ReLU in front, `bn` = that BatchNorm's saved block, CO its
+// channels): the result dh = conv^T(dy, w) is NOT stored. The layers this is for widen on the way back (16 -> 64 channels: dy is a
+// quarter of dh), and K6's backward needs the whole batch's two sums before it can produce any dx - so instead of writing dh for K6
+// to read twice, the (memory-bound, cheap) GEMM runs twice:
+//   EPI 1: the ReLU gate from the BatchNorm's input `aux` at the result's positions, and this workgroup's
+//          (sum g, sum g * (aux - mean)) in double per channel -> partial[c][workgroup]: the two sums of K6's first backward launch;
+//   EPI 2: the same dh again (same bits), gated, then K6's dx expression
+//          dx = (((g - gm) - (aux - mean) * kk) * invstd) * gamma (+ dz) with the per-channel (gm, kk, gamma) from `coef`
+//          (ursa_bn_bwd_coef_f32 between the two launches), stored to y.
+struct Epi1x1 {
+    const float* aux;      // the BatchNorm's input, [N, CO, HW]
+    const float* dz;       // EPI 2: the gradient reaching the residual sum on its other path, or nullptr
+    const float* coef;     // EPI 2: [3][CO] gm, kk, gamma
+    double2* partial;      // EPI 1: [CO][gridDim.x * gridDim.y]
+};
+
+template <int CI, int CO, int HW, bool FLIP, bool XBN = false, int EPI = 0>
+__global__ __launch_bounds__(kThreads, (EPI && CO < 256) ? 2 : 1) void k_conv1x1(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int N,
                                                       int ipw, int npc,        // npc: position chunks of an image this workgroup walks (grid.y covers the rest)
-                                                      const float* __restrict__ bn)
+                                                      const float* __restrict__ bn, const Epi1x1 ep)
 {
     constexpr int CK = cmin(CI, 64), NCK = CI / CK, P = 64, PITCH = 80;
     constexpr int MT = CO / 16, NT = cmax(1, MT / 4), WPT = cmax(1, 4 / MT), NR = 4 / WPT;   // tiles per wave, waves per tile, runs per wave
@@ -58,6 +75,7 @@ __global__ __launch_bounds__(kThreads) void k_conv1x1(const float* __restrict__ 
     static_assert(CI % 16 == 0 && CO % 16 == 0 && HW % P == 0 && CI % CK == 0 && (CK * (P / 4)) % kThreads == 0, "geometry");
     static_assert(MT == 1 || MT == 2 || MT % 4 == 0, "output tiles per workgroup");
     static_assert(!(XBN && FLIP), "the BatchNorm sits in front of the forward layer");
+    static_assert(EPI == 0 || (FLIP && !XBN), "the backward epilogues belong to the flipped launch");
     __shared__ __attribute__((aligned(16))) float xs[CK * PITCH];
     __shared__ float tab[XBN ? 2 * CI : 1];                    // scale[CI], shift[CI]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -100,12 +118,39 @@ __global__ __launch_bounds__(kThreads) void k_conv1x1(const float* __restrict__ 
         }
     };
     f32x4 acc[NT][NR];
+    // EPI: this lane's output channels (one per tile it owns) are the same for the whole launch
+    float e_mean[NT], e_scale[NT], e_shift[NT], e_invstd[NT], e_gm[NT], e_kk[NT], e_w[NT];
+    double s1[NT], s2[NT];
+    if constexpr (EPI != 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int o = (tile0 + 4 * t) * 16 + j;
+            e_mean[t] = bn[o], e_invstd[t] = bn[CO + o], e_scale[t] = bn[2 * CO + o], e_shift[t] = bn[3 * CO + o];
+            s1[t] = 0.0, s2[t] = 0.0;
+            if constexpr (EPI == 2) e_gm[t] = ep.coef[o], e_kk[t] = ep.coef[CO + o], e_w[t] = ep.coef[2 * CO + o];
+        }
+    }
     if (steps > 0) load(0);
+    // EPI: the epilogue's own operands (x, dz at the result's positions) are asked for BEFORE the matrix work where they fit the
+    // register file (<= 16 float4), so that the epilogue does not start with a trip to memory
+    constexpr bool PREF = EPI != 0 && NT * NR * (EPI == 2 ? 2 : 1) <= 16;
+    f32x4 pxa[PREF ? NT : 1][PREF ? NR : 1], pdz[PREF && EPI == 2 ? NT : 1][PREF && EPI == 2 ? NR : 1];
     for (int ip = 0; ip < (n1 - n0) * npc; ++ip) {             // (image, position chunk); the channel chunks unrolled: wr's index static
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < NR; ++r) acc[t][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (PREF) {
+            const int n = n0 + ip / npc, pc = pc0 + ip % npc;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const size_t off = ((size_t)n * CO + (tile0 + 4 * t) * 16 + j) * HW + pc * P + (run0 + WPT * r) * 16 + 4 * k;
+                    pxa[t][r] = *reinterpret_cast<const f32x4*>(ep.aux + off);
+                    if constexpr (EPI == 2) { if (ep.dz) pdz[t][r] = *reinterpret_cast<const f32x4*>(ep.dz + off); }
+                }
+        }
 #pragma unroll
         for (int cc = 0; cc < NCK; ++cc) {
             const int s = ip * NCK + cc;
@@ -130,9 +175,59 @@ __global__ __launch_bounds__(kThreads) void k_conv1x1(const float* __restrict__ 
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
-                float* dst = y + ((size_t)n * CO + (tile0 + 4 * t) * 16 + j) * HW + pc * P + (run0 + WPT * r) * 16 + 4 * k;
-                *reinterpret_cast<f32x4*>(dst) = acc[t][r];
+                const size_t off = ((size_t)n * CO + (tile0 + 4 * t) * 16 + j) * HW + pc * P + (run0 + WPT * r) * 16 + 4 * k;
+                if constexpr (EPI == 0) {
+                    *reinterpret_cast<f32x4*>(y + off) = acc[t][r];
+                } else {
+                    f32x4 xa;
+                    if constexpr (PREF) xa = pxa[t][r]; else xa = *reinterpret_cast<const f32x4*>(ep.aux + off);
+                    f32x4 v = acc[t][r];
+                    if constexpr (EPI == 1) {
+                        const double md = (double)e_mean[t];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float ge = fmaf(xa[e], e_scale[t], e_shift[t]) > 0.f ? v[e] : 0.f;
+                            s1[t] += (double)ge;
+                            s2[t] = fma((double)ge, (double)xa[e] - md, s2[t]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float ge = fmaf(xa[e], e_scale[t], e_shift[t]) > 0.f ? v[e] : 0.f;
+                            v[e] = (((ge - e_gm[t]) - (xa[e] - e_mean[t]) * e_kk[t]) * e_invstd[t]) * e_w[t];
+                        }
+                        if (ep.dz) {
+                            if constexpr (PREF) v = pdz[t][r] + v; else v = *reinterpret_cast<const f32x4*>(ep.dz + off) + v;
+                        }
+                        *reinterpret_cast<f32x4*>(y + off) = v;
+                    }
+                }
             }
+    }
+    if constexpr (EPI == 1) {
+        // a channel's four position groups (k) sit in lanes j, j + 16, j + 32, j + 48 of a wave; for MT < 4 the WPT waves
+        // wave % MT, wave % MT + MT, ... hold the same tile: fixed order everywhere
+        __shared__ double red[4][NT][16][2];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            double a = s1[t], b = s2[t];
+            a += __shfl_xor(a, 16); b += __shfl_xor(b, 16);
+            a += __shfl_xor(a, 32); b += __shfl_xor(b, 32);
+            if (k == 0) red[wave][t][j][0] = a, red[wave][t][j][1] = b;
+        }
+        __syncthreads();
+        const int nl = gridDim.x * gridDim.y, wg = blockIdx.y * gridDim.x + blockIdx.x;
+        if (k == 0 && (MT >= 4 || wave < MT)) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                double a = red[wave][t][j][0], b = red[wave][t][j][1];
+                if constexpr (MT < 4) {
+#pragma unroll
+                    for (int u = 1; u < WPT; ++u) a += red[wave + u * MT][t][j][0], b += red[wave + u * MT][t][j][1];
+                }
+                ep.partial[(size_t)((tile0 + 4 * t) * 16 + j) * nl + wg] = make_double2(a, b);
+            }
+        }
     }
 }
 
@@ -220,7 +315,7 @@ __global__ __launch_bounds__(kThreads) void k_conv1x1_wgrad(const float* __restr
         }
 }
 
-typedef void (*FwFn)(const float*, const float*, float*, int, int, int, const float*);
+typedef void (*FwFn)(const float*, const float*, float*, int, int, int, const float*, Epi1x1);
 
 // (CI, CO, H) of the launch: forward = the layer's (Cin, Cout); FLIP = (the layer's Cout, Cin). The bottleneck stages of
 // PreResNet-164: 16 <-> 64 at 32 x 32, 32 <-> 128 at 16 x 16, 64 <-> 256 at 8 x 8, and each stage's first block (16 -> 16, 64 -> 32,
@@ -231,6 +326,14 @@ FwFn fw_for(int64_t CI, int64_t CO, int64_t H, bool flip, bool xbn = false) {
     URSA_1X1(64, 16, 32) URSA_1X1(16, 64, 32) URSA_1X1(128, 32, 16) URSA_1X1(32, 128, 16) URSA_1X1(256, 64, 8) URSA_1X1(64, 256, 8)
     URSA_1X1(16, 16, 32) URSA_1X1(64, 32, 32) URSA_1X1(32, 64, 32) URSA_1X1(128, 64, 16) URSA_1X1(64, 128, 16)
 #undef URSA_1X1
+    return nullptr;
+}
+
+// K14: the widening input gradients behind a BatchNorm (conv1 of a Bottleneck block): (CI = the layer's outputs, CO = its inputs, H)
+FwFn bwd_for(int64_t CI, int64_t CO, int64_t H, int epi) {
+#define URSA_1X1B(ci, co, h) if (CI == ci && CO == co && H == h) return epi == 1 ? (FwFn)k_conv1x1<ci, co, h * h, true, false, 1> : (FwFn)k_conv1x1<ci, co, h * h, true, false, 2>;
+    URSA_1X1B(16, 64, 32) URSA_1X1B(32, 128, 16) URSA_1X1B(64, 256, 8) URSA_1X1B(32, 64, 32) URSA_1X1B(64, 128, 16)
+#undef URSA_1X1B
     return nullptr;
 }
 
@@ -266,7 +369,7 @@ extern "C" int ursa_conv1x1_f32(const float* x, const float* w, float* y, int64_
     int ipw, npc, gy;
     geometry_for(N, H, &ipw, &npc, &gy);
     hipLaunchKernelGGL(fn, dim3((unsigned)((N + ipw - 1) / ipw), (unsigned)gy), dim3(kThreads), 0, (hipStream_t)stream, x, w, y, (int)N, ipw, npc,
-                       (const float*)nullptr);
+                       (const float*)nullptr, Epi1x1{});
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? URSA_OK : (int)e;
 }
@@ -287,9 +390,47 @@ extern "C" int ursa_preact_conv1x1_f32(const float* x, const float* bn_save, con
     int ipw, npc, gy;
     geometry_for(N, H, &ipw, &npc, &gy);
     hipLaunchKernelGGL(fn, dim3((unsigned)((N + ipw - 1) / ipw), (unsigned)gy), dim3(kThreads), 0, (hipStream_t)stream, x, w, y, (int)N, ipw, npc,
-                       bn_save);
+                       bn_save, Epi1x1{});
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? URSA_OK : (int)e;
+}
+
+// K14: the input gradient of `conv1x1(relu(bn(x)))` and the BatchNorm's backward without storing the convolution's input gradient
+extern "C" int64_t ursa_preact_conv1x1_bwd_nl(int64_t N, int64_t Cd, int64_t Cx, int64_t H, int64_t W) {
+    if (N < 1 || N > (1 << 20) || H != W || !bwd_for(Cd, Cx, H, 1)) return 0;
+    int ipw, npc, gy;
+    geometry_for(N, H, &ipw, &npc, &gy);
+    return (int64_t)((N + ipw - 1) / ipw) * gy;
+}
+
+static int bwd_launch(int epi, const float* dy, const float* w, const float* x, const float* bn_save, double* out_partial, const float* coef,
+                      const float* dz, float* dx, int64_t N, int64_t Cd, int64_t Cx, int64_t H, int64_t W, ursa_stream_t stream) {
+    if (!dy || !w || !x || !bn_save || (epi == 1 ? !out_partial : (!coef || !dx))) return URSA_ENULL;
+    if (N < 1 || Cd < 1 || Cx < 1 || H < 1 || W < 1) return URSA_ESIZE;
+    if (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dz | (uintptr_t)dx | (uintptr_t)out_partial) & 15 || ((uintptr_t)w | (uintptr_t)bn_save | (uintptr_t)coef) & 3)
+        return URSA_EALIGN;
+    if (N > (1 << 20) || H != W) return URSA_EVALUE;
+    const FwFn fn = bwd_for(Cd, Cx, H, epi);
+    if (!fn) return URSA_EVALUE;
+    int ipw, npc, gy;
+    geometry_for(N, H, &ipw, &npc, &gy);
+    Epi1x1 ep;
+    ep.aux = x, ep.dz = dz, ep.coef = coef, ep.partial = reinterpret_cast<double2*>(out_partial);
+    hipLaunchKernelGGL(fn, dim3((unsigned)((N + ipw - 1) / ipw), (unsigned)gy), dim3(kThreads), 0, (hipStream_t)stream, dy, w, dx, (int)N, ipw, npc,
+                       bn_save, ep);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? URSA_OK : (int)e;
+}
+
+extern "C" int ursa_preact_conv1x1_bwd_sums_f32(const float* dy, const float* w, const float* x, const float* bn_save, double* out_partial,
+                                                int64_t N, int64_t Cd, int64_t Cx, int64_t H, int64_t W, ursa_stream_t stream) {
+    return bwd_launch(1, dy, w, x, bn_save, out_partial, nullptr, nullptr, nullptr, N, Cd, Cx, H, W, stream);
+}
+
+extern "C" int ursa_preact_conv1x1_bwd_dx_f32(const float* dy, const float* w, const float* x, const float* bn_save, const float* coef,
+                                              const float* dz, float* dx, int64_t N, int64_t Cd, int64_t Cx, int64_t H, int64_t W,
+                                              ursa_stream_t stream) {
+    return bwd_launch(2, dy, w, x, bn_save, nullptr, coef, dz, dx, N, Cd, Cx, H, W, stream);
 }
 
 // what ursa_conv.hip's plan_for() asks for a 1x1 / stride 1 weight gradient: the launch, its K slices and the floats of one slice

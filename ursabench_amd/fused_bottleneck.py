@@ -10,6 +10,11 @@ the rows of x as it stages them (`ursa_preact_conv1x1_f32`); the weight gradient
 which need x and the saved block only. Every value has the bits of the K6 (two-launch form) + K12 path it replaces
 (tests/test_fused_bottleneck_gpu.py).
 
+K14: where the layer narrows (a block's conv1: 64 -> 16 ...), the convolution's input gradient dh is the widest tensor of the
+unit and K6's backward would read it twice after K12 wrote it; `ursa_preact_conv1x1_bwd_*` run the memory-bound flipped GEMM twice
+instead - once for the BatchNorm backward's two sums, once more applying K6's dx expression - and dh never exists in memory
+(`URSA_K14=0`: K12's launch + K6's two).
+
 Taken by `models._PreActBottleneck` when `eligible`; `URSA_K13=0` keeps the K6 + K12 launches (A/B).
 """
 import os
@@ -20,6 +25,7 @@ from torch.autograd.function import once_differentiable
 from . import _native, fused_bn, fused_conv
 
 _on = os.environ.get('URSA_K13', '1') != '0'
+_k14 = os.environ.get('URSA_K14', '1') != '0'
 #: below this many bytes of activation K6 may take its one-pass form (one workgroup per channel, a different summation tree)
 #: and the fold saves little: the K6 + K12 launches stay
 MIN_BYTES = 8 << 20
@@ -34,6 +40,15 @@ def enabled(flag=None):
     return old
 
 
+def recompute_backward(flag=None):
+    """Query / set whether the narrowing layers' backward takes K14 (two GEMM passes, no stored input gradient)."""
+    global _k14
+    old = _k14
+    if flag is not None:
+        _k14 = bool(flag)
+    return old
+
+
 def _aligned(t):
     t = t.contiguous()
     return t.clone() if t.data_ptr() % 16 else t
@@ -43,7 +58,7 @@ class _BNReLUConv1x1(torch.autograd.Function):
     """(z, y) = (a [+ b], conv1x1(relu(bn(z)), w)); z is returned only in the residual form (b given)."""
 
     @staticmethod
-    def forward(ctx, a, b, gamma, beta, running_mean, running_var, eps, momentum, w, ws_floats):
+    def forward(ctx, a, b, gamma, beta, running_mean, running_var, eps, momentum, w, ws_floats, k14):
         ctx.set_materialize_grads(False)
         K = _native.default_kernels()
         C = a.shape[1]
@@ -54,7 +69,7 @@ class _BNReLUConv1x1(torch.autograd.Function):
         x = a if b is None else z
         y = K.preact_conv1x1(x, save, w)
         ctx.save_for_backward(x, gamma, beta, save, w)
-        ctx.residual, ctx.ws_floats, ctx.weight = b is not None, ws_floats, w
+        ctx.residual, ctx.ws_floats, ctx.weight, ctx.k14 = b is not None, ws_floats, w, k14
         ctx.sink = getattr(fused_conv._tls, 'sink', None)
         if b is None:
             return y
@@ -68,7 +83,7 @@ class _BNReLUConv1x1(torch.autograd.Function):
         K = _native.default_kernels()
         C = x.shape[1]
         if dy is None:                                          # y unused: only the sum's own gradient flows
-            return dz, (dz if ctx.residual else None), None, None, None, None, None, None, None, None
+            return dz, (dz if ctx.residual else None), None, None, None, None, None, None, None, None, None
         dy = _aligned(dy)
         dw = None
         if ctx.needs_input_grad[8]:
@@ -79,12 +94,16 @@ class _BNReLUConv1x1(torch.autograd.Function):
             else:
                 dw = torch.empty_like(w)
                 K.conv_wgrad_reduce([(first(), dw)])
-        dh = K.conv1x1(dy, w, flip=True)
         dx = torch.empty_like(x)
         dgb = x.new_empty(2, C)
-        K.bn_relu_backward(x, dh, dx, gamma, beta, save[0], save[1], dgb[0], dgb[1], x.new_empty(_native.bn_ws_floats(C)), relu=True,
-                           dz=None if dz is None else _aligned(dz), two_launch=True, gate=save[2:])
-        return dx, (dx if ctx.residual else None), dgb[0], dgb[1], None, None, None, None, dw, None
+        dz = None if dz is None else _aligned(dz)
+        if ctx.k14:                                             # K14: the flipped GEMM twice, its result never stored
+            K.preact_conv1x1_bwd(dy, w, x, save, gamma, dx, dgb[0], dgb[1], dz=dz)
+        else:
+            dh = K.conv1x1(dy, w, flip=True)
+            K.bn_relu_backward(x, dh, dx, gamma, beta, save[0], save[1], dgb[0], dgb[1], x.new_empty(_native.bn_ws_floats(C)), relu=True,
+                               dz=dz, two_launch=True, gate=save[2:])
+        return dx, (dx if ctx.residual else None), dgb[0], dgb[1], None, None, None, None, dw, None, None
 
 
 def eligible(bn, conv, a, b=None):
@@ -117,7 +136,8 @@ def eligible(bn, conv, a, b=None):
         N, cin, H, W = a.shape
         ok = (K.preact_conv1x1_supported(a.shape, conv.out_channels) and K.conv1x1_supported((N, conv.out_channels, H, W), cin, flip=True))
         ws = K.conv_wgrad_ws_floats(a.shape, conv.out_channels, 1, 1) if w.requires_grad else 0
-        plan = conv.__dict__['_ursa_k13'] = (key, bool(ok) and (ws > 0 or not w.requires_grad), ws)
+        k14 = K.preact_conv1x1_bwd_nl((N, conv.out_channels, H, W), cin) > 0
+        plan = conv.__dict__['_ursa_k13'] = (key, bool(ok) and (ws > 0 or not w.requires_grad), ws, k14)
     return plan[1]
 
 
@@ -127,6 +147,6 @@ def bn_relu_conv1x1(bn, conv, x):
     a, b = x if isinstance(x, tuple) else (x, None)
     if bn.num_batches_tracked is not None:                      # None inside util.deferred_bn_counters
         bn.num_batches_tracked.add_(1)
-    ws = conv.__dict__['_ursa_k13'][2]
-    out = _BNReLUConv1x1.apply(a, b, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, conv.weight, ws)
+    _, _, ws, k14 = conv.__dict__['_ursa_k13']
+    out = _BNReLUConv1x1.apply(a, b, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, conv.weight, ws, k14 and _k14)
     return (a, out) if b is None else out
