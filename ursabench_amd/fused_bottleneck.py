@@ -136,7 +136,9 @@ def eligible(bn, conv, a, b=None):
         N, cin, H, W = a.shape
         ok = (K.preact_conv1x1_supported(a.shape, conv.out_channels) and K.conv1x1_supported((N, conv.out_channels, H, W), cin, flip=True))
         ws = K.conv_wgrad_ws_floats(a.shape, conv.out_channels, 1, 1) if w.requires_grad else 0
-        k14 = K.preact_conv1x1_bwd_nl((N, conv.out_channels, H, W), cin) > 0
+        # K14 where it pays: at 8 x 8 (256 <- 64 channels: the kernel holds 64 + 128 weight / accumulator registers per lane and
+        # runs one wave per SIMD) the two passes take 98 us against 93 for K12's launch + K6's two (profiles/r06_k12_bench.json)
+        k14 = K.preact_conv1x1_bwd_nl((N, conv.out_channels, H, W), cin) > 0 and H * W >= 256
         plan = conv.__dict__['_ursa_k13'] = (key, bool(ok) and (ws > 0 or not w.requires_grad), ws, k14)
     return plan[1]
 
