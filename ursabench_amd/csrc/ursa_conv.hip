@@ -71,7 +71,6 @@ struct Fuse {
     // EPI
     int nl;                                 // lines = partial sums per output channel this launch leaves in out_partial
     int line_sz;                            // workgroups (grid.x indices) per line
-    int xcd_remap;                          // paired backward launch: eighths of each role per XCD (0: plain order)
     const float* aux;                       // EPI 2: the addend (shape of y); EPI 3: the BatchNorm input at y's positions
     const float* bsave;                     // EPI 3: [4][Cout] of that BatchNorm (mean, invstd, alpha, beta')
     u64* slots;                             // [Cout][grid.x][2]: zero at launch, zero again when the launch has drained
@@ -1063,22 +1062,11 @@ __global__ __launch_bounds__(kThreads, MINW) void k_bwd_pair(const float* __rest
     using A = Fw<CIN_A, COUT_WG_A, W_A, R_A, PH_A, MODE_A>;
     using B = Wg<CIN_B, COUT_WG_B, WO_B, R_B, STRIDE_B, 9, PH_B>;
     __shared__ __attribute__((aligned(16))) float smem[cmax(A::SMEM, B::SMEM)];
-    int na = gx_a * gy_a, nb = gx_b * gy_b;
-    int id = blockIdx.x, base_a = 0, base_b = 0;
-    // Workgroups go to the 8 XCDs round-robin by index, and each XCD has its own L2: with the plain order the four bands of an
-    // image (and the two roles, which read the same dy and x) land on different XCDs and every one of them fetches its rows and
-    // halos from memory again (45.6 MB per launch at 16 channels; 27.3 MB with this order, profiles/r06_pair_xcd_ab.json). When both roles divide by 8,
-    // XCD k takes the k-th eighth of EACH role instead - the same images in both: which workgroup computes what changes, no bit does.
-    if (na % 8 == 0 && nb % 8 == 0 && f.xcd_remap) {
-        const int k = id & 7;
-        id >>= 3, na >>= 3, nb >>= 3;
-        base_a = k * na, base_b = k * nb;
-    }
-    const int m = na < nb ? na : nb;
+    const int na = gx_a * gy_a, nb = gx_b * gy_b, m = na < nb ? na : nb;
+    const int id = blockIdx.x;
     int role, idx;
     if (id < 2 * m) role = id & 1, idx = id >> 1;
     else role = na > nb ? 0 : 1, idx = id - m;
-    idx += role == 0 ? base_a : base_b;
     if (role == 0)      // dx' = gate(conv_flip(dy, w)): staged tensor dy [N, Cd, ..], result g [N, Cx, ..]
         conv_body<CIN_A, COUT_WG_A, W_A, R_A, PH_A, MODE_A, 0, 0, 3>(dy, w, g, N, Cx, ipw_a, 1, f, smem, idx % gx_a, idx / gx_a, gx_a);
     else                // dW partial sums: x operand = relu(bn(x)) rebuilt from f.bsave while staged
@@ -1376,13 +1364,6 @@ extern "C" int ursa_preact_bwd_pair_f32(const float* dy, const float* w, float* 
     Fuse f = {};
     f.nl = ga.nl, f.line_sz = ga.line_sz, f.aux = x, f.bsave = bn_save;
     f.out_partial = reinterpret_cast<double2*>(out_partial);
-    // (measured per shape, tools/exp/r06_pair_xcd_ab.sh: HBM bytes per launch at 16 channels 45.6 -> 27.3 MB, about the operands
-    // themselves; us per launch 16 ch 17.9 -> 18.0, 32 ch 18.05 -> 17.8, 16 -> 32 stride 2 16.0 -> 14.7 - but 64 ch 17.9 -> 18.9 and
-    // 32 -> 64 stride 2 16.0 -> 16.5, whose images are spread over 4 / 2 output-channel groups: those keep the plain order)
-    f.xcd_remap = Cd != 64;
-#ifdef URSA_DEBUG_KNOBS
-    if (const char* e = getenv("URSA_PAIR_XCD")) f.xcd_remap = atoi(e) != 0;        // A/B: 0 = workgroups in plain order
-#endif
     const int na = ga.S * a.gy, nb = b.slices * b.gy;
     hipLaunchKernelGGL(fn, dim3(na + nb), dim3(kThreads), 0, (hipStream_t)stream, dy, w, g, x, ws, (int)N, (int)Cd, (int)Cx, a.ipw, b.ipw,
                        ga.S, a.gy, b.slices, b.gy, f);
